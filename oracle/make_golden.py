@@ -1,0 +1,130 @@
+"""Generate the golden fixtures under ``tests/golden/`` by running the
+reference's OWN modules (imported unmodified from /root/reference through
+``oracle/ref_shims.py``) on PyTorch-CPU.
+
+TEST INFRASTRUCTURE.  Run in the build container only:
+
+    TORCHDYNAMO_DISABLE=1 python -m oracle.make_golden
+
+What is the reference's and what is restated
+--------------------------------------------
+The model code (``SphericalFourierNeuralOperatorNet``, ``SpectralConv``,
+``_contract_lwise``, ``MLP``, ``EncoderDecoder``, ``nn.InstanceNorm2d``) is the
+reference's, byte for byte.  The SHT underneath it is ``oracle/sht.py`` because
+torch-harmonics is not installable here; that restatement is
+pinned separately against scipy (``tests/test_oracle_sht.py``).
+
+Each fixture stores: constructor kwargs, the reference ``state_dict``, a seeded
+input, the forward output, and gradients of ``sum(y * g)`` (seeded ``g``) w.r.t.
+the input and every parameter.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_shims
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _run_model(cls, kwargs, batch, seed, name):
+    torch.manual_seed(seed)
+    model = cls(**kwargs)
+    model.train()
+    x = torch.rand(batch, kwargs["inp_chans"], *kwargs["inp_shape"], requires_grad=True)
+    g = torch.randn(batch, kwargs["out_chans"], *kwargs["out_shape"])
+    y = model(x)
+    (y * g).sum().backward()
+    rec = {"kwargs": np.array(json.dumps(kwargs)), "x": _np(x), "g": _np(g), "y": _np(y), "gx": _np(x.grad)}
+    for k, v in model.state_dict().items():
+        rec["param/" + k] = _np(v)
+    for k, p in model.named_parameters():
+        rec["grad/" + k] = _np(p.grad)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path)/1e6:.2f} MB  |y|={y.abs().mean().item():.4f}")
+
+
+def sfno_fixtures():
+    SFNO = ref_shims.import_reference_sfno()
+    # BASELINE config 1: the reference's test fixture (tests/testutils.py:33-36,
+    # tests/test_trainers.py:90-92): 64x128, 5 channels, ctor defaults, 2 layers
+    _run_model(
+        SFNO,
+        dict(inp_shape=(64, 128), out_shape=(64, 128), inp_chans=5, out_chans=5, num_layers=2),
+        batch=1, seed=333, name="sfno_tiny_64x128.npz",
+    )
+    # the grid of tests/test_models.py:66-103 (36x72), B=2, odd-ish sizes, scale 3 like config 2
+    _run_model(
+        SFNO,
+        dict(inp_shape=(37, 72), out_shape=(37, 72), inp_chans=3, out_chans=3, num_layers=3, scale_factor=3,
+             embed_dim=16, mlp_ratio=2),
+        batch=2, seed=334, name="sfno_small_37x72.npz",
+    )
+
+
+def spectral_conv_fixtures():
+    sc = ref_shims.import_reference_module("makani.models.common.spectral_convolution")
+    th = sys.modules["torch_harmonics"]
+    rec = {}
+    # (nlat_in, nlon_in, grid_in) -> (nlat_out, nlon_out, grid_out), lmax, mmax, Cin, Cout, B, operator
+    cases = [
+        (33, 64, "equiangular", 33, 64, "equiangular", 16, 17, 4, 6, 2, "dhconv"),
+        (33, 64, "equiangular", 12, 24, "legendre-gauss", 12, 13, 8, 8, 1, "dhconv"),   # down-sampling (block 0)
+        (12, 24, "legendre-gauss", 33, 64, "equiangular", 12, 13, 8, 8, 2, "dhconv"),   # up-sampling (last block)
+        (12, 24, "legendre-gauss", 12, 24, "legendre-gauss", 12, 12, 6, 4, 2, "diagonal"),  # lmax == mmax: the reference init only broadcasts then
+    ]
+    for idx, (h0, w0, g0, h1, w1, g1, lmax, mmax, cin, cout, B, op) in enumerate(cases):
+        torch.manual_seed(100 + idx)
+        fwd = th.RealSHT(h0, w0, lmax=lmax, mmax=mmax, grid=g0).float()
+        inv = th.InverseRealSHT(h1, w1, lmax=lmax, mmax=mmax, grid=g1).float()
+        layer = sc.SpectralConv(fwd, inv, cin, cout, operator_type=op, bias=False, gain=2.0)
+        x = torch.randn(B, cin, h0, w0, requires_grad=True)
+        y, res = layer(x)
+        gy = torch.randn_like(y)
+        gr = torch.randn_like(res)
+        ((y * gy).sum() + (res * gr).sum()).backward()
+        p = f"case{idx}/"
+        rec[p + "meta"] = np.array(json.dumps(dict(h0=h0, w0=w0, g0=g0, h1=h1, w1=w1, g1=g1, lmax=lmax, mmax=mmax,
+                                                  cin=cin, cout=cout, B=B, op=op)))
+        rec[p + "x"], rec[p + "w"], rec[p + "y"], rec[p + "res"] = _np(x), _np(layer.weight), _np(y), _np(res)
+        rec[p + "gy"], rec[p + "gr"], rec[p + "gx"], rec[p + "gw"] = _np(gy), _np(gr), _np(x.grad), _np(layer.weight.grad)
+    rec["ncases"] = np.array(len(cases))
+    path = os.path.join(OUT, "spectral_conv.npz")
+    np.savez_compressed(path, **rec)
+    print(f"spectral_conv.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def contraction_fixtures():
+    con = ref_shims.import_reference_module("makani.models.common.contractions")
+    torch.manual_seed(7)
+    x = torch.randn(2, 1, 6, 9, 10, dtype=torch.complex64)
+    w = torch.randn(1, 6, 5, 9, dtype=torch.complex64)
+    wd = torch.randn(1, 6, 5, 9, 10, dtype=torch.complex64)
+    y = con._contract_dense_pytorch(x, w, separable=False, operator_type="dhconv")
+    yd = con._contract_dense_pytorch(x, wd, separable=False, operator_type="diagonal")
+    path = os.path.join(OUT, "contractions.npz")
+    np.savez_compressed(path, x=_np(x), w=_np(w), wd=_np(wd), y=_np(y), yd=_np(yd))
+    print(f"contractions.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def main():
+    if not ref_shims.reference_available():
+        raise SystemExit("reference tree not found; golden fixtures can only be generated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    contraction_fixtures()
+    spectral_conv_fixtures()
+    sfno_fixtures()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+"""Pin the restated CPU model (oracle/sfno.py) against fixtures produced by the
+reference's own modules (oracle/make_golden.py)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import sfno as osf
+from oracle import sht as osht
+
+
+def test_contraction_matches_reference():
+    g = load_golden("contractions.npz")
+    x, w, wd = (torch.from_numpy(g[k]) for k in ("x", "w", "wd"))
+    assert rel_l2(osf.contract_lwise(x, w), torch.from_numpy(g["y"])) < 1e-6
+    assert rel_l2(osf.contract_lmwise(x, wd), torch.from_numpy(g["yd"])) < 1e-6
+
+
+def test_spectral_conv_matches_reference():
+    g = load_golden("spectral_conv.npz")
+    for i in range(int(g["ncases"])):
+        p = f"case{i}/"
+        m = json.loads(str(g[p + "meta"]))
+        fwd = osht.RealSHT(m["h0"], m["w0"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g0"]).float()
+        inv = osht.InverseRealSHT(m["h1"], m["w1"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g1"]).float()
+        layer = osf.SpectralConv(fwd, inv, m["cin"], m["cout"], operator_type=m["op"])
+        with torch.no_grad():
+            layer.weight.copy_(torch.from_numpy(g[p + "w"]))
+        x = torch.from_numpy(g[p + "x"]).requires_grad_(True)
+        y, res = layer(x)
+        ((y * torch.from_numpy(g[p + "gy"])).sum() + (res * torch.from_numpy(g[p + "gr"])).sum()).backward()
+        assert rel_l2(y, torch.from_numpy(g[p + "y"])) < 1e-6
+        assert rel_l2(res, torch.from_numpy(g[p + "res"])) < 1e-6
+        assert rel_l2(x.grad, torch.from_numpy(g[p + "gx"])) < 1e-5
+        assert rel_l2(layer.weight.grad, torch.from_numpy(g[p + "gw"])) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz"])
+def test_sfno_matches_reference(name):
+    g = load_golden(name)
+    kwargs = json.loads(str(g["kwargs"]))
+    model = osf.SphericalFourierNeuralOperatorNet(**kwargs)
+    sd = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = model(x)
+    (y * torch.from_numpy(g["g"])).sum().backward()
+    assert rel_l2(y, torch.from_numpy(g["y"])) < 1e-6
+    assert rel_l2(x.grad, torch.from_numpy(g["gx"])) < 1e-5
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, torch.from_numpy(g["grad/" + k])) < 2e-5, k
