@@ -1,0 +1,329 @@
+"""bench.py — SFNO train-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + backward + gradient clipping + AdamW update of
+``sfno_sc3_layers8_edim384`` (config/sfnonet.yaml: scale_factor 3, 8 layers, embed_dim 384,
+dhconv, instance norm, mlp_ratio 2) at 721 x 1440, 73 -> 73 channels, batch 1 per GPU,
+bf16 autocast (fp32 spectral path), synthetic DummyLoader-shaped data resident in HBM.
+N > 1: one process per GPU (torchrun env), data parallel over RCCL with the gradient
+all-reduce overlapped with backward; "scaling": "weak".
+
+Rank 0 prints ONE JSON line (see DESIGN.md §7 for every field).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+CONFIGS = {
+    # BASELINE.json configs[1]
+    "sfno_sc3_layers8_edim384": dict(inp_shape=(721, 1440), out_shape=(721, 1440), inp_chans=73, out_chans=73,
+                                     scale_factor=3, embed_dim=384, num_layers=8, mlp_ratio=2, operator_type="dhconv",
+                                     normalization_layer="instance_norm", activation_function="gelu", big_skip=True,
+                                     model_grid_type="equiangular", sht_grid_type="legendre-gauss"),
+    # small stand-in with the same structure (plumbing / CI on small GPUs)
+    "sfno_debug": dict(inp_shape=(91, 180), out_shape=(91, 180), inp_chans=8, out_chans=8, scale_factor=3,
+                       embed_dim=64, num_layers=4, mlp_ratio=2),
+}
+PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def quadrature_weights(nlat, nlon, device):
+    """Clenshaw-Curtis area weights normalised to sum 1 (GridQuadrature, makani/utils/grids.py:102-191)."""
+    from makani_amd import legendre
+    _, w = legendre.colatitudes(nlat, "equiangular")
+    q = torch.from_numpy(w).float()[:, None].expand(nlat, nlon) / (2.0 * nlon)
+    return q.to(device).contiguous()
+
+
+def l2_loss(pred, tar, q):
+    d = (pred.float() - tar.float()) ** 2
+    return torch.mean(torch.sum(d * q, dim=(-2, -1)))
+
+
+class GradReducer:
+    """Data-parallel gradient averaging over RCCL, overlapped with backward: every parameter's
+    gradient is all-reduced (async) from its post-accumulate hook — the eight 283 MB spectral
+    weights are natural large messages, the small pointwise parameters are flushed in one bucket."""
+
+    def __init__(self, model, world):
+        self.world = world
+        self.handles = []
+        self.small = []
+        self.big_bytes = 8 << 20
+        if world > 1:
+            for p in model.parameters():
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        g = torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad
+        if g.numel() * g.element_size() >= self.big_bytes:
+            self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True), g))
+        else:
+            self.small.append(g)
+
+    def finish(self):
+        if self.world == 1:
+            return
+        if self.small:
+            flat = torch.cat([g.reshape(-1) for g in self.small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(self.world)
+            off = 0
+            for g in self.small:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
+            self.small = []
+        for h, g in self.handles:
+            h.wait()
+            g.div_(self.world)
+        self.handles = []
+
+
+def build_model(cfg_name, device, seed):
+    import makani_amd as ma
+    torch.manual_seed(seed)
+    model = ma.SphericalFourierNeuralOperatorNet(**CONFIGS[cfg_name]).to(device)
+    return model
+
+
+def make_optimizer(model):
+    # config/sfnonet.yaml:50-54,114-117.  foreach (multi-tensor) path: it views the complex64
+    # spectral weights as real; the fused path rejects complex parameters.
+    params = [p for p in model.parameters() if p.requires_grad]
+    return torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0, foreach=True)
+
+
+def clip_grads(model, max_norm):
+    """global-norm clipping (makani/utils/training/training_helpers.py:123-165), complex grads viewed as real"""
+    grads = [torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad for p in model.parameters() if p.grad is not None]
+    norms = torch._foreach_norm(grads)
+    total = torch.linalg.vector_norm(torch.stack(norms))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    torch._foreach_mul_(grads, coef)
+    return total
+
+
+def train_step(model, opt, reducer, inp, tar, q, amp):
+    opt.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        pred = model(inp)
+    loss = l2_loss(pred, tar, q)
+    loss.backward()
+    reducer.finish()
+    clip_grads(model, 32.0)
+    opt.step()
+    return loss
+
+
+def sht_bandwidth(device, reps=5):
+    """Secondary metric 'fwd SHT GB/s' (BASELINE.md §2): S1 ERA5-shaped, S2 model-shaped."""
+    import makani_amd as ma
+    out = {}
+    for name, C, lmax, mmax in (("S1_c73_L721_M721", 73, 721, 721), ("S2_c384_L240_M241", 384, 240, 241)):
+        S = ma.RealSHT(721, 1440, lmax=lmax, mmax=mmax, grid="equiangular").to(device)
+        x = torch.rand(1, C, 721, 1440, device=device)
+        S(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            S(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        nbytes = C * 721 * 1440 * 4 + C * lmax * mmax * 8
+        out[name] = dict(ms=dt * 1e3, GBps=nbytes / dt / 1e9)
+        del S, x
+        torch.cuda.empty_cache()
+    return out
+
+
+def _timed_cpu(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(cfg_name):
+    """Reference-equivalent CPU path — the oracle (the reference's model code restated over the
+    restated torch-harmonics SHT, fp32, all host cores) — timed on a BOUNDED sample of the same
+    workload: ONE forward+backward of each distinct stage of the network at full size
+    (first block, one internal block, last block, encoder, decoder+big-skip).  The step time is
+    their composition t_first + (L-2) t_mid + t_last + t_enc + t_dec; optimizer time is excluded
+    (it favours the CPU number)."""
+    import psutil
+    from oracle import sfno as osf
+    from oracle import sht as osht
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = CONFIGS[cfg_name]
+    H, W = cfg["inp_shape"]
+    E, nl, sf = cfg["embed_dim"], cfg["num_layers"], cfg["scale_factor"]
+    h, w = H // sf, W // sf
+    ml, mm = h, w // 2 + 1
+    torch.manual_seed(333)
+    act = torch.nn.GELU
+    trans_down = osht.RealSHT(H, W, lmax=ml, mmax=mm, grid="equiangular").float()
+    itrans_up = osht.InverseRealSHT(H, W, lmax=ml, mmax=mm, grid="equiangular").float()
+    trans = osht.RealSHT(h, w, lmax=ml, mmax=mm, grid="legendre-gauss").float()
+    itrans = osht.InverseRealSHT(h, w, lmax=ml, mmax=mm, grid="legendre-gauss").float()
+
+    def fb(module, shape):
+        x = torch.rand(*shape, requires_grad=True)
+        def run():
+            module(x).square().mean().backward()
+        return _timed_cpu(run)
+
+    notes = []
+    t_first = fb(osf.NeuralOperatorBlock(trans_down, itrans, E, "dhconv", cfg["mlp_ratio"], act, False), (1, E, H, W))
+    t_mid = fb(osf.NeuralOperatorBlock(trans, itrans, E, "dhconv", cfg["mlp_ratio"], act, False), (1, E, h, w))
+    t_enc = fb(osf._encdec(1, cfg["inp_chans"], E, E, act), (1, cfg["inp_chans"], H, W))
+    t_dec = fb(osf._encdec(1, E, cfg["out_chans"], E, act, gain=0.5), (1, E, H, W))
+    need = 20 * E * H * W * 4
+    if psutil.virtual_memory().available > 1.5 * need:
+        t_last = fb(osf.NeuralOperatorBlock(trans, itrans_up, E, "dhconv", cfg["mlp_ratio"], act, False), (1, E, h, w))
+    else:
+        t_last = t_first + (t_mid - 0.0) * (H * W) / (h * w) * 0.8
+        notes.append("last block extrapolated (host RAM too small to hold its fp32 activations)")
+    step = t_first + (nl - 2) * t_mid + t_last + t_enc + t_dec
+    return dict(value=1.0 / step, unit="samples/s", cores=cores, kind="port",
+                sample=f"oracle fp32 on CPU, one fwd+bwd of each stage at full size: first block {t_first:.1f} s, "
+                       f"internal block {t_mid:.1f} s (x{nl - 2}), last block {t_last:.1f} s, encoder {t_enc:.1f} s, "
+                       f"decoder {t_dec:.1f} s -> step {step:.1f} s (optimizer excluded). " + " ".join(notes),
+                ms_per_step=step * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="sfno_sc3_layers8_edim384", choices=list(CONFIGS))
+    ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (not the BASELINE metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sht-metric", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from makani_amd import ops
+
+    cfg = CONFIGS[args.config]
+    H, W = cfg["inp_shape"]
+    B = 1
+    model = build_model(args.config, device, seed=333)            # same seed on every rank -> same init
+    opt = make_optimizer(model)
+    reducer = GradReducer(model, world)
+    torch.manual_seed(333 + rank)                                  # DummyLoader: fixed U[0,1) tensors on device
+    inp = torch.rand(B, cfg["inp_chans"], H, W, device=device)
+    tar = torch.rand(B, cfg["out_chans"], H, W, device=device)
+    q = quadrature_weights(H, W, device)
+    amp = not args.fp32
+
+    for _ in range(args.warmup):
+        train_step(model, opt, reducer, inp, tar, q, amp)
+    torch.cuda.synchronize()
+
+    ops.PROFILER.reset()
+    ops.PROFILER.enabled = True
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, opt, reducer, inp, tar, q, amp)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILER.enabled = False
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    final_loss = float(loss)
+
+    if rank == 0:
+        prof = ops.PROFILER.summary()
+        # dominant HIP kernel = largest accumulated time among our launches
+        dom_name = max(prof, key=lambda k: prof[k]["ms_total"]) if prof else None
+        roofline = None
+        kernels = {}
+        for k, d in sorted(prof.items(), key=lambda kv: -kv[1]["ms_total"]):
+            tf = d["flops"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e12 if d["flops"] else None
+            gb = d["bytes"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e9
+            kernels[k] = dict(launches_per_step=d["launches"] / args.steps, ms_avg=round(d["ms_avg"], 4),
+                              ms_per_step=round(d["ms_total"] / args.steps, 3),
+                              TFLOPs_dense=round(tf, 2) if tf else None, GBps_algorithmic=round(gb, 1))
+        if dom_name:
+            d = prof[dom_name]
+            if d["flops"]:
+                ach = d["flops"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e12
+                roofline = dict(kernel=dom_name, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF,
+                                unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TF, 4), traffic=None,
+                                note="dense-formulation fp32 flops per launch / HIP-event launch time; the kernel "
+                                     "skips the structurally-zero l<m half (DESIGN.md §4)")
+            else:
+                ach = d["bytes"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e9
+                roofline = dict(kernel=dom_name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+        hip_ms = sum(d["ms_total"] for d in prof.values()) / args.steps
+        out = {
+            "metric": "SFNO train samples/sec at 721x1440x73ch",
+            "value": world * B * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if amp else "f32",
+            "data": "synthetic",
+            "config": {"workload": args.config, "grid": f"{H}x{W}", "channels": cfg["inp_chans"],
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32"},
+            "roofline": roofline,
+            "hip_kernels": kernels,
+            "hip_kernel_ms_per_step": round(hip_ms, 2),
+            "final_loss": final_loss,
+        }
+        if world == 1 and not args.no_sht_metric and args.config == "sfno_sc3_layers8_edim384":
+            del model, opt
+            torch.cuda.empty_cache()
+            out["fwd_sht"] = sht_bandwidth(device)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * makani_amd.h — C ABI of libmakani_amd.so (gfx950 / MI355X).
+ *
+ * The reference (NVIDIA/makani) has no FFI of its own: its hot path is Python
+ * calling torch ops.  This header is therefore the boundary a
+ * maintainer would bind *behind* the reference's nn.Module interface; every
+ * entry point names the reference call it replaces (paths relative to
+ * /root/reference).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers (hipMalloc'ed / torch-allocated), 16-byte aligned;
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream); every call
+ *    only enqueues work, nothing synchronises;
+ *  - return value: 0 on success, negative MK_E* code on invalid arguments,
+ *    positive hipError_t if the launch failed. mk_last_error() gives a message;
+ *  - dtype codes: MK_F32 = 0, MK_BF16 = 1.
+ *
+ * Internal spectral layouts (all fp32, planar re/im, padded to multiples of 4):
+ *  F-layout  F[m][ri][row][k]   m < M, ri in {re,im}, row < R (R = B*Cp), k < Kp    (lat-major, feeds Legendre)
+ *  S-layout  S[l][m][ri][row]   l < L, m < M, row < R                                (coefficients)
+ *  W-layout  W[l][ri][i][o]     dhconv weights, i < Cip, o < Cop (zero padded)
+ */
+#ifndef MAKANI_AMD_H
+#define MAKANI_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_F32 0
+#define MK_BF16 1
+
+#define MK_EINVAL -1   /* bad argument (shape / alignment / dtype)            */
+#define MK_EUNSUP -2   /* unsupported size (e.g. odd nlon, prime factor > 31)  */
+
+/* triangular structure of the spherical-harmonic index space (P_l^m = 0 for l < m) */
+#define MK_TRI_NONE 0
+#define MK_TRI_ROW_GE 1 /* only output rows i >= t are computed                (Legendre analysis, t = m)   */
+#define MK_TRI_K_GE 2   /* contraction runs over k >= t only                   (Legendre synthesis, t = m)  */
+#define MK_TRI_ROW_LE 3 /* only output rows i <= t are computed                (dhconv fwd/dgrad, t = l)    */
+#define MK_TRI_K_LE 4   /* contraction runs over k <= t only                   (dhconv wgrad, t = l)        */
+/* with t = batch_index / inner (the OUTER batch index) */
+
+/* Strided batched GEMM descriptor:  C[b][i][j] (+)= sum_k A[b][i][k] * B[b][j][k]
+ * Element strides.  One of {a_row, a_k} must be 1 (same for B); c_col must be 1.
+ * Two-level batch: b = outer * inner + in;  offset = outer * x_batch + in * x_inner.
+ * Complex variant: *_im = element offset from the real plane to the imaginary plane. */
+typedef struct MkGemm {
+    const float* A;
+    const float* B;
+    float* C;
+    long long a_batch, a_row, a_k;
+    long long b_batch, b_col, b_k;
+    long long c_batch, c_row, c_col;
+    long long a_inner, b_inner, c_inner;
+    long long a_im, b_im, c_im;
+    int M, N, K, batch; /* batch = outer count * inner */
+    int inner;          /* >= 1 */
+    int tri_mode;
+    int conj_a, conj_b;
+    int beta; /* 0: C = A*B^T ; 1: C += A*B^T */
+} MkGemm;
+
+const char* mk_last_error(void);
+int mk_version(void);
+
+/* ---- fp32 MFMA batched GEMMs ------------------------------------------------
+ * mk_sgemm_batched : real.  Replaces the two einsums of th.RealSHT.forward /
+ *   th.InverseRealSHT.forward [torch-harmonics, un-vendored; call sites
+ *   makani/models/common/spectral_convolution.py:239,241,253] and their autograd.
+ * mk_cgemm_batched : complex (planar).  Replaces _contract_lwise
+ *   (makani/models/common/contractions.py:23-24) and its autograd. */
+int mk_sgemm_batched(const MkGemm* g, void* stream);
+int mk_cgemm_batched(const MkGemm* g, void* stream);
+
+/* ---- longitude FFTs ----------------------------------------------------------
+ * mk_rfft_rows: x[row][lat][lon] (f32|bf16)  ->  F-layout, modes m < mmax:
+ *     X_m = w_m * sum_n x_n exp(-2 pi i m n / nlon),  w = (w_dc, w_pos, w_nyq)
+ *   Replaces `2*pi*torch.fft.rfft(x, norm="forward")[..., :mmax]` (th.RealSHT.forward;
+ *   in-tree twin makani/mpu/fft.py:157-160) and, with other weights, the adjoint of irfft.
+ * mk_irfft_rows: F-layout -> x[row][lat][lon] (f32|bf16):
+ *     x_n = sum_m w_m * ( Re X_m cos(2 pi m n/nlon) - Im X_m sin(2 pi m n/nlon) )
+ *   Replaces `torch.fft.irfft(X, n=nlon, norm="forward")` incl. the Im(m=0)/Im(Nyquist)
+ *   drop (th.InverseRealSHT.forward; twin makani/mpu/fft.py:242) and the adjoint of rfft.
+ * x holds B*C planes; plane (b, c) maps to F row b*Cp + c (R = B*Cp rows, pad rows untouched).
+ * `twiddle` = device table of nlon float2: exp(-2 pi i q / nlon) (host fp64 -> fp32).
+ * `radix`   = host array of `nradix` radices whose product is nlon/2.               */
+int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* twiddle, const int* radix, int nradix,
+                 int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos, float w_nyq,
+                 void* stream);
+int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* twiddle, const int* radix, int nradix,
+                  int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos, float w_nyq,
+                  void* stream);
+
+/* ---- layout changes ------------------------------------------------------------
+ * complex64 dhconv parameter (Cin, Cout, L) [makani/models/common/spectral_convolution.py:164-193]
+ * <-> W-layout, and S-layout <-> complex64 (rows, L, M) tensors at the RealSHT API boundary. */
+int mk_weight_to_wlayout(const float* w_c64, float* W, int cin, int cout, int cip, int cop, int L, void* stream);
+int mk_wlayout_to_weight_grad(const float* gW, float* gw_c64, int cin, int cout, int cip, int cop, int L, void* stream);
+int mk_slayout_to_complex(const float* S, float* out_c64, int B, int C, int Cp, int L, int M, void* stream);
+int mk_complex_to_slayout(const float* in_c64, float* S, int B, int C, int Cp, int L, int M, void* stream);
+
+/* ---- pointwise blocks -----------------------------------------------------------
+ * All operate on NCHW planes: x[(b*channels + c)][hw], dtype f32 | bf16, fp32 arithmetic.
+ * `ws` is a caller-provided scratch of >= planes * mk_pointwise_chunks(hw, dtype) * 2 floats.
+ *
+ * Instance norm = nn.InstanceNorm2d(C, eps, affine=True) at makani/models/networks/sfnonet.py:618-620
+ * (statistics in fp32 as in makani/mpu/layer_norm.py:147-168); optional fused exact-erf GELU
+ * (nn.GELU, sfnonet.py:392-393).  stats: (planes, 2) f32 = {mean, rstd}.
+ * Backward: sums (planes, 2) f32 = {sum ga, sum ga * xhat} (dbeta / dgamma per plane),
+ * gx = rstd*gamma*(ga - mean(ga) - xhat*mean(ga*xhat)), ga = gy * (gelu'(a) if fused).       */
+int mk_pointwise_chunks(long long hw, int dtype);
+int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long long planes, long long hw, float eps,
+                      void* stream);
+int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma, const float* beta,
+                      long long planes, int channels, long long hw, int fuse_gelu, void* stream);
+int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
+                    const float* beta, float* sums, float* ws, long long planes, int channels, long long hw,
+                    int fuse_gelu, void* stream);
+/* y = gelu(x + bias[c])  — the bias+activation of the 1x1 convolutions in MLP / EncoderDecoder
+ * (makani/models/common/layers.py:603-643,768-823).  bias may be NULL (plain GELU).
+ * Backward: gx = gy * gelu'(x + bias[c]); optional sums (planes,2): sums[p][0] = sum gx (bias grad). */
+int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int dtype, long long planes, int channels,
+                     long long hw, void* stream);
+int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy, void* gx, float* sums, float* ws, int dtype,
+                     long long planes, int channels, long long hw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAKANI_AMD_H */

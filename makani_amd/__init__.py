@@ -1,0 +1,10 @@
+"""makani_amd — MI355X-native SFNO / spherical-harmonic-transform hot path behind
+makani's nn.Module plug-in API.  HIP kernels live in ``csrc/`` behind the C ABI of
+``include/makani_amd.h``; this package is the host-side mirror of the reference interface."""
+from .sht import RealSHT, InverseRealSHT
+from .spectral_conv import SpectralConv
+from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv
+from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, SpectralFilterLayer
+
+__all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
+           "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer"]

@@ -1,0 +1,102 @@
+"""ctypes binding of libmakani_amd.so (the C ABI in include/makani_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+tensor is not on a GPU, calls raise.  Build with ``python -m makani_amd.build``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmakani_amd.so")
+
+MK_F32, MK_BF16 = 0, 1
+TRI_NONE, TRI_ROW_GE, TRI_K_GE, TRI_ROW_LE, TRI_K_LE = 0, 1, 2, 3, 4
+
+c_ll, c_int, c_f, c_vp = C.c_longlong, C.c_int, C.c_float, C.c_void_p
+
+
+class MkGemm(C.Structure):
+    _fields_ = [
+        ("A", c_vp), ("B", c_vp), ("C", c_vp),
+        ("a_batch", c_ll), ("a_row", c_ll), ("a_k", c_ll),
+        ("b_batch", c_ll), ("b_col", c_ll), ("b_k", c_ll),
+        ("c_batch", c_ll), ("c_row", c_ll), ("c_col", c_ll),
+        ("a_inner", c_ll), ("b_inner", c_ll), ("c_inner", c_ll),
+        ("a_im", c_ll), ("b_im", c_ll), ("c_im", c_ll),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int),
+        ("inner", c_int), ("tri_mode", c_int),
+        ("conj_a", c_int), ("conj_b", c_int), ("beta", c_int),
+    ]
+
+
+_SIGS = {
+    "mk_version": ([], c_int),
+    "mk_sgemm_batched": ([C.POINTER(MkGemm), c_vp], c_int),
+    "mk_cgemm_batched": ([C.POINTER(MkGemm), c_vp], c_int),
+    "mk_rfft_rows": ([c_vp, c_int, c_vp, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                      c_int, c_f, c_f, c_f, c_vp], c_int),
+    "mk_irfft_rows": ([c_vp, c_vp, c_int, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                       c_int, c_f, c_f, c_f, c_vp], c_int),
+    "mk_weight_to_wlayout": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_wlayout_to_weight_grad": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_slayout_to_complex": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_complex_to_slayout": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_pointwise_chunks": ([c_ll, c_int], c_int),
+    "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp], c_int),
+    "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
+    "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
+    "mk_bias_gelu_fwd": ([c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
+    "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
+}
+
+EXPORTS = sorted(list(_SIGS) + ["mk_last_error"])
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+                "(run `python -m makani_amd.build`).  There is no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        L.mk_last_error.argtypes = []
+        L.mk_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mk_last_error().decode()
+        raise RuntimeError(f"libmakani_amd {what} failed (code {rc}): {msg}")
+
+
+def stream():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return c_vp(0)
+    if not t.is_cuda:
+        raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+    return c_vp(t.data_ptr())
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return MK_F32
+    if t.dtype == torch.bfloat16:
+        return MK_BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")

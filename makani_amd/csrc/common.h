@@ -1,0 +1,62 @@
+// Shared device/host helpers for libmakani_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/makani_amd.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define MK_NUM_XCD 8
+
+// ---- error plumbing -----------------------------------------------------------
+void mk_set_error(const char* fmt, ...);
+
+#define MK_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            mk_set_error(__VA_ARGS__); \
+            return MK_EINVAL;          \
+        }                              \
+    } while (0)
+
+static inline int mk_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mk_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ---- bf16 <-> f32 (round-to-nearest-even, matches torch's .to(bfloat16)) -------
+__device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ u16 f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+
+// XCD-aware remap of a 1-D block id: consecutive ids handed to one XCD (blocks b, b+8, b+16 ...
+// run on XCD b%8 — speed only, never correctness).  Bijective for any n (guide §5 "XCD swizzle").
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk / MK_NUM_XCD, r = nblk % MK_NUM_XCD;
+    const int xcd = bid % MK_NUM_XCD, j = bid / MK_NUM_XCD;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + j;
+}
+
+// exact-erf GELU and its derivative (nn.GELU default, approximate='none')
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

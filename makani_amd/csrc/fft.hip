@@ -1,0 +1,404 @@
+// Longitude real FFTs of the spherical harmonic transform (gfx950).
+//
+//   mk_rfft_rows : x[row][lat][lon] (f32|bf16) -> F[m][ri][row][lat]  (truncated to mmax modes, weighted)
+//   mk_irfft_rows: F[m][ri][row][lat]          -> x[row][lat][lon]    (zero-padded beyond mmax, weighted)
+//
+// HBM-bound kernels.  One workgroup transforms RB consecutive latitudes of one (batch, channel)
+// plane: rows are read/written as full contiguous lines (16 B / lane), the spectrum side is
+// written in lat-major F-layout so the Legendre GEMM (batched over m, contracting lat) streams it
+// with unit stride.  A real length-N transform runs as a complex length-N/2 Stockham autosort FFT
+// in LDS (mixed radix 2/3/4/5 + generic small primes, twiddles from a host-fp64 table), followed
+// by the Hermitian untangling step; truncation to mmax modes / zero padding happen in that step,
+// so only the modes the SHT keeps ever touch HBM.  Work items are handed to XCDs in contiguous
+// ranges (xcd_remap) so that lat-adjacent workgroups share an L2 and their RB-float runs of the
+// F-layout merge into full lines before write-back.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr int MAX_RADIX_PASSES = 16;
+constexpr int MAX_GENERIC_RADIX = 32;
+
+struct RadixList {
+    int n;
+    int r[MAX_RADIX_PASSES];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+// forward DFT_R (sign -1) in registers
+template <int R>
+__device__ __forceinline__ void dft_small(float2* v);
+
+template <>
+__device__ __forceinline__ void dft_small<2>(float2* v) {
+    const float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+template <>
+__device__ __forceinline__ void dft_small<3>(float2* v) {
+    const float c = 0.86602540378443865f;
+    const float2 s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const float2 m = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
+    const float2 q = make_float2(c * d.y, -c * d.x);
+    v[0] = cadd(v[0], s);
+    v[1] = cadd(m, q);
+    v[2] = csub(m, q);
+}
+template <>
+__device__ __forceinline__ void dft_small<4>(float2* v) {
+    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    const float2 t2 = cadd(v[1], v[3]), t3 = mul_neg_i(csub(v[1], v[3]));
+    v[0] = cadd(t0, t2);
+    v[1] = cadd(t1, t3);
+    v[2] = csub(t0, t2);
+    v[3] = csub(t1, t3);
+}
+template <>
+__device__ __forceinline__ void dft_small<5>(float2* v) {
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]);
+    const float2 b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+    const float2 p1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    const float2 p2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    const float2 q1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const float2 q2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    const float2 iq1 = mul_neg_i(q1), iq2 = mul_neg_i(q2);
+    v[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+    v[1] = cadd(p1, iq1);
+    v[4] = csub(p1, iq1);
+    v[2] = cadd(p2, iq2);
+    v[3] = csub(p2, iq2);
+}
+
+// One Stockham pass (decimation in time) of radix R over RB rows of length n2 held in LDS.
+//   src/dst: [RB][LS] float2;  tw: exp(-2 pi i q / N), N = 2*n2;  Ns = product of earlier radices.
+template <int R>
+__device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, float2* __restrict__ dst,
+                                              const float2* __restrict__ tw, int RB, int LS, int n2, int N, int Ns,
+                                              int tid) {
+    const int nb = n2 / R;               // butterflies per row
+    const int tstep = N / (Ns * R);      // twiddle index step
+    for (int idx = tid; idx < RB * nb; idx += NT) {
+        const int row = idx / nb, j = idx - row * nb;
+        const int k = j % Ns;
+        const float2* s = src + row * LS;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = s[j + r * nb];
+        if (Ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[k * r * tstep]);
+        }
+        dft_small<R>(v);
+        const int j0 = (j - k) * R + k;
+        float2* d = dst + row * LS + j0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) d[r * Ns] = v[r];
+    }
+}
+
+// generic radix (small odd primes > 5): O(R^2) with table twiddles
+__device__ __noinline__ void stockham_pass_generic(const float2* __restrict__ src, float2* __restrict__ dst,
+                                                   const float2* __restrict__ tw, int R, int RB, int LS, int n2,
+                                                   int N, int Ns, int tid) {
+    const int nb = n2 / R;
+    const int tstep = N / (Ns * R);
+    const int rstep = N / R;
+    for (int idx = tid; idx < RB * nb; idx += NT) {
+        const int row = idx / nb, j = idx - row * nb;
+        const int k = j % Ns;
+        const float2* s = src + row * LS;
+        const int j0 = (j - k) * R + k;
+        float2* d = dst + row * LS + j0;
+        for (int o = 0; o < R; ++o) {
+            float2 acc = make_float2(0.f, 0.f);
+            for (int r = 0; r < R; ++r) {
+                float2 x = s[j + r * nb];
+                x = cmul(x, tw[k * r * tstep]);
+                x = cmul(x, tw[((r * o) % R) * rstep]);
+                acc = cadd(acc, x);
+            }
+            d[o * Ns] = acc;
+        }
+    }
+}
+
+// runs all passes; returns pointer to the buffer holding the result
+__device__ __forceinline__ float2* run_passes(float2* a, float2* b, const float2* tw, const RadixList& rl, int RB,
+                                              int LS, int n2, int N, int tid) {
+    float2* src = a;
+    float2* dst = b;
+    int Ns = 1;
+    for (int p = 0; p < rl.n; ++p) {
+        const int R = rl.r[p];
+        switch (R) {
+            case 2: stockham_pass<2>(src, dst, tw, RB, LS, n2, N, Ns, tid); break;
+            case 3: stockham_pass<3>(src, dst, tw, RB, LS, n2, N, Ns, tid); break;
+            case 4: stockham_pass<4>(src, dst, tw, RB, LS, n2, N, Ns, tid); break;
+            case 5: stockham_pass<5>(src, dst, tw, RB, LS, n2, N, Ns, tid); break;
+            default: stockham_pass_generic(src, dst, tw, R, RB, LS, n2, N, Ns, tid); break;
+        }
+        Ns *= R;
+        __syncthreads();
+        float2* t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
+}
+
+template <typename T>
+__device__ __forceinline__ float2 load_pair(const T* p);
+template <>
+__device__ __forceinline__ float2 load_pair<float>(const float* p) {
+    return *reinterpret_cast<const float2*>(p);
+}
+template <>
+__device__ __forceinline__ float2 load_pair<u16>(const u16* p) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+}
+template <typename T>
+__device__ __forceinline__ void store_pair(T* p, float a, float b);
+template <>
+__device__ __forceinline__ void store_pair<float>(float* p, float a, float b) {
+    *reinterpret_cast<float2*>(p) = make_float2(a, b);
+}
+template <>
+__device__ __forceinline__ void store_pair<u16>(u16* p, float a, float b) {
+    *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void rfft_kernel(const T* __restrict__ x, float* __restrict__ F,
+                                                  const float2* __restrict__ tw_g, const RadixList rl, int C, int Cp,
+                                                  long long rows, int nlat, int nlon, int mmax, int kp, int RB, int nkg, float w_dc,
+                                                  float w_pos, float w_nyq) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int N = nlon, n2 = nlon / 2, LS = n2 + 1;
+    float2* bufA = reinterpret_cast<float2*>(smem_raw);
+    float2* bufB = bufA + RB * LS;
+    float2* tw = bufB + RB * LS;
+    const int tid = threadIdx.x;
+
+    const long long item = xcd_remap(blockIdx.x, gridDim.x);
+    const long long bc = item / nkg;
+    const int k0 = (int)(item % nkg) * RB;
+    const int nr = min(RB, nlat - k0);
+    const long long frow = (bc / C) * Cp + (bc % C);   // row of this plane in the F-layout
+
+    for (int q = tid; q < N; q += NT) tw[q] = tw_g[q];
+
+    // load rows: z[j] = x[2j] + i x[2j+1]
+    const T* xr = x + (bc * nlat + k0) * (long long)nlon;
+    for (int idx = tid; idx < RB * n2; idx += NT) {
+        const int row = idx / n2, j = idx - row * n2;
+        float2 z = make_float2(0.f, 0.f);
+        if (row < nr) z = load_pair<T>(xr + (long long)row * nlon + 2 * j);
+        bufA[row * LS + j] = z;
+    }
+    __syncthreads();
+
+    const float2* Z = run_passes(bufA, bufB, tw, rl, RB, LS, n2, N, tid);
+
+    // Hermitian untangle + truncate + weight, write lat-major
+    const long long plane = rows * (long long)kp;   // elements per (m, ri) plane
+    for (int idx = tid; idx < mmax * RB; idx += NT) {
+        const int r = idx % RB, m = idx / RB;
+        if (r >= nr) continue;
+        const int ma = (m == n2) ? 0 : m;
+        const int mb = (m == 0 || m == n2) ? 0 : n2 - m;
+        const float2 A = Z[r * LS + ma];
+        const float2 Bc = cconj(Z[r * LS + mb]);
+        const float2 u = cadd(A, Bc), t = csub(A, Bc);
+        const float2 wt = cmul(tw[m], t);
+        float w = w_pos;
+        float2 X = make_float2(0.5f * (u.x + wt.y), 0.5f * (u.y - wt.x));
+        if (m == 0) {
+            w = w_dc;
+            X.y = 0.f;
+        } else if (m == n2) {
+            w = w_nyq;
+            X.y = 0.f;
+        }
+        float* o = F + (long long)(2 * m) * plane + frow * kp + k0 + r;
+        o[0] = w * X.x;
+        o[plane] = w * X.y;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void irfft_kernel(const float* __restrict__ F, T* __restrict__ x,
+                                                   const float2* __restrict__ tw_g, const RadixList rl, int C, int Cp,
+                                                   long long rows, int nlat, int nlon, int mmax, int kp, int RB, int nkg, float w_dc,
+                                                   float w_pos, float w_nyq) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int N = nlon, n2 = nlon / 2, LS = n2 + 1;
+    float2* bufA = reinterpret_cast<float2*>(smem_raw);
+    float2* bufB = bufA + RB * LS;
+    float2* tw = bufB + RB * LS;
+    const int tid = threadIdx.x;
+
+    const long long item = xcd_remap(blockIdx.x, gridDim.x);
+    const long long bc = item / nkg;
+    const int k0 = (int)(item % nkg) * RB;
+    const int nr = min(RB, nlat - k0);
+    const long long frow = (bc / C) * Cp + (bc % C);   // row of this plane in the F-layout
+
+    for (int q = tid; q < N; q += NT) tw[q] = tw_g[q];
+
+    // stage the weighted half spectrum X'[m], m = 0..n2 (zero beyond mmax) into bufB[r][m]
+    const long long plane = rows * (long long)kp;
+    for (int idx = tid; idx < (n2 + 1) * RB; idx += NT) {
+        const int r = idx % RB, m = idx / RB;
+        float2 X = make_float2(0.f, 0.f);
+        if (m < mmax && r < nr) {
+            const float* s = F + (long long)(2 * m) * plane + frow * kp + k0 + r;
+            X = make_float2(s[0], s[plane]);
+            if (m == 0) {
+                X = make_float2(w_dc * X.x, 0.f);
+            } else if (m == n2) {
+                X = make_float2(w_nyq * X.x, 0.f);
+            } else {
+                X = make_float2(0.5f * w_pos * X.x, 0.5f * w_pos * X.y);
+            }
+        }
+        bufB[r * LS + m] = X;
+    }
+    __syncthreads();
+
+    // Zs[j] = (A + Bc) + i conj(W^j) (A - Bc),  A = X'[j], Bc = conj(X'[n2-j]); store conj(Zs)
+    for (int idx = tid; idx < RB * n2; idx += NT) {
+        const int row = idx / n2, j = idx - row * n2;
+        const float2 A = bufB[row * LS + j];
+        const float2 Bc = cconj(bufB[row * LS + n2 - j]);
+        const float2 u = cadd(A, Bc), t = csub(A, Bc);
+        const float2 wt = cmul(cconj(tw[j]), t);           // W^{-j} (A - Bc)
+        const float2 Zs = make_float2(u.x - wt.y, u.y + wt.x);   // u + i*wt
+        bufA[row * LS + j] = cconj(Zs);
+    }
+    __syncthreads();
+
+    const float2* Z = run_passes(bufA, bufB, tw, rl, RB, LS, n2, N, tid);
+
+    // x[2j] + i x[2j+1] = conj(FFT(conj(Zs)))
+    T* xr = x + (bc * nlat + k0) * (long long)nlon;
+    for (int idx = tid; idx < RB * n2; idx += NT) {
+        const int row = idx / n2, j = idx - row * n2;
+        if (row >= nr) continue;
+        const float2 z = Z[row * LS + j];
+        store_pair<T>(xr + (long long)row * nlon + 2 * j, z.x, -z.y);
+    }
+}
+
+int plan(int nlon, const int* radix, int nradix, RadixList* rl, int* RB, size_t* lds) {
+    MK_REQUIRE(nlon >= 4 && (nlon % 2) == 0, "fft: nlon=%d must be even and >= 4", nlon);
+    MK_REQUIRE(radix && nradix >= 1 && nradix <= MAX_RADIX_PASSES, "fft: bad radix list");
+    const int n2 = nlon / 2;
+    long long prod = 1;
+    rl->n = nradix;
+    for (int i = 0; i < nradix; ++i) {
+        MK_REQUIRE(radix[i] >= 2 && radix[i] < MAX_GENERIC_RADIX, "fft: unsupported radix %d", radix[i]);
+        rl->r[i] = radix[i];
+        prod *= radix[i];
+    }
+    MK_REQUIRE(prod == n2, "fft: radix product %lld != nlon/2 = %d", prod, n2);
+    const size_t LS = n2 + 1;
+    const size_t budget = 104 * 1024;
+    const size_t twb = (size_t)nlon * 8;
+    if (twb + 2 * LS * 8 > budget) {
+        mk_set_error("fft: nlon=%d does not fit the LDS plan", nlon);
+        return MK_EUNSUP;
+    }
+    int rb = 16;
+    while (rb > 1 && twb + 2 * (size_t)rb * LS * 8 > budget) rb >>= 1;
+    *RB = rb;
+    *lds = twb + 2 * (size_t)rb * LS * 8;
+    return 0;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) {
+        mk_set_error("fft: hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* twiddle, const int* radix, int nradix,
+                            int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos,
+                            float w_nyq, void* stream) {
+    MK_REQUIRE(x && F && twiddle, "rfft: null pointer");
+    MK_REQUIRE(B > 0 && C > 0 && Cp >= C && nlat > 0 && kp >= nlat, "rfft: bad shape B=%d C=%d Cp=%d nlat=%d kp=%d", B, C, Cp, nlat, kp);
+    const long long rows = (long long)B * Cp;      // rows of the F-layout
+    const long long planes = (long long)B * C;     // planes of x
+    MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "rfft: mmax=%d out of range for nlon=%d", mmax, nlon);
+    RadixList rl;
+    int RB;
+    size_t lds;
+    int rc = plan(nlon, radix, nradix, &rl, &RB, &lds);
+    if (rc) return rc;
+    const int nkg = (nlat + RB - 1) / RB;
+    const long long nblk = planes * nkg;
+    MK_REQUIRE(nblk < (1ll << 31), "rfft: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    const float2* tw = reinterpret_cast<const float2*>(twiddle);
+    if (x_dtype == MK_F32) {
+        if ((rc = set_lds(rfft_kernel<float>, lds))) return rc;
+        hipLaunchKernelGGL(rfft_kernel<float>, dim3((unsigned)nblk), dim3(NT), lds, s, (const float*)x, F, tw, rl, C, Cp, rows,
+                           nlat, nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+    } else if (x_dtype == MK_BF16) {
+        if ((rc = set_lds(rfft_kernel<u16>, lds))) return rc;
+        hipLaunchKernelGGL(rfft_kernel<u16>, dim3((unsigned)nblk), dim3(NT), lds, s, (const u16*)x, F, tw, rl, C, Cp, rows,
+                           nlat, nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+    } else {
+        MK_REQUIRE(false, "rfft: bad dtype %d", x_dtype);
+    }
+    return mk_check_launch("mk_rfft_rows");
+}
+
+extern "C" int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* twiddle, const int* radix, int nradix,
+                             int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos,
+                             float w_nyq, void* stream) {
+    MK_REQUIRE(x && F && twiddle, "irfft: null pointer");
+    MK_REQUIRE(B > 0 && C > 0 && Cp >= C && nlat > 0 && kp >= nlat, "irfft: bad shape B=%d C=%d Cp=%d nlat=%d kp=%d", B, C, Cp, nlat, kp);
+    const long long rows = (long long)B * Cp;
+    const long long planes = (long long)B * C;
+    MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "irfft: mmax=%d out of range for nlon=%d", mmax, nlon);
+    RadixList rl;
+    int RB;
+    size_t lds;
+    int rc = plan(nlon, radix, nradix, &rl, &RB, &lds);
+    if (rc) return rc;
+    const int nkg = (nlat + RB - 1) / RB;
+    const long long nblk = planes * nkg;
+    MK_REQUIRE(nblk < (1ll << 31), "irfft: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    const float2* tw = reinterpret_cast<const float2*>(twiddle);
+    if (x_dtype == MK_F32) {
+        if ((rc = set_lds(irfft_kernel<float>, lds))) return rc;
+        hipLaunchKernelGGL(irfft_kernel<float>, dim3((unsigned)nblk), dim3(NT), lds, s, F, (float*)x, tw, rl, C, Cp, rows, nlat,
+                           nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+    } else if (x_dtype == MK_BF16) {
+        if ((rc = set_lds(irfft_kernel<u16>, lds))) return rc;
+        hipLaunchKernelGGL(irfft_kernel<u16>, dim3((unsigned)nblk), dim3(NT), lds, s, F, (u16*)x, tw, rl, C, Cp, rows, nlat,
+                           nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+    } else {
+        MK_REQUIRE(false, "irfft: bad dtype %d", x_dtype);
+    }
+    return mk_check_launch("mk_irfft_rows");
+}

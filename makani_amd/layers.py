@@ -1,0 +1,173 @@
+"""Pointwise blocks of the SFNO (boundary rows a8-a11 of SURVEY.md §8a).
+
+State-dict layout and initialisation follow
+``makani/models/common/layers.py:537-661`` (EncoderDecoder) and ``:664-894`` (MLP):
+``<name>.fwd.<idx>.weight`` of shape ``(Cout, Cin, 1, 1)``.
+
+Instance norm, bias+GELU and the norm+GELU fusion are HIP kernels.  The channel
+GEMMs (1x1 convolutions) are issued as plain library GEMMs (hipBLASLt through
+``torch.matmul`` / ``torch.baddbmm``) on the NCHW planes — see DESIGN.md §5 for
+why that is the round-1 choice and what replaces it.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class PointwiseConv(nn.Module):
+    """1x1 convolution on NCHW: ``y[b] = W @ x[b]`` with ``x[b]`` viewed as (Cin, H*W).
+    Parameter names/shapes of ``nn.Conv2d(cin, cout, 1)``."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def matmul(self, x, add_to=None):
+        """bias-free product; ``add_to`` (same shape as the result) is fused as the GEMM's C input."""
+        B, C, H, W = x.shape
+        if C != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {C}")
+        w = self.weight.view(self.out_channels, self.in_channels)
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            w, x = w.to(dt), x.to(dt)
+            add_to = add_to.to(dt) if add_to is not None else None
+        elif w.dtype != x.dtype:
+            w = w.to(x.dtype)
+        x3 = x.reshape(B, C, H * W)
+        with torch.autocast(device_type="cuda", enabled=False):
+            if B == 1:      # one plain GEMM (Cout x Cin) @ (Cin x HW), HW contiguous
+                if add_to is None:
+                    y = torch.mm(w, x3[0])
+                else:
+                    y = torch.addmm(add_to.reshape(self.out_channels, H * W), w, x3[0])
+            else:
+                wb = w.unsqueeze(0).expand(B, -1, -1)
+                if add_to is None:
+                    y = torch.bmm(wb, x3)
+                else:
+                    y = torch.baddbmm(add_to.reshape(B, self.out_channels, H * W), wb, x3)
+        return y.view(B, self.out_channels, H, W)
+
+    def forward(self, x, add_to=None):
+        y = self.matmul(x, add_to)
+        if self.bias is not None:
+            y = y + self.bias.to(y.dtype).view(1, -1, 1, 1)
+        return y
+
+
+class _Act(nn.Module):
+    """placeholder keeping the reference's Sequential indices; GELU is fused into the previous op."""
+
+    def __init__(self, act_layer):
+        super().__init__()
+        self.is_gelu = act_layer is nn.GELU
+        self.act = None if self.is_gelu else act_layer()
+
+    def forward(self, x):
+        return ops.BiasGeluFn.apply(x, None) if self.is_gelu else self.act(x)
+
+
+def _conv_act(conv: PointwiseConv, act: _Act, x):
+    """act(conv(x) + bias) with bias+GELU fused in one HIP pass."""
+    if act.is_gelu:
+        return ops.BiasGeluFn.apply(conv.matmul(x), conv.bias)
+    return act.act(conv(x))
+
+
+class MLP(nn.Module):
+    """``makani/models/common/layers.py:664-894`` for ``input_format="nchw"``, no dropout."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, output_bias=True,
+                 input_format="nchw", drop_rate=0.0, drop_type="iid", checkpointing=False, gain=1.0, use_te=False,
+                 **kwargs):
+        super().__init__()
+        if input_format != "nchw":
+            raise NotImplementedError("the HIP MLP implements input_format='nchw'")
+        if drop_rate > 0.0:
+            raise NotImplementedError("dropout inside the MLP is not part of the accelerated path (drop_rate must be 0)")
+        self.checkpointing = checkpointing
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        fc1 = PointwiseConv(in_features, hidden_features, bias=True)
+        fc2 = PointwiseConv(hidden_features, out_features, bias=output_bias)
+        for p in (fc1.weight, fc1.bias, fc2.weight, fc2.bias):
+            if p is not None:
+                p.is_shared_mp = ["spatial"]
+        nn.init.normal_(fc1.weight, mean=0.0, std=math.sqrt(2.0 / in_features))
+        nn.init.constant_(fc1.bias, 0.0)
+        nn.init.normal_(fc2.weight, mean=0.0, std=math.sqrt(gain / hidden_features))
+        if fc2.bias is not None:
+            nn.init.constant_(fc2.bias, 0.0)
+        self.fwd = nn.Sequential(fc1, _Act(act_layer), nn.Identity(), fc2, nn.Identity())
+
+    def _run(self, x):
+        h = _conv_act(self.fwd[0], self.fwd[1], x)
+        return self.fwd[3](h)
+
+    def forward(self, x):
+        if self.checkpointing and torch.is_grad_enabled():
+            return torch.utils.checkpoint.checkpoint(self._run, x, use_reentrant=False)
+        return self._run(x)
+
+
+class EncoderDecoder(nn.Module):
+    """``makani/models/common/layers.py:537-661`` for ``input_format="nchw"``, groups=1."""
+
+    def __init__(self, num_layers, input_dim, output_dim, hidden_dim, act_layer, gain=1.0, input_format="nchw", groups=1):
+        super().__init__()
+        if input_format != "nchw" or groups != 1:
+            raise NotImplementedError("the HIP EncoderDecoder implements input_format='nchw', groups=1")
+        mods, cur = [], input_dim
+        for _ in range(num_layers):
+            c = PointwiseConv(cur, hidden_dim, bias=True)
+            c.weight.is_shared_mp = ["spatial"]
+            c.bias.is_shared_mp = ["spatial"]
+            nn.init.normal_(c.weight, mean=0.0, std=math.sqrt(2.0 / cur))
+            nn.init.constant_(c.bias, 0.0)
+            mods += [c, _Act(act_layer)]
+            cur = hidden_dim
+        c = PointwiseConv(cur, output_dim, bias=False)
+        c.weight.is_shared_mp = ["spatial"]
+        nn.init.normal_(c.weight, mean=0.0, std=math.sqrt(gain / cur))
+        mods.append(c)
+        self.fwd = nn.Sequential(*mods)
+
+    def forward(self, x):
+        mods = list(self.fwd)
+        i = 0
+        while i < len(mods) - 1:
+            x = _conv_act(mods[i], mods[i + 1], x)
+            i += 2
+        return mods[-1](x)
+
+
+class InstanceNorm2d(nn.Module):
+    """``nn.InstanceNorm2d(num_features, eps, affine, track_running_stats=False)``
+    (``makani/models/networks/sfnonet.py:618-620``); ``forward(x, fuse_gelu=True)`` applies an exact
+    GELU in the same pass (the block's ``act_layer0``, ``sfnonet.py:387-393``)."""
+
+    def __init__(self, num_features, eps=1e-5, affine=False, track_running_stats=False):
+        super().__init__()
+        if track_running_stats:
+            raise NotImplementedError("running statistics are not used by the SFNO and are not implemented")
+        self.num_features, self.eps, self.affine = num_features, eps, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+            self.weight.is_shared_mp = ["spatial"]
+            self.bias.is_shared_mp = ["spatial"]
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+    def forward(self, x, fuse_gelu=False):
+        if x.dim() != 4 or x.shape[1] != self.num_features:
+            raise ValueError(f"expected (B, {self.num_features}, H, W), got {tuple(x.shape)}")
+        return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu)

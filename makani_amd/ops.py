@@ -1,0 +1,445 @@
+"""Host-side launchers and autograd Functions over the internal spectral layouts.
+
+Layouts (all fp32, see include/makani_amd.h):
+  F-layout  (M, 2, R, Kp)   longitude spectrum, latitude contiguous     R = B * Cp
+  S-layout  (L, M, 2, R)    spherical harmonic coefficients, channel contiguous
+  W-layout  (L, 2, Cip, Cop) dhconv weights
+Entries of an S tensor with l < m are NEVER read by any kernel (P_l^m = 0 there) and may hold
+garbage; only the conversion to complex64 at the API boundary materialises them as zeros.
+
+Everything here launches on ``torch.cuda.current_stream()`` through the C ABI — there is no
+CPU implementation behind these functions.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MkGemm, check, dtype_code, lib, ptr, stream
+from . import legendre as _leg
+
+
+def round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+# --------------------------------------------------------------------------- #
+# optional per-launch timing (used by bench.py): HIP events on the launch stream
+# --------------------------------------------------------------------------- #
+class LaunchProfiler:
+    """Records one (start, end) HIP-event pair per C-ABI launch on the stream the kernel is
+    launched on (torch's current stream) together with its algorithmic work."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (name, start_event, end_event, flops, bytes)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        """name -> dict(launches, ms_total, ms_avg, flops, bytes); call after a device synchronize."""
+        out = {}
+        for name, e0, e1, fl, by in self.records:
+            d = out.setdefault(name, dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms_total"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        for d in out.values():
+            d["ms_avg"] = d["ms_total"] / d["launches"]
+        return out
+
+
+PROFILER = LaunchProfiler()
+
+
+class _timed:
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if PROFILER.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILER.enabled:
+            self.e1.record()
+            PROFILER.records.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+        return False
+
+
+# --------------------------------------------------------------------------- #
+# FFT plans
+# --------------------------------------------------------------------------- #
+@dataclass
+class FftPlan:
+    nlon: int
+    radix: object          # ctypes int array
+    nradix: int
+    twiddle: torch.Tensor  # (nlon, 2) float32 on the device
+
+
+_PLANS = {}
+
+
+def fft_plan(nlon: int, device) -> FftPlan:
+    key = (nlon, str(device))
+    p = _PLANS.get(key)
+    if p is None:
+        radix = _leg.factorize_half(nlon)
+        arr = (C.c_int * len(radix))(*radix)
+        tw = torch.from_numpy(_leg.twiddle_table(nlon)).to(device)
+        p = FftPlan(nlon, arr, len(radix), tw)
+        _PLANS[key] = p
+    return p
+
+
+def rfft_rows(x: torch.Tensor, mmax: int, Cp: int, w) -> torch.Tensor:
+    """x (B, C, nlat, nlon) f32|bf16 -> F (mmax, 2, B*Cp, Kp);  X_m = w_m sum_n x_n e^{-i m n 2pi/N}."""
+    B, Cc, nlat, nlon = x.shape
+    x = x.contiguous()
+    plan = fft_plan(nlon, x.device)
+    kp = round4(nlat)
+    F = torch.empty((mmax, 2, B * Cp, kp), dtype=torch.float32, device=x.device)
+    nbytes = B * Cc * nlat * (nlon * x.element_size() + mmax * 8)
+    with _timed(f"rfft_{nlon}", nbytes=nbytes):
+        check(lib().mk_rfft_rows(ptr(x), dtype_code(x), ptr(F), ptr(plan.twiddle), plan.radix, plan.nradix, B, Cc, Cp,
+                                 nlat, nlon, mmax, kp, w[0], w[1], w[2], stream()), "mk_rfft_rows")
+    return F
+
+
+def irfft_rows(F: torch.Tensor, B: int, Cc: int, nlat: int, nlon: int, out_dtype, w) -> torch.Tensor:
+    """F (mmax, 2, B*Cp, Kp) -> x (B, C, nlat, nlon);  x_n = sum_m w_m (Re X_m cos - Im X_m sin)."""
+    mmax, _, R, kp = F.shape
+    Cp = R // B
+    plan = fft_plan(nlon, F.device)
+    x = torch.empty((B, Cc, nlat, nlon), dtype=out_dtype, device=F.device)
+    nbytes = B * Cc * nlat * (nlon * x.element_size() + mmax * 8)
+    with _timed(f"irfft_{nlon}", nbytes=nbytes):
+        check(lib().mk_irfft_rows(ptr(F), ptr(x), dtype_code(x), ptr(plan.twiddle), plan.radix, plan.nradix, B, Cc,
+                                  Cp, nlat, nlon, mmax, kp, w[0], w[1], w[2], stream()), "mk_irfft_rows")
+    return x
+
+
+# --------------------------------------------------------------------------- #
+# Legendre GEMMs (real, batched over m)
+# --------------------------------------------------------------------------- #
+def _gemm(**kw) -> MkGemm:
+    g = MkGemm()
+    for f, _ in MkGemm._fields_:
+        setattr(g, f, 0)
+    g.inner = 1
+    g.c_col = 1
+    for k, v in kw.items():
+        setattr(g, k, v)
+    return g
+
+
+def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int) -> torch.Tensor:
+    """S[l][m][ri][row] = sum_k mat[m][l][k] F[m][ri][row][k]      (rows l >= m only)."""
+    M, _, R, kp = F.shape
+    Mm, L, kpm = mat.shape
+    assert Mm == M and kpm == kp and F.is_contiguous() and mat.is_contiguous()
+    S = torch.empty((L, M, 2, R), dtype=torch.float32, device=F.device)
+    g = _gemm(A=mat.data_ptr(), B=F.data_ptr(), C=S.data_ptr(),
+              a_batch=L * kp, a_row=kp, a_k=1,
+              b_batch=2 * R * kp, b_col=kp, b_k=1,
+              c_batch=2 * R, c_row=M * 2 * R,
+              M=L, N=2 * R, K=nlat, batch=M, tri_mode=_lib.TRI_ROW_GE)
+    # dense-formulation work: 2 * (2R) * nlat * L * M flops
+    with _timed(f"legendre_analysis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
+                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
+        check(lib().mk_sgemm_batched(C.byref(g), stream()), "legendre_analysis")
+    return S
+
+
+def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor) -> torch.Tensor:
+    """F[m][ri][row][k] = sum_{l >= m} S[l][m][ri][row] mat[m][l][k]."""
+    L, M, _, R = S.shape
+    Mm, Lm, kp = mat.shape
+    assert Mm == M and Lm == L and S.is_contiguous() and mat.is_contiguous()
+    F = torch.empty((M, 2, R, kp), dtype=torch.float32, device=S.device)
+    g = _gemm(A=S.data_ptr(), B=mat.data_ptr(), C=F.data_ptr(),
+              a_batch=2 * R, a_row=1, a_k=M * 2 * R,
+              b_batch=L * kp, b_col=1, b_k=kp,
+              c_batch=2 * R * kp, c_row=kp,
+              M=2 * R, N=kp, K=L, batch=M, tri_mode=_lib.TRI_K_GE)
+    with _timed(f"legendre_synthesis_k{kp}", flops=2.0 * 2 * R * kp * L * M,
+                nbytes=4.0 * (2 * R * kp * M + 2 * R * L * M + M * L * kp)):
+        check(lib().mk_sgemm_batched(C.byref(g), stream()), "legendre_synthesis")
+    return F
+
+
+# --------------------------------------------------------------------------- #
+# dhconv (complex, batched over l)
+# --------------------------------------------------------------------------- #
+def weight_to_wlayout(weight: torch.Tensor) -> torch.Tensor:
+    """complex64 (1, Cin, Cout, L) -> W (L, 2, Cip, Cop), zero padded."""
+    G, cin, cout, L = weight.shape
+    assert G == 1 and weight.dtype == torch.complex64
+    cip, cop = round4(cin), round4(cout)
+    wr = torch.view_as_real(weight.contiguous())
+    alloc = torch.zeros if (cip != cin or cop != cout) else torch.empty
+    W = alloc((L, 2, cip, cop), dtype=torch.float32, device=weight.device)
+    check(lib().mk_weight_to_wlayout(ptr(wr), ptr(W), cin, cout, cip, cop, L, stream()), "weight_to_wlayout")
+    return W
+
+
+def wlayout_to_weight_grad(gW: torch.Tensor, cin: int, cout: int) -> torch.Tensor:
+    L, _, cip, cop = gW.shape
+    out = torch.empty((1, cin, cout, L, 2), dtype=torch.float32, device=gW.device)
+    check(lib().mk_wlayout_to_weight_grad(ptr(gW), ptr(out), cin, cout, cip, cop, L, stream()), "wlayout_to_weight_grad")
+    return torch.view_as_complex(out)
+
+
+def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int) -> torch.Tensor:
+    """T[l][m][ri][b][o] = sum_i S[l][m][.][b][i] * W[l][.][i][o]   (complex; rows m <= l only)."""
+    L, M, _, R = S.shape
+    Lw, _, cip, cop = W.shape
+    assert Lw == L and R == B * cip
+    Ro = B * cop
+    T = torch.empty((L, M, 2, Ro), dtype=torch.float32, device=S.device)
+    g = _gemm(A=S.data_ptr(), B=W.data_ptr(), C=T.data_ptr(),
+              a_batch=M * 2 * R, a_inner=cip, a_row=2 * R, a_k=1, a_im=R,
+              b_batch=2 * cip * cop, b_inner=0, b_col=1, b_k=cop, b_im=cip * cop,
+              c_batch=M * 2 * Ro, c_inner=cop, c_row=2 * Ro, c_im=Ro,
+              M=M, N=cop, K=cin, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE)
+    # dense-formulation work: 8 * B * Cin * Cout * L * M flops (complex MAC = 8 real flops)
+    with _timed("dhconv_fwd", flops=8.0 * B * cin * cop * L * M,
+                nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
+        check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_fwd")
+    return T
+
+
+def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int) -> torch.Tensor:
+    """gS[l][m][b][i] = sum_o gT[l][m][b][o] * conj(W[l][i][o])."""
+    L, M, _, Ro = gT.shape
+    _, _, cip, cop = W.shape
+    R = B * cip
+    gS = torch.empty((L, M, 2, R), dtype=torch.float32, device=gT.device)
+    g = _gemm(A=gT.data_ptr(), B=W.data_ptr(), C=gS.data_ptr(),
+              a_batch=M * 2 * Ro, a_inner=cop, a_row=2 * Ro, a_k=1, a_im=Ro,
+              b_batch=2 * cip * cop, b_inner=0, b_col=cop, b_k=1, b_im=cip * cop,
+              c_batch=M * 2 * R, c_inner=cip, c_row=2 * R, c_im=R,
+              M=M, N=cin, K=cout, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, conj_b=1)
+    with _timed("dhconv_dgrad", flops=8.0 * B * cin * cout * L * M,
+                nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
+        check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_dgrad")
+    return gS
+
+
+def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int) -> torch.Tensor:
+    """gW[l][i][o] = sum_{b, m <= l} conj(S[l][m][b][i]) * gT[l][m][b][o]."""
+    L, M, _, R = S.shape
+    Ro = gT.shape[-1]
+    cip, cop = R // B, Ro // B
+    gW = torch.empty((L, 2, cip, cop), dtype=torch.float32, device=S.device)
+    for b in range(B):
+        g = _gemm(A=S.data_ptr() + 4 * b * cip, B=gT.data_ptr() + 4 * b * cop, C=gW.data_ptr(),
+                  a_batch=M * 2 * R, a_row=1, a_k=2 * R, a_im=R,
+                  b_batch=M * 2 * Ro, b_col=1, b_k=2 * Ro, b_im=Ro,
+                  c_batch=2 * cip * cop, c_row=cop, c_im=cip * cop,
+                  M=cip, N=cop, K=M, batch=L, inner=1, tri_mode=_lib.TRI_K_LE, conj_a=1, beta=1 if b > 0 else 0)
+        with _timed("dhconv_wgrad", flops=8.0 * cip * cop * L * M,
+                    nbytes=4.0 * (2 * cip * L * M + 2 * cop * L * M + 2 * cip * cop * L)):
+            check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_wgrad")
+    return gW
+
+
+# --------------------------------------------------------------------------- #
+# API-boundary layout changes
+# --------------------------------------------------------------------------- #
+def s_to_complex(S: torch.Tensor, B: int, Cc: int) -> torch.Tensor:
+    L, M, _, R = S.shape
+    out = torch.empty((B, Cc, L, M, 2), dtype=torch.float32, device=S.device)
+    check(lib().mk_slayout_to_complex(ptr(S), ptr(out), B, Cc, R // B, L, M, stream()), "slayout_to_complex")
+    return torch.view_as_complex(out)
+
+
+def complex_to_s(c: torch.Tensor) -> torch.Tensor:
+    B, Cc, L, M = c.shape
+    Cp = round4(Cc)
+    cr = torch.view_as_real(c.contiguous())
+    S = torch.empty((L, M, 2, B * Cp), dtype=torch.float32, device=c.device)
+    check(lib().mk_complex_to_slayout(ptr(cr), ptr(S), B, Cc, Cp, L, M, stream()), "complex_to_slayout")
+    return S
+
+
+# --------------------------------------------------------------------------- #
+# autograd Functions (linear maps with constant matrices: nothing is saved but the matrix)
+# --------------------------------------------------------------------------- #
+class RfftFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mmax, Cp, w):
+        ctx.meta = (x.shape, x.dtype, w)
+        return rfft_rows(x, mmax, Cp, w)
+
+    @staticmethod
+    def backward(ctx, gF):
+        (B, Cc, nlat, nlon), dt, w = ctx.meta
+        return irfft_rows(gF.contiguous(), B, Cc, nlat, nlon, dt, w), None, None, None
+
+
+class IrfftFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, F, B, Cc, nlat, nlon, out_dtype, w):
+        ctx.meta = (F.shape[0], F.shape[2] // B, w)
+        return irfft_rows(F, B, Cc, nlat, nlon, out_dtype, w)
+
+    @staticmethod
+    def backward(ctx, gx):
+        mmax, Cp, w = ctx.meta
+        return rfft_rows(gx, mmax, Cp, w), None, None, None, None, None, None
+
+
+class AnalysisFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, F, mat, nlat):
+        ctx.mat = mat
+        return legendre_analysis(F, mat, nlat)
+
+    @staticmethod
+    def backward(ctx, gS):
+        return legendre_synthesis(gS.contiguous(), ctx.mat), None, None
+
+
+class SynthesisFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S, mat, nlat):
+        ctx.mat, ctx.nlat = mat, nlat
+        return legendre_synthesis(S, mat)
+
+    @staticmethod
+    def backward(ctx, gF):
+        return legendre_analysis(gF.contiguous(), ctx.mat, ctx.nlat), None, None
+
+
+class DhconvFn(torch.autograd.Function):
+    """y[b,o,l,m] = sum_i x[b,i,l,m] w[i,o,l] on S-layout tensors
+    (``_contract_lwise``, makani/models/common/contractions.py:23-24)."""
+
+    @staticmethod
+    def forward(ctx, S, weight, B):
+        _, cin, cout, _ = weight.shape
+        W = weight_to_wlayout(weight)
+        ctx.save_for_backward(S, W)
+        ctx.meta = (B, cin, cout)
+        return dhconv_fwd(S, W, B, cin)
+
+    @staticmethod
+    def backward(ctx, gT):
+        S, W = ctx.saved_tensors
+        B, cin, cout = ctx.meta
+        gT = gT.contiguous()
+        gS = dhconv_dgrad(gT, W, B, cin, cout) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = wlayout_to_weight_grad(dhconv_wgrad(S, gT, B), cin, cout)
+        return gS, gw, None
+
+
+class SToComplexFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S, B, Cc):
+        return s_to_complex(S, B, Cc)
+
+    @staticmethod
+    def backward(ctx, gc):
+        return complex_to_s(gc), None, None
+
+
+class ComplexToSFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c):
+        ctx.meta = c.shape[:2]
+        return complex_to_s(c)
+
+    @staticmethod
+    def backward(ctx, gS):
+        B, Cc = ctx.meta
+        return s_to_complex(gS.contiguous(), B, Cc)
+
+
+# --------------------------------------------------------------------------- #
+# pointwise
+# --------------------------------------------------------------------------- #
+def _ws(planes, hw, dtype, device):
+    ch = lib().mk_pointwise_chunks(hw, _lib.MK_BF16 if dtype == torch.bfloat16 else _lib.MK_F32)
+    return torch.empty((planes * ch * 2,), dtype=torch.float32, device=device)
+
+
+class InstanceNormFn(torch.autograd.Function):
+    """nn.InstanceNorm2d(affine) (+ fused exact GELU); fp32 statistics, io in the input dtype."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, fuse_gelu):
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        planes, hw = B * Cc, H * W
+        dt = dtype_code(x)
+        stats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(planes, hw, x.dtype, x.device)
+        g = gamma.float().contiguous() if gamma is not None else None
+        b = beta.float().contiguous() if beta is not None else None
+        check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, stream()), "instnorm_stats")
+        y = torch.empty_like(x)
+        check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(stats), ptr(g), ptr(b), planes, Cc, hw,
+                                      1 if fuse_gelu else 0, stream()), "instnorm_apply")
+        ctx.save_for_backward(x, stats, g, b)
+        ctx.fuse_gelu = fuse_gelu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, g, b = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        planes, hw = B * Cc, H * W
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gx = torch.empty_like(x)
+        sums = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(planes, hw, x.dtype, x.device)
+        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(sums),
+                                    ptr(ws), planes, Cc, hw, 1 if ctx.fuse_gelu else 0, stream()), "instnorm_bwd")
+        s = sums.view(B, Cc, 2).sum(0)
+        dgamma = s[:, 1].contiguous() if g is not None else None
+        dbeta = s[:, 0].contiguous() if b is not None else None
+        return gx, dgamma, dbeta, None, None
+
+
+class BiasGeluFn(torch.autograd.Function):
+    """y = gelu(x + bias[c]) on NCHW (bias may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        bf = bias.float().contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        check(lib().mk_bias_gelu_fwd(ptr(x), ptr(bf), ptr(y), dtype_code(x), B * Cc, Cc, H * W, stream()), "bias_gelu_fwd")
+        ctx.save_for_backward(x, bf)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, bf = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        planes, hw = B * Cc, H * W
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gx = torch.empty_like(x)
+        need_b = bf is not None and ctx.needs_input_grad[1]
+        sums = torch.empty((planes, 2), dtype=torch.float32, device=x.device) if need_b else None
+        ws = _ws(planes, hw, x.dtype, x.device) if need_b else None
+        check(lib().mk_bias_gelu_bwd(ptr(x), ptr(bf), ptr(gy), ptr(gx), ptr(sums), ptr(ws), dtype_code(x), planes, Cc,
+                                     hw, stream()), "bias_gelu_bwd")
+        gb = sums.view(B, Cc, 2)[:, :, 0].sum(0) if need_b else None
+        return gx, gb

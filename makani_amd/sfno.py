@@ -1,0 +1,233 @@
+"""Drop-in SFNO network (boundary B3 of SURVEY.md §8b).
+
+``SphericalFourierNeuralOperatorNet`` takes the constructor arguments of
+``makani/models/networks/sfnonet.py:518-553`` (unknown keyword arguments are
+accepted and ignored, as the reference does at ``:552``), produces the same
+``state_dict`` keys and shapes, and maps ``(B, inp_chans, H, W) -> (B, out_chans, H, W)``.
+It can be named in a makani yaml as ``nettype: "makani_amd/sfno.py:SphericalFourierNeuralOperatorNet"``
+(``makani/models/model_registry.py:189-192``).
+
+Scope: the serial (one GPU per model instance) configuration family of
+BASELINE.json — ``spectral_transform="sht"``, ``filter_type="linear"``,
+``operator_type="dhconv"``, ``normalization_layer in {"instance_norm", "none"}``,
+``pos_embed="none"``, all drop rates 0.  Anything else raises ``NotImplementedError``.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv
+from .sht import InverseRealSHT, RealSHT
+from .spectral_conv import SpectralConv
+
+
+class SpectralFilterLayer(nn.Module):
+    """``sfnonet.py:52-166`` for ``filter_type="linear"``."""
+
+    def __init__(self, forward_transform, inverse_transform, embed_dim, filter_type="linear", operator_type="diagonal",
+                 hidden_size_factor=1, rank=1.0, separable=False, complex_activation="real", spectral_layers=1,
+                 bias=False, drop_rate=0.0, gain=1.0):
+        super().__init__()
+        if filter_type != "linear":
+            raise NotImplementedError("only filter_type='linear' (SpectralConv) is implemented")
+        self.filter = SpectralConv(forward_transform, inverse_transform, embed_dim, embed_dim,
+                                   operator_type=operator_type, separable=separable, bias=bias, gain=gain)
+
+    def forward(self, x):
+        return self.filter(x)
+
+
+class NeuralOperatorBlock(nn.Module):
+    """``sfnonet.py:169-408``: filter -> norm0 -> act -> MLP -> norm1 -> + outer_skip(residual)."""
+
+    def __init__(self, forward_transform, inverse_transform, embed_dim, filter_type="linear", operator_type="diagonal",
+                 mlp_ratio=2.0, mlp_drop_rate=0.0, path_drop_rate=0.0, act_layer=nn.GELU,
+                 norm_layer=(nn.Identity, nn.Identity), rank=1.0, separable=False, inner_skip="linear",
+                 outer_skip=None, use_mlp=False, comm_feature_name="matmul", complex_activation="real",
+                 spectral_layers=1, bias=False, final_activation=False, checkpointing_level=0):
+        super().__init__()
+        if path_drop_rate > 0.0 or mlp_drop_rate > 0.0:
+            raise NotImplementedError("drop rates must be 0 on the accelerated path")
+        self.input_shape_loc = (forward_transform.nlat, forward_transform.nlon)
+        self.output_shape_loc = (inverse_transform.nlat, inverse_transform.nlon)
+
+        self.norm0 = norm_layer[0]()
+        gain_factor = 1.0 if act_layer == nn.Identity else 2.0
+
+        if inner_skip == "linear":
+            self.inner_skip = PointwiseConv(embed_dim, embed_dim, bias=False)
+            gain_factor /= 2.0
+            nn.init.normal_(self.inner_skip.weight, std=math.sqrt(gain_factor / embed_dim))
+        elif inner_skip == "identity":
+            self.inner_skip = nn.Identity()
+            gain_factor /= 2.0
+        elif inner_skip == "none":
+            pass
+        else:
+            raise ValueError(f"Unknown skip connection type {inner_skip}")
+
+        self.filter = SpectralFilterLayer(forward_transform, inverse_transform, embed_dim, filter_type, operator_type,
+                                          hidden_size_factor=mlp_ratio, rank=rank, separable=separable,
+                                          complex_activation=complex_activation, spectral_layers=spectral_layers,
+                                          bias=bias, drop_rate=path_drop_rate, gain=gain_factor)
+        self.act_is_gelu = act_layer is nn.GELU
+        self.act_layer0 = act_layer()
+        self.norm1 = norm_layer[1]()
+
+        gain_factor = 2.0 if (final_activation and act_layer != nn.Identity) else 1.0
+        if outer_skip == "linear":
+            self.outer_skip = PointwiseConv(embed_dim, embed_dim, bias=False)
+            gain_factor /= 2.0
+            nn.init.normal_(self.outer_skip.weight, std=math.sqrt(gain_factor / embed_dim))
+        elif outer_skip == "identity":
+            self.outer_skip = nn.Identity()
+            gain_factor /= 2.0
+        elif outer_skip == "none" or outer_skip is None:
+            pass
+        else:
+            raise ValueError(f"Unknown skip connection type {outer_skip}")
+
+        if use_mlp:
+            self.mlp = MLP(in_features=embed_dim, hidden_features=int(embed_dim * mlp_ratio), act_layer=act_layer,
+                           drop_rate=mlp_drop_rate, drop_type="features", checkpointing=(checkpointing_level >= 2),
+                           gain=gain_factor)
+        self.drop_path = nn.Identity()
+        if final_activation:
+            self.act_layer1 = act_layer()
+
+    def forward(self, x):
+        x, residual = self.filter(x)
+
+        fuse = self.act_is_gelu and isinstance(self.norm0, InstanceNorm2d) and not hasattr(self, "inner_skip")
+        x = self.norm0(x, fuse_gelu=True) if fuse else self.norm0(x)
+        if hasattr(self, "inner_skip"):
+            x = x + self.inner_skip(residual)
+        if not fuse:
+            x = self.act_layer0(x)
+
+        if hasattr(self, "mlp"):
+            x = self.mlp(x)
+        x = self.norm1(x)
+        x = self.drop_path(x)
+
+        if hasattr(self, "outer_skip"):
+            if isinstance(self.outer_skip, PointwiseConv):
+                x = self.outer_skip(residual, add_to=x)        # skip GEMM accumulates into x (beta = 1)
+            else:
+                x = x + self.outer_skip(residual)
+        if hasattr(self, "act_layer1"):
+            x = self.act_layer1(x)
+        return x
+
+
+class SphericalFourierNeuralOperatorNet(nn.Module):
+    """``makani/models/networks/sfnonet.py:411-934`` on the MI355X HIP path."""
+
+    def __init__(self, spectral_transform="sht", model_grid_type="equiangular", sht_grid_type="legendre-gauss",
+                 filter_type="linear", operator_type="dhconv", inp_shape=(721, 1440), out_shape=(721, 1440),
+                 scale_factor=8, inp_chans=2, out_chans=2, embed_dim=32, num_layers=4, use_mlp=True, mlp_ratio=2.0,
+                 encoder_ratio=1, decoder_ratio=1, activation_function="gelu", encoder_layers=1, pos_embed="none",
+                 pos_drop_rate=0.0, path_drop_rate=0.0, mlp_drop_rate=0.0, normalization_layer="instance_norm",
+                 max_modes=None, hard_thresholding_fraction=1.0, big_skip=True, rank=1.0, separable=False,
+                 complex_activation="real", spectral_layers=3, bias=False, checkpointing_level=0, **kwargs):
+        super().__init__()
+        if spectral_transform != "sht":
+            raise NotImplementedError("only spectral_transform='sht' is implemented")
+        if pos_embed not in ("none", "None", None):
+            raise NotImplementedError("pos_embed must be 'none' on the accelerated path")
+        if pos_drop_rate > 0.0 or path_drop_rate > 0.0 or mlp_drop_rate > 0.0:
+            raise NotImplementedError("drop rates must be 0 on the accelerated path")
+
+        self.inp_shape, self.out_shape = tuple(inp_shape), tuple(out_shape)
+        self.inp_chans, self.out_chans, self.embed_dim = inp_chans, out_chans, embed_dim
+        self.big_skip = big_skip
+        self.checkpointing_level = checkpointing_level
+        self.h = int(self.inp_shape[0] // scale_factor)
+        self.w = int(self.inp_shape[1] // scale_factor)
+        self._init_spectral_transforms(model_grid_type, sht_grid_type, hard_thresholding_fraction, max_modes)
+
+        try:
+            act = {"relu": nn.ReLU, "gelu": nn.GELU, "silu": nn.SiLU}[activation_function]
+        except KeyError:
+            raise ValueError(f"Unknown activation function {activation_function}")
+
+        self.encoder = EncoderDecoder(num_layers=encoder_layers, input_dim=inp_chans, output_dim=embed_dim,
+                                      hidden_dim=int(encoder_ratio * embed_dim), act_layer=act, input_format="nchw")
+        self.pos_drop = nn.Identity()
+
+        if normalization_layer == "instance_norm":
+            norm = partial(InstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True, track_running_stats=False)
+        elif normalization_layer == "none":
+            norm = nn.Identity
+        else:
+            raise NotImplementedError(f"Error, normalization {normalization_layer} not implemented.")
+
+        self.blocks = nn.ModuleList([])
+        for i in range(num_layers):
+            first, last = i == 0, i == num_layers - 1
+            self.blocks.append(NeuralOperatorBlock(
+                self.trans_down if first else self.trans,
+                self.itrans_up if last else self.itrans,
+                embed_dim, filter_type=filter_type, operator_type=operator_type, mlp_ratio=mlp_ratio,
+                mlp_drop_rate=mlp_drop_rate, path_drop_rate=0.0, act_layer=act, norm_layer=(norm, norm),
+                inner_skip="none", outer_skip="linear", use_mlp=use_mlp, rank=rank, separable=separable,
+                complex_activation=complex_activation, spectral_layers=spectral_layers, bias=bias,
+                checkpointing_level=checkpointing_level))
+
+        self.decoder = EncoderDecoder(num_layers=encoder_layers, input_dim=embed_dim, output_dim=out_chans,
+                                      hidden_dim=int(decoder_ratio * embed_dim), act_layer=act,
+                                      gain=0.5 if big_skip else 1.0, input_format="nchw")
+        if big_skip:
+            self.residual_transform = PointwiseConv(inp_chans, out_chans, bias=False)
+            self.residual_transform.weight.is_shared_mp = ["spatial"]
+            self.residual_transform.weight.sharded_dims_mp = [None, None, None, None]
+            nn.init.normal_(self.residual_transform.weight, mean=0.0, std=math.sqrt(0.5 / inp_chans))
+
+    def _init_spectral_transforms(self, model_grid_type, sht_grid_type, hard_thresholding_fraction, max_modes):
+        if max_modes is not None:
+            modes_lat, modes_lon = max_modes
+        else:
+            modes_lat = int(self.h * hard_thresholding_fraction)
+            modes_lon = int((self.w // 2 + 1) * hard_thresholding_fraction)
+        self.trans_down = RealSHT(*self.inp_shape, lmax=modes_lat, mmax=modes_lon, grid=model_grid_type).float()
+        self.itrans_up = InverseRealSHT(*self.out_shape, lmax=modes_lat, mmax=modes_lon, grid=model_grid_type).float()
+        self.trans = RealSHT(self.h, self.w, lmax=modes_lat, mmax=modes_lon, grid=sht_grid_type).float()
+        self.itrans = InverseRealSHT(self.h, self.w, lmax=modes_lat, mmax=modes_lon, grid=sht_grid_type).float()
+        self.inp_shape_loc = (self.trans_down.nlat, self.trans_down.nlon)
+        self.out_shape_loc = (self.itrans_up.nlat, self.itrans_up.nlon)
+        self.h_loc, self.w_loc = self.itrans.nlat, self.itrans.nlon
+
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}
+
+    def _forward_features(self, x):
+        for blk in self.blocks:
+            if self.checkpointing_level >= 3 and torch.is_grad_enabled():
+                x = checkpoint(blk, x, use_reentrant=False)
+            else:
+                x = blk(x)
+        return x
+
+    def forward(self, x):
+        if self.big_skip:
+            if self.out_shape != self.inp_shape:
+                B, C = x.shape[:2]
+                residual = self.itrans_up.synthesis(self.trans_down.analysis(x), B, C, out_dtype=x.dtype)
+            else:
+                residual = x
+        if self.checkpointing_level >= 1 and torch.is_grad_enabled():
+            x = checkpoint(self.encoder, x, use_reentrant=False)
+        else:
+            x = self.encoder(x)
+        x = self.pos_drop(x)
+        x = self._forward_features(x)
+        if self.checkpointing_level >= 1 and torch.is_grad_enabled():
+            x = checkpoint(self.decoder, x, use_reentrant=False)
+        else:
+            x = self.decoder(x)
+        if self.big_skip:
+            x = self.residual_transform(residual, add_to=x)
+        return x

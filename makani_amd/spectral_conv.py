@@ -1,0 +1,95 @@
+"""Drop-in ``SpectralConv`` (boundary B2 of SURVEY.md §8b).
+
+Mirrors ``makani/models/common/spectral_convolution.py:116-264``: same
+constructor, same ``weight`` parameter (complex64, ``(G, Cin/G, Cout/G, L)``
+for ``dhconv``) with the ``is_shared_mp`` / ``sharded_dims_mp`` annotations,
+same ``forward(x) -> (y, residual)`` and the same ``ValueError`` conditions.
+
+The arithmetic is one HIP pipeline in fp32 that never leaves the internal layouts:
+  x --rFFT--> F --Legendre--> S --dhconv (complex MFMA GEMM)--> T --Legendre^T--> F' --irFFT--> y
+with the bf16<->fp32 casts of the reference (``:237-239,252-256``) fused into
+the FFT kernels' loads and stores.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .sht import RealSHT, InverseRealSHT
+
+
+class SpectralConv(nn.Module):
+    def __init__(self, forward_transform, inverse_transform, in_channels, out_channels, num_groups=1,
+                 operator_type="dhconv", separable=False, bias=False, gain=1.0):
+        super().__init__()
+        if in_channels % num_groups != 0:
+            raise ValueError(f"in_channels ({in_channels}) must be divisible by num_groups ({num_groups})")
+        if out_channels % num_groups != 0:
+            raise ValueError(f"out_channels ({out_channels}) must be divisible by num_groups ({num_groups})")
+
+        self.forward_transform = forward_transform
+        self.inverse_transform = inverse_transform
+        self.in_channels, self.out_channels, self.num_groups = in_channels, out_channels, num_groups
+        self.modes_lat = inverse_transform.lmax
+        self.modes_lon = inverse_transform.mmax
+        self.scale_residual = (forward_transform.nlat != inverse_transform.nlat) or (
+            forward_transform.nlon != inverse_transform.nlon
+        )
+        if hasattr(forward_transform, "grid"):
+            self.scale_residual = self.scale_residual or (forward_transform.grid != inverse_transform.grid)
+        self.operator_type = operator_type
+        self.separable = separable
+
+        if forward_transform.lmax != self.modes_lat:
+            raise ValueError(f"forward transform lmax ({forward_transform.lmax}) must match modes_lat ({self.modes_lat})")
+        if forward_transform.mmax != self.modes_lon:
+            raise ValueError(f"forward transform mmax ({forward_transform.mmax}) must match modes_lon ({self.modes_lon})")
+        if not isinstance(forward_transform, RealSHT) or not isinstance(inverse_transform, InverseRealSHT):
+            raise TypeError("makani_amd.SpectralConv needs makani_amd RealSHT / InverseRealSHT transforms")
+
+        self.modes_lat_local, self.modes_lon_local = self.modes_lat, self.modes_lon
+        self.nlat_local, self.nlon_local = inverse_transform.nlat, inverse_transform.nlon
+
+        weight_shape = [num_groups, in_channels // num_groups]
+        if not separable:
+            weight_shape += [out_channels // num_groups]
+        if operator_type == "diagonal":
+            weight_shape += [self.modes_lat_local, self.modes_lon_local]
+        elif operator_type == "dhconv":
+            weight_shape += [self.modes_lat_local]
+        else:
+            raise ValueError(f"Unsupported operator type f{operator_type}")
+        if operator_type != "dhconv" or separable or num_groups != 1:
+            raise NotImplementedError(
+                "the HIP contraction implements operator_type='dhconv', separable=False, num_groups=1 "
+                "(the configuration of every BASELINE config)"
+            )
+
+        scale = math.sqrt(gain / (in_channels // num_groups)) * torch.ones(self.modes_lat_local, dtype=torch.complex64)
+        scale[0] *= math.sqrt(2.0)
+        self.weight = nn.Parameter(scale * torch.randn(*weight_shape, dtype=torch.complex64))
+        self.weight.is_shared_mp = ["matmul", "w"]
+        self.weight.sharded_dims_mp = [None for _ in weight_shape]
+        self.weight.sharded_dims_mp[-1] = "h"
+
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(1, out_channels, 1, 1))
+            self.bias.is_shared_mp = ["model"]
+            self.bias.sharded_dims_mp = [None, None, None, None]
+
+    def forward(self, x):
+        if x.dim() != 4:
+            raise ValueError(f"expected (B, C, H, W), got {tuple(x.shape)}")
+        dtype = x.dtype
+        B, C = x.shape[:2]
+        residual = x
+        S = self.forward_transform.analysis(x)                    # fp32 coefficients, bf16 read fused
+        if self.scale_residual:
+            residual = self.inverse_transform.synthesis(S, B, C, out_dtype=dtype)
+        T = ops.DhconvFn.apply(S, self.weight, B)
+        y = self.inverse_transform.synthesis(T, B, self.out_channels, out_dtype=dtype)
+        if hasattr(self, "bias"):
+            y = y + self.bias.to(dtype=y.dtype)
+        return y, residual

@@ -1,0 +1,303 @@
+"""GPU parity tests for the raw HIP kernels, called through the C ABI (ctypes),
+against fp64 CPU references (torch / numpy) on seeded inputs."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# --------------------------------------------------------------------------- #
+# batched GEMM engine
+# --------------------------------------------------------------------------- #
+def _store_operand(x, kc):
+    """x (batch, rows, K) -> storage + (row_stride, k_stride, batch_stride); unit stride along k (kc) or rows."""
+    b, r, k = x.shape
+    if kc:
+        kp = (k + 3) // 4 * 4 + 4
+        t = torch.full((b, r, kp), 3.0)          # finite garbage inside the float4 reach: must be masked by K
+        t[:, :, :k] = x
+        return t, kp, 1, r * kp
+    assert r % 4 == 0
+    t = x.transpose(1, 2).contiguous()           # (b, k, r)
+    return t, 1, r, k * r
+
+
+def _tri_mask(mode, batch, M, K, inner):
+    from makani_amd import _lib
+    rows = torch.ones(batch, M, dtype=torch.bool)
+    ks = torch.ones(batch, K, dtype=torch.bool)
+    t = torch.arange(batch) // inner
+    i = torch.arange(M)[None, :]
+    k = torch.arange(K)[None, :]
+    if mode == _lib.TRI_ROW_GE:
+        pass  # rows i < t are either skipped (tile) or computed; compared only where i >= t
+    if mode == _lib.TRI_ROW_LE:
+        rows = i <= t[:, None]
+    if mode == _lib.TRI_K_GE:
+        ks = k >= t[:, None]
+    if mode == _lib.TRI_K_LE:
+        ks = k <= t[:, None]
+    return rows, ks
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("tri", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K,batch", [(68, 132, 37, 11), (200, 72, 129, 5), (12, 300, 16, 9)])
+def test_sgemm_batched(a_kc, b_kc, tri, M, N, K, batch):
+    from makani_amd import _lib
+    from makani_amd._lib import MkGemm, lib, check
+    torch.manual_seed(M * 1000 + N + tri)
+    A = torch.randn(batch, M, K)
+    B = torch.randn(batch, N, K)
+    rows_ok, k_ok = _tri_mask(tri, batch, M, K, 1)
+    ref = torch.einsum("bik,bjk->bij", A.double() * k_ok[:, None, :], B.double())
+    At, a_row, a_k, a_b = _store_operand(A, a_kc)
+    Bt, b_col, b_k, b_b = _store_operand(B, b_kc)
+    Ad, Bd = At.contiguous().to(_dev()), Bt.contiguous().to(_dev())
+    Cd = torch.full((batch, M, N + 4), -123.0, device=_dev())
+    g = MkGemm()
+    for f, _ in MkGemm._fields_:
+        setattr(g, f, 0)
+    g.A, g.B, g.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    g.a_batch, g.a_row, g.a_k = a_b, a_row, a_k
+    g.b_batch, g.b_col, g.b_k = b_b, b_col, b_k
+    g.c_batch, g.c_row, g.c_col = M * (N + 4), N + 4, 1
+    g.M, g.N, g.K, g.batch, g.inner, g.tri_mode = M, N, K, batch, 1, tri
+    check(lib().mk_sgemm_batched(C.byref(g), C.c_void_p(0)), "sgemm")
+    torch.cuda.synchronize()
+    out = Cd.cpu()
+    assert (out[:, :, N:] == -123.0).all(), "wrote outside the N extent"
+    got = out[:, :, :N].double()
+    if tri == _lib.TRI_ROW_GE:
+        valid = (torch.arange(M)[None, :] >= torch.arange(batch)[:, None])
+    else:
+        valid = rows_ok
+    vm = valid[:, :, None].expand_as(ref)
+    err = ((got - ref)[vm]).norm() / ref[vm].norm()
+    assert torch.isfinite(got[vm]).all()
+    assert err < 2e-6, err
+    if tri == _lib.TRI_ROW_LE:
+        assert (out[:, :, :N][~vm] == -123.0).all(), "rows beyond the triangular bound must not be written"
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("tri,conj_a,conj_b,beta", [(3, 0, 0, 0), (3, 0, 1, 0), (4, 1, 0, 0), (4, 1, 0, 1), (0, 1, 1, 1)])
+@pytest.mark.parametrize("M,N,K,outer,inner", [(36, 140, 24, 7, 2), (100, 64, 52, 9, 1)])
+def test_cgemm_batched(a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, inner):
+    from makani_amd import _lib
+    from makani_amd._lib import MkGemm, lib, check
+    torch.manual_seed(17 + M + tri)
+    batch = outer * inner
+    A = torch.randn(batch, M, K, dtype=torch.complex128)
+    B = torch.randn(batch, N, K, dtype=torch.complex128)
+    C0 = torch.randn(batch, M, N, dtype=torch.complex128)
+    rows_ok, k_ok = _tri_mask(tri, batch, M, K, inner)
+    Ae = A.conj() if conj_a else A
+    Be = B.conj() if conj_b else B
+    ref = torch.einsum("bik,bjk->bij", Ae * k_ok[:, None, :], Be)
+    if beta:
+        ref = ref + C0
+
+    def planar(x, kc):           # (batch, rows, K) complex -> (batch, 2, ...) float32 planes
+        xr = torch.stack([x.real, x.imag], dim=1).float()
+        if not kc:
+            xr = xr.transpose(2, 3)
+        return xr.contiguous()
+
+    Ap, Bp = planar(A, a_kc), planar(B, b_kc)
+    Cp = torch.stack([C0.real, C0.imag], dim=1).float().contiguous()
+    for t, kc in ((Ap, a_kc), (Bp, b_kc)):
+        assert t.shape[-1] % 4 == 0 and t.shape[-2] % 4 == 0
+    Ad, Bd, Cd = Ap.to(_dev()), Bp.to(_dev()), Cp.to(_dev())
+    g = MkGemm()
+    for f, _ in MkGemm._fields_:
+        setattr(g, f, 0)
+    g.A, g.B, g.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    pa, pb = M * K, N * K
+    # batch index = outer * inner + in  ->  linear: use a_batch = inner * 2*pa, a_inner = 2*pa
+    g.a_batch, g.a_inner, g.a_im = inner * 2 * pa, 2 * pa, pa
+    g.b_batch, g.b_inner, g.b_im = inner * 2 * pb, 2 * pb, pb
+    g.c_batch, g.c_inner, g.c_im = inner * 2 * M * N, 2 * M * N, M * N
+    g.a_row, g.a_k = (K, 1) if a_kc else (1, M)
+    g.b_col, g.b_k = (K, 1) if b_kc else (1, N)
+    g.c_row, g.c_col = N, 1
+    g.M, g.N, g.K, g.batch, g.inner, g.tri_mode = M, N, K, batch, inner, tri
+    g.conj_a, g.conj_b, g.beta = conj_a, conj_b, beta
+    check(lib().mk_cgemm_batched(C.byref(g), C.c_void_p(0)), "cgemm")
+    torch.cuda.synchronize()
+    out = Cd.cpu().double()
+    got = torch.complex(out[:, 0], out[:, 1])
+    vm = rows_ok[:, :, None].expand_as(ref)
+    err = (got - ref)[vm].abs().pow(2).sum().sqrt() / ref[vm].abs().pow(2).sum().sqrt()
+    assert err < 2e-6, err
+    if tri == _lib.TRI_ROW_LE:   # untouched rows keep their input
+        assert ((got - C0)[~vm].abs() < 1e-6).all()
+
+
+# --------------------------------------------------------------------------- #
+# FFT
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,nlat,nlon,mmax", [(1, 3, 5, 16, 9), (2, 5, 9, 24, 13), (1, 4, 19, 72, 20),
+                                              (1, 2, 33, 128, 65), (1, 2, 8, 480, 241), (1, 1, 9, 1440, 241),
+                                              (1, 2, 7, 28, 15), (1, 1, 20, 360, 181)])
+def test_rfft_rows(dtype, B, C, nlat, nlon, mmax):
+    from makani_amd import ops
+    torch.manual_seed(nlon)
+    x = torch.randn(B, C, nlat, nlon).to(dtype)
+    Cp = ops.round4(C)
+    c = 2 * math.pi / nlon
+    F = ops.rfft_rows(x.to(_dev()), mmax, Cp, (c, c, c))
+    torch.cuda.synchronize()
+    F = F.cpu()
+    ref = 2 * math.pi * torch.fft.rfft(x.double(), dim=-1, norm="forward")[..., :mmax]     # (B,C,nlat,M)
+    got = torch.complex(F[:, 0], F[:, 1]).view(mmax, B, Cp, -1)[:, :, :C, :nlat].permute(1, 2, 3, 0)
+    assert rel_l2(got, ref) < 3e-6
+    # weighted variant = adjoint of irfft: w = (1, 2, 1)
+    F2 = ops.rfft_rows(x.to(_dev()), mmax, Cp, (1.0, 2.0, 1.0)).cpu()
+    got2 = torch.complex(F2[:, 0], F2[:, 1]).view(mmax, B, Cp, -1)[:, :, :C, :nlat].permute(1, 2, 3, 0)
+    ref2 = torch.fft.rfft(x.double(), dim=-1)[..., :mmax] * 2
+    ref2[..., 0] /= 2
+    if mmax - 1 == nlon // 2:
+        ref2[..., -1] /= 2
+    assert rel_l2(got2, ref2) < 3e-6
+    assert (got2[..., 0].imag == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,nlat,nlon,mmax", [(1, 3, 5, 16, 9), (2, 5, 9, 24, 10), (1, 4, 19, 72, 20),
+                                              (1, 2, 33, 128, 65), (1, 2, 8, 480, 241), (1, 1, 9, 1440, 241)])
+def test_irfft_rows(dtype, B, C, nlat, nlon, mmax):
+    from makani_amd import ops
+    torch.manual_seed(nlon + 1)
+    Cp = ops.round4(C)
+    kp = ops.round4(nlat)
+    X = torch.randn(B, C, nlat, mmax, dtype=torch.complex128)
+    F = torch.full((mmax, 2, B, Cp, kp), float("nan"))
+    F[:, 0, :, :C, :nlat] = X.real.permute(3, 0, 1, 2).float()
+    F[:, 1, :, :C, :nlat] = X.imag.permute(3, 0, 1, 2).float()
+    F = F.view(mmax, 2, B * Cp, kp).contiguous()
+    x = ops.irfft_rows(F.to(_dev()), B, C, nlat, nlon, dtype, (1.0, 2.0, 1.0))
+    torch.cuda.synchronize()
+    Xr = X.clone()
+    Xr[..., 0] = Xr[..., 0].real.to(torch.complex128)
+    if mmax - 1 == nlon // 2:
+        Xr[..., -1] = Xr[..., -1].real.to(torch.complex128)
+    ref = torch.fft.irfft(Xr, n=nlon, dim=-1, norm="forward")
+    tol = 3e-6 if dtype == torch.float32 else 6e-3
+    assert rel_l2(x.cpu(), ref) < tol
+    assert x.dtype == dtype
+
+
+def test_fft_adjoint_pair_fullsize():
+    """<rfft(x), Y> == <x, rfft^T(Y)> at the BASELINE row length (size-independent property)."""
+    from makani_amd import ops
+    torch.manual_seed(5)
+    B, C, nlat, nlon, mmax = 1, 4, 16, 1440, 241
+    c = 2 * math.pi / nlon
+    x = torch.randn(B, C, nlat, nlon, device=_dev())
+    F = ops.rfft_rows(x, mmax, 4, (c, c, c))
+    Y = torch.randn_like(F)
+    Y[..., nlat:] = 0
+    xt = ops.irfft_rows(Y, B, C, nlat, nlon, torch.float32, (c, c, c))
+    Yv = Y.clone()
+    Yv[0, 1] = 0                      # Im of m=0 carries no information
+    lhs = (F.double() * Yv.double())[..., :nlat].sum().item()
+    rhs = (x.double() * xt.double()).sum().item()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-5
+
+
+# --------------------------------------------------------------------------- #
+# layout changes
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("cin,cout,L", [(6, 5, 9), (32, 32, 8), (40, 70, 33)])
+def test_weight_layout_roundtrip(cin, cout, L):
+    from makani_amd import ops
+    w = torch.randn(1, cin, cout, L, dtype=torch.complex64)
+    W = ops.weight_to_wlayout(w.to(_dev())).cpu()
+    cip, cop = ops.round4(cin), ops.round4(cout)
+    assert W.shape == (L, 2, cip, cop)
+    ref = torch.zeros(L, 2, cip, cop)
+    ref[:, 0, :cin, :cout] = w[0].real.permute(2, 0, 1)
+    ref[:, 1, :cin, :cout] = w[0].imag.permute(2, 0, 1)
+    assert torch.equal(W, ref)
+    back = ops.wlayout_to_weight_grad(W.to(_dev()), cin, cout).cpu()
+    assert torch.equal(back, w)
+
+
+@pytest.mark.parametrize("B,C,L,M", [(1, 3, 5, 6), (2, 33, 40, 35), (2, 8, 12, 13)])
+def test_s_layout_roundtrip(B, C, L, M):
+    from makani_amd import ops
+    c = torch.randn(B, C, L, M, dtype=torch.complex64)
+    S = ops.complex_to_s(c.to(_dev()))
+    Cp = ops.round4(C)
+    assert S.shape == (L, M, 2, B * Cp)
+    Sc = S.cpu().view(L, M, 2, B, Cp)
+    assert torch.equal(Sc[:, :, 0, :, :C].permute(2, 3, 0, 1), c.real)
+    assert (Sc[..., C:] == 0).all()
+    back = ops.s_to_complex(S, B, C).cpu()
+    tri = torch.tril(torch.ones(L, M, dtype=torch.bool))     # l >= m kept, rest exact zeros
+    assert torch.equal(back, torch.where(tri, c, torch.zeros_like(c)))
+
+
+# --------------------------------------------------------------------------- #
+# pointwise
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)])
+@pytest.mark.parametrize("fuse_gelu", [False, True])
+@pytest.mark.parametrize("B,C,H,W", [(2, 5, 12, 24), (1, 3, 37, 72), (1, 4, 7, 9), (1, 2, 240, 480)])
+def test_instance_norm(dtype, tol, fuse_gelu, B, C, H, W):
+    from makani_amd import ops
+    torch.manual_seed(B * C + H)
+    x = (torch.randn(B, C, H, W) * 2 + 3).to(dtype)
+    gamma = torch.randn(C) + 1
+    beta = torch.randn(C)
+    gy = torch.randn(B, C, H, W).to(dtype)
+    xd = x.to(_dev()).requires_grad_(True)
+    gd, bd = gamma.to(_dev()).requires_grad_(True), beta.to(_dev()).requires_grad_(True)
+    y = ops.InstanceNormFn.apply(xd, gd, bd, 1e-6, fuse_gelu)
+    y.backward(gy.to(_dev()))
+    torch.cuda.synchronize()
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.instance_norm(xr, weight=gr, bias=br, eps=1e-6)
+    if fuse_gelu:
+        yr = torch.nn.functional.gelu(yr)
+    yr.backward(gy.double())
+    assert y.dtype == dtype
+    assert rel_l2(y, yr) < tol
+    assert rel_l2(xd.grad, xr.grad) < (tol * 5 if dtype == torch.float32 else 2e-2)
+    assert rel_l2(gd.grad, gr.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert rel_l2(bd.grad, br.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_bias_gelu(dtype, tol, with_bias):
+    from makani_amd import ops
+    B, C, H, W = 2, 6, 9, 20
+    x = torch.randn(B, C, H, W).to(dtype)
+    b = torch.randn(C) if with_bias else None
+    gy = torch.randn(B, C, H, W).to(dtype)
+    xd = x.to(_dev()).requires_grad_(True)
+    bd = b.to(_dev()).requires_grad_(True) if with_bias else None
+    y = ops.BiasGeluFn.apply(xd, bd)
+    y.backward(gy.to(_dev()))
+    xr = x.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if with_bias else None
+    yr = torch.nn.functional.gelu(xr + (br.view(1, -1, 1, 1) if with_bias else 0))
+    yr.backward(gy.double())
+    assert rel_l2(y, yr) < tol
+    assert rel_l2(xd.grad, xr.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+    if with_bias:
+        assert rel_l2(bd.grad, br.grad) < (1e-5 if dtype == torch.float32 else 2e-2)

@@ -1,0 +1,225 @@
+"""GPU parity tests of the drop-in modules (through the C ABI) against
+ (a) the CPU oracle on the same seeded inputs,
+ (b) the golden fixtures produced by the reference's own modules,
+ (c) size-independent properties at the BASELINE sizes (721 x 1440)."""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# tolerances: fp32 ops rel-L2 <= 1e-5, fp32 end-to-end <= 1e-4, bf16 AMP end-to-end <= 2e-2
+TOL_OP, TOL_E2E, TOL_BF16 = 1e-5, 1e-4, 2e-2
+
+
+@pytest.mark.parametrize("grid,nlat,nlon,lmax,mmax", [
+    ("equiangular", 33, 64, 16, 17), ("legendre-gauss", 12, 24, 12, 13), ("equiangular", 37, 72, 12, 13),
+    ("legendre-gauss", 60, 120, 60, 61), ("equiangular", 91, 180, 45, 46), ("lobatto", 32, 64, 20, 21),
+    ("equiangular", 181, 360, 60, 61)])
+def test_sht_matches_oracle(grid, nlat, nlon, lmax, mmax):
+    import makani_amd as ma
+    from oracle import sht as osht
+    torch.manual_seed(nlat)
+    x = torch.randn(2, 5, nlat, nlon)
+    S = ma.RealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid).to(DEV)
+    So = osht.RealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+    xd = x.to(DEV).requires_grad_(True)
+    c = S(xd)
+    co = So(x.double())
+    assert c.dtype == torch.complex64 and c.shape == co.shape
+    assert rel_l2(c, co) < TOL_OP
+    # exact zeros above the diagonal, as torch-harmonics produces
+    tri = torch.triu(torch.ones(lmax, mmax, dtype=torch.bool), diagonal=1)
+    assert (c.detach().cpu()[..., tri] == 0).all()
+    # gradient of a seeded linear functional
+    g = torch.randn(2, 5, lmax, mmax, dtype=torch.complex64)
+    torch.view_as_real(c).mul(torch.view_as_real(g.to(DEV))).sum().backward()
+    xo = x.double().requires_grad_(True)
+    torch.view_as_real(So(xo)).mul(torch.view_as_real(g.to(torch.complex128))).sum().backward()
+    assert rel_l2(xd.grad, xo.grad) < TOL_OP
+
+    I = ma.InverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid).to(DEV)
+    Io = osht.InverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+    coef = torch.randn(2, 5, lmax, mmax, dtype=torch.complex64)
+    cd = coef.to(DEV).requires_grad_(True)
+    y = I(cd)
+    cof = coef.to(torch.complex128).requires_grad_(True)
+    yo = Io(cof)
+    assert y.shape == yo.shape and rel_l2(y, yo) < TOL_OP
+    gy = torch.randn_like(yo)
+    (y * gy.float().to(DEV)).sum().backward()
+    (yo * gy).sum().backward()
+    gref = cof.grad.clone()
+    mask = torch.tril(torch.ones(lmax, mmax, dtype=torch.bool))
+    assert rel_l2(cd.grad.cpu() * mask, gref * mask) < TOL_OP
+
+
+def test_sht_leading_dims_and_errors():
+    import makani_amd as ma
+    S = ma.RealSHT(12, 24, grid="legendre-gauss").to(DEV)
+    I = ma.InverseRealSHT(12, 24, grid="legendre-gauss").to(DEV)
+    assert (S.lmax, S.mmax, S.nlat, S.nlon, S.grid) == (12, 13, 12, 24, "legendre-gauss")
+    x = torch.randn(12, 24, device=DEV)
+    assert S(x).shape == (12, 13)
+    x = torch.randn(3, 12, 24, device=DEV)
+    assert S(x).shape == (3, 12, 13)
+    x = torch.randn(2, 3, 4, 12, 24, device=DEV)
+    c = S(x)
+    assert c.shape == (2, 3, 4, 12, 13)
+    assert I(c).shape == (2, 3, 4, 12, 24)
+    with pytest.raises(ValueError):
+        S(torch.randn(1, 1, 13, 24, device=DEV))
+    with pytest.raises(TypeError):
+        S(torch.randn(1, 1, 12, 24, device=DEV, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        ma.RealSHT(12, 24, grid="nonsense")
+    with pytest.raises(NotImplementedError):
+        ma.RealSHT(12, 25)
+    with pytest.raises(RuntimeError):
+        ma.RealSHT(12, 24)(torch.randn(1, 1, 12, 24))       # CPU tensor: no fallback
+
+
+def test_spectral_conv_matches_reference_golden():
+    import makani_amd as ma
+    g = load_golden("spectral_conv.npz")
+    ran = 0
+    for i in range(int(g["ncases"])):
+        p = f"case{i}/"
+        m = json.loads(str(g[p + "meta"]))
+        if m["op"] != "dhconv":
+            with pytest.raises(NotImplementedError):
+                ma.SpectralConv(ma.RealSHT(m["h0"], m["w0"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g0"]),
+                                ma.InverseRealSHT(m["h1"], m["w1"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g1"]),
+                                m["cin"], m["cout"], operator_type=m["op"])
+            continue
+        fwd = ma.RealSHT(m["h0"], m["w0"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g0"])
+        inv = ma.InverseRealSHT(m["h1"], m["w1"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g1"])
+        layer = ma.SpectralConv(fwd, inv, m["cin"], m["cout"], operator_type=m["op"]).to(DEV)
+        with torch.no_grad():
+            layer.weight.copy_(torch.from_numpy(g[p + "w"]))
+        x = torch.from_numpy(g[p + "x"]).to(DEV).requires_grad_(True)
+        y, res = layer(x)
+        ((y * torch.from_numpy(g[p + "gy"]).to(DEV)).sum() + (res * torch.from_numpy(g[p + "gr"]).to(DEV)).sum()).backward()
+        assert rel_l2(y, torch.from_numpy(g[p + "y"])) < TOL_OP, i
+        assert rel_l2(res, torch.from_numpy(g[p + "res"])) < TOL_OP, i
+        assert rel_l2(x.grad, torch.from_numpy(g[p + "gx"])) < 2 * TOL_OP, i
+        assert rel_l2(layer.weight.grad, torch.from_numpy(g[p + "gw"])) < 2 * TOL_OP, i
+        ran += 1
+    assert ran == 3
+
+
+def _load_model(name, cls):
+    g = load_golden(name)
+    kwargs = json.loads(str(g["kwargs"]))
+    model = cls(**kwargs)
+    sd = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
+    model.load_state_dict(sd, strict=True)
+    return g, kwargs, model
+
+
+@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz"])
+def test_sfno_matches_reference_golden_fp32(name):
+    import makani_amd as ma
+    g, kwargs, model = _load_model(name, ma.SphericalFourierNeuralOperatorNet)
+    model = model.to(DEV)
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    y = model(x)
+    (y * torch.from_numpy(g["g"]).to(DEV)).sum().backward()
+    assert rel_l2(y, torch.from_numpy(g["y"])) < TOL_E2E
+    assert rel_l2(x.grad, torch.from_numpy(g["gx"])) < TOL_E2E
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = torch.from_numpy(g["grad/" + k])
+        if k.endswith("mlp.fwd.3.bias"):
+            # gradient of a per-channel constant in front of an instance norm: exactly 0 in exact
+            # arithmetic, pure round-off in any implementation -> compare on an absolute scale
+            wmax = float(np.abs(g["grad/" + k.replace("bias", "weight")]).max())
+            assert p.grad.abs().max().item() < 1e-2 * max(wmax, 1e-3), k
+            continue
+        e = rel_l2(p.grad, ref)
+        worst = max(worst, e)
+        assert e < 2 * TOL_E2E, (k, e)
+
+
+def test_sfno_bf16_autocast_matches_oracle():
+    import makani_amd as ma
+    from oracle import sfno as osf
+    g, kwargs, model = _load_model("sfno_small_37x72.npz", ma.SphericalFourierNeuralOperatorNet)
+    _, _, omodel = _load_model("sfno_small_37x72.npz", osf.SphericalFourierNeuralOperatorNet)
+    model = model.to(DEV)
+    x = torch.from_numpy(g["x"])
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = model(x.to(DEV))
+    assert y.dtype == torch.bfloat16
+    yo = omodel(x)
+    assert rel_l2(y.float(), yo) < TOL_BF16
+
+
+def test_sfno_batch_split_equivalence():
+    """reference tests/test_models.py:105-207: a batch of 2 equals two batches of 1 (fwd and grads)."""
+    import makani_amd as ma
+    g, kwargs, model = _load_model("sfno_small_37x72.npz", ma.SphericalFourierNeuralOperatorNet)
+    model = model.to(DEV)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    gy = torch.from_numpy(g["g"]).to(DEV)
+    y = model(x)
+    (y * gy).sum().backward()
+    full = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    ys = []
+    for i in range(2):
+        yi = model(x[i:i + 1])
+        (yi * gy[i:i + 1]).sum().backward()
+        ys.append(yi)
+    assert rel_l2(torch.cat(ys), y) < 5e-6
+    for k, p in model.named_parameters():
+        if k.endswith("mlp.fwd.3.bias"):
+            continue
+        assert rel_l2(p.grad, full[k]) < 5e-5, k
+
+
+# ---- properties at the BASELINE sizes ------------------------------------------------------
+def test_fullsize_sht_roundtrip_and_linearity():
+    """721 x 1440, lmax 240, mmax 241 (config 2's trans_down / itrans_up): band-limited fields survive
+    isht -> sht, and the transform is linear."""
+    import makani_amd as ma
+    torch.manual_seed(1)
+    S = ma.RealSHT(721, 1440, lmax=240, mmax=241, grid="equiangular").to(DEV)
+    I = ma.InverseRealSHT(721, 1440, lmax=240, mmax=241, grid="equiangular").to(DEV)
+    c = torch.tril(torch.randn(1, 6, 240, 241, dtype=torch.complex64)).to(DEV)
+    c[..., 0] = c[..., 0].real.to(torch.complex64)
+    x = I(c)
+    assert x.shape == (1, 6, 721, 1440)
+    c2 = S(x)
+    assert rel_l2(c2, c) < 2e-5
+    a = torch.randn(1, 6, 721, 1440, device=DEV)
+    b = torch.randn(1, 6, 721, 1440, device=DEV)
+    lhs = S(2.0 * a - 0.5 * b)
+    rhs = 2.0 * S(a) - 0.5 * S(b)
+    assert rel_l2(lhs, rhs) < 2e-6
+    # constant field -> only (l, m) = (0, 0), value sqrt(4 pi)
+    one = S(torch.ones(1, 1, 721, 1440, device=DEV))[0, 0]
+    assert abs(one[0, 0].real.item() - math.sqrt(4 * math.pi)) < 1e-4
+    one[0, 0] = 0
+    assert one.abs().max().item() < 1e-4
+
+
+def test_fullsize_sht_vs_oracle_one_channel():
+    import makani_amd as ma
+    from oracle import sht as osht
+    torch.manual_seed(2)
+    x = torch.rand(1, 2, 721, 1440)
+    S = ma.RealSHT(721, 1440, lmax=240, mmax=241, grid="equiangular").to(DEV)
+    So = osht.RealSHT(721, 1440, lmax=240, mmax=241, grid="equiangular").float()
+    c = S(x.to(DEV))
+    co = So(x)
+    co64 = osht.RealSHT(721, 1440, lmax=240, mmax=241, grid="equiangular")(x.double())
+    # the HIP path must be at least as close to the fp64 truth as the fp32 CPU path, and within tolerance of it
+    assert rel_l2(c, co64) < TOL_OP
+    assert rel_l2(c, co64) < 3 * rel_l2(co, co64) + 1e-6
