@@ -14,8 +14,12 @@ from conftest import load_golden, rel_l2
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-# tolerances: fp32 ops rel-L2 <= 1e-5, fp32 end-to-end <= 1e-4, bf16 AMP end-to-end <= 2e-2
-TOL_OP, TOL_E2E, TOL_BF16 = 1e-5, 1e-4, 2e-2
+# tolerances: fp32 ops rel-L2 <= 1e-5, fp32 end-to-end <= 1e-4.
+# bf16 AMP end-to-end: 4e-2, the reference's own bf16 tolerance (tests/distributed/tests_distributed_layers.py:539),
+# AND no worse than 1.5x the error the CPU oracle itself makes under bf16 autocast on the same input
+# (measured: the reference's own modules under CPU bf16 autocast sit 2.4e-2 from their fp32 result on this
+# 16-channel random-weight model, so a flat 2e-2 is not attainable by any bf16 implementation here).
+TOL_OP, TOL_E2E, TOL_BF16 = 1e-5, 1e-4, 4e-2
 
 
 @pytest.mark.parametrize("grid,nlat,nlon,lmax,mmax", [
@@ -158,7 +162,10 @@ def test_sfno_bf16_autocast_matches_oracle():
         y = model(x.to(DEV))
     assert y.dtype == torch.bfloat16
     yo = omodel(x)
-    assert rel_l2(y.float(), yo) < TOL_BF16
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        yo_bf16 = omodel(x)
+    e_hip, e_cpu = rel_l2(y.float(), yo), rel_l2(yo_bf16.float(), yo)
+    assert e_hip < TOL_BF16 and e_hip < 1.5 * e_cpu, (e_hip, e_cpu)
 
 
 def test_sfno_batch_split_equivalence():
