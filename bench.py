@@ -100,10 +100,11 @@ def build_model(cfg_name, device, seed):
 
 
 def make_optimizer(model):
-    # config/sfnonet.yaml:50-54,114-117.  foreach (multi-tensor) path: it views the complex64
-    # spectral weights as real; the fused path rejects complex parameters.
+    # AdamW, betas (0.9, 0.95), lr 1e-3, weight decay 0 (config/sfnonet.yaml:50-54,114-117) as one fused
+    # HIP pass per tensor; complex64 spectral weights are updated through their real view.
+    from makani_amd.optim import FusedAdamW
     params = [p for p in model.parameters() if p.requires_grad]
-    return torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0, foreach=True)
+    return FusedAdamW(params, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
 
 
 def clip_grads(model, max_norm):
@@ -123,8 +124,7 @@ def train_step(model, opt, reducer, inp, tar, q, amp):
     loss = l2_loss(pred, tar, q)
     loss.backward()
     reducer.finish()
-    clip_grads(model, 32.0)
-    opt.step()
+    opt.step(max_grad_norm=32.0)          # global-norm clipping folded into the AdamW pass
     return loss
 
 

@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/prof1
-export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof1 -o r01 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sht-metric > gpurun_out/prof1/bench.log 2>&1
-echo "prof rc=$?"
-ls -R gpurun_out/prof1 | head -30
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -q --tb=short --timeout=300 -x > gpurun_out/t_all.log 2>&1
+echo "tests rc=$?"; tail -4 gpurun_out/t_all.log
+timeout 300 python tools/microbench.py > gpurun_out/micro.log 2>&1; cat gpurun_out/micro.log
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sht-metric > gpurun_out/bench_full.log 2>&1
+echo "bench rc=$?"; tail -1 gpurun_out/bench_full.log | cut -c1-400

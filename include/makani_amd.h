@@ -125,6 +125,15 @@ int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int dtype, long 
 int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy, void* gx, float* sums, float* ws, int dtype,
                      long long planes, int channels, long long hw, void* stream);
 
+/* ---- optimizer ------------------------------------------------------------------------
+ * One fused AdamW update (torch.optim.AdamW semantics: decoupled weight decay, bias correction with
+ * `step` >= 1) over a flat fp32 tensor; complex64 parameters are passed as their real view
+ * (as makani views them, makani/mpu/mappings.py:467-489).  The reference's train step uses AdamW
+ * (config/sfnonet.yaml:50-54) after global-norm clipping (utils/training/training_helpers.py:123-165):
+ * `grad_scale` (device pointer, may be NULL) is that clipping coefficient, applied to g on the fly. */
+int mk_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* grad_scale, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

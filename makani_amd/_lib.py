@@ -48,6 +48,7 @@ _SIGS = {
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
     "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
     "mk_bias_gelu_fwd": ([c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
+    "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
     "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
 }
 

@@ -12,7 +12,21 @@
 // so only the modes the SHT keeps ever touch HBM.  Work items are handed to XCDs in contiguous
 // ranges (xcd_remap) so that lat-adjacent workgroups share an L2 and their RB-float runs of the
 // F-layout merge into full lines before write-back.
-#include "common.h"
+#include <stdlib.h>
+
+#include "fft_common.h"
+
+int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, const float* twiddle, int B, int C, int Cp,
+                         int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos, float w_nyq, void* stream);
+
+static bool use_fast_fft() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MAKANI_AMD_FFT_GENERIC");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
 
 namespace {
 
@@ -24,59 +38,6 @@ struct RadixList {
     int n;
     int r[MAX_RADIX_PASSES];
 };
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-
-// forward DFT_R (sign -1) in registers
-template <int R>
-__device__ __forceinline__ void dft_small(float2* v);
-
-template <>
-__device__ __forceinline__ void dft_small<2>(float2* v) {
-    const float2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
-}
-template <>
-__device__ __forceinline__ void dft_small<3>(float2* v) {
-    const float c = 0.86602540378443865f;
-    const float2 s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-    const float2 m = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
-    const float2 q = make_float2(c * d.y, -c * d.x);
-    v[0] = cadd(v[0], s);
-    v[1] = cadd(m, q);
-    v[2] = csub(m, q);
-}
-template <>
-__device__ __forceinline__ void dft_small<4>(float2* v) {
-    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-    const float2 t2 = cadd(v[1], v[3]), t3 = mul_neg_i(csub(v[1], v[3]));
-    v[0] = cadd(t0, t2);
-    v[1] = cadd(t1, t3);
-    v[2] = csub(t0, t2);
-    v[3] = csub(t1, t3);
-}
-template <>
-__device__ __forceinline__ void dft_small<5>(float2* v) {
-    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
-    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
-    const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]);
-    const float2 b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
-    const float2 p1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-    const float2 p2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
-    const float2 q1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
-    const float2 q2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
-    const float2 iq1 = mul_neg_i(q1), iq2 = mul_neg_i(q2);
-    v[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
-    v[1] = cadd(p1, iq1);
-    v[4] = csub(p1, iq1);
-    v[2] = cadd(p2, iq2);
-    v[3] = csub(p2, iq2);
-}
 
 // One Stockham pass (decimation in time) of radix R over RB rows of length n2 held in LDS.
 //   src/dst: [RB][LS] float2;  tw: exp(-2 pi i q / N), N = 2*n2;  Ns = product of earlier radices.
@@ -153,28 +114,6 @@ __device__ __forceinline__ float2* run_passes(float2* a, float2* b, const float2
         dst = t;
     }
     return src;
-}
-
-template <typename T>
-__device__ __forceinline__ float2 load_pair(const T* p);
-template <>
-__device__ __forceinline__ float2 load_pair<float>(const float* p) {
-    return *reinterpret_cast<const float2*>(p);
-}
-template <>
-__device__ __forceinline__ float2 load_pair<u16>(const u16* p) {
-    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
-    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
-}
-template <typename T>
-__device__ __forceinline__ void store_pair(T* p, float a, float b);
-template <>
-__device__ __forceinline__ void store_pair<float>(float* p, float a, float b) {
-    *reinterpret_cast<float2*>(p) = make_float2(a, b);
-}
-template <>
-__device__ __forceinline__ void store_pair<u16>(u16* p, float a, float b) {
-    *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -347,6 +286,11 @@ extern "C" int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* t
     const long long rows = (long long)B * Cp;      // rows of the F-layout
     const long long planes = (long long)B * C;     // planes of x
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "rfft: mmax=%d out of range for nlon=%d", mmax, nlon);
+    MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "rfft: bad dtype %d", x_dtype);
+    if (use_fast_fft()) {
+        const int frc = mk_fft_fast_dispatch(false, x, F, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, kp, w_dc, w_pos, w_nyq, stream);
+        if (frc != -1000) return frc;
+    }
     RadixList rl;
     int RB;
     size_t lds;
@@ -379,6 +323,11 @@ extern "C" int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* 
     const long long rows = (long long)B * Cp;
     const long long planes = (long long)B * C;
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "irfft: mmax=%d out of range for nlon=%d", mmax, nlon);
+    MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "irfft: bad dtype %d", x_dtype);
+    if (use_fast_fft()) {
+        const int frc = mk_fft_fast_dispatch(true, F, x, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, kp, w_dc, w_pos, w_nyq, stream);
+        if (frc != -1000) return frc;
+    }
     RadixList rl;
     int RB;
     size_t lds;

@@ -1,0 +1,62 @@
+// Fused AdamW step over one flat fp32 tensor (complex64 parameters are passed as their
+// interleaved real view).  One HBM pass: reads p, g, m, v and writes p, m, v (28 B / element);
+// the global-norm clipping coefficient is read from device memory so the host never syncs.
+// Update rule = torch.optim.AdamW (decoupled weight decay, bias-corrected moments).
+#include "common.h"
+
+namespace {
+constexpr int NT = 256;
+
+__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   const float* __restrict__ grad_scale, float lr, float beta1,
+                                                   float beta2, float eps, float weight_decay, float bc1_inv,
+                                                   float bc2_rsqrt) {
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    const float decay = 1.f - lr * weight_decay;
+    const float step = lr * bc1_inv;
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * NT;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * gs;
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mv[e] = beta1 * mv[e] + (1.f - beta1) * gv[e];
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * gv[e] * gv[e];
+            const float denom = sqrtf(vv[e]) * bc2_rsqrt + eps;
+            pv[e] = pv[e] * decay - step * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    // tail
+    if (blockIdx.x == 0) {
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += NT) {
+            const float gi = g[i] * gs;
+            const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+            const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            p[i] = p[i] * decay - step * (mi / (sqrtf(vi) * bc2_rsqrt + eps));
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mk_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* grad_scale,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                             void* stream) {
+    MK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+    MK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw: pointers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    long long blocks = (n / 4 + NT - 1) / NT;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, grad_scale,
+                       lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    return mk_check_launch("mk_adamw_step");
+}

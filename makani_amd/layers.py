@@ -43,10 +43,11 @@ class PointwiseConv(nn.Module):
         x3 = x.reshape(B, C, H * W)
         with torch.autocast(device_type="cuda", enabled=False):
             if B == 1:      # one plain GEMM (Cout x Cin) @ (Cin x HW), HW contiguous
+                x2 = x.reshape(C, H * W)                      # a view: no select/copy in backward
                 if add_to is None:
-                    y = torch.mm(w, x3[0])
+                    y = torch.mm(w, x2)
                 else:
-                    y = torch.addmm(add_to.reshape(self.out_channels, H * W), w, x3[0])
+                    y = torch.addmm(add_to.reshape(self.out_channels, H * W), w, x2)
             else:
                 wb = w.unsqueeze(0).expand(B, -1, -1)
                 if add_to is None:

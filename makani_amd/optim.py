@@ -1,0 +1,48 @@
+"""Fused AdamW + global-norm gradient clipping for the SFNO train step (one HBM pass per
+parameter tensor; the 566 M real numbers of complex64 spectral weights dominate the step)."""
+import torch
+
+from ._lib import check, lib, ptr, stream
+
+
+def _real(t):
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW`` semantics (state keys ``step`` / ``exp_avg`` / ``exp_avg_sq``), executed by
+    ``mk_adamw_step``.  ``step(max_grad_norm=...)`` folds makani's global-norm clipping
+    (``makani/utils/training/training_helpers.py:123-165``) into the same pass."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def grad_norm(self):
+        grads = [_real(p.grad) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm=None):
+        scale = None
+        if max_grad_norm is not None:
+            total = self.grad_norm()
+            scale = torch.clamp(max_grad_norm / (total + 1e-6), max=1.0).float().reshape(1)
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                pr, gr = _real(p), _real(p.grad)
+                if not (pr.is_contiguous() and gr.is_contiguous()) or pr.dtype != torch.float32:
+                    raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 parameters and gradients")
+                check(lib().mk_adamw_step(ptr(pr), ptr(gr), ptr(_real(st["exp_avg"])), ptr(_real(st["exp_avg_sq"])),
+                                          pr.numel(), ptr(scale), group["lr"], b1, b2, group["eps"],
+                                          group["weight_decay"], int(st["step"]), stream()), "mk_adamw_step")
+        return None

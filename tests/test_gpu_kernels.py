@@ -150,7 +150,7 @@ def test_cgemm_batched(a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, in
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C,nlat,nlon,mmax", [(1, 3, 5, 16, 9), (2, 5, 9, 24, 13), (1, 4, 19, 72, 20),
                                               (1, 2, 33, 128, 65), (1, 2, 8, 480, 241), (1, 1, 9, 1440, 241),
-                                              (1, 2, 7, 28, 15), (1, 1, 20, 360, 181)])
+                                              (1, 2, 7, 28, 15), (1, 1, 20, 360, 181), (2, 3, 19, 128, 40), (1, 5, 33, 480, 100)])
 def test_rfft_rows(dtype, B, C, nlat, nlon, mmax):
     from makani_amd import ops
     torch.manual_seed(nlon)
@@ -176,7 +176,8 @@ def test_rfft_rows(dtype, B, C, nlat, nlon, mmax):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C,nlat,nlon,mmax", [(1, 3, 5, 16, 9), (2, 5, 9, 24, 10), (1, 4, 19, 72, 20),
-                                              (1, 2, 33, 128, 65), (1, 2, 8, 480, 241), (1, 1, 9, 1440, 241)])
+                                              (1, 2, 33, 128, 65), (1, 2, 8, 480, 241), (1, 1, 9, 1440, 241),
+                                              (1, 3, 21, 360, 100), (2, 2, 17, 72, 37), (1, 2, 12, 28, 15)])
 def test_irfft_rows(dtype, B, C, nlat, nlon, mmax):
     from makani_amd import ops
     torch.manual_seed(nlon + 1)
@@ -301,3 +302,28 @@ def test_bias_gelu(dtype, tol, with_bias):
     assert rel_l2(xd.grad, xr.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
     if with_bias:
         assert rel_l2(bd.grad, br.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_fused_adamw_matches_torch():
+    from makani_amd.optim import FusedAdamW
+    torch.manual_seed(3)
+    shapes = [(1, 6, 5, 9), (33,), (7, 13, 1, 1)]
+    def make():
+        torch.manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(*shapes[0], dtype=torch.complex64, device=_dev()))]
+        ps += [torch.nn.Parameter(torch.randn(*s_, device=_dev())) for s_ in shapes[1:]]
+        return ps
+    a, b = make(), make()
+    oa = FusedAdamW(a, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
+    ob = torch.optim.AdamW(b, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, foreach=True)
+    for it in range(4):
+        torch.manual_seed(10 + it)
+        for pa, pb in zip(a, b):
+            g = torch.randn_like(pa) * 3
+            pa.grad, pb.grad = g.clone(), g.clone()
+        torch.nn.utils.clip_grad_norm_(b, 2.0, foreach=True)
+        ob.step()
+        oa.step(max_grad_norm=2.0)
+    for pa, pb in zip(a, b):
+        assert rel_l2(pa, pb) < 2e-6
+    assert set(oa.state[a[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
