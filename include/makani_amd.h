@@ -125,6 +125,21 @@ int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int dtype, long 
 int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy, void* gx, float* sums, float* ws, int dtype,
                      long long planes, int channels, long long hw, void* stream);
 
+/* ---- bf16 channel GEMMs (1x1 convolutions on NCHW planes) ---------------------------------
+ * Replace nn.Conv2d(kernel_size=1) of MLP / EncoderDecoder / outer_skip / residual_transform
+ * (makani/models/common/layers.py:603-643,768-823; makani/models/networks/sfnonet.py:335-338,726-730)
+ * and its autograd under bf16 autocast.  All tensors bf16 except bias (f32) and dW/part (f32).
+ *   mk_conv1x1_nn:   Y[b][m][n] = epi( sum_k A[m][k] X[b][k][n] ),  n = pixel (contiguous), n % 8 == 0
+ *       A: (M, lda) k-contiguous, zero padded to lda (multiple of 8).  Forward: A = W; dgrad: A = W^T.
+ *       epi(v) = v + bias[m]; if act: (Ypre = v), v = gelu(v); if G: v *= gelu'(G[b][m][n]); if R: v += R[b][m][n].
+ *   mk_conv1x1_wgrad: dW[m][k] (+)= sum_{b,n} G[b][m][n] X[b][k][n]; `part` = scratch of
+ *       mk_conv1x1_wgrad_workspace(M, K, B, N) floats (split-pixel partial tiles, reduced deterministically). */
+int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, const float* bias, const void* R, const void* G,
+                  int M, int K, int lda, int B, long long N, int act, void* stream);
+long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N);
+int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* part, int M, int K, int B, long long N,
+                     int accumulate, void* stream);
+
 /* ---- optimizer ------------------------------------------------------------------------
  * One fused AdamW update (torch.optim.AdamW semantics: decoupled weight decay, bias correction with
  * `step` >= 1) over a flat fp32 tensor; complex64 parameters are passed as their real view

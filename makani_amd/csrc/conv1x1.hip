@@ -1,0 +1,345 @@
+// bf16-MFMA channel GEMMs for the pointwise (1x1 convolution) blocks on NCHW planes (gfx950).
+//
+//   mk_conv1x1_nn :  Y[b][m][n] = epi( sum_k A[m][k] * X[b][k][n] )      (forward and data-gradient)
+//        A = weights (M x Kp, k contiguous, zero padded), X = activations with the PIXEL index contiguous.
+//        The activation operand is k-strided for an MFMA fragment (a lane needs 8 consecutive k at one
+//        pixel); it is staged row-major [k][n] into LDS with plain 16-byte writes and fetched with the
+//        CDNA4 transpose read ds_read_b64_tr_b16 (two per fragment), so no shuffling instructions are spent.
+//        epilogue: + bias[m], exact GELU (optionally also storing the pre-activation for backward),
+//        + residual R[b][m][n] (the skip connection), * gelu'(G[b][m][n]) (activation backward).
+//   mk_conv1x1_wgrad : dW[m][k] = sum_{b,n} G[b][m][n] * X[b][k][n]       (weight gradient)
+//        both operands pixel-contiguous = k-contiguous for the contraction: plain ds_read_b128 fragments;
+//        the huge contraction (pixels) is split over workgroups, fp32 partial tiles are reduced by a
+//        second tiny kernel (deterministic, no atomics).
+//
+// Tiles: 256 threads = 4 waves (2 x 2); v_mfma_f32_32x32x16_bf16, fp32 accumulate; BK = 32;
+// double-buffered LDS with register-staged prefetch, one barrier per k-tile.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int NT = 256;
+constexpr int BK = 32;
+
+struct ConvNN {
+    const u16* A;        // (M, lda) weights, k contiguous, lda % 8 == 0, zero beyond K
+    const u16* X;        // (B, K, N)
+    u16* Y;              // (B, M, N)
+    u16* Ypre;           // optional: pre-activation (B, M, N)
+    const float* bias;   // optional (M)
+    const u16* R;        // optional residual (B, M, N), added after activation
+    const u16* G;        // optional: multiply result by gelu'(G)  (B, M, N)
+    int M, K, lda, B;
+    long long N;
+    int act;
+};
+
+__device__ __forceinline__ uint4 ld16(const u16* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(NT, 2) void conv_nn_kernel(const ConvNN p, int tilesM, long long tilesN) {
+    constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;        // MFMA tiles per wave
+    constexpr int PA = BK + 8;                       // A pitch (u16): 80 B  -> conflict-free b128 reads
+    constexpr int PB = BN + 32;                      // X pitch (u16): rows 16 dwords apart mod 64 -> conflict-free tr reads
+    constexpr int NA = (BM * BK / 8) / NT;           // 16-byte chunks per thread
+    constexpr int NB_ = (BK * BN / 8) / NT;
+    static_assert(NA >= 1 && NB_ >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM * PA + BK * PB)];
+    u16* As = smem;                    // [2][BM][PA]
+    u16* Bs = smem + 2 * BM * PA;      // [2][BK][PB]
+
+    // tile decode: all M-tiles of one pixel range are adjacent block ids (share X in L2)
+    // xcd_remap: consecutive virtual ids stay on one XCD, so the tilesM tiles that re-read the same X
+    // columns hit that XCD's L2 instead of HBM
+    const long long bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = (int)(bid % tilesM);
+    const long long tnb = bid / tilesM;
+    const int b = (int)(tnb / tilesN);
+    const long long tn = tnb % tilesN;
+    const int m0 = tm * BM;
+    const long long n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const u16* Xb = p.X + (long long)b * p.K * p.N;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[NA], rb[NB_];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int f = tid + q * NT;
+            const int row = f >> 2, c = f & 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m0 + row < p.M && k0 + c * 8 < p.lda) v = ld16(p.A + (long long)(m0 + row) * p.lda + k0 + c * 8);
+            ra[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NB_; ++q) {
+            const int f = tid + q * NT;
+            const int kk = f / (BN / 8), c = f % (BN / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (k0 + kk < p.K && n0 + c * 8 < p.N) v = ld16(Xb + (long long)(k0 + kk) * p.N + n0 + c * 8);
+            rb[q] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int f = tid + q * NT;
+            const int row = f >> 2, c = f & 3;
+            *reinterpret_cast<uint4*>(As + buf * BM * PA + row * PA + c * 8) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NB_; ++q) {
+            const int f = tid + q * NT;
+            const int kk = f / (BN / 8), c = f % (BN / 8);
+            *reinterpret_cast<uint4*>(Bs + buf * BK * PB + kk * PB + c * 8) = rb[q];
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    // per-lane LDS offsets of the fragments
+    const int s = lane & 15, g1 = (lane >> 4) & 1;
+    const int a_off = (wm * WM + l31) * PA + lh * 8;                                   // + i*32*PA + ks*16
+    const int b_off = (lh * 8 + (s >> 2)) * PB + wn * WN + g1 * 16 + (s & 3) * 4;      // + (ks*16 [+4])*PB + j*32
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        const u16* Ab = As + buf * BM * PA;
+        const u16* Bb = Bs + buf * BK * PB;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(Ab + a_off + i * 32 * PA + ks * 16));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const u16* q0 = Bb + b_off + (ks * 16) * PB + j * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * PB));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[j] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue
+    const long long plane = (long long)b * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= p.M) continue;
+            const float bv = p.bias ? p.bias[m] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const long long n = n0 + wn * WN + j * 32 + l31;
+                if (n >= p.N) continue;
+                const long long o = plane + (long long)m * p.N + n;
+                float v = acc[i][j][r] + bv;
+                if (p.act) {
+                    if (p.Ypre) p.Ypre[o] = f32_to_bf16(v);
+                    v = gelu_f(v);
+                }
+                if (p.G) v *= gelu_grad_f(bf16_to_f32(p.G[o]));
+                if (p.R) v += bf16_to_f32(p.R[o]);
+                p.Y[o] = f32_to_bf16(v);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: part[s][m][k] = sum_{n in split s} G[b][m][n] X[b][k][n];   tile 128 (m) x 128 (k-channel)
+struct ConvWg {
+    const u16* G;   // (B, M, N)
+    const u16* X;   // (B, K, N)
+    float* part;    // (S, M, K) fp32 partials
+    int M, K, B, S;
+    long long N;
+    long long chunk;   // pixels per split (multiple of BK)
+};
+
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int tilesM, int tilesK) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int PA = BK + 8;
+    constexpr int NA = (BM * BK / 8) / NT;   // 2
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * PA];
+    u16* As = smem;
+    u16* Bs = smem + 2 * BM * PA;
+
+    const int bid = blockIdx.x;
+    const int tm = bid % tilesM;
+    const int tk = (bid / tilesM) % tilesK;
+    const int sp = bid / (tilesM * tilesK);          // split index over (b, pixel chunk)
+    const int m0 = tm * BM, c0 = tk * BN;
+    const int splits_per_b = p.S / p.B;
+    const int b = sp / splits_per_b;
+    const long long nbeg = (long long)(sp % splits_per_b) * p.chunk;
+    const long long nend = min(p.N, nbeg + p.chunk);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const u16* Gb = p.G + (long long)b * p.M * p.N;
+    const u16* Xb = p.X + (long long)b * p.K * p.N;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[NA], rb[NA];
+    auto load_tiles = [&](long long n) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int f = tid + q * NT;
+            const int row = f >> 2, c = f & 3;
+            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+            if (n + c * 8 < nend) {
+                if (m0 + row < p.M) va = ld16(Gb + (long long)(m0 + row) * p.N + n + c * 8);
+                if (c0 + row < p.K) vb = ld16(Xb + (long long)(c0 + row) * p.N + n + c * 8);
+            }
+            ra[q] = va;
+            rb[q] = vb;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int f = tid + q * NT;
+            const int row = f >> 2, c = f & 3;
+            *reinterpret_cast<uint4*>(As + buf * BM * PA + row * PA + c * 8) = ra[q];
+            *reinterpret_cast<uint4*>(Bs + buf * BN * PA + row * PA + c * 8) = rb[q];
+        }
+    };
+
+    const int nk = (int)((nend - nbeg + BK - 1) / BK);
+    if (nk > 0) {
+        load_tiles(nbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int a_off = (wm * 64 + l31) * PA + lh * 8;
+    const int b_off = (wn * 64 + l31) * PA + lh * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(nbeg + (long long)(kt + 1) * BK);
+        const u16* Ab = As + buf * BM * PA;
+        const u16* Bb = Bs + buf * BN * PA;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(Ab + a_off + i * 32 * PA + ks * 16));
+                bfr[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(Bb + b_off + i * 32 * PA + ks * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = p.part + (long long)sp * p.M * p.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M && c < p.K) out[(long long)m * p.K + c] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void reduce_splits(const float* __restrict__ part, float* __restrict__ out, long long n, int S, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < S; ++k) s += part[(long long)k * n + i];
+    out[i] = s;
+}
+
+}  // namespace
+
+extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, const float* bias, const void* R,
+                             const void* G, int M, int K, int lda, int B, long long N, int act, void* stream) {
+    MK_REQUIRE(A && X && Y, "conv1x1_nn: null pointer");
+    MK_REQUIRE(M > 0 && K > 0 && B > 0 && N > 0, "conv1x1_nn: bad shape M=%d K=%d B=%d N=%lld", M, K, B, N);
+    MK_REQUIRE((lda % 8) == 0 && lda >= K, "conv1x1_nn: lda=%d must be a multiple of 8 and >= K=%d", lda, K);
+    MK_REQUIRE((N % 8) == 0, "conv1x1_nn: pixel count %lld must be a multiple of 8", N);
+    MK_REQUIRE((((uintptr_t)A | (uintptr_t)X) & 15) == 0, "conv1x1_nn: operands must be 16-byte aligned");
+    ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
+    constexpr int BM = 128, BN = 256;
+    const int tm = (M + BM - 1) / BM;
+    const long long tn = (N + BN - 1) / BN;
+    const long long nb = (long long)tm * tn * B;
+    MK_REQUIRE(nb < (1ll << 31), "conv1x1_nn: grid too large");
+    hipLaunchKernelGGL((conv_nn_kernel<BM, BN>), dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, p, tm, tn);
+    return mk_check_launch("mk_conv1x1_nn");
+}
+
+extern "C" long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N) {
+    // number of fp32 elements the caller must provide as `part`
+    const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
+    long long per_b = 1024 / ((long long)tiles * B);
+    if (per_b < 1) per_b = 1;
+    const long long maxs = (N + 2047) / 2048;      // at least 2048 pixels per split
+    if (per_b > maxs) per_b = maxs;
+    return per_b * B * (long long)M * K;
+}
+
+extern "C" int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* part, int M, int K, int B, long long N,
+                                int accumulate, void* stream) {
+    MK_REQUIRE(G && X && dW && part, "conv1x1_wgrad: null pointer");
+    MK_REQUIRE(M > 0 && K > 0 && B > 0 && N > 0 && (N % 8) == 0, "conv1x1_wgrad: bad shape");
+    const int tm = (M + 127) / 128, tk = (K + 127) / 128;
+    const long long S = mk_conv1x1_wgrad_workspace(M, K, B, N) / ((long long)M * K);
+    const long long per_b = S / B;
+    long long chunk = (N + per_b - 1) / per_b;
+    chunk = (chunk + BK - 1) / BK * BK;
+    ConvWg p{(const u16*)G, (const u16*)X, part, M, K, B, (int)S, N, chunk};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(tm * tk * S)), dim3(NT), 0, s, p, tm, tk);
+    const long long n = (long long)M * K;
+    hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dW, n, (int)S, accumulate);
+    return mk_check_launch("mk_conv1x1_wgrad");
+}

@@ -10,11 +10,25 @@ GEMMs (1x1 convolutions) are issued as plain library GEMMs (hipBLASLt through
 why that is the round-1 choice and what replaces it.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from . import ops
+
+
+_HIP_NN = os.environ.get("MAKANI_AMD_CONV", "lib") == "hip"
+
+
+def hip_conv_eligible(x) -> bool:
+    """Opt-in (MAKANI_AMD_CONV=hip): route forward / data-gradient channel GEMMs to the HIP NN kernel with
+    fused bias/GELU/skip epilogues instead of the library GEMM.  bf16 compute, pixel count % 8 == 0."""
+    if not _HIP_NN or not x.is_cuda or x.dim() != 4 or (x.shape[-1] * x.shape[-2]) % 8 != 0:
+        return False
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda") == torch.bfloat16
+    return x.dtype == torch.bfloat16
 
 
 class PointwiseConv(nn.Module):
@@ -33,30 +47,20 @@ class PointwiseConv(nn.Module):
         B, C, H, W = x.shape
         if C != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {C}")
-        w = self.weight.view(self.out_channels, self.in_channels)
+        if not x.is_cuda:
+            raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
-            w, x = w.to(dt), x.to(dt)
+            x = x.to(dt)
             add_to = add_to.to(dt) if add_to is not None else None
-        elif w.dtype != x.dtype:
-            w = w.to(x.dtype)
-        x3 = x.reshape(B, C, H * W)
         with torch.autocast(device_type="cuda", enabled=False):
-            if B == 1:      # one plain GEMM (Cout x Cin) @ (Cin x HW), HW contiguous
-                x2 = x.reshape(C, H * W)                      # a view: no select/copy in backward
-                if add_to is None:
-                    y = torch.mm(w, x2)
-                else:
-                    y = torch.addmm(add_to.reshape(self.out_channels, H * W), w, x2)
-            else:
-                wb = w.unsqueeze(0).expand(B, -1, -1)
-                if add_to is None:
-                    y = torch.bmm(wb, x3)
-                else:
-                    y = torch.baddbmm(add_to.reshape(B, self.out_channels, H * W), wb, x3)
-        return y.view(B, self.out_channels, H, W)
+            return ops.ConvMmFn.apply(x.contiguous(), self.weight, add_to)
 
     def forward(self, x, add_to=None):
+        if hip_conv_eligible(x):
+            xb = x.to(torch.bfloat16)
+            r = add_to.to(torch.bfloat16) if add_to is not None else None
+            return ops.Conv1x1Fn.apply(xb, self.weight, self.bias, r)
         y = self.matmul(x, add_to)
         if self.bias is not None:
             y = y + self.bias.to(y.dtype).view(1, -1, 1, 1)
@@ -73,6 +77,11 @@ class _Act(nn.Module):
 
     def forward(self, x):
         return ops.BiasGeluFn.apply(x, None) if self.is_gelu else self.act(x)
+
+
+def _conv_gelu_conv(c1: PointwiseConv, c2: PointwiseConv, x):
+    """c2(gelu(c1(x))) as one autograd node on the bf16 HIP GEMMs (fused bias/GELU/gelu' epilogues)."""
+    return ops.ConvGeluConvFn.apply(x.to(torch.bfloat16), c1.weight, c1.bias, c2.weight, c2.bias)
 
 
 def _conv_act(conv: PointwiseConv, act: _Act, x):
@@ -109,6 +118,8 @@ class MLP(nn.Module):
         self.fwd = nn.Sequential(fc1, _Act(act_layer), nn.Identity(), fc2, nn.Identity())
 
     def _run(self, x):
+        if self.fwd[1].is_gelu and hip_conv_eligible(x):
+            return _conv_gelu_conv(self.fwd[0], self.fwd[3], x)
         h = _conv_act(self.fwd[0], self.fwd[1], x)
         return self.fwd[3](h)
 
@@ -142,6 +153,8 @@ class EncoderDecoder(nn.Module):
 
     def forward(self, x):
         mods = list(self.fwd)
+        if len(mods) == 3 and mods[1].is_gelu and hip_conv_eligible(x):
+            return _conv_gelu_conv(mods[0], mods[2], x)
         i = 0
         while i < len(mods) - 1:
             x = _conv_act(mods[i], mods[i + 1], x)

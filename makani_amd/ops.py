@@ -443,3 +443,169 @@ class BiasGeluFn(torch.autograd.Function):
                                      hw, stream()), "bias_gelu_bwd")
         gb = sums.view(B, Cc, 2)[:, :, 0].sum(0) if need_b else None
         return gx, gb
+
+
+# --------------------------------------------------------------------------- #
+# bf16 channel GEMMs (1x1 convolutions on NCHW planes)
+# --------------------------------------------------------------------------- #
+def round8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def pad_weight_bf16(w2d: torch.Tensor) -> torch.Tensor:
+    """(M, K) any float dtype -> (M, round8(K)) bf16, zero padded (the A operand of mk_conv1x1_nn)."""
+    M, K = w2d.shape
+    lda = round8(K)
+    if lda == K:
+        return w2d.to(torch.bfloat16).contiguous()
+    out = torch.zeros((M, lda), dtype=torch.bfloat16, device=w2d.device)
+    out[:, :K] = w2d
+    return out
+
+
+def conv1x1_nn(A: torch.Tensor, K: int, x: torch.Tensor, bias=None, act=False, want_pre=False, residual=None,
+               gelu_grad_of=None):
+    """y[b] = epi(A[:, :K] @ x[b]);  x (B, K, H, W) bf16, A (M, lda) bf16 -> y (B, M, H, W) bf16 (and pre-activation)."""
+    B, Kx, H, W = x.shape
+    assert Kx == K and x.dtype == torch.bfloat16 and A.dtype == torch.bfloat16
+    x = x.contiguous()
+    M, lda = A.shape
+    N = H * W
+    y = torch.empty((B, M, H, W), dtype=torch.bfloat16, device=x.device)
+    ypre = torch.empty_like(y) if (act and want_pre) else None
+    bf = bias.float().contiguous() if bias is not None else None
+    r = residual.contiguous() if residual is not None else None
+    g = gelu_grad_of.contiguous() if gelu_grad_of is not None else None
+    with _timed(f"conv1x1_nn_m{M}_k{K}_n{N}", flops=2.0 * B * M * K * N, nbytes=2.0 * B * N * (M + K)):
+        check(lib().mk_conv1x1_nn(ptr(A), ptr(x), ptr(y), ptr(ypre), ptr(bf), ptr(r), ptr(g), M, K, lda, B, N,
+                                  1 if act else 0, stream()), "mk_conv1x1_nn")
+    return y, ypre
+
+
+def conv1x1_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW[m][k] = sum_{b,n} g[b][m][n] x[b][k][n]  -> (M, K) fp32."""
+    B, M, H, W = g.shape
+    K = x.shape[1]
+    N = H * W
+    g, x = g.contiguous(), x.contiguous()
+    nws = lib().mk_conv1x1_wgrad_workspace(M, K, B, N)
+    part = torch.empty((nws,), dtype=torch.float32, device=g.device)
+    dW = torch.empty((M, K), dtype=torch.float32, device=g.device)
+    with _timed(f"conv1x1_wgrad_m{M}_k{K}_n{N}", flops=2.0 * B * M * K * N, nbytes=2.0 * B * N * (M + K)):
+        check(lib().mk_conv1x1_wgrad(ptr(g), ptr(x), ptr(dW), ptr(part), M, K, B, N, 0, stream()), "mk_conv1x1_wgrad")
+    return dW
+
+
+def _sum_planes(t: torch.Tensor) -> torch.Tensor:
+    return t.sum(dim=(0, 2, 3), dtype=torch.float32)
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    """y = W x (+ bias) (+ residual) on NCHW bf16; weight is the fp32 (M, K, 1, 1) parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        M, K = weight.shape[0], weight.shape[1]
+        A = pad_weight_bf16(weight.view(M, K))
+        y, _ = conv1x1_nn(A, K, x, bias=bias, residual=residual)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        M, K = weight.shape[0], weight.shape[1]
+        gy = gy.contiguous()
+        gx = gw = gb = gr = None
+        if ctx.needs_input_grad[0]:
+            At = pad_weight_bf16(weight.view(M, K).t())
+            gx, _ = conv1x1_nn(At, M, gy)
+        if ctx.needs_input_grad[1]:
+            gw = conv1x1_wgrad(gy, x).view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _sum_planes(gy)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            gr = gy
+        return gx, gw, gb, gr
+
+
+class ConvGeluConvFn(torch.autograd.Function):
+    """y = W2 gelu(W1 x + b1) (+ b2) (+ residual): the MLP / EncoderDecoder pattern
+    (makani/models/common/layers.py:603-643,768-823) with bias+GELU fused into the first GEMM's
+    epilogue and gelu' fused into the epilogue of the second GEMM's data-gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        H1, K = w1.shape[0], w1.shape[1]
+        M = w2.shape[0]
+        h, a1 = conv1x1_nn(pad_weight_bf16(w1.view(H1, K)), K, x, bias=b1, act=True, want_pre=True)
+        y, _ = conv1x1_nn(pad_weight_bf16(w2.view(M, H1)), H1, h, bias=b2)
+        ctx.save_for_backward(x, w1, w2, a1, h)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, w2, a1, h = ctx.saved_tensors
+        H1, K = w1.shape[0], w1.shape[1]
+        M = w2.shape[0]
+        gy = gy.contiguous()
+        # ga1 = (W2^T gy) * gelu'(a1)
+        ga1, _ = conv1x1_nn(pad_weight_bf16(w2.view(M, H1).t()), M, gy, gelu_grad_of=a1)
+        gw2 = conv1x1_wgrad(gy, h).view_as(w2) if ctx.needs_input_grad[3] else None
+        gb2 = _sum_planes(gy) if (ctx.has_b[1] and ctx.needs_input_grad[4]) else None
+        gw1 = conv1x1_wgrad(ga1, x).view_as(w1) if ctx.needs_input_grad[1] else None
+        gb1 = _sum_planes(ga1) if (ctx.has_b[0] and ctx.needs_input_grad[2]) else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx, _ = conv1x1_nn(pad_weight_bf16(w1.view(H1, K).t()), H1, ga1)
+        return gx, gw1, gb1, gw2, gb2
+
+
+class ConvMmFn(torch.autograd.Function):
+    """y = W x (+ residual) with the forward / data-gradient products issued as plain library GEMMs
+    (hipBLASLt through torch.mm: measured 2x faster than the round-1 HIP NN kernel on these
+    pixel-contiguous shapes) and the weight gradient on the HIP split-pixel kernel
+    (mk_conv1x1_wgrad: 1.1-3.7x faster than the library on these huge-K shapes)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, residual):
+        B, K, H, W = x.shape
+        M = weight.shape[0]
+        w = weight.view(M, K).to(x.dtype)
+        N = H * W
+        if B == 1:
+            x2 = x.reshape(K, N)
+            y = torch.mm(w, x2) if residual is None else torch.addmm(residual.reshape(M, N), w, x2)
+        else:
+            wb = w.unsqueeze(0).expand(B, -1, -1)
+            x3 = x.reshape(B, K, N)
+            y = torch.bmm(wb, x3) if residual is None else torch.baddbmm(residual.reshape(B, M, N), wb, x3)
+        ctx.save_for_backward(x, weight)
+        ctx.has_res = residual is not None
+        return y.view(B, M, H, W)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        B, K, H, W = x.shape
+        M = weight.shape[0]
+        N = H * W
+        gy = gy.contiguous()
+        gx = gw = gr = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.view(M, K).t().to(gy.dtype).contiguous()
+            if B == 1:
+                gx = torch.mm(wt, gy.reshape(M, N)).view(B, K, H, W)
+            else:
+                gx = torch.bmm(wt.unsqueeze(0).expand(B, -1, -1), gy.reshape(B, M, N)).view(B, K, H, W)
+        if ctx.needs_input_grad[1]:
+            if gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and N % 8 == 0:
+                gw = conv1x1_wgrad(gy, x).view_as(weight)
+            else:
+                gw = torch.einsum("bmn,bkn->mk", gy.reshape(B, M, N).float(), x.reshape(B, K, N).float()).view_as(weight).to(weight.dtype)
+        if ctx.has_res and ctx.needs_input_grad[2]:
+            gr = gy
+        return gx, gw, gr

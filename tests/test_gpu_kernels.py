@@ -327,3 +327,58 @@ def test_fused_adamw_matches_torch():
     for pa, pb in zip(a, b):
         assert rel_l2(pa, pb) < 2e-6
     assert set(oa.state[a[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+# --------------------------------------------------------------------------- #
+# bf16 channel GEMMs
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("B,M,K,H,W", [(1, 64, 32, 8, 32), (2, 73, 40, 12, 24), (1, 40, 73, 37, 72), (1, 384, 768, 16, 40),
+                                     (2, 130, 260, 10, 52)])
+def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
+    from makani_amd import ops
+    torch.manual_seed(M + K)
+    x = torch.randn(B, K, H, W).bfloat16()
+    w = (torch.randn(M, K) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(M)
+    res = torch.randn(B, M, H, W).bfloat16()
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), x.double())
+    A = ops.pad_weight_bf16(w.to(_dev()))
+    y, _ = ops.conv1x1_nn(A, K, x.to(_dev()))
+    assert rel_l2(y, ref) < 4e-3                                    # bf16 output rounding only
+    y, pre = ops.conv1x1_nn(A, K, x.to(_dev()), bias=bias.to(_dev()), act=True, want_pre=True, residual=res.to(_dev()))
+    pre_ref = ref + bias.double().view(1, -1, 1, 1)
+    assert rel_l2(pre, pre_ref) < 4e-3
+    assert rel_l2(y, torch.nn.functional.gelu(pre_ref) + res.double()) < 5e-3
+    gsrc = torch.randn(B, M, H, W).bfloat16()
+    y, _ = ops.conv1x1_nn(A, K, x.to(_dev()), gelu_grad_of=gsrc.to(_dev()))
+    gd = gsrc.double().requires_grad_(True)
+    torch.nn.functional.gelu(gd).sum().backward()
+    assert rel_l2(y, ref * gd.grad) < 5e-3
+    # weight gradient: dW[m][k] = sum g[b][m][n] x[b][k][n]
+    g = torch.randn(B, M, H, W).bfloat16()
+    dW = ops.conv1x1_wgrad(g.to(_dev()), x.to(_dev()))
+    dref = torch.einsum("bmhw,bkhw->mk", g.double(), x.double())
+    assert dW.dtype == torch.float32 and rel_l2(dW, dref) < 1e-5
+
+
+def test_conv_gelu_conv_autograd():
+    from makani_amd import ops
+    torch.manual_seed(4)
+    B, K, Hd, M, H, W = 2, 24, 48, 20, 6, 16
+    x = torch.randn(B, K, H, W)
+    w1 = torch.randn(Hd, K, 1, 1) / math.sqrt(K)
+    b1 = torch.randn(Hd) * 0.1
+    w2 = torch.randn(M, Hd, 1, 1) / math.sqrt(Hd)
+    b2 = torch.randn(M) * 0.1
+    gy = torch.randn(B, M, H, W)
+    dev_t = [t.to(_dev()).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = ops.ConvGeluConvFn.apply(dev_t[0].bfloat16(), *dev_t[1:])
+    y.backward(gy.to(_dev()).bfloat16())
+    ref_t = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    xr = ref_t[0].bfloat16().double()          # same rounded input
+    h = torch.nn.functional.gelu(torch.nn.functional.conv2d(xr, ref_t[1], ref_t[2]))
+    yr = torch.nn.functional.conv2d(h, ref_t[3], ref_t[4])
+    yr.backward(gy.double())
+    assert rel_l2(y, yr) < 1e-2
+    for d, r in zip(dev_t, ref_t):
+        assert rel_l2(d.grad, r.grad) < 2e-2, d.shape

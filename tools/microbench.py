@@ -78,6 +78,23 @@ def pointwise():
         print(f"bias_gelu fwd     {H}x{W}: {ms:7.3f} ms  {2*nb/ms/1e6:7.1f} GB/s")
 
 
+def conv():
+    for (M, K, H, W) in ((384, 384, 721, 1440), (768, 384, 721, 1440), (384, 768, 721, 1440), (768, 384, 240, 480),
+                         (384, 768, 240, 480), (384, 384, 240, 480), (384, 73, 721, 1440), (73, 384, 721, 1440)):
+        x = torch.randn(1, K, H, W, device=dev).bfloat16()
+        w = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
+        A = ops.pad_weight_bf16(w)
+        fl = 2.0 * M * K * H * W
+        nb = 2.0 * H * W * (M + K)
+        ms = timeit(lambda: ops.conv1x1_nn(A, K, x))
+        ms2 = timeit(lambda: torch.mm(w, x.view(K, H * W)))
+        g = torch.randn(1, M, H, W, device=dev).bfloat16()
+        ms3 = timeit(lambda: ops.conv1x1_wgrad(g, x))
+        ms4 = timeit(lambda: torch.mm(g.view(M, H * W), x.view(K, H * W).t()))
+        print(f"conv M={M} K={K} {H}x{W}: nn hip {ms:7.3f} ms ({fl/ms/1e9:6.0f} TF, {nb/ms/1e6:6.0f} GB/s) | torch.mm {ms2:7.3f} ms ({fl/ms2/1e9:6.0f} TF)"
+              f" || wgrad hip {ms3:7.3f} ms ({fl/ms3/1e9:6.0f} TF) | torch {ms4:7.3f} ms ({fl/ms4/1e9:6.0f} TF)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fft", "legendre", "dhconv", "pointwise"]
     for w in which:
