@@ -22,44 +22,63 @@ struct Rounds {
     static constexpr int value = (ITEMS + NT - 1) / NT;
 };
 
-// One in-place Stockham pass of radix R (Ns = product of earlier radices) over RB rows in LDS.
-// LoadFn(row, pos) -> float2 ; StoreFn(row, pos, float2).  Loads of ALL butterflies of a thread
-// happen before the barrier, stores after it, so load and store may alias the same LDS buffer.
-template <int N2, int R, int NS, int RB, bool SYNC_BETWEEN, typename LoadFn, typename StoreFn>
-__device__ __forceinline__ void fft_pass(const float2* __restrict__ tw, LoadFn load, StoreFn store, int tid) {
-    constexpr int N = 2 * N2;
-    constexpr int NB = N2 / R;
-    constexpr int ITEMS = RB * NB;
-    constexpr int NR = Rounds<ITEMS>::value;
-    constexpr int TSTEP = N / (NS * R);
-    float2 v[NR][R];
+// One in-place Stockham pass of radix R (Ns = product of earlier radices) over RB rows, split into
+// its load half and its twiddle + butterfly + store half so that the loads of the NEXT work item can
+// be issued early (software prefetch) and so that load and store may alias the same LDS buffer
+// (all loads of a thread happen before the barrier, all stores after it).
+template <int N2, int R, int RB>
+struct PassShape {
+    static constexpr int NB = N2 / R;
+    static constexpr int ITEMS = RB * NB;
+    static constexpr int NR = Rounds<ITEMS>::value;
+};
+
+template <int N2, int R, int RB>
+using PassRegs = float2[PassShape<N2, R, RB>::NR][R];
+
+template <int N2, int R, int RB, typename LoadFn>
+__device__ __forceinline__ void pass_load(PassRegs<N2, R, RB>& v, LoadFn load, int tid) {
+    using S = PassShape<N2, R, RB>;
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
+    for (int q = 0; q < S::NR; ++q) {
         const int idx = tid + q * NT;
-        if (idx < ITEMS) {
-            const int row = idx / NB, j = idx % NB;
-            const int k = j % NS;
+        if (idx < S::ITEMS) {
+            const int row = idx / S::NB, j = idx % S::NB;
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[q][r] = load(row, j + r * NB);
+            for (int r = 0; r < R; ++r) v[q][r] = load(row, j + r * S::NB);
+        }
+    }
+}
+
+template <int N2, int R, int NS, int RB, typename StoreFn>
+__device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB>& v, const float2* __restrict__ tw,
+                                                   StoreFn store, int tid) {
+    using S = PassShape<N2, R, RB>;
+    constexpr int TSTEP = 2 * N2 / (NS * R);
+#pragma unroll
+    for (int q = 0; q < S::NR; ++q) {
+        const int idx = tid + q * NT;
+        if (idx < S::ITEMS) {
+            const int row = idx / S::NB, j = idx % S::NB;
+            const int k = j % NS;
             if (NS > 1) {
 #pragma unroll
                 for (int r = 1; r < R; ++r) v[q][r] = cmul(v[q][r], tw[k * r * TSTEP]);
             }
             Dft<R>::run(v[q]);
-        }
-    }
-    if (SYNC_BETWEEN) __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        const int idx = tid + q * NT;
-        if (idx < ITEMS) {
-            const int row = idx / NB, j = idx % NB;
-            const int k = j % NS;
             const int j0 = (j - k) * R + k;
 #pragma unroll
             for (int o = 0; o < R; ++o) store(row, j0 + o * NS, v[q][Dft<R>::loc(o)]);
         }
     }
+}
+
+template <int N2, int R, int NS, int RB, bool SYNC_BETWEEN, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ tw, LoadFn load, StoreFn store, int tid) {
+    float2 v[PassShape<N2, R, RB>::NR][R];
+    pass_load<N2, R, RB>(v, load, tid);
+    if (SYNC_BETWEEN) __syncthreads();
+    pass_compute_store<N2, R, NS, RB>(v, tw, store, tid);
 }
 
 struct ItemRange {
@@ -91,21 +110,29 @@ __global__ __launch_bounds__(NT) void rfft_fast_kernel(const T* __restrict__ x, 
 
     const ItemRange it = my_items(nitems);
     const long long plane = rows * (long long)kp;
+    auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
+    auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
+    // rows of work item `itm` straight from global memory (first pass operands)
+    float2 v1[PassShape<N2, R1, RB>::NR][R1];
+    auto prefetch = [&](long long itm) {
+        const long long bc_ = itm / nkg;
+        const int k0_ = (int)(itm - bc_ * nkg) * RB;
+        const int nr_ = min(RB, nlat - k0_);
+        const T* xr_ = x + (bc_ * nlat + k0_) * (long long)N;
+        pass_load<N2, R1, RB>(v1, [&](int row, int pos) -> float2 {
+            return row < nr_ ? load_pair<T>(xr_ + (long long)row * N + 2 * pos) : make_float2(0.f, 0.f);
+        }, tid);
+    };
+    if (it.begin < it.end) prefetch(it.begin);
     for (long long item = it.begin; item < it.end; ++item) {
         const long long bc = item / nkg;
         const int k0 = (int)(item - bc * nkg) * RB;
         const int nr = min(RB, nlat - k0);
         const long long frow = (bc / C) * Cp + (bc % C);
-        const T* xr = x + (bc * nlat + k0) * (long long)N;
 
-        auto ld_global = [&](int row, int pos) -> float2 {
-            return row < nr ? load_pair<T>(xr + (long long)row * N + 2 * pos) : make_float2(0.f, 0.f);
-        };
-        auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
-        auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
-
-        fft_pass<N2, R1, 1, RB, false>(tw, ld_global, st_lds, tid);
+        pass_compute_store<N2, R1, 1, RB>(v1, tw, st_lds, tid);
         __syncthreads();
+        if (item + 1 < it.end) prefetch(item + 1);       // in flight during passes 2, 3 and the untangle step
         fft_pass<N2, R2, R1, RB, true>(tw, ld_lds, st_lds, tid);
         __syncthreads();
         if constexpr (R3 > 1) {
@@ -156,30 +183,54 @@ __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict_
 
     const ItemRange it = my_items(nitems);
     const long long plane = rows * (long long)kp;
+    // weighted half spectrum X'[m], m = 0..N2 (zero beyond mmax) of work item `itm`, prefetched into registers
+    constexpr int NSPEC = ((N2 + 1) * RB + NT - 1) / NT;
+    // register prefetch of the next item's spectrum only where it fits without squeezing the pass
+    // registers (it costs 2*NSPEC VGPRs that stay live across the passes); measured: 480 +36 %, 1440 -14 %
+    constexpr bool PF = NSPEC <= 16;
+    float2 spec[NSPEC];
+    auto prefetch = [&](long long itm) {
+        const long long bc_ = itm / nkg;
+        const int k0_ = (int)(itm - bc_ * nkg) * RB;
+        const int nr_ = min(RB, nlat - k0_);
+        const long long frow_ = (bc_ / C) * Cp + (bc_ % C);
+#pragma unroll
+        for (int q = 0; q < NSPEC; ++q) {
+            const int idx = tid + q * NT;
+            const int r = idx % RB, m = idx / RB;
+            float2 X = make_float2(0.f, 0.f);
+            if (m < mmax && r < nr_) {
+                const float* sp = F + (long long)(2 * m) * plane + frow_ * kp + k0_ + r;
+                X = make_float2(sp[0], sp[plane]);
+            }
+            spec[q] = X;
+        }
+    };
+    if (PF && it.begin < it.end) prefetch(it.begin);
     for (long long item = it.begin; item < it.end; ++item) {
         const long long bc = item / nkg;
         const int k0 = (int)(item - bc * nkg) * RB;
         const int nr = min(RB, nlat - k0);
-        const long long frow = (bc / C) * Cp + (bc % C);
         T* xr = x + (bc * nlat + k0) * (long long)N;
+        if (!PF) prefetch(item);
 
-        // weighted half spectrum X'[m], m = 0..N2 (zero beyond mmax) -> buf[r][m]
-        for (int idx = tid; idx < (N2 + 1) * RB; idx += NT) {
+#pragma unroll
+        for (int q = 0; q < NSPEC; ++q) {
+            const int idx = tid + q * NT;
             const int r = idx % RB, m = idx / RB;
-            float2 X = make_float2(0.f, 0.f);
-            if (m < mmax && r < nr) {
-                const float* s = F + (long long)(2 * m) * plane + frow * kp + k0 + r;
-                X = make_float2(s[0], s[plane]);
+            if (m <= N2) {
+                float2 X = spec[q];
                 if (m == 0)
                     X = make_float2(w_dc * X.x, 0.f);
                 else if (m == N2)
                     X = make_float2(w_nyq * X.x, 0.f);
                 else
                     X = make_float2(0.5f * w_pos * X.x, 0.5f * w_pos * X.y);
+                buf[r * LS + m] = X;
             }
-            buf[r * LS + m] = X;
         }
         __syncthreads();
+        if (PF && item + 1 < it.end) prefetch(item + 1);       // in flight during the pre-twiddle and the passes
 
         // in-place pre-twiddle on the pairs (j, N2-j): Zs[j] = (A + Bc) + i conj(W^j)(A - Bc); store conj(Zs)
         for (int idx = tid; idx < RB * (N2 / 2 + 1); idx += NT) {
