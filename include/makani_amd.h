@@ -39,7 +39,8 @@ extern "C" {
 #define MK_TRI_K_GE 2   /* contraction runs over k >= t only                   (Legendre synthesis, t = m)  */
 #define MK_TRI_ROW_LE 3 /* only output rows i <= t are computed                (dhconv fwd/dgrad, t = l)    */
 #define MK_TRI_K_LE 4   /* contraction runs over k <= t only                   (dhconv wgrad, t = l)        */
-/* with t = batch_index / inner (the OUTER batch index) */
+/* with t = batch_index / inner + tri_off  (the OUTER batch index, shifted by the shard offset when the
+ * triangular index space is sharded across ranks; t may be negative or exceed the extent) */
 
 /* Strided batched GEMM descriptor:  C[b][i][j] (+)= sum_k A[b][i][k] * B[b][j][k]
  * Element strides.  One of {a_row, a_k} must be 1 (same for B); c_col must be 1.
@@ -57,6 +58,7 @@ typedef struct MkGemm {
     int M, N, K, batch; /* batch = outer count * inner */
     int inner;          /* >= 1 */
     int tri_mode;
+    int tri_off;
     int conj_a, conj_b;
     int beta; /* 0: C = A*B^T ; 1: C += A*B^T */
 } MkGemm;
@@ -97,7 +99,8 @@ int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* twiddle, co
  * <-> W-layout, and S-layout <-> complex64 (rows, L, M) tensors at the RealSHT API boundary. */
 int mk_weight_to_wlayout(const float* w_c64, float* W, int cin, int cout, int cip, int cop, int L, void* stream);
 int mk_wlayout_to_weight_grad(const float* gW, float* gw_c64, int cin, int cout, int cip, int cop, int L, void* stream);
-int mk_slayout_to_complex(const float* S, float* out_c64, int B, int C, int Cp, int L, int M, void* stream);
+int mk_slayout_to_complex(const float* S, float* out_c64, int B, int C, int Cp, int L, int M, int l_off, int m_off,
+                          void* stream);
 int mk_complex_to_slayout(const float* in_c64, float* S, int B, int C, int Cp, int L, int M, void* stream);
 
 /* ---- pointwise blocks -----------------------------------------------------------

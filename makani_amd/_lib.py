@@ -26,7 +26,7 @@ class MkGemm(C.Structure):
         ("a_inner", c_ll), ("b_inner", c_ll), ("c_inner", c_ll),
         ("a_im", c_ll), ("b_im", c_ll), ("c_im", c_ll),
         ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int),
-        ("inner", c_int), ("tri_mode", c_int),
+        ("inner", c_int), ("tri_mode", c_int), ("tri_off", c_int),
         ("conj_a", c_int), ("conj_b", c_int), ("beta", c_int),
     ]
 
@@ -41,7 +41,7 @@ _SIGS = {
                        c_int, c_f, c_f, c_f, c_vp], c_int),
     "mk_weight_to_wlayout": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_wlayout_to_weight_grad": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
-    "mk_slayout_to_complex": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_slayout_to_complex": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_complex_to_slayout": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_pointwise_chunks": ([c_ll, c_int], c_int),
     "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp], c_int),

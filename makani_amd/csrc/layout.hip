@@ -49,9 +49,11 @@ __global__ void w_to_weight_grad(const float* __restrict__ gW, float2* __restric
     }
 }
 
-// S[l][m][ri][b][cp] -> out[b][c][l][m] (complex64); entries with l < m are exact zeros
+// S[l][m][ri][b][cp] -> out[b][c][l][m] (complex64); entries with l + l_off < m + m_off are exact zeros
+// (l_off / m_off = first degree / order of this shard; 0 when not sharded)
 // grid: (ceil(M/32), ceil(C/32), B*L), block (32, 8)
-__global__ void s_to_complex(const float* __restrict__ S, float2* __restrict__ out, int B, int C, int Cp, int L, int M) {
+__global__ void s_to_complex(const float* __restrict__ S, float2* __restrict__ out, int B, int C, int Cp, int L, int M,
+                             int l_off, int m_off) {
     __shared__ float tre[TS][TS + 1], tim[TS][TS + 1];
     const int b = blockIdx.z / L, l = blockIdx.z % L;
     const int c0 = blockIdx.y * TS, m0 = blockIdx.x * TS;
@@ -59,7 +61,7 @@ __global__ void s_to_complex(const float* __restrict__ S, float2* __restrict__ o
     for (int mm = threadIdx.y; mm < TS; mm += 8) {
         const int m = m0 + mm, c = c0 + threadIdx.x;
         float re = 0.f, im = 0.f;
-        if (m < M && c < C && m <= l) {
+        if (m < M && c < C && m + m_off <= l + l_off) {
             const long long base = (((long long)l * M + m) * 2) * R + (long long)b * Cp + c;
             re = S[base];
             im = S[base + R];
@@ -114,11 +116,12 @@ extern "C" int mk_wlayout_to_weight_grad(const float* gW, float* gw_c64, int cin
     return mk_check_launch("mk_wlayout_to_weight_grad");
 }
 
-extern "C" int mk_slayout_to_complex(const float* S, float* out_c64, int B, int C, int Cp, int L, int M, void* stream) {
+extern "C" int mk_slayout_to_complex(const float* S, float* out_c64, int B, int C, int Cp, int L, int M, int l_off,
+                                     int m_off, void* stream) {
     MK_REQUIRE(S && out_c64 && B > 0 && C > 0 && Cp >= C && L > 0 && M > 0, "slayout_to_complex: bad args");
     MK_REQUIRE((long long)B * L < 65536, "slayout_to_complex: B*L too large for grid.z");
     dim3 grid((M + TS - 1) / TS, (C + TS - 1) / TS, B * L), block(TS, 8);
-    hipLaunchKernelGGL(s_to_complex, grid, block, 0, (hipStream_t)stream, S, (float2*)out_c64, B, C, Cp, L, M);
+    hipLaunchKernelGGL(s_to_complex, grid, block, 0, (hipStream_t)stream, S, (float2*)out_c64, B, C, Cp, L, M, l_off, m_off);
     return mk_check_launch("mk_slayout_to_complex");
 }
 

@@ -101,20 +101,20 @@ __device__ __forceinline__ BlockCoord decode_block(const MkGemm& p, int tilesM, 
     c.khi = p.K;
     c.active = c.b < p.batch;
     if (!c.active) return c;
-    const int tt = c.b / p.inner;
+    const int tt = c.b / p.inner + p.tri_off;
     switch (p.tri_mode) {
         case MK_TRI_ROW_GE:
             if (c.i0 + BM <= tt) c.active = false;
             break;
         case MK_TRI_K_GE:
-            c.klo = min(tt, p.K);
+            c.klo = max(0, min(tt, p.K));
             break;
         case MK_TRI_ROW_LE:
-            c.Meff = min(p.M, tt + 1);
+            c.Meff = max(0, min(p.M, tt + 1));
             if (c.i0 >= c.Meff) c.active = false;
             break;
         case MK_TRI_K_LE:
-            c.khi = min(p.K, tt + 1);
+            c.khi = max(0, min(p.K, tt + 1));
             break;
         default:
             break;

@@ -1,0 +1,316 @@
+"""Spatial (h x w) model-parallel spherical harmonic transforms over RCCL all-to-all.
+
+Counterpart of ``torch_harmonics.distributed`` as makani uses it
+(``makani/models/networks/sfnonet.py:786-805,823-838``; schedule mirrored in-tree by
+``makani/mpu/fft.py:148-182,214-249`` and ``makani/mpu/mappings.py:38-67``):
+
+forward   (w) planes<->lon all-to-all -> rFFT over full longitude, truncated
+          (w) m<->planes all-to-all   -> (h) planes<->lat all-to-all
+          Legendre analysis over full latitude with the local m-slice of the matrix
+          (h) l<->planes all-to-all
+inverse   the same four exchanges in reverse order around synthesis and irFFT.
+
+Differences from the reference's NCCL pattern, chosen for xGMI (point-to-point links, every
+peer pair has its own link): each exchange is ONE ``all_to_all`` on the internal F/S layouts
+(fp32 planar, the layouts the HIP kernels consume), the sharded index is always the OUTERMOST or
+a plane index, so send chunks are contiguous slices where possible; only kept modes travel
+(truncation happens before the first spectral exchange); the triangular structure is carried
+through the shards (``tri_off``) so the GEMMs skip the structurally-zero half on every rank.
+
+Local compute goes through a small backend object.  The product backend is the HIP library
+(``HipBackend``) — there is no CPU fallback; tests inject the CPU oracle to verify the
+exchange schedule with gloo.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import legendre as _leg
+from . import ops
+from .sht import RealSHT, InverseRealSHT
+
+_POLAR = None      # "h" group: latitude / degree l
+_AZIMUTH = None    # "w" group: longitude / order m
+_INIT = False
+
+
+def init(polar_group, azimuth_group):
+    """``thd.init(polar_group, azimuth_group)`` (``sfnonet.py:786-789``); ``None`` = not split."""
+    global _POLAR, _AZIMUTH, _INIT
+    _POLAR, _AZIMUTH, _INIT = polar_group, azimuth_group, True
+
+
+def is_initialized() -> bool:
+    return _INIT
+
+
+def polar_group():
+    return _POLAR
+
+
+def azimuth_group():
+    return _AZIMUTH
+
+
+def _size(group) -> int:
+    return 1 if group is None else dist.get_world_size(group)
+
+
+def _rank(group) -> int:
+    return 0 if group is None else dist.get_rank(group)
+
+
+def polar_group_size():
+    return _size(_POLAR)
+
+
+def azimuth_group_size():
+    return _size(_AZIMUTH)
+
+
+def polar_group_rank():
+    return _rank(_POLAR)
+
+
+def azimuth_group_rank():
+    return _rank(_AZIMUTH)
+
+
+def compute_split_shapes(size: int, num_chunks: int) -> List[int]:
+    """ceil-div chunks, the last one smaller; floor-div fallback when the last would be empty
+    (used by ``makani/mpu/fft.py:50-51``, ``makani/utils/grids.py:154-165``)."""
+    if num_chunks == 1:
+        return [size]
+    chunk = (size + num_chunks - 1) // num_chunks
+    last = max(0, size - chunk * (num_chunks - 1))
+    if last == 0:
+        chunk = size // num_chunks
+        last = size - chunk * (num_chunks - 1)
+    return [chunk] * (num_chunks - 1) + [last]
+
+
+def split_tensor_along_dim(tensor, dim, num_chunks):
+    if tensor.shape[dim] < num_chunks:
+        raise ValueError(f"cannot split dimension {dim} of size {tensor.shape[dim]} into {num_chunks} chunks")
+    return torch.split(tensor, compute_split_shapes(tensor.shape[dim], num_chunks), dim=dim)
+
+
+# --------------------------------------------------------------------------- #
+# the exchange primitive
+# --------------------------------------------------------------------------- #
+def _pad_to4(t: torch.Tensor, dim: int) -> torch.Tensor:
+    n = t.shape[dim]
+    if n % 4 == 0:
+        return t
+    shape = list(t.shape)
+    shape[dim] = 4 - n % 4
+    return torch.cat([t, t.new_zeros(shape)], dim=dim)
+
+
+def _exchange(recv, send, group):
+    """one all-to-all; RCCL ("nccl") has it natively, gloo (CPU tests) is served by paired isend/irecv"""
+    if dist.get_backend(group) != "gloo":
+        dist.all_to_all(recv, send, group=group)
+        return
+    me = dist.get_rank(group)
+    recv[me].copy_(send[me])
+    ops_ = []
+    for peer in range(len(send)):
+        if peer == me:
+            continue
+        gp = dist.get_global_rank(group, peer)
+        ops_.append(dist.P2POp(dist.isend, send[peer], gp, group=group))
+        ops_.append(dist.P2POp(dist.irecv, recv[peer], gp, group=group))
+    for req in dist.batch_isend_irecv(ops_):
+        req.wait()
+
+
+class _TransposeFn(torch.autograd.Function):
+    """Split ``x`` along ``sdim`` into one chunk per peer (sizes ``ssizes``), exchange, concatenate what
+    arrives along ``cdim`` (``makani/mpu/mappings.py:38-67``).  ``svalid``/padded dims: a padded dim is
+    narrowed to its valid extent before splitting and re-padded to a multiple of 4 after concatenation.
+    Backward is the reverse exchange."""
+
+    @staticmethod
+    def forward(ctx, x, sdim, ssizes, cdim, csizes, group):
+        P = dist.get_world_size(group)
+        me = dist.get_rank(group)
+        assert len(ssizes) == P and len(csizes) == P
+        svalid = sum(ssizes)
+        xs = x.narrow(sdim, 0, svalid) if x.shape[sdim] != svalid else x
+        xc = xs.narrow(cdim, 0, csizes[me]) if xs.shape[cdim] != csizes[me] else xs
+        send = [c.contiguous() for c in torch.split(xc, ssizes, dim=sdim)]
+        recv = []
+        for src in range(P):
+            shape = list(send[me].shape)
+            shape[cdim] = csizes[src]
+            recv.append(torch.empty(shape, dtype=x.dtype, device=x.device))
+        _exchange(recv, send, group)
+        y = torch.cat(recv, dim=cdim)
+        ctx.meta = (sdim, ssizes, cdim, csizes, group, x.shape, me)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sdim, ssizes, cdim, csizes, group, xshape, me = ctx.meta
+        P = len(ssizes)
+        g = gy.narrow(cdim, 0, sum(csizes)) if gy.shape[cdim] != sum(csizes) else gy
+        send = [c.contiguous() for c in torch.split(g, csizes, dim=cdim)]
+        recv = []
+        for src in range(P):
+            shape = list(send[me].shape)
+            shape[sdim] = ssizes[src]
+            recv.append(torch.empty(shape, dtype=gy.dtype, device=gy.device))
+        _exchange(recv, send, group)
+        gx = torch.cat(recv, dim=sdim)
+        # restore the (padded) input extents
+        for d in (sdim, cdim):
+            if gx.shape[d] != xshape[d]:
+                shape = list(gx.shape)
+                shape[d] = xshape[d] - gx.shape[d]
+                gx = torch.cat([gx, gx.new_zeros(shape)], dim=d)
+        return gx, None, None, None, None, None
+
+
+def transpose(x, sdim, ssizes, cdim, csizes, group, pad_dims=()):
+    """exchange (no-op for a group of one), then zero-pad ``pad_dims`` to multiples of 4 (kernel layouts)."""
+    if group is not None and dist.get_world_size(group) > 1:
+        x = _TransposeFn.apply(x, sdim, list(ssizes), cdim, list(csizes), group)
+    for d in pad_dims:
+        x = _pad_to4(x, d)
+    return x
+
+
+# --------------------------------------------------------------------------- #
+# local compute backends
+# --------------------------------------------------------------------------- #
+class HipBackend:
+    """Local compute on the HIP library (the product path)."""
+
+    @staticmethod
+    def rfft(x4, mmax, w):
+        return ops.RfftFn.apply(x4, mmax, ops.round4(x4.shape[1]), w)
+
+    @staticmethod
+    def irfft(F, planes, nlat, nlon, dtype, w):
+        return ops.IrfftFn.apply(F, 1, planes, nlat, nlon, dtype, w)
+
+    @staticmethod
+    def analysis(F, mat, nlat, m_off):
+        return ops.AnalysisFn.apply(F.contiguous(), mat, nlat, m_off)
+
+    @staticmethod
+    def synthesis(S, mat, nlat, m_off):
+        return ops.SynthesisFn.apply(S.contiguous(), mat, nlat, m_off)
+
+
+_BACKEND = HipBackend
+
+
+def set_backend(backend):
+    """Test hook: replace the local-compute backend (tests inject the CPU oracle to check the
+    exchange schedule with gloo).  The default and only product backend is ``HipBackend``."""
+    global _BACKEND
+    _BACKEND = backend
+
+
+def _offsets(sizes):
+    out = [0]
+    for s in sizes:
+        out.append(out[-1] + s)
+    return out
+
+
+class _DistBase:
+    def _setup_dist(self):
+        if not is_initialized():
+            raise RuntimeError("makani_amd.distributed.init(polar_group, azimuth_group) has not been called")
+        self.comm_size_polar, self.comm_rank_polar = polar_group_size(), polar_group_rank()
+        self.comm_size_azimuth, self.comm_rank_azimuth = azimuth_group_size(), azimuth_group_rank()
+        self.lat_shapes = compute_split_shapes(self.nlat, self.comm_size_polar)
+        self.lon_shapes = compute_split_shapes(self.nlon, self.comm_size_azimuth)
+        self.l_shapes = compute_split_shapes(self.lmax, self.comm_size_polar)
+        self.m_shapes = compute_split_shapes(self.mmax, self.comm_size_azimuth)
+        self.m_off = _offsets(self.m_shapes)[self.comm_rank_azimuth]
+        self.l_off = _offsets(self.l_shapes)[self.comm_rank_polar]
+
+    def _plane_shapes(self, planes):
+        return compute_split_shapes(planes, self.comm_size_azimuth), compute_split_shapes(planes, self.comm_size_polar)
+
+
+class DistributedRealSHT(RealSHT, _DistBase):
+    """``thd.DistributedRealSHT``: local ``(B, C, nlat_loc, nlon_loc)`` -> local ``(B, C, l_loc, m_loc)``.
+    Keeps only the m-slice of the Legendre matrix this azimuth rank needs."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="equiangular", norm="ortho", csphase=True):
+        super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
+        self._setup_dist()
+        m0, m1 = self.m_off, self.m_off + self.m_shapes[self.comm_rank_azimuth]
+        self.weights = self.weights[m0:m1].contiguous()
+
+    def analysis(self, x4: torch.Tensor) -> torch.Tensor:
+        """(B, C, nlat_loc, nlon_loc) -> S-layout (l_loc, m_loc, 2, round4(B*C)), planes = b*C + c."""
+        B, C = x4.shape[:2]
+        if B > 1 and C % 4:
+            raise NotImplementedError("distributed SHT needs C % 4 == 0 when B > 1")
+        hl, wl = self.lat_shapes[self.comm_rank_polar], self.lon_shapes[self.comm_rank_azimuth]
+        if x4.shape[-2] != hl or x4.shape[-1] != wl:
+            raise ValueError(f"expected local shape (..., {hl}, {wl}), got {tuple(x4.shape)}")
+        P = B * C
+        pw, ph = self._plane_shapes(P)
+        x = x4.reshape(1, P, hl, wl)
+        # (w) planes <-> lon
+        x = transpose(x, 1, pw, 3, self.lon_shapes, azimuth_group())
+        F = _BACKEND.rfft(x.contiguous(), self.mmax, self._w)                       # (M, 2, round4(P_w), kp_loc)
+        # (w) m <-> planes
+        F = transpose(F, 0, self.m_shapes, 2, pw, azimuth_group(), pad_dims=(2,))      # (M_loc, 2, round4(P), kp_loc)
+        # (h) planes <-> lat
+        F = transpose(F, 2, ph, 3, self.lat_shapes, polar_group(), pad_dims=(2, 3))    # (M_loc, 2, round4(P_h), kp)
+        S = _BACKEND.analysis(F, self.weights, self.nlat, self.m_off)                 # (L, M_loc, 2, round4(P_h))
+        # (h) l <-> planes
+        S = transpose(S, 0, self.l_shapes, 3, ph, polar_group(), pad_dims=(3,))        # (L_loc, M_loc, 2, round4(P))
+        return S
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from .sht import _as4d
+        x4, lead = _as4d(x, 2)
+        S = self.analysis(x4)
+        c = ops.SToComplexFn.apply(S, x4.shape[0], x4.shape[1], self.l_off, self.m_off)
+        return c.reshape(*lead, c.shape[-2], c.shape[-1])
+
+
+class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
+    """``thd.DistributedInverseRealSHT``: local ``(B, C, l_loc, m_loc)`` -> local ``(B, C, nlat_loc, nlon_loc)``."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="equiangular", norm="ortho", csphase=True):
+        super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
+        self._setup_dist()
+        m0, m1 = self.m_off, self.m_off + self.m_shapes[self.comm_rank_azimuth]
+        self.pct = self.pct[m0:m1].contiguous()
+
+    def synthesis(self, S: torch.Tensor, B: int, C: int, out_dtype=torch.float32) -> torch.Tensor:
+        P = B * C
+        if B > 1 and C % 4:
+            raise NotImplementedError("distributed SHT needs C % 4 == 0 when B > 1")
+        pw, ph = self._plane_shapes(P)
+        hl, wl = self.lat_shapes[self.comm_rank_polar], self.lon_shapes[self.comm_rank_azimuth]
+        # (h) planes <-> l
+        S = transpose(S, 3, ph, 0, self.l_shapes, polar_group(), pad_dims=(3,))       # (L, M_loc, 2, round4(P_h))
+        F = _BACKEND.synthesis(S, self.pct, self.nlat, self.m_off)                    # (M_loc, 2, round4(P_h), kp)
+        # (h) lat <-> planes
+        F = transpose(F, 3, self.lat_shapes, 2, ph, polar_group(), pad_dims=(2, 3))    # (M_loc, 2, round4(P), kp_loc)
+        # (w) planes <-> m
+        F = transpose(F, 2, pw, 0, self.m_shapes, azimuth_group(), pad_dims=(2,))      # (M, 2, round4(P_w), kp_loc)
+        x = _BACKEND.irfft(F.contiguous(), pw[self.comm_rank_azimuth], hl, self.nlon, out_dtype, self._w)
+        # (w) lon <-> planes
+        x = transpose(x, 3, self.lon_shapes, 1, pw, azimuth_group())                  # (1, P, hl, wl)
+        return x.reshape(B, C, hl, wl)
+
+    def forward(self, c: torch.Tensor) -> torch.Tensor:
+        from .sht import _as4d
+        c4, lead = _as4d(c, 2)
+        S = ops.ComplexToSFn.apply(c4)
+        x = self.synthesis(S, c4.shape[0], c4.shape[1])
+        return x.reshape(*lead, x.shape[-2], x.shape[-1])

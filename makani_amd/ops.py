@@ -141,7 +141,7 @@ def _gemm(**kw) -> MkGemm:
     return g
 
 
-def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int) -> torch.Tensor:
+def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int = 0) -> torch.Tensor:
     """S[l][m][ri][row] = sum_k mat[m][l][k] F[m][ri][row][k]      (rows l >= m only)."""
     M, _, R, kp = F.shape
     Mm, L, kpm = mat.shape
@@ -151,7 +151,7 @@ def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int) -> torch.Te
               a_batch=L * kp, a_row=kp, a_k=1,
               b_batch=2 * R * kp, b_col=kp, b_k=1,
               c_batch=2 * R, c_row=M * 2 * R,
-              M=L, N=2 * R, K=nlat, batch=M, tri_mode=_lib.TRI_ROW_GE)
+              M=L, N=2 * R, K=nlat, batch=M, tri_mode=_lib.TRI_ROW_GE, tri_off=m_off)
     # dense-formulation work: 2 * (2R) * nlat * L * M flops
     with _timed(f"legendre_analysis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
                 nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
@@ -159,7 +159,7 @@ def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int) -> torch.Te
     return S
 
 
-def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor) -> torch.Tensor:
+def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, m_off: int = 0) -> torch.Tensor:
     """F[m][ri][row][k] = sum_{l >= m} S[l][m][ri][row] mat[m][l][k]."""
     L, M, _, R = S.shape
     Mm, Lm, kp = mat.shape
@@ -169,7 +169,7 @@ def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor) -> torch.Tensor:
               a_batch=2 * R, a_row=1, a_k=M * 2 * R,
               b_batch=L * kp, b_col=1, b_k=kp,
               c_batch=2 * R * kp, c_row=kp,
-              M=2 * R, N=kp, K=L, batch=M, tri_mode=_lib.TRI_K_GE)
+              M=2 * R, N=kp, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
     with _timed(f"legendre_synthesis_k{kp}", flops=2.0 * 2 * R * kp * L * M,
                 nbytes=4.0 * (2 * R * kp * M + 2 * R * L * M + M * L * kp)):
         check(lib().mk_sgemm_batched(C.byref(g), stream()), "legendre_synthesis")
@@ -198,7 +198,7 @@ def wlayout_to_weight_grad(gW: torch.Tensor, cin: int, cout: int) -> torch.Tenso
     return torch.view_as_complex(out)
 
 
-def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int) -> torch.Tensor:
+def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int, tri_off: int = 0) -> torch.Tensor:
     """T[l][m][ri][b][o] = sum_i S[l][m][.][b][i] * W[l][.][i][o]   (complex; rows m <= l only)."""
     L, M, _, R = S.shape
     Lw, _, cip, cop = W.shape
@@ -209,7 +209,7 @@ def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int) -> torch.Tens
               a_batch=M * 2 * R, a_inner=cip, a_row=2 * R, a_k=1, a_im=R,
               b_batch=2 * cip * cop, b_inner=0, b_col=1, b_k=cop, b_im=cip * cop,
               c_batch=M * 2 * Ro, c_inner=cop, c_row=2 * Ro, c_im=Ro,
-              M=M, N=cop, K=cin, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE)
+              M=M, N=cop, K=cin, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off)
     # dense-formulation work: 8 * B * Cin * Cout * L * M flops (complex MAC = 8 real flops)
     with _timed("dhconv_fwd", flops=8.0 * B * cin * cop * L * M,
                 nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
@@ -217,7 +217,7 @@ def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int) -> torch.Tens
     return T
 
 
-def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int) -> torch.Tensor:
+def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int, tri_off: int = 0) -> torch.Tensor:
     """gS[l][m][b][i] = sum_o gT[l][m][b][o] * conj(W[l][i][o])."""
     L, M, _, Ro = gT.shape
     _, _, cip, cop = W.shape
@@ -227,14 +227,14 @@ def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int)
               a_batch=M * 2 * Ro, a_inner=cop, a_row=2 * Ro, a_k=1, a_im=Ro,
               b_batch=2 * cip * cop, b_inner=0, b_col=cop, b_k=1, b_im=cip * cop,
               c_batch=M * 2 * R, c_inner=cip, c_row=2 * R, c_im=R,
-              M=M, N=cin, K=cout, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, conj_b=1)
+              M=M, N=cin, K=cout, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off, conj_b=1)
     with _timed("dhconv_dgrad", flops=8.0 * B * cin * cout * L * M,
                 nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
         check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_dgrad")
     return gS
 
 
-def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int) -> torch.Tensor:
+def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0) -> torch.Tensor:
     """gW[l][i][o] = sum_{b, m <= l} conj(S[l][m][b][i]) * gT[l][m][b][o]."""
     L, M, _, R = S.shape
     Ro = gT.shape[-1]
@@ -245,7 +245,8 @@ def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int) -> torch.Tensor:
                   a_batch=M * 2 * R, a_row=1, a_k=2 * R, a_im=R,
                   b_batch=M * 2 * Ro, b_col=1, b_k=2 * Ro, b_im=Ro,
                   c_batch=2 * cip * cop, c_row=cop, c_im=cip * cop,
-                  M=cip, N=cop, K=M, batch=L, inner=1, tri_mode=_lib.TRI_K_LE, conj_a=1, beta=1 if b > 0 else 0)
+                  M=cip, N=cop, K=M, batch=L, inner=1, tri_mode=_lib.TRI_K_LE, tri_off=tri_off, conj_a=1,
+                  beta=1 if b > 0 else 0)
         with _timed("dhconv_wgrad", flops=8.0 * cip * cop * L * M,
                     nbytes=4.0 * (2 * cip * L * M + 2 * cop * L * M + 2 * cip * cop * L)):
             check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_wgrad")
@@ -255,10 +256,10 @@ def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # API-boundary layout changes
 # --------------------------------------------------------------------------- #
-def s_to_complex(S: torch.Tensor, B: int, Cc: int) -> torch.Tensor:
+def s_to_complex(S: torch.Tensor, B: int, Cc: int, l_off: int = 0, m_off: int = 0) -> torch.Tensor:
     L, M, _, R = S.shape
     out = torch.empty((B, Cc, L, M, 2), dtype=torch.float32, device=S.device)
-    check(lib().mk_slayout_to_complex(ptr(S), ptr(out), B, Cc, R // B, L, M, stream()), "slayout_to_complex")
+    check(lib().mk_slayout_to_complex(ptr(S), ptr(out), B, Cc, R // B, L, M, l_off, m_off, stream()), "slayout_to_complex")
     return torch.view_as_complex(out)
 
 
@@ -300,24 +301,24 @@ class IrfftFn(torch.autograd.Function):
 
 class AnalysisFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, F, mat, nlat):
-        ctx.mat = mat
-        return legendre_analysis(F, mat, nlat)
+    def forward(ctx, F, mat, nlat, m_off=0):
+        ctx.mat, ctx.m_off = mat, m_off
+        return legendre_analysis(F, mat, nlat, m_off)
 
     @staticmethod
     def backward(ctx, gS):
-        return legendre_synthesis(gS.contiguous(), ctx.mat), None, None
+        return legendre_synthesis(gS.contiguous(), ctx.mat, ctx.m_off), None, None, None
 
 
 class SynthesisFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, S, mat, nlat):
-        ctx.mat, ctx.nlat = mat, nlat
-        return legendre_synthesis(S, mat)
+    def forward(ctx, S, mat, nlat, m_off=0):
+        ctx.mat, ctx.nlat, ctx.m_off = mat, nlat, m_off
+        return legendre_synthesis(S, mat, m_off)
 
     @staticmethod
     def backward(ctx, gF):
-        return legendre_analysis(gF.contiguous(), ctx.mat, ctx.nlat), None, None
+        return legendre_analysis(gF.contiguous(), ctx.mat, ctx.nlat, ctx.m_off), None, None, None
 
 
 class DhconvFn(torch.autograd.Function):
@@ -325,33 +326,34 @@ class DhconvFn(torch.autograd.Function):
     (``_contract_lwise``, makani/models/common/contractions.py:23-24)."""
 
     @staticmethod
-    def forward(ctx, S, weight, B):
+    def forward(ctx, S, weight, B, tri_off=0):
+        """tri_off = (first l of this shard) - (first m of this shard); 0 when not sharded."""
         _, cin, cout, _ = weight.shape
         W = weight_to_wlayout(weight)
         ctx.save_for_backward(S, W)
-        ctx.meta = (B, cin, cout)
-        return dhconv_fwd(S, W, B, cin)
+        ctx.meta = (B, cin, cout, tri_off)
+        return dhconv_fwd(S, W, B, cin, tri_off)
 
     @staticmethod
     def backward(ctx, gT):
         S, W = ctx.saved_tensors
-        B, cin, cout = ctx.meta
+        B, cin, cout, tri_off = ctx.meta
         gT = gT.contiguous()
-        gS = dhconv_dgrad(gT, W, B, cin, cout) if ctx.needs_input_grad[0] else None
+        gS = dhconv_dgrad(gT, W, B, cin, cout, tri_off) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            gw = wlayout_to_weight_grad(dhconv_wgrad(S, gT, B), cin, cout)
-        return gS, gw, None
+            gw = wlayout_to_weight_grad(dhconv_wgrad(S, gT, B, tri_off), cin, cout)
+        return gS, gw, None, None
 
 
 class SToComplexFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, S, B, Cc):
-        return s_to_complex(S, B, Cc)
+    def forward(ctx, S, B, Cc, l_off=0, m_off=0):
+        return s_to_complex(S, B, Cc, l_off, m_off)
 
     @staticmethod
     def backward(ctx, gc):
-        return complex_to_s(gc), None, None
+        return complex_to_s(gc), None, None, None, None
 
 
 class ComplexToSFn(torch.autograd.Function):

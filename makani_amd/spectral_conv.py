@@ -49,8 +49,19 @@ class SpectralConv(nn.Module):
         if not isinstance(forward_transform, RealSHT) or not isinstance(inverse_transform, InverseRealSHT):
             raise TypeError("makani_amd.SpectralConv needs makani_amd RealSHT / InverseRealSHT transforms")
 
-        self.modes_lat_local, self.modes_lon_local = self.modes_lat, self.modes_lon
-        self.nlat_local, self.nlon_local = inverse_transform.nlat, inverse_transform.nlon
+        # spatial model parallelism: the weight is sharded along l over the "h" group and shared over "w"
+        # (spectral_convolution.py:169-173,195-198)
+        self._tri_off = 0
+        if hasattr(inverse_transform, "l_shapes"):
+            ih, iw = inverse_transform.comm_rank_polar, inverse_transform.comm_rank_azimuth
+            self.modes_lat_local = inverse_transform.l_shapes[ih]
+            self.modes_lon_local = inverse_transform.m_shapes[iw]
+            self.nlat_local = inverse_transform.lat_shapes[ih]
+            self.nlon_local = inverse_transform.lon_shapes[iw]
+            self._tri_off = inverse_transform.l_off - inverse_transform.m_off
+        else:
+            self.modes_lat_local, self.modes_lon_local = self.modes_lat, self.modes_lon
+            self.nlat_local, self.nlon_local = inverse_transform.nlat, inverse_transform.nlon
 
         weight_shape = [num_groups, in_channels // num_groups]
         if not separable:
@@ -88,7 +99,7 @@ class SpectralConv(nn.Module):
         S = self.forward_transform.analysis(x)                    # fp32 coefficients, bf16 read fused
         if self.scale_residual:
             residual = self.inverse_transform.synthesis(S, B, C, out_dtype=dtype)
-        T = ops.DhconvFn.apply(S, self.weight, B)
+        T = ops.DhconvFn.apply(S, self.weight, B, self._tri_off)
         y = self.inverse_transform.synthesis(T, B, self.out_channels, out_dtype=dtype)
         if hasattr(self, "bias"):
             y = y + self.bias.to(dtype=y.dtype)

@@ -1,0 +1,172 @@
+"""Multi-process CPU tests (gloo, 127.0.0.1) of the N > 1 host logic:
+ * the h x w all-to-all schedule of the distributed SHT (makani_amd/distributed.py) reproduces the serial
+   transform, forward and backward — the pattern of the reference's
+   tests/distributed/tests_distributed_layers.py:69-223.  Local compute is injected from the CPU oracle
+   (test-only backend); on a GPU the same schedule runs on the HIP kernels.
+ * the data-parallel gradient reducer of bench.py averages gradients (incl. complex ones)."""
+import math
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleBackend:
+    """CPU local compute on the internal F/S layouts (torch ops; differentiable by autograd)."""
+
+    @staticmethod
+    def rfft(x4, mmax, w):
+        B, P, nlat, nlon = x4.shape
+        X = torch.fft.rfft(x4[0], dim=-1, norm="backward")[..., :mmax]          # (P, nlat, M) unnormalised sums
+        wv = torch.full((mmax,), w[1], dtype=x4.dtype)
+        wv[0] = w[0]
+        if mmax - 1 == nlon // 2:
+            wv[-1] = w[2]
+        X = X * wv
+        F = torch.stack([X.real, X.imag], dim=0).permute(3, 0, 1, 2)             # (M, 2, P, nlat)
+        Rp, kp = (P + 3) // 4 * 4, (nlat + 3) // 4 * 4
+        return torch.nn.functional.pad(F, (0, kp - nlat, 0, Rp - P))
+
+    @staticmethod
+    def irfft(F, planes, nlat, nlon, dtype, w):
+        M = F.shape[0]
+        X = torch.complex(F[:, 0, :planes, :nlat], F[:, 1, :planes, :nlat]).permute(1, 2, 0)   # (P, nlat, M)
+        s = torch.full((M,), 2.0, dtype=F.dtype)
+        s[0] = 1.0
+        wv = torch.full((M,), w[1], dtype=F.dtype)
+        wv[0] = w[0]
+        mask = torch.ones(M, dtype=F.dtype)
+        mask[0] = 0.0
+        if M - 1 == nlon // 2:
+            s[-1], wv[-1], mask[-1] = 1.0, w[2], 0.0
+        X = torch.complex(X.real, X.imag * mask) * (wv / s)
+        return torch.fft.irfft(X, n=nlon, dim=-1, norm="forward").unsqueeze(0).to(dtype)
+
+    @staticmethod
+    def analysis(F, mat, nlat, m_off):
+        return torch.einsum("mlk,mirk->lmir", mat.to(F.dtype), F)
+
+    @staticmethod
+    def synthesis(S, mat, nlat, m_off):
+        return torch.einsum("lmir,mlk->mirk", S, mat.to(S.dtype))
+
+
+def _s_to_complex(S, B, C):
+    L, M, _, R = S.shape
+    return torch.complex(S[:, :, 0, : B * C], S[:, :, 1, : B * C]).permute(2, 0, 1).reshape(B, C, L, M)
+
+
+def _complex_to_s(c):
+    B, C, L, M = c.shape
+    S = torch.stack([c.real, c.imag], dim=0).reshape(2, B * C, L, M).permute(2, 3, 0, 1)
+    return torch.nn.functional.pad(S, (0, (-(B * C)) % 4)).contiguous()
+
+
+def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd.distributed as thd
+        from oracle import sht as osht
+        ih, iw = rank // w, rank % w
+        hg = wg = None
+        for j in range(w):                       # polar groups: same iw
+            g = dist.new_group([i * w + j for i in range(h)])
+            if j == iw:
+                hg = g
+        for i in range(h):                       # azimuth groups: same ih
+            g = dist.new_group([i * w + j for j in range(w)])
+            if i == ih:
+                wg = g
+        thd.init(hg if h > 1 else None, wg if w > 1 else None)
+        thd.set_backend(OracleBackend)
+        torch.manual_seed(7)
+        x = torch.randn(B, C, nlat, nlon, dtype=torch.float64)
+        fwd = thd.DistributedRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+        inv = thd.DistributedInverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+        assert fwd.lat_shapes == thd.compute_split_shapes(nlat, h) and fwd.m_shapes == thd.compute_split_shapes(mmax, w)
+        lat0, lon0 = sum(fwd.lat_shapes[:ih]), sum(fwd.lon_shapes[:iw])
+        l0, m0 = sum(fwd.l_shapes[:ih]), sum(fwd.m_shapes[:iw])
+        hl, wl, ll, ml = fwd.lat_shapes[ih], fwd.lon_shapes[iw], fwd.l_shapes[ih], fwd.m_shapes[iw]
+        assert (fwd.l_off, fwd.m_off) == (l0, m0)
+
+        # ---- forward + its gradient ----
+        xl = x[..., lat0:lat0 + hl, lon0:lon0 + wl].clone().requires_grad_(True)
+        S = fwd.analysis(xl)
+        assert S.shape == (ll, ml, 2, (B * C + 3) // 4 * 4)
+        c = _s_to_complex(S, B, C)
+        So = osht.RealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+        xs = x.clone().requires_grad_(True)
+        cref = So(xs)
+        assert (c - cref[..., l0:l0 + ll, m0:m0 + ml]).abs().max().item() < 1e-5
+        G = torch.randn(B, C, lmax, mmax, dtype=torch.complex128)
+        (torch.view_as_real(c) * torch.view_as_real(G[..., l0:l0 + ll, m0:m0 + ml])).sum().backward()
+        (torch.view_as_real(cref) * torch.view_as_real(G)).sum().backward()
+        gref = xs.grad[..., lat0:lat0 + hl, lon0:lon0 + wl]
+        assert (xl.grad - gref).abs().max().item() < 1e-5 * max(1.0, gref.abs().max().item())
+
+        # ---- inverse + its gradient ----
+        coef = torch.tril(torch.randn(B, C, lmax, mmax, dtype=torch.complex128))
+        cl = coef[..., l0:l0 + ll, m0:m0 + ml].clone().requires_grad_(True)
+        y = inv.synthesis(_complex_to_s(cl), B, C, out_dtype=torch.float64)
+        Io = osht.InverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+        cs = coef.clone().requires_grad_(True)
+        yref = Io(cs)
+        assert y.shape == (B, C, hl, wl)
+        assert (y - yref[..., lat0:lat0 + hl, lon0:lon0 + wl]).abs().max().item() < 1e-5
+        Gy = torch.randn(B, C, nlat, nlon, dtype=torch.float64)
+        (y * Gy[..., lat0:lat0 + hl, lon0:lon0 + wl]).sum().backward()
+        (yref * Gy).sum().backward()
+        tri = torch.tril(torch.ones(lmax, mmax, dtype=torch.bool))[l0:l0 + ll, m0:m0 + ml]
+        gc_ref = cs.grad[..., l0:l0 + ll, m0:m0 + ml]
+        assert ((cl.grad - gc_ref) * tri).abs().max().item() < 1e-5 * max(1.0, gc_ref.abs().max().item())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w", [(2, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("nlat,nlon,lmax,mmax,grid,B,C", [(33, 64, 16, 17, "equiangular", 1, 6), (12, 24, 12, 13, "legendre-gauss", 2, 8)])
+def test_distributed_sht_schedule_matches_serial(h, w, nlat, nlon, lmax, mmax, grid, B, C):
+    world = h * w
+    mp.spawn(_worker_sht, args=(world, _free_port(), h, w, nlat, nlon, lmax, mmax, grid, B, C), nprocs=world, join=True)
+
+
+def _worker_dp(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        torch.manual_seed(0)
+        model = torch.nn.Module()
+        model.a = torch.nn.Parameter(torch.randn(5, 3))
+        model.c = torch.nn.Parameter(torch.randn(4, 2, dtype=torch.complex64))
+        model.big = torch.nn.Parameter(torch.randn(3 * 1024 * 1024))          # > 8 MB: async path
+        red = bench.GradReducer(model, world)
+        loss = (model.a.sum() * (rank + 1)) + (torch.view_as_real(model.c).sum() * (rank + 2)) + model.big.sum() * rank
+        loss.backward()
+        red.finish()
+        mean = sum(range(1, world + 1)) / world
+        assert torch.allclose(model.a.grad, torch.full_like(model.a, mean))
+        assert torch.allclose(torch.view_as_real(model.c.grad), torch.full((4, 2, 2), mean + 1.0))
+        assert torch.allclose(model.big.grad, torch.full_like(model.big, (world - 1) / 2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_grad_reducer_world2():
+    mp.spawn(_worker_dp, args=(2, _free_port()), nprocs=2, join=True)
