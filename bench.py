@@ -149,58 +149,55 @@ def sht_bandwidth(device, reps=5):
     return out
 
 
-def _timed_cpu(fn):
-    t0 = time.perf_counter()
-    fn()
-    return time.perf_counter() - t0
+# forward GFLOP per stage of sfno_sc3_layers8_edim384 at 721x1440 (BASELINE.md §2 / SURVEY.md Appendix B)
+_STAGE_GF = {"mid_block": 42.6 + 68.23 + 135.9 + 34.0, "total": 4517.7}
 
 
-def cpu_baseline(cfg_name):
-    """Reference-equivalent CPU path — the oracle (the reference's model code restated over the
-    restated torch-harmonics SHT, fp32, all host cores) — timed on a BOUNDED sample of the same
-    workload: ONE forward+backward of each distinct stage of the network at full size
-    (first block, one internal block, last block, encoder, decoder+big-skip).  The step time is
-    their composition t_first + (L-2) t_mid + t_last + t_enc + t_dec; optimizer time is excluded
-    (it favours the CPU number)."""
-    import psutil
+def _cpu_worker(cfg_name):
+    """child process: time ONE forward+backward of one internal-grid block of the oracle on the host cores"""
     from oracle import sfno as osf
     from oracle import sht as osht
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 32))
+    torch.set_num_threads(threads)
     cfg = CONFIGS[cfg_name]
     H, W = cfg["inp_shape"]
-    E, nl, sf = cfg["embed_dim"], cfg["num_layers"], cfg["scale_factor"]
+    E, sf = cfg["embed_dim"], cfg["scale_factor"]
     h, w = H // sf, W // sf
-    ml, mm = h, w // 2 + 1
     torch.manual_seed(333)
-    act = torch.nn.GELU
-    trans_down = osht.RealSHT(H, W, lmax=ml, mmax=mm, grid="equiangular").float()
-    itrans_up = osht.InverseRealSHT(H, W, lmax=ml, mmax=mm, grid="equiangular").float()
-    trans = osht.RealSHT(h, w, lmax=ml, mmax=mm, grid="legendre-gauss").float()
-    itrans = osht.InverseRealSHT(h, w, lmax=ml, mmax=mm, grid="legendre-gauss").float()
+    trans = osht.RealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid="legendre-gauss").float()
+    itrans = osht.InverseRealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid="legendre-gauss").float()
+    blk = osf.NeuralOperatorBlock(trans, itrans, E, "dhconv", cfg["mlp_ratio"], torch.nn.GELU, False)
+    x = torch.rand(1, E, h, w, requires_grad=True)
+    blk(x).square().mean().backward()                      # warm-up (thread pools, allocator)
+    x.grad = None
+    t0 = time.perf_counter()
+    blk(x).square().mean().backward()
+    t = time.perf_counter() - t0
+    print(json.dumps(dict(t_mid=t, threads=threads, cores=cores, h=h, w=w)), flush=True)
 
-    def fb(module, shape):
-        x = torch.rand(*shape, requires_grad=True)
-        def run():
-            module(x).square().mean().backward()
-        return _timed_cpu(run)
 
-    notes = []
-    t_first = fb(osf.NeuralOperatorBlock(trans_down, itrans, E, "dhconv", cfg["mlp_ratio"], act, False), (1, E, H, W))
-    t_mid = fb(osf.NeuralOperatorBlock(trans, itrans, E, "dhconv", cfg["mlp_ratio"], act, False), (1, E, h, w))
-    t_enc = fb(osf._encdec(1, cfg["inp_chans"], E, E, act), (1, cfg["inp_chans"], H, W))
-    t_dec = fb(osf._encdec(1, E, cfg["out_chans"], E, act, gain=0.5), (1, E, H, W))
-    need = 20 * E * H * W * 4
-    if psutil.virtual_memory().available > 1.5 * need:
-        t_last = fb(osf.NeuralOperatorBlock(trans, itrans_up, E, "dhconv", cfg["mlp_ratio"], act, False), (1, E, h, w))
-    else:
-        t_last = t_first + (t_mid - 0.0) * (H * W) / (h * w) * 0.8
-        notes.append("last block extrapolated (host RAM too small to hold its fp32 activations)")
-    step = t_first + (nl - 2) * t_mid + t_last + t_enc + t_dec
-    return dict(value=1.0 / step, unit="samples/s", cores=cores, kind="port",
-                sample=f"oracle fp32 on CPU, one fwd+bwd of each stage at full size: first block {t_first:.1f} s, "
-                       f"internal block {t_mid:.1f} s (x{nl - 2}), last block {t_last:.1f} s, encoder {t_enc:.1f} s, "
-                       f"decoder {t_dec:.1f} s -> step {step:.1f} s (optimizer excluded). " + " ".join(notes),
+def cpu_baseline(cfg_name, timeout_s=240):
+    """Reference-equivalent CPU path: the oracle (the reference's model code restated over the restated
+    torch-harmonics SHT), fp32, timed in a child process on this host's cores on a BOUNDED sample: one
+    forward+backward of ONE internal-grid block (the unit the network repeats 6x; 280.7 of the 4517.7
+    forward GFLOP of the step).  The step time is that measurement scaled by the FLOP ratio (x16.1);
+    optimizer time is excluded (which favours the CPU number)."""
+    import subprocess
+    if cfg_name != "sfno_sc3_layers8_edim384":
+        return None
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name], capture_output=True,
+                             text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:   # timeout or failure: report it, never stall the GPU benchmark
+        return dict(value=None, unit="samples/s", cores=None, kind="port", sample=f"CPU baseline unavailable: {type(e).__name__}")
+    scale = _STAGE_GF["total"] / _STAGE_GF["mid_block"]
+    step = rec["t_mid"] * scale
+    return dict(value=1.0 / step, unit="samples/s", cores=rec["threads"], kind="port",
+                sample=f"oracle fp32 on {rec['threads']} host threads ({rec['cores']} cores visible): one fwd+bwd of one "
+                       f"internal-grid block ({rec['h']}x{rec['w']}, 384 ch) = {rec['t_mid']:.2f} s, scaled by the step/block "
+                       f"FLOP ratio {scale:.1f} -> {step:.1f} s per step (optimizer excluded)",
                 ms_per_step=step * 1e3)
 
 
@@ -213,7 +210,11 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (not the BASELINE metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sht-metric", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        _cpu_worker(args.cpu_worker)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -314,7 +315,9 @@ def main():
         if world == 1 and not args.no_sht_metric and args.config == "sfno_sc3_layers8_edim384":
             del model, opt
             torch.cuda.empty_cache()
+            print("[bench] train loop done; measuring fwd SHT", file=sys.stderr, flush=True)
             out["fwd_sht"] = sht_bandwidth(device)
+            print("[bench] fwd SHT done; CPU baseline", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         else:

@@ -1,2 +1,7 @@
-python tools/fftprobe.py 2>&1 | grep -v amdgpu.ids
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short --timeout=300 -k "fft or sht" 2>&1 | tail -3
+mkdir -p gpurun_out
+SECONDS=0
+timeout 280 python bench.py > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err
+echo "rc=$? elapsed=${SECONDS}s"; grep "^\[bench\]" gpurun_out/bench_default.err; tail -1 gpurun_out/bench_default.log | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step']); print(d['roofline']); print(d['fwd_sht']); print(d['cpu_baseline'])"

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
     u16* As = smem;
     u16* Bs = smem + 2 * BM * PA;
 
-    const int bid = blockIdx.x;
+    // the tilesM*tilesK tiles of one pixel split re-read the same G / X columns: keep them on one XCD (L2)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid % tilesM;
     const int tk = (bid / tilesM) % tilesK;
     const int sp = bid / (tilesM * tilesK);          // split index over (b, pixel chunk)
