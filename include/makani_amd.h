@@ -74,6 +74,11 @@ int mk_version(void);
  *   (makani/models/common/contractions.py:23-24) and its autograd. */
 int mk_sgemm_batched(const MkGemm* g, void* stream);
 int mk_cgemm_batched(const MkGemm* g, void* stream);
+/* Same contracts on the bf16 matrix cores: every fp32 operand is split on the fly into `limbs` bf16 limbs
+ * (3: x = hi+mid+lo, 6 MFMAs per product, fp32 round-off class, measured rel-L2 1.8e-7 vs fp64;
+ *  2: x = hi+mid, 3 MFMAs, ~4e-6), fp32 accumulation.  6/16 resp. 3/16 of the exact-fp32 MFMA time. */
+int mk_sgemm_split_batched(const MkGemm* g, int limbs, void* stream);
+int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream);
 
 /* ---- longitude FFTs ----------------------------------------------------------
  * mk_rfft_rows: x[row][lat][lon] (f32|bf16)  ->  F-layout, modes m < mmax:

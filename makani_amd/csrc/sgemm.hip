@@ -18,9 +18,13 @@
 //     wave issues 4 ds_read_b32 for 4 (real) / 6 for 8 (complex) MFMAs of 64 cycles each.
 //   * XCD-aware grid: batch b runs on XCD b % 8 (all its tiles share A[b]/B[b] in that XCD's L2),
 //     and every XCD gets every 8th batch so the triangular work is balanced.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
+
+using gemm::BlockCoord;
+using gemm::decode_block;
+using gemm::validate;
 
 constexpr int BK = 16;
 constexpr int NT = 256;
@@ -81,46 +85,6 @@ struct TileStage {
         }
     }
 };
-
-struct BlockCoord {
-    int b, i0, j0, Meff, klo, khi;
-    bool active;
-};
-
-template <int BM, int BN>
-__device__ __forceinline__ BlockCoord decode_block(const MkGemm& p, int tilesM, int tilesN) {
-    BlockCoord c;
-    const int xcd = blockIdx.x % MK_NUM_XCD, j = blockIdx.x / MK_NUM_XCD;
-    const int tpb = tilesM * tilesN;
-    c.b = (j / tpb) * MK_NUM_XCD + xcd;
-    const int t = j % tpb;
-    c.i0 = (t / tilesN) * BM;
-    c.j0 = (t % tilesN) * BN;
-    c.Meff = p.M;
-    c.klo = 0;
-    c.khi = p.K;
-    c.active = c.b < p.batch;
-    if (!c.active) return c;
-    const int tt = c.b / p.inner + p.tri_off;
-    switch (p.tri_mode) {
-        case MK_TRI_ROW_GE:
-            if (c.i0 + BM <= tt) c.active = false;
-            break;
-        case MK_TRI_K_GE:
-            c.klo = max(0, min(tt, p.K));
-            break;
-        case MK_TRI_ROW_LE:
-            c.Meff = max(0, min(p.M, tt + 1));
-            if (c.i0 >= c.Meff) c.active = false;
-            break;
-        case MK_TRI_K_LE:
-            c.khi = max(0, min(p.K, tt + 1));
-            break;
-        default:
-            break;
-    }
-    return c;
-}
 
 // ---- real kernel -----------------------------------------------------------------
 template <int BM, int BN, bool A_KC, bool B_KC>
@@ -320,35 +284,6 @@ __global__ __launch_bounds__(NT, 2) void cgemm_kernel(const MkGemm p, int tilesM
             }
         }
     }
-}
-
-int validate(const MkGemm* g, bool cplx, bool* a_kc, bool* b_kc) {
-    MK_REQUIRE(g && g->A && g->B && g->C, "gemm: null pointer");
-    MK_REQUIRE(g->M > 0 && g->N > 0 && g->K >= 0 && g->batch > 0, "gemm: bad extents M=%d N=%d K=%d batch=%d", g->M,
-               g->N, g->K, g->batch);
-    MK_REQUIRE(g->c_col == 1, "gemm: c_col must be 1");
-    MK_REQUIRE(g->a_k == 1 || g->a_row == 1, "gemm: A needs a unit stride");
-    MK_REQUIRE(g->b_k == 1 || g->b_col == 1, "gemm: B needs a unit stride");
-    MK_REQUIRE(g->inner >= 1 && g->batch % g->inner == 0, "gemm: inner must be >= 1 and divide batch");
-    *a_kc = (g->a_k == 1);
-    *b_kc = (g->b_k == 1);
-    // vector loads along the unit-stride dim: 16-byte alignment of everything else
-    auto al = [](long long s) { return (s & 3) == 0; };
-    MK_REQUIRE(((uintptr_t)g->A & 15) == 0 && ((uintptr_t)g->B & 15) == 0, "gemm: A/B must be 16-byte aligned");
-    MK_REQUIRE(al(g->a_batch) && al(g->b_batch) && al(g->a_inner) && al(g->b_inner),
-               "gemm: batch strides must be multiples of 4");
-    if (*a_kc) {
-        MK_REQUIRE(al(g->a_row), "gemm: a_row must be a multiple of 4");
-    } else {
-        MK_REQUIRE(al(g->a_k) && (g->M & 3) == 0, "gemm: row-contiguous A needs a_k %% 4 == 0 and M %% 4 == 0");
-    }
-    if (*b_kc) {
-        MK_REQUIRE(al(g->b_col), "gemm: b_col must be a multiple of 4");
-    } else {
-        MK_REQUIRE(al(g->b_k) && (g->N & 3) == 0, "gemm: col-contiguous B needs b_k %% 4 == 0 and N %% 4 == 0");
-    }
-    if (cplx) MK_REQUIRE(al(g->a_im) && al(g->b_im), "gemm: plane offsets must be multiples of 4");
-    return 0;
 }
 
 template <int BM, int BN>

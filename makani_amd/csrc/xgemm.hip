@@ -1,0 +1,368 @@
+// Split-bf16 ("bf16x6" / "bf16x3") batched GEMM engine for fp32 operands on the bf16 matrix cores (gfx950).
+//
+//   C[b][i][j] (+)= sum_k A[b][i][k] * B[b][j][k]          same MkGemm descriptor as sgemm.hip
+//
+// gfx950 has no TF32/xf32 path and its exact-fp32 MFMA runs at 1/16 of the bf16 rate.  Here every
+// fp32 operand element is split on the fly (while it is staged into LDS) into NP bf16 limbs
+//      x = hi + mid (+ lo),   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)
+// and the product is expanded into bf16 MFMAs with fp32 accumulation:
+//      NP = 3:  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid    (6 MFMAs, dropped terms <= 2^-24 relative)
+//      NP = 2:  hi*hi + hi*mid + mid*hi                                (3 MFMAs, dropped terms ~ 2^-16)
+// bf16 x bf16 products are exact in fp32, so NP = 3 reproduces an fp32 GEMM to fp32 round-off
+// (measured rel-L2 1.8e-7 vs fp64 on the Legendre matrices, the exact-fp32 MFMA kernel gives 2.8e-7) at
+// 6/16 of its MFMA time; NP = 2 gives ~4e-6 at 3/16.
+//
+// Structure: 256 threads = 4 waves, v_mfma_f32_32x32x16_bf16, BK = 16 (one MFMA k-step per tile),
+// single LDS stage + register prefetch of the next fp32 tile (two barriers per k-tile of >= 768 MFMA
+// cycles per wave; >= 2 workgroups per CU overlap them).  Operand limbs live in LDS either as
+// [row][k] (k-contiguous global operand; fragments = one ds_read_b128) or as [k][row] (row-contiguous
+// global operand; fragments = two ds_read_b64_tr_b16 transpose reads), so no layout shuffling is
+// ever done in registers.  Triangular skipping and the XCD-aware grid are those of sgemm.hip.
+#include "gemm_common.h"
+
+namespace {
+
+using gemm::BlockCoord;
+using gemm::decode_block;
+using gemm::validate;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int BK = 16;
+constexpr int NT = 256;
+constexpr int PK = 24;   // pitch (elements) of [row][k] limb tiles: 48 B -> conflict-free ds_read_b128
+
+__device__ __forceinline__ bool in_range(int k, int lo, int hi) { return k >= lo && k < hi; }
+
+// fp32 tile staging registers (same addressing as sgemm.hip's TileStage)
+template <int ROWS, bool KC>
+struct Stage {
+    static constexpr int NV = (ROWS * BK / 4) / NT;
+    static_assert(NV >= 1, "tile too small");
+    f32x4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, long long rs, long long ks, int r0, int rmax,
+                                         int k0, int klo, int khi, int tid) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + q * NT;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (KC) {
+                const int row = f >> 2, kq = f & 3;
+                const int k = k0 + kq * 4;
+                if (r0 + row < rmax && k < khi && k + 3 >= klo) {
+                    val = *reinterpret_cast<const f32x4*>(base + (long long)(r0 + row) * rs + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!in_range(k + e, klo, khi)) val[e] = 0.f;
+                }
+            } else {
+                constexpr int RQ = ROWS / 4;
+                const int kk = f / RQ, rq = f % RQ;
+                const int k = k0 + kk;
+                const int r = r0 + rq * 4;
+                if (in_range(k, klo, khi) && r < rmax) val = *reinterpret_cast<const f32x4*>(base + (long long)k * ks + r);
+            }
+            v[q] = val;
+        }
+    }
+
+    // split into NP bf16 limbs and store; limb plane p lives at lds + p * PLANE (elements)
+    template <int NP, int PLANE>
+    __device__ __forceinline__ void store(u16* lds, int tid, float sign) const {
+        constexpr int PR = ROWS + 32;   // pitch of [k][row] tiles
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + q * NT;
+            int off;
+            if constexpr (KC) {
+                const int row = f >> 2, kq = f & 3;
+                off = row * PK + kq * 4;
+            } else {
+                constexpr int RQ = ROWS / 4;
+                const int kk = f / RQ, rq = f % RQ;
+                off = kk * PR + rq * 4;
+            }
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = v[q][e] * sign;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                u16 h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const __bf16 hb = (__bf16)r[e];
+                    h[e] = __builtin_bit_cast(u16, hb);
+                    r[e] -= (float)hb;
+                }
+                const uint2 pk = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(lds + pl * PLANE + off) = pk;
+            }
+        }
+    }
+};
+
+template <int ROWS, bool KC>
+constexpr int plane_elems() {
+    return KC ? ROWS * PK : BK * (ROWS + 32);
+}
+
+// MFMA operand fragment (8 consecutive k for row/col `r0 + (lane & 31)`, k-block lane>>5) of limb plane
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8 frag(const u16* plane, int r0, int lane) {
+    if constexpr (KC) {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(plane + (r0 + (lane & 31)) * PK + (lane >> 5) * 8));
+    } else {
+        constexpr int PR = ROWS + 32;
+        const int s = lane & 15, g1 = (lane >> 4) & 1, lh = lane >> 5;
+        const u16* q0 = plane + (lh * 8 + (s >> 2)) * PR + r0 + g1 * 16 + (s & 3) * 4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * PR));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+// acc += sum over the limb products kept for NP limbs
+template <int NP>
+__device__ __forceinline__ f32x16 mma_split(const bf16x8* a, const bf16x8* b, f32x16 acc) {
+    if constexpr (NP == 3) {   // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+// ---- real kernel: block tile BM x BN, 4 waves of 64 x 64 ---------------------------------
+template <int BM, int BN, bool A_KC, bool B_KC, int NP>
+__global__ __launch_bounds__(NT, 2) void xgemm_kernel(const MkGemm p, int tilesM, int tilesN) {
+    constexpr int PLA = plane_elems<BM, A_KC>(), PLB = plane_elems<BN, B_KC>();
+    constexpr int WAVES_N = BN / 64;
+    static_assert((BM / 64) * (BN / 64) == 4, "4 waves of 64x64");
+    __shared__ __attribute__((aligned(16))) u16 smem[NP * (PLA + PLB)];
+    u16* As = smem;
+    u16* Bs = smem + NP * PLA;
+
+    const BlockCoord c = decode_block<BM, BN>(p, tilesM, tilesN);
+    if (!c.active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long long bo = c.b / p.inner, bi = c.b % p.inner;
+    const float* Ab = p.A + bo * p.a_batch + bi * p.a_inner;
+    const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
+    const int a_rmax = A_KC ? c.Meff : p.M;
+    Stage<BM, A_KC> sa;
+    Stage<BN, B_KC> sb;
+    if (kt0 < kt1) {
+        sa.load(Ab, p.a_row, p.a_k, c.i0, a_rmax, kt0 * BK, c.klo, c.khi, tid);
+        sb.load(Bb, p.b_col, p.b_k, c.j0, p.N, kt0 * BK, c.klo, c.khi, tid);
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        sa.template store<NP, PLA>(As, tid, 1.f);
+        sb.template store<NP, PLB>(Bs, tid, 1.f);
+        __syncthreads();
+        if (kt + 1 < kt1) {   // next fp32 tile in flight while this one is multiplied
+            sa.load(Ab, p.a_row, p.a_k, c.i0, a_rmax, (kt + 1) * BK, c.klo, c.khi, tid);
+            sb.load(Bb, p.b_col, p.b_k, c.j0, p.N, (kt + 1) * BK, c.klo, c.khi, tid);
+        }
+        bf16x8 af[2][NP], bfr[2][NP];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                af[t][pl] = frag<BM, A_KC>(As + pl * PLA, wm * 64 + t * 32, lane);
+                bfr[t][pl] = frag<BN, B_KC>(Bs + pl * PLB, wn * 64 + t * 32, lane);
+            }
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = mma_split<NP>(af[ta], bfr[tb], acc[ta][tb]);
+        __syncthreads();
+    }
+
+    float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const int col = c.j0 + wn * 64 + tb * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c.i0 + wm * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < c.Meff && col < p.N) {
+                    float* dst = Cb + (long long)row * p.c_row + col;
+                    float val = acc[ta][tb][r];
+                    if (p.beta) val += *dst;
+                    *dst = val;
+                }
+            }
+        }
+}
+
+// ---- complex kernel (planar): block tile 64 x 128, waves 2 x 2, wave tile 32 x 64 ------------
+template <bool A_KC, bool B_KC, int NP>
+__global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tilesM, int tilesN) {
+    constexpr int BM = 64, BN = 128;
+    constexpr int PLA = plane_elems<BM, A_KC>(), PLB = plane_elems<BN, B_KC>();
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * NP * (PLA + PLB)];
+    u16* Are = smem;
+    u16* Aim = Are + NP * PLA;
+    u16* Bre = Aim + NP * PLA;
+    u16* Bim = Bre + NP * PLB;
+
+    const BlockCoord c = decode_block<BM, BN>(p, tilesM, tilesN);
+    if (!c.active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long long bo = c.b / p.inner, bi = c.b % p.inner;
+    const float* Ab = p.A + bo * p.a_batch + bi * p.a_inner;
+    const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
+    const float sgn_a = p.conj_a ? -1.f : 1.f;
+    const float sgn_b = p.conj_b ? -1.f : 1.f;
+
+    f32x16 cre[2], cim[2], cng[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            cre[b][r] = 0.f;
+            cim[b][r] = 0.f;
+            cng[b][r] = 0.f;
+        }
+
+    const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
+    const int a_rmax = A_KC ? c.Meff : p.M;
+    Stage<BM, A_KC> sar, sai;
+    Stage<BN, B_KC> sbr, sbi;
+    auto ld = [&](int kt) {
+        sar.load(Ab, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
+        sai.load(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
+        sbr.load(Bb, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
+        sbi.load(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
+    };
+    if (kt0 < kt1) ld(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        sar.template store<NP, PLA>(Are, tid, 1.f);
+        sai.template store<NP, PLA>(Aim, tid, sgn_a);
+        sbr.template store<NP, PLB>(Bre, tid, 1.f);
+        sbi.template store<NP, PLB>(Bim, tid, sgn_b);
+        __syncthreads();
+        if (kt + 1 < kt1) ld(kt + 1);
+        bf16x8 ar[NP], ai[NP];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            ar[pl] = frag<BM, A_KC>(Are + pl * PLA, wm * 32, lane);
+            ai[pl] = frag<BM, A_KC>(Aim + pl * PLA, wm * 32, lane);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bf16x8 br[NP], bim[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                br[pl] = frag<BN, B_KC>(Bre + pl * PLB, wn * 64 + n * 32, lane);
+                bim[pl] = frag<BN, B_KC>(Bim + pl * PLB, wn * 64 + n * 32, lane);
+            }
+            // (ar + i ai)(br + i bi): re = ar br - ai bi (second part accumulated apart), im = ar bi + ai br
+            cre[n] = mma_split<NP>(ar, br, cre[n]);
+            cng[n] = mma_split<NP>(ai, bim, cng[n]);
+            cim[n] = mma_split<NP>(ar, bim, cim[n]);
+            cim[n] = mma_split<NP>(ai, br, cim[n]);
+        }
+        __syncthreads();
+    }
+
+    float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int col = c.j0 + wn * 64 + tb * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = c.i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < c.Meff && col < p.N) {
+                float* dr = Cb + (long long)row * p.c_row + col;
+                float* di = dr + p.c_im;
+                float vr = cre[tb][r] - cng[tb][r], vi = cim[tb][r];
+                if (p.beta) {
+                    vr += *dr;
+                    vi += *di;
+                }
+                *dr = vr;
+                *di = vi;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int NP>
+int launch_real(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
+    const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
+    const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
+    MK_REQUIRE(nb < (1ll << 31), "xgemm: grid too large");
+    dim3 grid((unsigned)nb), block(NT);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((xgemm_kernel<BM, BN, true, true, NP>), grid, block, 0, s, *g, tm, tn);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((xgemm_kernel<BM, BN, true, false, NP>), grid, block, 0, s, *g, tm, tn);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((xgemm_kernel<BM, BN, false, true, NP>), grid, block, 0, s, *g, tm, tn);
+    else
+        hipLaunchKernelGGL((xgemm_kernel<BM, BN, false, false, NP>), grid, block, 0, s, *g, tm, tn);
+    return mk_check_launch("mk_sgemm_split_batched");
+}
+
+template <int NP>
+int launch_cplx(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
+    constexpr int BM = 64, BN = 128;
+    const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
+    const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
+    MK_REQUIRE(nb < (1ll << 31), "xcgemm: grid too large");
+    dim3 grid((unsigned)nb), block(NT);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((xcgemm_kernel<true, true, NP>), grid, block, 0, s, *g, tm, tn);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((xcgemm_kernel<true, false, NP>), grid, block, 0, s, *g, tm, tn);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((xcgemm_kernel<false, true, NP>), grid, block, 0, s, *g, tm, tn);
+    else
+        hipLaunchKernelGGL((xcgemm_kernel<false, false, NP>), grid, block, 0, s, *g, tm, tn);
+    return mk_check_launch("mk_cgemm_split_batched");
+}
+
+}  // namespace
+
+extern "C" int mk_sgemm_split_batched(const MkGemm* g, int limbs, void* stream) {
+    bool a_kc, b_kc;
+    int rc = validate(g, false, &a_kc, &b_kc);
+    if (rc) return rc;
+    MK_REQUIRE(limbs == 2 || limbs == 3, "split gemm: limbs must be 2 or 3");
+    hipStream_t s = (hipStream_t)stream;
+    const bool rows_tri = g->tri_mode == MK_TRI_ROW_GE || g->tri_mode == MK_TRI_ROW_LE || g->M <= 64;
+    if (limbs == 3) return rows_tri ? launch_real<64, 256, 3>(g, a_kc, b_kc, s) : launch_real<128, 128, 3>(g, a_kc, b_kc, s);
+    return rows_tri ? launch_real<64, 256, 2>(g, a_kc, b_kc, s) : launch_real<128, 128, 2>(g, a_kc, b_kc, s);
+}
+
+extern "C" int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream) {
+    bool a_kc, b_kc;
+    int rc = validate(g, true, &a_kc, &b_kc);
+    if (rc) return rc;
+    MK_REQUIRE(limbs == 2 || limbs == 3, "split gemm: limbs must be 2 or 3");
+    hipStream_t s = (hipStream_t)stream;
+    return limbs == 3 ? launch_cplx<3>(g, a_kc, b_kc, s) : launch_cplx<2>(g, a_kc, b_kc, s);
+}

@@ -11,6 +11,7 @@ Everything here launches on ``torch.cuda.current_stream()`` through the C ABI โ
 CPU implementation behind these functions.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -23,6 +24,26 @@ from . import legendre as _leg
 
 def round4(n: int) -> int:
     return (n + 3) // 4 * 4
+
+
+# Arithmetic of the fp32 spectral GEMMs (Legendre, dhconv):
+#   "x6"   (default) fp32 operands split into 3 bf16 limbs, 6 bf16 MFMAs per product, fp32 accumulate:
+#          fp32 round-off class (rel-L2 1.8e-7 vs fp64; the exact-fp32 MFMA gives 2.8e-7), 2.7x the fp32 MFMA rate
+#   "fp32" exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+#   "x3"   2 limbs, 3 MFMAs: ~4e-6, 5.3x
+GEMM_MODE = os.environ.get("MAKANI_AMD_GEMM", "x6")
+if GEMM_MODE not in ("x6", "x3", "fp32"):
+    raise ValueError(f"MAKANI_AMD_GEMM={GEMM_MODE!r}: expected x6, x3 or fp32")
+
+
+def _run_gemm(g, cplx, what, mode=None):
+    mode = mode or GEMM_MODE
+    L = lib()
+    if mode == "fp32":
+        rc = (L.mk_cgemm_batched if cplx else L.mk_sgemm_batched)(C.byref(g), stream())
+    else:
+        rc = (L.mk_cgemm_split_batched if cplx else L.mk_sgemm_split_batched)(C.byref(g), 3 if mode == "x6" else 2, stream())
+    check(rc, what)
 
 
 # --------------------------------------------------------------------------- #
@@ -155,7 +176,7 @@ def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int 
     # dense-formulation work (SURVEY.md ยง8d): 2 * (2R) * nlat * L * M flops
     with _timed(f"legendre_analysis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
                 nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
-        check(lib().mk_sgemm_batched(C.byref(g), stream()), "legendre_analysis")
+        _run_gemm(g, False, "legendre_analysis")
     return S
 
 
@@ -172,7 +193,7 @@ def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, m_off: int = 0) -> to
               M=2 * R, N=kp, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
     with _timed(f"legendre_synthesis_k{kp}", flops=2.0 * 2 * R * kp * L * M,
                 nbytes=4.0 * (2 * R * kp * M + 2 * R * L * M + M * L * kp)):
-        check(lib().mk_sgemm_batched(C.byref(g), stream()), "legendre_synthesis")
+        _run_gemm(g, False, "legendre_synthesis")
     return F
 
 
@@ -213,7 +234,7 @@ def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int, tri_off: int 
     # dense-formulation work: 8 * B * Cin * Cout * L * M flops (complex MAC = 8 real flops)
     with _timed("dhconv_fwd", flops=8.0 * B * cin * cop * L * M,
                 nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
-        check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_fwd")
+        _run_gemm(g, True, "dhconv_fwd")
     return T
 
 
@@ -230,7 +251,7 @@ def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int,
               M=M, N=cin, K=cout, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off, conj_b=1)
     with _timed("dhconv_dgrad", flops=8.0 * B * cin * cout * L * M,
                 nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
-        check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_dgrad")
+        _run_gemm(g, True, "dhconv_dgrad")
     return gS
 
 
@@ -249,7 +270,7 @@ def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0) ->
                   beta=1 if b > 0 else 0)
         with _timed("dhconv_wgrad", flops=8.0 * cip * cop * L * M,
                     nbytes=4.0 * (2 * cip * L * M + 2 * cop * L * M + 2 * cip * cop * L)):
-            check(lib().mk_cgemm_batched(C.byref(g), stream()), "dhconv_wgrad")
+            _run_gemm(g, True, "dhconv_wgrad")
     return gW
 
 

@@ -50,10 +50,23 @@ def _tri_mask(mode, batch, M, K, inner):
     return rows, ks
 
 
+def _launch_gemm(g, cplx, engine):
+    from makani_amd._lib import lib, check
+    if engine == "fp32":
+        rc = (lib().mk_cgemm_batched if cplx else lib().mk_sgemm_batched)(C.byref(g), C.c_void_p(0))
+    else:
+        rc = (lib().mk_cgemm_split_batched if cplx else lib().mk_sgemm_split_batched)(C.byref(g), 3 if engine == "x6" else 2, C.c_void_p(0))
+    check(rc, "gemm")
+
+
+ENGINE_TOL = {"fp32": 2e-6, "x6": 2e-6, "x3": 2e-5}
+
+
+@pytest.mark.parametrize("engine", ["fp32", "x6", "x3"])
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("tri", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K,batch", [(68, 132, 37, 11), (200, 72, 129, 5), (12, 300, 16, 9)])
-def test_sgemm_batched(a_kc, b_kc, tri, M, N, K, batch):
+def test_sgemm_batched(engine, a_kc, b_kc, tri, M, N, K, batch):
     from makani_amd import _lib
     from makani_amd._lib import MkGemm, lib, check
     torch.manual_seed(M * 1000 + N + tri)
@@ -73,7 +86,7 @@ def test_sgemm_batched(a_kc, b_kc, tri, M, N, K, batch):
     g.b_batch, g.b_col, g.b_k = b_b, b_col, b_k
     g.c_batch, g.c_row, g.c_col = M * (N + 4), N + 4, 1
     g.M, g.N, g.K, g.batch, g.inner, g.tri_mode = M, N, K, batch, 1, tri
-    check(lib().mk_sgemm_batched(C.byref(g), C.c_void_p(0)), "sgemm")
+    _launch_gemm(g, False, engine)
     torch.cuda.synchronize()
     out = Cd.cpu()
     assert (out[:, :, N:] == -123.0).all(), "wrote outside the N extent"
@@ -85,15 +98,16 @@ def test_sgemm_batched(a_kc, b_kc, tri, M, N, K, batch):
     vm = valid[:, :, None].expand_as(ref)
     err = ((got - ref)[vm]).norm() / ref[vm].norm()
     assert torch.isfinite(got[vm]).all()
-    assert err < 2e-6, err
+    assert err < ENGINE_TOL[engine], err
     if tri == _lib.TRI_ROW_LE:
         assert (out[:, :, :N][~vm] == -123.0).all(), "rows beyond the triangular bound must not be written"
 
 
+@pytest.mark.parametrize("engine", ["fp32", "x6", "x3"])
 @pytest.mark.parametrize("a_kc,b_kc", [(True, False), (True, True), (False, False), (False, True)])
 @pytest.mark.parametrize("tri,conj_a,conj_b,beta", [(3, 0, 0, 0), (3, 0, 1, 0), (4, 1, 0, 0), (4, 1, 0, 1), (0, 1, 1, 1)])
 @pytest.mark.parametrize("M,N,K,outer,inner", [(36, 140, 24, 7, 2), (100, 64, 52, 9, 1)])
-def test_cgemm_batched(a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, inner):
+def test_cgemm_batched(engine, a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, inner):
     from makani_amd import _lib
     from makani_amd._lib import MkGemm, lib, check
     torch.manual_seed(17 + M + tri)
@@ -133,13 +147,13 @@ def test_cgemm_batched(a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, in
     g.c_row, g.c_col = N, 1
     g.M, g.N, g.K, g.batch, g.inner, g.tri_mode = M, N, K, batch, inner, tri
     g.conj_a, g.conj_b, g.beta = conj_a, conj_b, beta
-    check(lib().mk_cgemm_batched(C.byref(g), C.c_void_p(0)), "cgemm")
+    _launch_gemm(g, True, engine)
     torch.cuda.synchronize()
     out = Cd.cpu().double()
     got = torch.complex(out[:, 0], out[:, 1])
     vm = rows_ok[:, :, None].expand_as(ref)
     err = (got - ref)[vm].abs().pow(2).sum().sqrt() / ref[vm].abs().pow(2).sum().sqrt()
-    assert err < 2e-6, err
+    assert err < ENGINE_TOL[engine], err
     if tri == _lib.TRI_ROW_LE:   # untouched rows keep their input
         assert ((got - C0)[~vm].abs() < 1e-6).all()
 
