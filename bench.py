@@ -36,6 +36,7 @@ CONFIGS = {
                        embed_dim=64, num_layers=4, mlp_ratio=2),
 }
 PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TF = 2500.0    # dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -53,42 +54,68 @@ def l2_loss(pred, tar, q):
 
 
 class GradReducer:
-    """Data-parallel gradient averaging over RCCL, overlapped with backward: every parameter's
-    gradient is all-reduced (async) from its post-accumulate hook — the eight 283 MB spectral
-    weights are natural large messages, the small pointwise parameters are flushed in one bucket."""
+    """Gradient reduction over RCCL, overlapped with backward: every parameter's gradient is all-reduced
+    (async) from its post-accumulate hook — the eight 283 MB spectral weights are natural large messages,
+    small parameters are flushed in one bucket per group.
 
-    def __init__(self, model, world):
-        self.world = world
+    data parallel:   mean over the data group (all ranks when no model parallelism).
+    spatial h x w:   SUM over the groups a parameter is shared across, as makani's hook does
+                     (makani/mpu/mappings.py:460-523): spectral weights (l-sharded over h) over "w",
+                     everything else over "spatial"; then the data-parallel mean."""
+
+    def __init__(self, model, data_group=None, data_size=1, spatial_group=None, w_group=None):
+        self.data_group, self.data_size = data_group, data_size
+        self.spatial_group, self.w_group = spatial_group, w_group
         self.handles = []
-        self.small = []
+        self.small = {}
         self.big_bytes = 8 << 20
-        if world > 1:
-            for p in model.parameters():
-                p.register_post_accumulate_grad_hook(self._hook)
+        self.active = data_size > 1 or spatial_group is not None
+        if self.active:
+            for name, p in model.named_parameters():
+                p.register_post_accumulate_grad_hook(lambda q, n=name: self._hook(q, n))
 
-    def _hook(self, p):
+    def _groups_for(self, name):
+        out = []
+        if self.spatial_group is not None:
+            if name.endswith("filter.filter.weight"):
+                if self.w_group is not None:
+                    out.append((self.w_group, 1.0))
+            else:
+                out.append((self.spatial_group, 1.0))
+        if self.data_size > 1:
+            out.append((self.data_group, 1.0 / self.data_size))
+        return out
+
+    def _hook(self, p, name):
         g = torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad
-        if g.numel() * g.element_size() >= self.big_bytes:
-            self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True), g))
+        groups = self._groups_for(name)
+        if not groups:
+            return
+        if g.numel() * g.element_size() >= self.big_bytes and len(groups) == 1:
+            grp, scale = groups[0]
+            self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=grp, async_op=True), g, scale))
         else:
-            self.small.append(g)
+            self.small.setdefault(tuple(id(x[0]) for x in groups), (groups, []))[1].append(g)
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
-        if self.small:
-            flat = torch.cat([g.reshape(-1) for g in self.small])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(self.world)
+        for groups, grads in self.small.values():
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            for grp, scale in groups:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=grp)
+                if scale != 1.0:
+                    flat.mul_(scale)
             off = 0
-            for g in self.small:
+            for g in grads:
                 n = g.numel()
                 g.copy_(flat[off:off + n].view_as(g))
                 off += n
-            self.small = []
-        for h, g in self.handles:
+        self.small = {}
+        for h, g, scale in self.handles:
             h.wait()
-            g.div_(self.world)
+            if scale != 1.0:
+                g.mul_(scale)
         self.handles = []
 
 
@@ -117,14 +144,36 @@ def clip_grads(model, max_norm):
     return total
 
 
-def train_step(model, opt, reducer, inp, tar, q, amp):
+class ClipState:
+    """global gradient norm when the spectral weights are sharded over the h group: their squared norms
+    are summed over h, replicated parameters count once (training_helpers.py:123-165)."""
+
+    def __init__(self, model, h_group):
+        self.h_group = h_group
+        self.sharded = [p for n, p in model.named_parameters() if n.endswith("filter.filter.weight")]
+        self.repl = [p for n, p in model.named_parameters() if not n.endswith("filter.filter.weight")]
+
+    def scale(self, max_norm):
+        def sq(ps):
+            gs = [torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad for p in ps if p.grad is not None]
+            return torch.stack(torch._foreach_norm(gs)).square().sum() if gs else torch.zeros((), device="cuda")
+        s = sq(self.sharded)
+        dist.all_reduce(s, group=self.h_group)
+        total = torch.sqrt(s + sq(self.repl))
+        return torch.clamp(max_norm / (total + 1e-6), max=1.0).float().reshape(1)
+
+
+def train_step(model, opt, reducer, inp, tar, q, amp, clip=None):
     opt.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         pred = model(inp)
     loss = l2_loss(pred, tar, q)
     loss.backward()
     reducer.finish()
-    opt.step(max_grad_norm=32.0)          # global-norm clipping folded into the AdamW pass
+    if clip is not None and clip.h_group is not None:
+        opt.step(grad_scale=clip.scale(32.0))
+    else:
+        opt.step(max_grad_norm=32.0)      # global-norm clipping folded into the AdamW pass
     return loss
 
 
@@ -210,6 +259,9 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (not the BASELINE metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sht-metric", action="store_true")
+    ap.add_argument("--parallelism", default=os.environ.get("MAKANI_AMD_PARALLELISM", "dp"),
+                    help="'dp' (default: one sample per GPU, weak scaling) or 'hHwW' e.g. h4w2: spatial model "
+                         "parallelism over H x W GPUs per model instance (strong scaling), remaining ranks data parallel")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -222,27 +274,79 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    backend = os.environ.get("MAKANI_AMD_BENCH_BACKEND", "nccl")    # "gloo": functional test of N ranks on one GPU
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from makani_amd import ops
+    import makani_amd.distributed as thd
+
+    # ---- process-group tree: world -> data x (h x w), as makani/utils/comm.py:114-201 ----
+    par = args.parallelism
+    ph = pw = 1
+    if par != "dp":
+        import re
+        mt = re.fullmatch(r"h(\d+)w(\d+)", par)
+        if not mt:
+            raise SystemExit(f"--parallelism {par!r}: expected 'dp' or 'hHwW'")
+        ph, pw = int(mt.group(1)), int(mt.group(2))
+    msize = ph * pw
+    if world % msize:
+        raise SystemExit(f"world size {world} is not a multiple of h*w = {msize}")
+    dsize = world // msize
+    d_idx, m_idx = rank // msize, rank % msize
+    ih, iw = m_idx // pw, m_idx % pw
+    data_group = spatial_group = h_group = w_group = None
+    if world > 1:
+        for d in range(dsize):
+            base = d * msize
+            if msize > 1:
+                g = dist.new_group(list(range(base, base + msize)))
+                if d == d_idx:
+                    spatial_group = g
+                for j in range(pw):
+                    g = dist.new_group([base + i * pw + j for i in range(ph)])
+                    if d == d_idx and j == iw:
+                        h_group = g
+                for i in range(ph):
+                    g = dist.new_group([base + i * pw + j for j in range(pw)])
+                    if d == d_idx and i == ih:
+                        w_group = g
+        if dsize > 1:
+            for m in range(msize):
+                g = dist.new_group([d * msize + m for d in range(dsize)])
+                if m == m_idx:
+                    data_group = g
+    if msize > 1:
+        thd.init(h_group if ph > 1 else None, w_group if pw > 1 else None, spatial_group)
 
     cfg = CONFIGS[args.config]
     H, W = cfg["inp_shape"]
     B = 1
     model = build_model(args.config, device, seed=333)            # same seed on every rank -> same init
     opt = make_optimizer(model)
-    reducer = GradReducer(model, world)
-    torch.manual_seed(333 + rank)                                  # DummyLoader: fixed U[0,1) tensors on device
+    reducer = GradReducer(model, data_group, dsize, spatial_group if msize > 1 else None, w_group if pw > 1 else None)
+    torch.manual_seed(333 + d_idx)                                 # DummyLoader: fixed U[0,1) tensors on device
     inp = torch.rand(B, cfg["inp_chans"], H, W, device=device)
     tar = torch.rand(B, cfg["out_chans"], H, W, device=device)
     q = quadrature_weights(H, W, device)
+    if msize > 1:                                                  # this rank's lat/lon shard (dataloaders shard likewise)
+        lat0, lon0 = sum(model.trans_down.lat_shapes[:ih]), sum(model.trans_down.lon_shapes[:iw])
+        hl, wl = model.inp_shape_loc
+        inp = inp[..., lat0:lat0 + hl, lon0:lon0 + wl].contiguous()
+        tar = tar[..., lat0:lat0 + hl, lon0:lon0 + wl].contiguous()
+        q = q[lat0:lat0 + hl, lon0:lon0 + wl].contiguous()
     amp = not args.fp32
+    clip = ClipState(model, h_group if ph > 1 else None)
 
     for _ in range(args.warmup):
-        train_step(model, opt, reducer, inp, tar, q, amp)
+        train_step(model, opt, reducer, inp, tar, q, amp, clip)
     torch.cuda.synchronize()
 
     ops.PROFILER.reset()
@@ -252,7 +356,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(model, opt, reducer, inp, tar, q, amp)
+        loss = train_step(model, opt, reducer, inp, tar, q, amp, clip)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -282,10 +386,16 @@ def main():
             d = prof[dom_name]
             if d["flops"]:
                 ach = d["flops"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e12
-                roofline = dict(kernel=dom_name, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF,
-                                unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TF, 4), traffic=None,
-                                note="dense-formulation fp32 flops per launch / HIP-event launch time; the kernel "
-                                     "skips the structurally-zero l<m half (DESIGN.md §4)")
+                if dom_name.startswith("conv1x1"):
+                    peak, eng = PEAK_BF16_MFMA_TF, "bf16 MFMA"
+                else:   # fp32 spectral GEMM: peak of the engine it runs on, in fp32-equivalent flops
+                    peak, eng = {"fp32": (PEAK_F32_MFMA_TF, "exact-fp32 MFMA"),
+                                 "x6": (PEAK_BF16_MFMA_TF / 6, "bf16 MFMA, 6 limb products per fp32 product"),
+                                 "x3": (PEAK_BF16_MFMA_TF / 3, "bf16 MFMA, 3 limb products per fp32 product")}[ops.GEMM_MODE]
+                roofline = dict(kernel=dom_name, bound="mfma", achieved=round(ach, 2), peak=round(peak, 1),
+                                unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+                                note=f"dense-formulation fp32-equivalent flops per launch / HIP-event launch time; "
+                                     f"engine: {eng}; the kernel skips the structurally-zero l<m half (DESIGN.md §4)")
             else:
                 ach = d["bytes"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e9
                 roofline = dict(kernel=dom_name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -293,19 +403,19 @@ def main():
         hip_ms = sum(d["ms_total"] for d in prof.values()) / args.steps
         out = {
             "metric": "SFNO train samples/sec at 721x1440x73ch",
-            "value": world * B * args.steps / elapsed,
+            "value": dsize * B * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if msize == 1 else "strong",
             "vs_baseline": None,
             "dtype": "bf16" if amp else "f32",
             "data": "synthetic",
             "config": {"workload": args.config, "grid": f"{H}x{W}", "channels": cfg["inp_chans"],
-                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "global_batch": dsize * B, "parallelism": f"dp{dsize}" + (f"_h{ph}w{pw}" if msize > 1 else ""),
                        "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32"},
             "roofline": roofline,
             "hip_kernels": kernels,

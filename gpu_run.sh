@@ -1,8 +1,6 @@
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -q --tb=short --timeout=300 > gpurun_out/t_all.log 2>&1
-echo "tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/t_all.log | tail -8
-MAKANI_AMD_GEMM=fp32 timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q --tb=short --timeout=300 2>&1 | tail -2
-MAKANI_AMD_GEMM=x3 timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q --tb=line --timeout=300 2>&1 | tail -6
-timeout 250 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_full.log 2>gpurun_out/bench_full.err
-echo "bench rc=$?"; tail -1 gpurun_out/bench_full.log | cut -c1-200
-timeout 100 python __graft_entry__.py smoke 2>&1 | tail -1
+export MAKANI_AMD_BENCH_BACKEND=gloo
+for par in dp h2w1 h1w2 h2w2; do
+  n=2; [ $par = h2w2 ] && n=4
+  echo "== $par n=$n"
+  timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus $n --config sfno_debug --parallelism $par --steps 3 --warmup 1 --no-cpu-baseline --no-sht-metric 2>&1 | grep -E "^\{|Error|error|Traceback" | cut -c1-330
+done

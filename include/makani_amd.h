@@ -116,7 +116,10 @@ int mk_complex_to_slayout(const float* in_c64, float* S, int B, int C, int Cp, i
  * (statistics in fp32 as in makani/mpu/layer_norm.py:147-168); optional fused exact-erf GELU
  * (nn.GELU, sfnonet.py:392-393).  stats: (planes, 2) f32 = {mean, rstd}.
  * Backward: sums (planes, 2) f32 = {sum ga, sum ga * xhat} (dbeta / dgamma per plane),
- * gx = rstd*gamma*(ga - mean(ga) - xhat*mean(ga*xhat)), ga = gy * (gelu'(a) if fused).       */
+ * gx = rstd*gamma*(ga - mean(ga) - xhat*mean(ga*xhat)), ga = gy * (gelu'(a) if fused).
+ * phase 0 = reduce + apply (serial); 1 = reduce only (writes the local `sums`); 2 = apply only with the
+ * caller-provided (all-reduced) `sums` and `hw_total` = pixels of the whole plane over all spatial ranks —
+ * the split DistributedInstanceNorm2d (makani/mpu/layer_norm.py:108-170) needs.                      */
 int mk_pointwise_chunks(long long hw, int dtype);
 int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long long planes, long long hw, float eps,
                       void* stream);
@@ -124,7 +127,7 @@ int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, con
                       long long planes, int channels, long long hw, int fuse_gelu, void* stream);
 int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
                     const float* beta, float* sums, float* ws, long long planes, int channels, long long hw,
-                    int fuse_gelu, void* stream);
+                    long long hw_total, int phase, int fuse_gelu, void* stream);
 /* y = gelu(x + bias[c])  — the bias+activation of the 1x1 convolutions in MLP / EncoderDecoder
  * (makani/models/common/layers.py:603-643,768-823).  bias may be NULL (plain GELU).
  * Backward: gx = gy * gelu'(x + bias[c]); optional sums (planes,2): sums[p][0] = sum gx (bias grad). */

@@ -234,14 +234,13 @@ template <typename T, bool GELU>
 __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx,
                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ sums,
-                                                   int channels, long long hw, int chunks) {
+                                                   int channels, long long hw, int chunks, float inv_total) {
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const int c = (int)(plane % channels);
     const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float inv = 1.0f / (float)hw;
-    const float m1 = sums[2 * plane] * inv, m2 = sums[2 * plane + 1] * inv;
+    const float m1 = sums[2 * plane] * inv_total, m2 = sums[2 * plane + 1] * inv_total;
     const float k = rstd * g;
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;
@@ -406,21 +405,26 @@ extern "C" int mk_instnorm_apply(const void* x, void* y, int dtype, const float*
 
 extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats,
                                const float* gamma, const float* beta, float* sums, float* ws, long long planes,
-                               int channels, long long hw, int fuse_gelu, void* stream) {
+                               int channels, long long hw, long long hw_total, int phase, int fuse_gelu, void* stream) {
     int rc = check_common(x, planes, hw, dtype, "instnorm_bwd");
     if (rc) return rc;
     MK_REQUIRE(gy && gx && stats && sums && ws && channels > 0, "instnorm_bwd: bad args");
+    MK_REQUIRE(phase >= 0 && phase <= 2 && hw_total >= hw, "instnorm_bwd: bad phase / hw_total");
     hipStream_t s = (hipStream_t)stream;
     const int fb = (int)((planes + 255) / 256);
+    const float inv_total = 1.0f / (float)hw_total;
 #define IN_BWD(T, G)                                                                                                   \
     do {                                                                                                               \
         const int ch = chunks_for<T>(hw);                                                                              \
         dim3 g((unsigned)(planes * ch));                                                                               \
-        hipLaunchKernelGGL((in_bwd_partial<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, stats, gamma, beta,  \
-                           ws, channels, hw, ch);                                                                      \
-        hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);                         \
-        hipLaunchKernelGGL((in_bwd_apply<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, (T*)gx, stats, gamma,  \
-                           beta, sums, channels, hw, ch);                                                              \
+        if (phase != 2) {                                                                                              \
+            hipLaunchKernelGGL((in_bwd_partial<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, stats, gamma,    \
+                               beta, ws, channels, hw, ch);                                                            \
+            hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);                     \
+        }                                                                                                              \
+        if (phase != 1)                                                                                                \
+            hipLaunchKernelGGL((in_bwd_apply<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, (T*)gx, stats,     \
+                               gamma, beta, sums, channels, hw, ch, inv_total);                                        \
     } while (0)
     if (dtype == MK_F32) {
         if (fuse_gelu) IN_BWD(float, true); else IN_BWD(float, false);

@@ -31,15 +31,39 @@ from . import legendre as _leg
 from . import ops
 from .sht import RealSHT, InverseRealSHT
 
+def _size(group) -> int:
+    return 1 if group is None else dist.get_world_size(group)
+
+
+def _rank(group) -> int:
+    return 0 if group is None else dist.get_rank(group)
+
+
 _POLAR = None      # "h" group: latitude / degree l
 _AZIMUTH = None    # "w" group: longitude / order m
+_SPATIAL = None    # "spatial" group: all h x w ranks of one model instance
 _INIT = False
 
 
-def init(polar_group, azimuth_group):
-    """``thd.init(polar_group, azimuth_group)`` (``sfnonet.py:786-789``); ``None`` = not split."""
-    global _POLAR, _AZIMUTH, _INIT
+def init(polar_group, azimuth_group, spatial_group=None):
+    """``thd.init(polar_group, azimuth_group)`` (``sfnonet.py:786-789``); ``None`` = not split.
+    ``spatial_group`` (makani's "spatial" = h x w, ``makani/utils/comm.py:114-201``) is needed by the
+    distributed instance norm; it defaults to whichever of the two groups is split when only one is."""
+    global _POLAR, _AZIMUTH, _SPATIAL, _INIT
     _POLAR, _AZIMUTH, _INIT = polar_group, azimuth_group, True
+    if spatial_group is None:
+        if _size(polar_group) > 1 and _size(azimuth_group) > 1:
+            raise ValueError("h and w are both split: pass the spatial (h x w) process group")
+        spatial_group = polar_group if _size(polar_group) > 1 else azimuth_group
+    _SPATIAL = spatial_group
+
+
+def spatial_group():
+    return _SPATIAL
+
+
+def spatial_size() -> int:
+    return _size(_POLAR) * _size(_AZIMUTH) if _INIT else 1
 
 
 def is_initialized() -> bool:
@@ -54,12 +78,6 @@ def azimuth_group():
     return _AZIMUTH
 
 
-def _size(group) -> int:
-    return 1 if group is None else dist.get_world_size(group)
-
-
-def _rank(group) -> int:
-    return 0 if group is None else dist.get_rank(group)
 
 
 def polar_group_size():
@@ -116,15 +134,22 @@ def _exchange(recv, send, group):
         return
     me = dist.get_rank(group)
     recv[me].copy_(send[me])
+    on_gpu = send[me].is_cuda                 # gloo moves host memory only: stage through the host
+    hs = [t.cpu() if on_gpu else t for t in send]
+    hr = [torch.empty(t.shape, dtype=t.dtype) if on_gpu else t for t in recv]
     ops_ = []
     for peer in range(len(send)):
         if peer == me:
             continue
         gp = dist.get_global_rank(group, peer)
-        ops_.append(dist.P2POp(dist.isend, send[peer], gp, group=group))
-        ops_.append(dist.P2POp(dist.irecv, recv[peer], gp, group=group))
+        ops_.append(dist.P2POp(dist.isend, hs[peer], gp, group=group))
+        ops_.append(dist.P2POp(dist.irecv, hr[peer], gp, group=group))
     for req in dist.batch_isend_irecv(ops_):
         req.wait()
+    if on_gpu:
+        for peer in range(len(send)):
+            if peer != me:
+                recv[peer].copy_(hr[peer])
 
 
 class _TransposeFn(torch.autograd.Function):
@@ -314,3 +339,24 @@ class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
         S = ops.ComplexToSFn.apply(c4)
         x = self.synthesis(S, c4.shape[0], c4.shape[1])
         return x.reshape(*lead, x.shape[-2], x.shape[-1])
+
+
+class DistributedInstanceNorm2d(nn.Module):
+    """``makani/mpu/layer_norm.py:108-170``: instance norm over planes sharded across the spatial group."""
+
+    def __init__(self, num_features, eps=1e-5, affine=False):
+        super().__init__()
+        self.num_features, self.eps, self.affine = num_features, eps, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+            self.weight.is_shared_mp = ["spatial"]
+            self.bias.is_shared_mp = ["spatial"]
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+    def forward(self, x, fuse_gelu=False):
+        if x.dim() != 4 or x.shape[1] != self.num_features:
+            raise ValueError(f"expected (B, {self.num_features}, H, W), got {tuple(x.shape)}")
+        return ops.DistInstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, spatial_group())

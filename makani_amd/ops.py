@@ -430,7 +430,7 @@ class InstanceNormFn(torch.autograd.Function):
         sums = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
         check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(sums),
-                                    ptr(ws), planes, Cc, hw, 1 if ctx.fuse_gelu else 0, stream()), "instnorm_bwd")
+                                    ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0, stream()), "instnorm_bwd")
         s = sums.view(B, Cc, 2).sum(0)
         dgamma = s[:, 1].contiguous() if g is not None else None
         dbeta = s[:, 0].contiguous() if b is not None else None
@@ -632,3 +632,95 @@ class ConvMmFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[2]:
             gr = gy
         return gx, gw, gr
+
+
+# --------------------------------------------------------------------------- #
+# distributed instance norm (spatial model parallelism)
+# --------------------------------------------------------------------------- #
+def merge_moments(means: torch.Tensor, variances: torch.Tensor, counts: torch.Tensor):
+    """Combine per-shard (mean, biased variance, count) along dim 0 into the moments of the union
+    (Chan et al.; same result as the sequential Welford merge of makani/mpu/layer_norm.py:54-81)."""
+    n = counts.sum(0)
+    mean = (means * counts).sum(0) / n
+    m2 = (variances * counts + counts * (means - mean) ** 2).sum(0)
+    return mean, m2 / n, n
+
+
+def _all_gather_stack(t, group):
+    import torch.distributed as dist
+    P = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and t.is_cuda:       # CPU-staged (gloo test runs on one GPU)
+        h = t.cpu()
+        out = [torch.empty_like(h) for _ in range(P)]
+        dist.all_gather(out, h, group=group)
+        return torch.stack(out, dim=0).to(t.device)
+    out = [torch.empty_like(t) for _ in range(P)]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out, dim=0)
+
+
+def _all_reduce_sum(t, group):
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+class DistInstanceNormFn(torch.autograd.Function):
+    """Instance norm over a plane that is sharded across the ``spatial`` process group
+    (``DistributedInstanceNorm2d``, makani/mpu/layer_norm.py:108-170): local fp32 statistics (HIP) ->
+    all-gather of (mean, var, count) -> merge -> normalise (+GELU) with the merged statistics (HIP).
+    Backward all-reduces the two per-plane sums between the HIP reduce and apply phases."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, fuse_gelu, group):
+        import torch.distributed as dist
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        planes, hw = B * Cc, H * W
+        dt = dtype_code(x)
+        stats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(planes, hw, x.dtype, x.device)
+        check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, stream()), "instnorm_stats")
+        P = dist.get_world_size(group)
+        local = torch.stack([stats[:, 0], 1.0 / stats[:, 1] ** 2 - eps, torch.full_like(stats[:, 0], float(hw))], dim=0)
+        allm = _all_gather_stack(local.contiguous(), group)      # (P, 3, planes)
+        mean, var, n = merge_moments(allm[:, 0], allm[:, 1].clamp_min(0.0), allm[:, 2])
+        mstats = torch.stack([mean, torch.rsqrt(var + eps)], dim=1).contiguous()
+        g = gamma.float().contiguous() if gamma is not None else None
+        b = beta.float().contiguous() if beta is not None else None
+        y = torch.empty_like(x)
+        check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(mstats), ptr(g), ptr(b), planes, Cc, hw,
+                                      1 if fuse_gelu else 0, stream()), "instnorm_apply")
+        ctx.save_for_backward(x, mstats, g, b)
+        ctx.meta = (fuse_gelu, group, None)
+        ctx.hw_total = n
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+        x, mstats, g, b = ctx.saved_tensors
+        fuse_gelu, group, _ = ctx.meta
+        B, Cc, H, W = x.shape
+        planes, hw = B * Cc, H * W
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gx = torch.empty_like(x)
+        sums = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(planes, hw, x.dtype, x.device)
+        fg = 1 if fuse_gelu else 0
+        hw_total = int(ctx.hw_total[0].item())
+        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), ptr(sums),
+                                    ptr(ws), planes, Cc, hw, hw_total, 1, fg, stream()), "instnorm_bwd(reduce)")
+        local = sums.view(B, Cc, 2).sum(0)                        # this rank's share of dgamma / dbeta
+        _all_reduce_sum(sums, group)
+        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), ptr(sums),
+                                    ptr(ws), planes, Cc, hw, hw_total, 2, fg, stream()), "instnorm_bwd(apply)")
+        dgamma = local[:, 1].contiguous() if g is not None else None
+        dbeta = local[:, 0].contiguous() if b is not None else None
+        return gx, dgamma, dbeta, None, None, None

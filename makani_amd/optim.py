@@ -23,9 +23,11 @@ class FusedAdamW(torch.optim.Optimizer):
         return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
 
     @torch.no_grad()
-    def step(self, closure=None, max_grad_norm=None):
-        scale = None
-        if max_grad_norm is not None:
+    def step(self, closure=None, max_grad_norm=None, grad_scale=None):
+        """``max_grad_norm``: clip by the global norm of the local gradients; ``grad_scale``: a precomputed
+        clipping coefficient (1-element device tensor) when the norm needs cross-rank reduction."""
+        scale = grad_scale
+        if scale is None and max_grad_norm is not None:
             total = self.grad_norm()
             scale = torch.clamp(max_grad_norm / (total + 1e-6), max=1.0).float().reshape(1)
         for group in self.param_groups:

@@ -156,7 +156,7 @@ def _worker_dp(rank, world, port):
         model.a = torch.nn.Parameter(torch.randn(5, 3))
         model.c = torch.nn.Parameter(torch.randn(4, 2, dtype=torch.complex64))
         model.big = torch.nn.Parameter(torch.randn(3 * 1024 * 1024))          # > 8 MB: async path
-        red = bench.GradReducer(model, world)
+        red = bench.GradReducer(model, dist.group.WORLD, world)
         loss = (model.a.sum() * (rank + 1)) + (torch.view_as_real(model.c).sum() * (rank + 2)) + model.big.sum() * rank
         loss.backward()
         red.finish()
