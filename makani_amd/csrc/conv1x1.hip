@@ -190,6 +190,7 @@ struct ConvWg {
 
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int tilesM, int tilesK) {
     constexpr int BM = 128, BN = 128;
+    constexpr int BK = 64;                   // 128-byte row segments: whole cache lines per row
     constexpr int PA = BK + 8;
     constexpr int NA = (BM * BK / 8) / NT;   // 2
     __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * PA];
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int f = tid + q * NT;
-            const int row = f >> 2, c = f & 3;
+            const int row = f >> 3, c = f & 7;
             uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
             if (n + c * 8 < nend) {
                 if (m0 + row < p.M) va = ld16(Gb + (long long)(m0 + row) * p.N + n + c * 8);
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int f = tid + q * NT;
-            const int row = f >> 2, c = f & 3;
+            const int row = f >> 3, c = f & 7;
             *reinterpret_cast<uint4*>(As + buf * BM * PA + row * PA + c * 8) = ra[q];
             *reinterpret_cast<uint4*>(Bs + buf * BN * PA + row * PA + c * 8) = rb[q];
         }
@@ -336,7 +337,7 @@ extern "C" int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* 
     const long long S = mk_conv1x1_wgrad_workspace(M, K, B, N) / ((long long)M * K);
     const long long per_b = S / B;
     long long chunk = (N + per_b - 1) / per_b;
-    chunk = (chunk + BK - 1) / BK * BK;
+    chunk = (chunk + 63) / 64 * 64;
     ConvWg p{(const u16*)G, (const u16*)X, part, M, K, B, (int)S, N, chunk};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(tm * tk * S)), dim3(NT), 0, s, p, tm, tk);
