@@ -1,4 +1,2 @@
-mkdir -p gpurun_out/prof3
-export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof3 -o r01c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sht-metric > gpurun_out/prof3/bench.log 2>&1
-echo "prof rc=$?"; grep '^{' gpurun_out/prof3/bench.log | cut -c1-200
+timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "conv" 2>&1 | tail -3
+python tools/microbench.py conv 2>&1 | grep -v amdgpu | cut -c1-135
