@@ -16,7 +16,7 @@
  *  - dtype codes: MK_F32 = 0, MK_BF16 = 1.
  *
  * Internal spectral layouts (all fp32, planar re/im, padded to multiples of 4):
- *  F-layout  F[m][ri][row][k]   m < M, ri in {re,im}, row < R (R = B*Cp), k < Kp    (lat-major, feeds Legendre)
+ *  F-layout  F[m][k][ri][row]   m < M, k < nlat, ri in {re,im}, row < R (R = B*Cp)  (k-major: rows contiguous)
  *  S-layout  S[l][m][ri][row]   l < L, m < M, row < R                                (coefficients)
  *  W-layout  W[l][ri][i][o]     dhconv weights, i < Cip, o < Cop (zero padded)
  */
@@ -90,13 +90,15 @@ int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream);
  *   Replaces `torch.fft.irfft(X, n=nlon, norm="forward")` incl. the Im(m=0)/Im(Nyquist)
  *   drop (th.InverseRealSHT.forward; twin makani/mpu/fft.py:242) and the adjoint of rfft.
  * x holds B*C planes; plane (b, c) maps to F row b*Cp + c (R = B*Cp rows, pad rows untouched).
+ * A workgroup transforms one latitude of 8-16 consecutive planes, so the F side is touched in runs of
+ * 8-16 consecutive rows and the Legendre GEMMs see both operands row-contiguous.
  * `twiddle` = device table of nlon float2: exp(-2 pi i q / nlon) (host fp64 -> fp32).
  * `radix`   = host array of `nradix` radices whose product is nlon/2.               */
 int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* twiddle, const int* radix, int nradix,
-                 int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos, float w_nyq,
+                 int B, int C, int Cp, int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq,
                  void* stream);
 int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* twiddle, const int* radix, int nradix,
-                  int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos, float w_nyq,
+                  int B, int C, int Cp, int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq,
                   void* stream);
 
 /* ---- layout changes ------------------------------------------------------------

@@ -38,9 +38,9 @@ _SIGS = {
     "mk_sgemm_split_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
     "mk_cgemm_split_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
     "mk_rfft_rows": ([c_vp, c_int, c_vp, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                      c_int, c_f, c_f, c_f, c_vp], c_int),
+                      c_f, c_f, c_f, c_vp], c_int),
     "mk_irfft_rows": ([c_vp, c_vp, c_int, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                       c_int, c_f, c_f, c_f, c_vp], c_int),
+                       c_f, c_f, c_f, c_vp], c_int),
     "mk_weight_to_wlayout": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_wlayout_to_weight_grad": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_slayout_to_complex": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),

@@ -17,7 +17,7 @@
 #include "fft_common.h"
 
 int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, const float* twiddle, int B, int C, int Cp,
-                         int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos, float w_nyq, void* stream);
+                         int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, void* stream);
 
 static bool use_fast_fft() {
     static int v = -1;
@@ -120,7 +120,7 @@ __device__ __forceinline__ float2* run_passes(float2* a, float2* b, const float2
 template <typename T>
 __global__ __launch_bounds__(NT) void rfft_kernel(const T* __restrict__ x, float* __restrict__ F,
                                                   const float2* __restrict__ tw_g, const RadixList rl, int C, int Cp,
-                                                  long long rows, int nlat, int nlon, int mmax, int kp, int RB, int nkg, float w_dc,
+                                                  long long rows, long long planes, int nlat, int nlon, int mmax, int RB, int ngr, float w_dc,
                                                   float w_pos, float w_nyq) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int N = nlon, n2 = nlon / 2, LS = n2 + 1;
@@ -130,19 +130,20 @@ __global__ __launch_bounds__(NT) void rfft_kernel(const T* __restrict__ x, float
     const int tid = threadIdx.x;
 
     const long long item = xcd_remap(blockIdx.x, gridDim.x);
-    const long long bc = item / nkg;
-    const int k0 = (int)(item % nkg) * RB;
-    const int nr = min(RB, nlat - k0);
-    const long long frow = (bc / C) * Cp + (bc % C);   // row of this plane in the F-layout
+    // work item = one latitude x RB consecutive (batch, channel) planes: the spectrum side is written as
+    // runs of RB consecutive rows of the k-major F^T layout  F[m][lat][ri][row]
+    const int klat = (int)(item / ngr);
+    const long long p0 = (item % ngr) * RB;
+    const int nr = (int)min((long long)RB, planes - p0);
 
     for (int q = tid; q < N; q += NT) tw[q] = tw_g[q];
 
     // load rows: z[j] = x[2j] + i x[2j+1]
-    const T* xr = x + (bc * nlat + k0) * (long long)nlon;
+    const T* xr = x + (p0 * nlat + klat) * (long long)nlon;     // row r of the item: xr + r * nlat * nlon
     for (int idx = tid; idx < RB * n2; idx += NT) {
         const int row = idx / n2, j = idx - row * n2;
         float2 z = make_float2(0.f, 0.f);
-        if (row < nr) z = load_pair<T>(xr + (long long)row * nlon + 2 * j);
+        if (row < nr) z = load_pair<T>(xr + (long long)row * nlat * nlon + 2 * j);
         bufA[row * LS + j] = z;
     }
     __syncthreads();
@@ -150,7 +151,6 @@ __global__ __launch_bounds__(NT) void rfft_kernel(const T* __restrict__ x, float
     const float2* Z = run_passes(bufA, bufB, tw, rl, RB, LS, n2, N, tid);
 
     // Hermitian untangle + truncate + weight, write lat-major
-    const long long plane = rows * (long long)kp;   // elements per (m, ri) plane
     for (int idx = tid; idx < mmax * RB; idx += NT) {
         const int r = idx % RB, m = idx / RB;
         if (r >= nr) continue;
@@ -169,16 +169,17 @@ __global__ __launch_bounds__(NT) void rfft_kernel(const T* __restrict__ x, float
             w = w_nyq;
             X.y = 0.f;
         }
-        float* o = F + (long long)(2 * m) * plane + frow * kp + k0 + r;
+        const long long pr = p0 + r;
+        float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
         o[0] = w * X.x;
-        o[plane] = w * X.y;
+        o[rows] = w * X.y;
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(NT) void irfft_kernel(const float* __restrict__ F, T* __restrict__ x,
                                                    const float2* __restrict__ tw_g, const RadixList rl, int C, int Cp,
-                                                   long long rows, int nlat, int nlon, int mmax, int kp, int RB, int nkg, float w_dc,
+                                                   long long rows, long long planes, int nlat, int nlon, int mmax, int RB, int ngr, float w_dc,
                                                    float w_pos, float w_nyq) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int N = nlon, n2 = nlon / 2, LS = n2 + 1;
@@ -188,21 +189,22 @@ __global__ __launch_bounds__(NT) void irfft_kernel(const float* __restrict__ F, 
     const int tid = threadIdx.x;
 
     const long long item = xcd_remap(blockIdx.x, gridDim.x);
-    const long long bc = item / nkg;
-    const int k0 = (int)(item % nkg) * RB;
-    const int nr = min(RB, nlat - k0);
-    const long long frow = (bc / C) * Cp + (bc % C);   // row of this plane in the F-layout
+    // work item = one latitude x RB consecutive (batch, channel) planes: the spectrum side is written as
+    // runs of RB consecutive rows of the k-major F^T layout  F[m][lat][ri][row]
+    const int klat = (int)(item / ngr);
+    const long long p0 = (item % ngr) * RB;
+    const int nr = (int)min((long long)RB, planes - p0);
 
     for (int q = tid; q < N; q += NT) tw[q] = tw_g[q];
 
     // stage the weighted half spectrum X'[m], m = 0..n2 (zero beyond mmax) into bufB[r][m]
-    const long long plane = rows * (long long)kp;
     for (int idx = tid; idx < (n2 + 1) * RB; idx += NT) {
         const int r = idx % RB, m = idx / RB;
         float2 X = make_float2(0.f, 0.f);
         if (m < mmax && r < nr) {
-            const float* s = F + (long long)(2 * m) * plane + frow * kp + k0 + r;
-            X = make_float2(s[0], s[plane]);
+            const long long pr = p0 + r;
+            const float* s = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
+            X = make_float2(s[0], s[rows]);
             if (m == 0) {
                 X = make_float2(w_dc * X.x, 0.f);
             } else if (m == n2) {
@@ -230,12 +232,12 @@ __global__ __launch_bounds__(NT) void irfft_kernel(const float* __restrict__ F, 
     const float2* Z = run_passes(bufA, bufB, tw, rl, RB, LS, n2, N, tid);
 
     // x[2j] + i x[2j+1] = conj(FFT(conj(Zs)))
-    T* xr = x + (bc * nlat + k0) * (long long)nlon;
+    T* xr = x + (p0 * nlat + klat) * (long long)nlon;
     for (int idx = tid; idx < RB * n2; idx += NT) {
         const int row = idx / n2, j = idx - row * n2;
         if (row >= nr) continue;
         const float2 z = Z[row * LS + j];
-        store_pair<T>(xr + (long long)row * nlon + 2 * j, z.x, -z.y);
+        store_pair<T>(xr + (long long)row * nlat * nlon + 2 * j, z.x, -z.y);
     }
 }
 
@@ -279,16 +281,16 @@ int set_lds(K kernel, size_t lds) {
 }  // namespace
 
 extern "C" int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* twiddle, const int* radix, int nradix,
-                            int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos,
+                            int B, int C, int Cp, int nlat, int nlon, int mmax, float w_dc, float w_pos,
                             float w_nyq, void* stream) {
     MK_REQUIRE(x && F && twiddle, "rfft: null pointer");
-    MK_REQUIRE(B > 0 && C > 0 && Cp >= C && nlat > 0 && kp >= nlat, "rfft: bad shape B=%d C=%d Cp=%d nlat=%d kp=%d", B, C, Cp, nlat, kp);
+    MK_REQUIRE(B > 0 && C > 0 && Cp >= C && nlat > 0, "rfft: bad shape B=%d C=%d Cp=%d nlat=%d", B, C, Cp, nlat);
     const long long rows = (long long)B * Cp;      // rows of the F-layout
     const long long planes = (long long)B * C;     // planes of x
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "rfft: mmax=%d out of range for nlon=%d", mmax, nlon);
     MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "rfft: bad dtype %d", x_dtype);
     if (use_fast_fft()) {
-        const int frc = mk_fft_fast_dispatch(false, x, F, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, kp, w_dc, w_pos, w_nyq, stream);
+        const int frc = mk_fft_fast_dispatch(false, x, F, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, w_dc, w_pos, w_nyq, stream);
         if (frc != -1000) return frc;
     }
     RadixList rl;
@@ -296,19 +298,19 @@ extern "C" int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* t
     size_t lds;
     int rc = plan(nlon, radix, nradix, &rl, &RB, &lds);
     if (rc) return rc;
-    const int nkg = (nlat + RB - 1) / RB;
-    const long long nblk = planes * nkg;
+    const int ngr = (int)((planes + RB - 1) / RB);
+    const long long nblk = (long long)nlat * ngr;
     MK_REQUIRE(nblk < (1ll << 31), "rfft: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const float2* tw = reinterpret_cast<const float2*>(twiddle);
     if (x_dtype == MK_F32) {
         if ((rc = set_lds(rfft_kernel<float>, lds))) return rc;
-        hipLaunchKernelGGL(rfft_kernel<float>, dim3((unsigned)nblk), dim3(NT), lds, s, (const float*)x, F, tw, rl, C, Cp, rows,
-                           nlat, nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+        hipLaunchKernelGGL(rfft_kernel<float>, dim3((unsigned)nblk), dim3(NT), lds, s, (const float*)x, F, tw, rl, C, Cp, rows, planes,
+                           nlat, nlon, mmax, RB, ngr, w_dc, w_pos, w_nyq);
     } else if (x_dtype == MK_BF16) {
         if ((rc = set_lds(rfft_kernel<u16>, lds))) return rc;
-        hipLaunchKernelGGL(rfft_kernel<u16>, dim3((unsigned)nblk), dim3(NT), lds, s, (const u16*)x, F, tw, rl, C, Cp, rows,
-                           nlat, nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+        hipLaunchKernelGGL(rfft_kernel<u16>, dim3((unsigned)nblk), dim3(NT), lds, s, (const u16*)x, F, tw, rl, C, Cp, rows, planes,
+                           nlat, nlon, mmax, RB, ngr, w_dc, w_pos, w_nyq);
     } else {
         MK_REQUIRE(false, "rfft: bad dtype %d", x_dtype);
     }
@@ -316,16 +318,16 @@ extern "C" int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* t
 }
 
 extern "C" int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* twiddle, const int* radix, int nradix,
-                             int B, int C, int Cp, int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos,
+                             int B, int C, int Cp, int nlat, int nlon, int mmax, float w_dc, float w_pos,
                              float w_nyq, void* stream) {
     MK_REQUIRE(x && F && twiddle, "irfft: null pointer");
-    MK_REQUIRE(B > 0 && C > 0 && Cp >= C && nlat > 0 && kp >= nlat, "irfft: bad shape B=%d C=%d Cp=%d nlat=%d kp=%d", B, C, Cp, nlat, kp);
+    MK_REQUIRE(B > 0 && C > 0 && Cp >= C && nlat > 0, "irfft: bad shape B=%d C=%d Cp=%d nlat=%d", B, C, Cp, nlat);
     const long long rows = (long long)B * Cp;
     const long long planes = (long long)B * C;
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "irfft: mmax=%d out of range for nlon=%d", mmax, nlon);
     MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "irfft: bad dtype %d", x_dtype);
     if (use_fast_fft()) {
-        const int frc = mk_fft_fast_dispatch(true, F, x, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, kp, w_dc, w_pos, w_nyq, stream);
+        const int frc = mk_fft_fast_dispatch(true, F, x, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, w_dc, w_pos, w_nyq, stream);
         if (frc != -1000) return frc;
     }
     RadixList rl;
@@ -333,19 +335,19 @@ extern "C" int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* 
     size_t lds;
     int rc = plan(nlon, radix, nradix, &rl, &RB, &lds);
     if (rc) return rc;
-    const int nkg = (nlat + RB - 1) / RB;
-    const long long nblk = planes * nkg;
+    const int ngr = (int)((planes + RB - 1) / RB);
+    const long long nblk = (long long)nlat * ngr;
     MK_REQUIRE(nblk < (1ll << 31), "irfft: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const float2* tw = reinterpret_cast<const float2*>(twiddle);
     if (x_dtype == MK_F32) {
         if ((rc = set_lds(irfft_kernel<float>, lds))) return rc;
-        hipLaunchKernelGGL(irfft_kernel<float>, dim3((unsigned)nblk), dim3(NT), lds, s, F, (float*)x, tw, rl, C, Cp, rows, nlat,
-                           nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+        hipLaunchKernelGGL(irfft_kernel<float>, dim3((unsigned)nblk), dim3(NT), lds, s, F, (float*)x, tw, rl, C, Cp, rows, planes, nlat,
+                           nlon, mmax, RB, ngr, w_dc, w_pos, w_nyq);
     } else if (x_dtype == MK_BF16) {
         if ((rc = set_lds(irfft_kernel<u16>, lds))) return rc;
-        hipLaunchKernelGGL(irfft_kernel<u16>, dim3((unsigned)nblk), dim3(NT), lds, s, F, (u16*)x, tw, rl, C, Cp, rows, nlat,
-                           nlon, mmax, kp, RB, nkg, w_dc, w_pos, w_nyq);
+        hipLaunchKernelGGL(irfft_kernel<u16>, dim3((unsigned)nblk), dim3(NT), lds, s, F, (u16*)x, tw, rl, C, Cp, rows, planes, nlat,
+                           nlon, mmax, RB, ngr, w_dc, w_pos, w_nyq);
     } else {
         MK_REQUIRE(false, "irfft: bad dtype %d", x_dtype);
     }

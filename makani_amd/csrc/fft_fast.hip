@@ -97,7 +97,7 @@ __device__ __forceinline__ ItemRange my_items(long long nitems) {
 template <int N2, int R1, int R2, int R3, int RB, typename T>
 __global__ __launch_bounds__(NT) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
                                                        const float2* __restrict__ tw_g, int C, int Cp, long long rows,
-                                                       int nlat, int mmax, int kp, int nkg, long long nitems,
+                                                       long long planes, int nlat, int mmax, int ngr, long long nitems,
                                                        float w_dc, float w_pos, float w_nyq) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
     constexpr int N = 2 * N2, LS = N2 + 1;
@@ -109,26 +109,26 @@ __global__ __launch_bounds__(NT) void rfft_fast_kernel(const T* __restrict__ x, 
     __syncthreads();
 
     const ItemRange it = my_items(nitems);
-    const long long plane = rows * (long long)kp;
     auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
     auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
     // rows of work item `itm` straight from global memory (first pass operands)
     float2 v1[PassShape<N2, R1, RB>::NR][R1];
+    // work item = one latitude x RB consecutive (batch, channel) planes (k-major F^T layout, see fft.hip)
+    const long long rstride = (long long)nlat * N;              // distance between the rows of an item
     auto prefetch = [&](long long itm) {
-        const long long bc_ = itm / nkg;
-        const int k0_ = (int)(itm - bc_ * nkg) * RB;
-        const int nr_ = min(RB, nlat - k0_);
-        const T* xr_ = x + (bc_ * nlat + k0_) * (long long)N;
+        const long long kl_ = itm / ngr;
+        const long long p0_ = (itm - kl_ * ngr) * RB;
+        const int nr_ = (int)min((long long)RB, planes - p0_);
+        const T* xr_ = x + (p0_ * nlat + kl_) * (long long)N;
         pass_load<N2, R1, RB>(v1, [&](int row, int pos) -> float2 {
-            return row < nr_ ? load_pair<T>(xr_ + (long long)row * N + 2 * pos) : make_float2(0.f, 0.f);
+            return row < nr_ ? load_pair<T>(xr_ + (long long)row * rstride + 2 * pos) : make_float2(0.f, 0.f);
         }, tid);
     };
     if (it.begin < it.end) prefetch(it.begin);
     for (long long item = it.begin; item < it.end; ++item) {
-        const long long bc = item / nkg;
-        const int k0 = (int)(item - bc * nkg) * RB;
-        const int nr = min(RB, nlat - k0);
-        const long long frow = (bc / C) * Cp + (bc % C);
+        const long long klat = item / ngr;
+        const long long p0 = (item - klat * ngr) * RB;
+        const int nr = (int)min((long long)RB, planes - p0);
 
         pass_compute_store<N2, R1, 1, RB>(v1, tw, st_lds, tid);
         __syncthreads();
@@ -159,9 +159,10 @@ __global__ __launch_bounds__(NT) void rfft_fast_kernel(const T* __restrict__ x, 
                 w = w_nyq;
                 X.y = 0.f;
             }
-            float* o = F + (long long)(2 * m) * plane + frow * kp + k0 + r;
+            const long long pr = p0 + r;
+            float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
             o[0] = w * X.x;
-            o[plane] = w * X.y;
+            o[rows] = w * X.y;
         }
         __syncthreads();
     }
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NT) void rfft_fast_kernel(const T* __restrict__ x, 
 template <int N2, int R1, int R2, int R3, int RB, typename T>
 __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict__ F, T* __restrict__ x,
                                                         const float2* __restrict__ tw_g, int C, int Cp, long long rows,
-                                                        int nlat, int mmax, int kp, int nkg, long long nitems,
+                                                        long long planes, int nlat, int mmax, int ngr, long long nitems,
                                                         float w_dc, float w_pos, float w_nyq) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
     constexpr int N = 2 * N2, LS = N2 + 1;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict_
     __syncthreads();
 
     const ItemRange it = my_items(nitems);
-    const long long plane = rows * (long long)kp;
+    const long long rstride = (long long)nlat * N;
     // weighted half spectrum X'[m], m = 0..N2 (zero beyond mmax) of work item `itm`, prefetched into registers
     constexpr int NSPEC = ((N2 + 1) * RB + NT - 1) / NT;
     // register prefetch of the next item's spectrum only where it fits without squeezing the pass
@@ -190,28 +191,28 @@ __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict_
     constexpr bool PF = NSPEC <= 16;
     float2 spec[NSPEC];
     auto prefetch = [&](long long itm) {
-        const long long bc_ = itm / nkg;
-        const int k0_ = (int)(itm - bc_ * nkg) * RB;
-        const int nr_ = min(RB, nlat - k0_);
-        const long long frow_ = (bc_ / C) * Cp + (bc_ % C);
+        const long long kl_ = itm / ngr;
+        const long long p0_ = (itm - kl_ * ngr) * RB;
+        const int nr_ = (int)min((long long)RB, planes - p0_);
 #pragma unroll
         for (int q = 0; q < NSPEC; ++q) {
             const int idx = tid + q * NT;
             const int r = idx % RB, m = idx / RB;
             float2 X = make_float2(0.f, 0.f);
             if (m < mmax && r < nr_) {
-                const float* sp = F + (long long)(2 * m) * plane + frow_ * kp + k0_ + r;
-                X = make_float2(sp[0], sp[plane]);
+                const long long pr = p0_ + r;
+                const float* sp = F + ((long long)m * nlat + kl_) * 2 * rows + (pr / C) * Cp + (pr % C);
+                X = make_float2(sp[0], sp[rows]);
             }
             spec[q] = X;
         }
     };
     if (PF && it.begin < it.end) prefetch(it.begin);
     for (long long item = it.begin; item < it.end; ++item) {
-        const long long bc = item / nkg;
-        const int k0 = (int)(item - bc * nkg) * RB;
-        const int nr = min(RB, nlat - k0);
-        T* xr = x + (bc * nlat + k0) * (long long)N;
+        const long long klat = item / ngr;
+        const long long p0 = (item - klat * ngr) * RB;
+        const int nr = (int)min((long long)RB, planes - p0);
+        T* xr = x + (p0 * nlat + klat) * (long long)N;
         if (!PF) prefetch(item);
 
 #pragma unroll
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict_
         auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
         auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
         auto st_global = [&](int row, int pos, float2 val) {
-            if (row < nr) store_pair<T>(xr + (long long)row * N + 2 * pos, val.x, -val.y);     // conj
+            if (row < nr) store_pair<T>(xr + (long long)row * rstride + 2 * pos, val.x, -val.y);     // conj
         };
 
         fft_pass<N2, R1, 1, RB, true>(tw, ld_lds, st_lds, tid);
@@ -271,9 +272,10 @@ __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict_
 
 template <int N2, int R1, int R2, int R3, int RB>
 int launch(bool inverse, const void* in, void* out, int dtype, const float2* tw, int B, int C, int Cp, int nlat, int mmax,
-           int kp, float w_dc, float w_pos, float w_nyq, hipStream_t s) {
-    const int nkg = (nlat + RB - 1) / RB;
-    const long long nitems = (long long)B * C * nkg;
+           float w_dc, float w_pos, float w_nyq, hipStream_t s) {
+    const long long planes = (long long)B * C;
+    const int ngr = (int)((planes + RB - 1) / RB);
+    const long long nitems = (long long)nlat * ngr;
     const long long rows = (long long)B * Cp;
     // persistent grid: a few workgroups per CU, each owning a contiguous item range
     constexpr size_t lds = (size_t)(RB * (N2 + 1) + 2 * N2) * 8;
@@ -286,17 +288,17 @@ int launch(bool inverse, const void* in, void* out, int dtype, const float2* tw,
     if (!inverse) {
         if (dtype == MK_F32)
             hipLaunchKernelGGL((rfft_fast_kernel<N2, R1, R2, R3, RB, float>), g, b, 0, s, (const float*)in, (float*)out, tw, C,
-                               Cp, rows, nlat, mmax, kp, nkg, nitems, w_dc, w_pos, w_nyq);
+                               Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
         else
             hipLaunchKernelGGL((rfft_fast_kernel<N2, R1, R2, R3, RB, u16>), g, b, 0, s, (const u16*)in, (float*)out, tw, C,
-                               Cp, rows, nlat, mmax, kp, nkg, nitems, w_dc, w_pos, w_nyq);
+                               Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
     } else {
         if (dtype == MK_F32)
             hipLaunchKernelGGL((irfft_fast_kernel<N2, R1, R2, R3, RB, float>), g, b, 0, s, (const float*)in, (float*)out, tw,
-                               C, Cp, rows, nlat, mmax, kp, nkg, nitems, w_dc, w_pos, w_nyq);
+                               C, Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
         else
             hipLaunchKernelGGL((irfft_fast_kernel<N2, R1, R2, R3, RB, u16>), g, b, 0, s, (const float*)in, (u16*)out, tw, C,
-                               Cp, rows, nlat, mmax, kp, nkg, nitems, w_dc, w_pos, w_nyq);
+                               Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
     }
     return mk_check_launch(inverse ? "mk_irfft_rows(fast)" : "mk_rfft_rows(fast)");
 }
@@ -305,15 +307,15 @@ int launch(bool inverse, const void* in, void* out, int dtype, const float2* tw,
 
 // returns -1000 if nlon has no specialised kernel (caller falls through to the generic one)
 int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, const float* twiddle, int B, int C, int Cp,
-                         int nlat, int nlon, int mmax, int kp, float w_dc, float w_pos, float w_nyq, void* stream) {
+                         int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, void* stream) {
     const float2* tw = reinterpret_cast<const float2*>(twiddle);
     hipStream_t s = (hipStream_t)stream;
     switch (nlon) {
-        case 1440: return launch<720, 10, 9, 8, 8>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, kp, w_dc, w_pos, w_nyq, s);
-        case 480: return launch<240, 10, 6, 4, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, kp, w_dc, w_pos, w_nyq, s);
-        case 360: return launch<180, 6, 6, 5, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, kp, w_dc, w_pos, w_nyq, s);
-        case 128: return launch<64, 4, 4, 4, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, kp, w_dc, w_pos, w_nyq, s);
-        case 72: return launch<36, 6, 6, 1, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, kp, w_dc, w_pos, w_nyq, s);
+        case 1440: return launch<720, 10, 9, 8, 8>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
+        case 480: return launch<240, 10, 6, 4, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
+        case 360: return launch<180, 6, 6, 5, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
+        case 128: return launch<64, 4, 4, 4, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
+        case 72: return launch<36, 6, 6, 1, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
         default: return -1000;
     }
 }

@@ -62,12 +62,14 @@ static inline int validate(const MkGemm* g, bool cplx, bool* a_kc, bool* b_kc) {
     if (*a_kc) {
         MK_REQUIRE(al(g->a_row), "gemm: a_row must be a multiple of 4");
     } else {
-        MK_REQUIRE(al(g->a_k) && (g->M & 3) == 0, "gemm: row-contiguous A needs a_k %% 4 == 0 and M %% 4 == 0");
+        MK_REQUIRE(al(g->a_k) && g->a_k >= ((g->M + 3) & ~3),
+                   "gemm: row-contiguous A needs a_k %% 4 == 0 and a_k >= M rounded up to 4 (16-byte row vectors)");
     }
     if (*b_kc) {
         MK_REQUIRE(al(g->b_col), "gemm: b_col must be a multiple of 4");
     } else {
-        MK_REQUIRE(al(g->b_k) && (g->N & 3) == 0, "gemm: col-contiguous B needs b_k %% 4 == 0 and N %% 4 == 0");
+        MK_REQUIRE(al(g->b_k) && g->b_k >= ((g->N + 3) & ~3),
+                   "gemm: col-contiguous B needs b_k %% 4 == 0 and b_k >= N rounded up to 4 (16-byte row vectors)");
     }
     if (cplx) MK_REQUIRE(al(g->a_im) && al(g->b_im), "gemm: plane offsets must be multiples of 4");
     return 0;

@@ -51,14 +51,15 @@ def init(polar_group, azimuth_group, spatial_group=None):
     distributed instance norm; it defaults to whichever of the two groups is split when only one is."""
     global _POLAR, _AZIMUTH, _SPATIAL, _INIT
     _POLAR, _AZIMUTH, _INIT = polar_group, azimuth_group, True
-    if spatial_group is None:
-        if _size(polar_group) > 1 and _size(azimuth_group) > 1:
-            raise ValueError("h and w are both split: pass the spatial (h x w) process group")
+    if spatial_group is None and not (_size(polar_group) > 1 and _size(azimuth_group) > 1):
         spatial_group = polar_group if _size(polar_group) > 1 else azimuth_group
     _SPATIAL = spatial_group
 
 
 def spatial_group():
+    """The h x w group (needed by the instance-norm statistics, not by the transforms)."""
+    if _INIT and _SPATIAL is None and _size(_POLAR) > 1 and _size(_AZIMUTH) > 1:
+        raise ValueError("h and w are both split: init() needs the spatial (h x w) process group")
     return _SPATIAL
 
 
@@ -219,16 +220,16 @@ class HipBackend:
         return ops.RfftFn.apply(x4, mmax, ops.round4(x4.shape[1]), w)
 
     @staticmethod
-    def irfft(F, planes, nlat, nlon, dtype, w):
-        return ops.IrfftFn.apply(F, 1, planes, nlat, nlon, dtype, w)
+    def irfft(F, planes, nlon, dtype, w):
+        return ops.IrfftFn.apply(F, 1, planes, nlon, dtype, w)
 
     @staticmethod
-    def analysis(F, mat, nlat, m_off):
-        return ops.AnalysisFn.apply(F.contiguous(), mat, nlat, m_off)
+    def analysis(F, mat, matT, m_off):
+        return ops.AnalysisFn.apply(F.contiguous(), mat, matT, m_off)
 
     @staticmethod
-    def synthesis(S, mat, nlat, m_off):
-        return ops.SynthesisFn.apply(S.contiguous(), mat, nlat, m_off)
+    def synthesis(S, mat, matT, nlat, m_off):
+        return ops.SynthesisFn.apply(S.contiguous(), mat, matT, nlat, m_off)
 
 
 _BACKEND = HipBackend
@@ -274,6 +275,7 @@ class DistributedRealSHT(RealSHT, _DistBase):
         self._setup_dist()
         m0, m1 = self.m_off, self.m_off + self.m_shapes[self.comm_rank_azimuth]
         self.weights = self.weights[m0:m1].contiguous()
+        self.weights_t = self.weights_t[m0:m1].contiguous()
 
     def analysis(self, x4: torch.Tensor) -> torch.Tensor:
         """(B, C, nlat_loc, nlon_loc) -> S-layout (l_loc, m_loc, 2, round4(B*C)), planes = b*C + c."""
@@ -288,12 +290,12 @@ class DistributedRealSHT(RealSHT, _DistBase):
         x = x4.reshape(1, P, hl, wl)
         # (w) planes <-> lon
         x = transpose(x, 1, pw, 3, self.lon_shapes, azimuth_group())
-        F = _BACKEND.rfft(x.contiguous(), self.mmax, self._w)                       # (M, 2, round4(P_w), kp_loc)
+        F = _BACKEND.rfft(x.contiguous(), self.mmax, self._w)                       # (M, hl, 2, round4(P_w))
         # (w) m <-> planes
-        F = transpose(F, 0, self.m_shapes, 2, pw, azimuth_group(), pad_dims=(2,))      # (M_loc, 2, round4(P), kp_loc)
+        F = transpose(F, 0, self.m_shapes, 3, pw, azimuth_group(), pad_dims=(3,))      # (M_loc, hl, 2, round4(P))
         # (h) planes <-> lat
-        F = transpose(F, 2, ph, 3, self.lat_shapes, polar_group(), pad_dims=(2, 3))    # (M_loc, 2, round4(P_h), kp)
-        S = _BACKEND.analysis(F, self.weights, self.nlat, self.m_off)                 # (L, M_loc, 2, round4(P_h))
+        F = transpose(F, 3, ph, 1, self.lat_shapes, polar_group(), pad_dims=(3,))      # (M_loc, nlat, 2, round4(P_h))
+        S = _BACKEND.analysis(F, self.weights, self.weights_t, self.m_off)            # (L, M_loc, 2, round4(P_h))
         # (h) l <-> planes
         S = transpose(S, 0, self.l_shapes, 3, ph, polar_group(), pad_dims=(3,))        # (L_loc, M_loc, 2, round4(P))
         return S
@@ -314,6 +316,7 @@ class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
         self._setup_dist()
         m0, m1 = self.m_off, self.m_off + self.m_shapes[self.comm_rank_azimuth]
         self.pct = self.pct[m0:m1].contiguous()
+        self.pct_t = self.pct_t[m0:m1].contiguous()
 
     def synthesis(self, S: torch.Tensor, B: int, C: int, out_dtype=torch.float32) -> torch.Tensor:
         P = B * C
@@ -323,12 +326,12 @@ class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
         hl, wl = self.lat_shapes[self.comm_rank_polar], self.lon_shapes[self.comm_rank_azimuth]
         # (h) planes <-> l
         S = transpose(S, 3, ph, 0, self.l_shapes, polar_group(), pad_dims=(3,))       # (L, M_loc, 2, round4(P_h))
-        F = _BACKEND.synthesis(S, self.pct, self.nlat, self.m_off)                    # (M_loc, 2, round4(P_h), kp)
+        F = _BACKEND.synthesis(S, self.pct, self.pct_t, self.nlat, self.m_off)        # (M_loc, nlat, 2, round4(P_h))
         # (h) lat <-> planes
-        F = transpose(F, 3, self.lat_shapes, 2, ph, polar_group(), pad_dims=(2, 3))    # (M_loc, 2, round4(P), kp_loc)
+        F = transpose(F, 1, self.lat_shapes, 3, ph, polar_group(), pad_dims=(3,))      # (M_loc, hl, 2, round4(P))
         # (w) planes <-> m
-        F = transpose(F, 2, pw, 0, self.m_shapes, azimuth_group(), pad_dims=(2,))      # (M, 2, round4(P_w), kp_loc)
-        x = _BACKEND.irfft(F.contiguous(), pw[self.comm_rank_azimuth], hl, self.nlon, out_dtype, self._w)
+        F = transpose(F, 3, pw, 0, self.m_shapes, azimuth_group(), pad_dims=(3,))      # (M, hl, 2, round4(P_w))
+        x = _BACKEND.irfft(F.contiguous(), pw[self.comm_rank_azimuth], self.nlon, out_dtype, self._w)
         # (w) lon <-> planes
         x = transpose(x, 3, self.lon_shapes, 1, pw, azimuth_group())                  # (1, P, hl, wl)
         return x.reshape(B, C, hl, wl)

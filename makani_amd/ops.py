@@ -1,7 +1,7 @@
 """Host-side launchers and autograd Functions over the internal spectral layouts.
 
 Layouts (all fp32, see include/makani_amd.h):
-  F-layout  (M, 2, R, Kp)   longitude spectrum, latitude contiguous     R = B * Cp
+  F-layout  (M, nlat, 2, R) longitude spectrum, k-major: rows (b, c) contiguous    R = B * Cp
   S-layout  (L, M, 2, R)    spherical harmonic coefficients, channel contiguous
   W-layout  (L, 2, Cip, Cop) dhconv weights
 Entries of an S tensor with l < m are NEVER read by any kernel (P_l^m = 0 there) and may hold
@@ -122,34 +122,37 @@ def fft_plan(nlon: int, device) -> FftPlan:
 
 
 def rfft_rows(x: torch.Tensor, mmax: int, Cp: int, w) -> torch.Tensor:
-    """x (B, C, nlat, nlon) f32|bf16 -> F (mmax, 2, B*Cp, Kp);  X_m = w_m sum_n x_n e^{-i m n 2pi/N}."""
+    """x (B, C, nlat, nlon) f32|bf16 -> F (mmax, nlat, 2, B*Cp);  X_m = w_m sum_n x_n e^{-i m n 2pi/N}."""
     B, Cc, nlat, nlon = x.shape
     x = x.contiguous()
     plan = fft_plan(nlon, x.device)
-    kp = round4(nlat)
-    F = torch.empty((mmax, 2, B * Cp, kp), dtype=torch.float32, device=x.device)
+    F = torch.empty((mmax, nlat, 2, B * Cp), dtype=torch.float32, device=x.device)
     nbytes = B * Cc * nlat * (nlon * x.element_size() + mmax * 8)
     with _timed(f"rfft_{nlon}", nbytes=nbytes):
         check(lib().mk_rfft_rows(ptr(x), dtype_code(x), ptr(F), ptr(plan.twiddle), plan.radix, plan.nradix, B, Cc, Cp,
-                                 nlat, nlon, mmax, kp, w[0], w[1], w[2], stream()), "mk_rfft_rows")
+                                 nlat, nlon, mmax, w[0], w[1], w[2], stream()), "mk_rfft_rows")
     return F
 
 
-def irfft_rows(F: torch.Tensor, B: int, Cc: int, nlat: int, nlon: int, out_dtype, w) -> torch.Tensor:
-    """F (mmax, 2, B*Cp, Kp) -> x (B, C, nlat, nlon);  x_n = sum_m w_m (Re X_m cos - Im X_m sin)."""
-    mmax, _, R, kp = F.shape
+def irfft_rows(F: torch.Tensor, B: int, Cc: int, nlon: int, out_dtype, w) -> torch.Tensor:
+    """F (mmax, nlat, 2, B*Cp) -> x (B, C, nlat, nlon);  x_n = sum_m w_m (Re X_m cos - Im X_m sin)."""
+    mmax, nlat, _, R = F.shape
     Cp = R // B
     plan = fft_plan(nlon, F.device)
     x = torch.empty((B, Cc, nlat, nlon), dtype=out_dtype, device=F.device)
     nbytes = B * Cc * nlat * (nlon * x.element_size() + mmax * 8)
     with _timed(f"irfft_{nlon}", nbytes=nbytes):
         check(lib().mk_irfft_rows(ptr(F), ptr(x), dtype_code(x), ptr(plan.twiddle), plan.radix, plan.nradix, B, Cc,
-                                  Cp, nlat, nlon, mmax, kp, w[0], w[1], w[2], stream()), "mk_irfft_rows")
+                                  Cp, nlat, nlon, mmax, w[0], w[1], w[2], stream()), "mk_irfft_rows")
     return x
 
 
 # --------------------------------------------------------------------------- #
-# Legendre GEMMs (real, batched over m)
+# Legendre GEMMs (real, batched over m).  Both operands are row-contiguous ("k-major"):
+#   analysis   S[l][j]   = sum_k  matT[m][k][l] * F[m][k][j]          j = (ri, row)
+#   synthesis  F[m][k][j] = sum_l  mat[m][l][k]  * S[l][m][j]
+# mat  = (M, L, Kp)  natural torch-harmonics layout, latitude padded to 4
+# matT = (M, nlat, Lp) its transpose, degree padded to 4
 # --------------------------------------------------------------------------- #
 def _gemm(**kw) -> MkGemm:
     g = MkGemm()
@@ -162,15 +165,15 @@ def _gemm(**kw) -> MkGemm:
     return g
 
 
-def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int = 0) -> torch.Tensor:
-    """S[l][m][ri][row] = sum_k mat[m][l][k] F[m][ri][row][k]      (rows l >= m only)."""
-    M, _, R, kp = F.shape
-    Mm, L, kpm = mat.shape
-    assert Mm == M and kpm == kp and F.is_contiguous() and mat.is_contiguous()
+def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 0) -> torch.Tensor:
+    """S[l][m][ri][row] = sum_k matT[m][k][l] F[m][k][ri][row]      (rows l >= m only)."""
+    M, nlat, _, R = F.shape
+    Mm, nk, Lp = matT.shape
+    assert Mm == M and nk == nlat and Lp >= L and F.is_contiguous() and matT.is_contiguous()
     S = torch.empty((L, M, 2, R), dtype=torch.float32, device=F.device)
-    g = _gemm(A=mat.data_ptr(), B=F.data_ptr(), C=S.data_ptr(),
-              a_batch=L * kp, a_row=kp, a_k=1,
-              b_batch=2 * R * kp, b_col=kp, b_k=1,
+    g = _gemm(A=matT.data_ptr(), B=F.data_ptr(), C=S.data_ptr(),
+              a_batch=nlat * Lp, a_row=1, a_k=Lp,
+              b_batch=nlat * 2 * R, b_col=1, b_k=2 * R,
               c_batch=2 * R, c_row=M * 2 * R,
               M=L, N=2 * R, K=nlat, batch=M, tri_mode=_lib.TRI_ROW_GE, tri_off=m_off)
     # dense-formulation work (SURVEY.md §8d): 2 * (2R) * nlat * L * M flops
@@ -180,19 +183,19 @@ def legendre_analysis(F: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int 
     return S
 
 
-def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, m_off: int = 0) -> torch.Tensor:
-    """F[m][ri][row][k] = sum_{l >= m} S[l][m][ri][row] mat[m][l][k]."""
+def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int = 0) -> torch.Tensor:
+    """F[m][k][ri][row] = sum_{l >= m} mat[m][l][k] S[l][m][ri][row]."""
     L, M, _, R = S.shape
     Mm, Lm, kp = mat.shape
-    assert Mm == M and Lm == L and S.is_contiguous() and mat.is_contiguous()
-    F = torch.empty((M, 2, R, kp), dtype=torch.float32, device=S.device)
-    g = _gemm(A=S.data_ptr(), B=mat.data_ptr(), C=F.data_ptr(),
-              a_batch=2 * R, a_row=1, a_k=M * 2 * R,
-              b_batch=L * kp, b_col=1, b_k=kp,
-              c_batch=2 * R * kp, c_row=kp,
-              M=2 * R, N=kp, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
-    with _timed(f"legendre_synthesis_k{kp}", flops=2.0 * 2 * R * kp * L * M,
-                nbytes=4.0 * (2 * R * kp * M + 2 * R * L * M + M * L * kp)):
+    assert Mm == M and Lm == L and kp >= nlat and S.is_contiguous() and mat.is_contiguous()
+    F = torch.empty((M, nlat, 2, R), dtype=torch.float32, device=S.device)
+    g = _gemm(A=mat.data_ptr(), B=S.data_ptr(), C=F.data_ptr(),
+              a_batch=L * kp, a_row=1, a_k=kp,
+              b_batch=2 * R, b_col=1, b_k=M * 2 * R,
+              c_batch=nlat * 2 * R, c_row=2 * R,
+              M=nlat, N=2 * R, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
+    with _timed(f"legendre_synthesis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
+                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
         _run_gemm(g, False, "legendre_synthesis")
     return F
 
@@ -305,41 +308,43 @@ class RfftFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gF):
         (B, Cc, nlat, nlon), dt, w = ctx.meta
-        return irfft_rows(gF.contiguous(), B, Cc, nlat, nlon, dt, w), None, None, None
+        return irfft_rows(gF.contiguous(), B, Cc, nlon, dt, w), None, None, None
 
 
 class IrfftFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, F, B, Cc, nlat, nlon, out_dtype, w):
-        ctx.meta = (F.shape[0], F.shape[2] // B, w)
-        return irfft_rows(F, B, Cc, nlat, nlon, out_dtype, w)
+    def forward(ctx, F, B, Cc, nlon, out_dtype, w):
+        ctx.meta = (F.shape[0], F.shape[3] // B, w)
+        return irfft_rows(F, B, Cc, nlon, out_dtype, w)
 
     @staticmethod
     def backward(ctx, gx):
         mmax, Cp, w = ctx.meta
-        return rfft_rows(gx, mmax, Cp, w), None, None, None, None, None, None
+        return rfft_rows(gx, mmax, Cp, w), None, None, None, None, None
 
 
 class AnalysisFn(torch.autograd.Function):
+    """S = analysis(F) with the (constant) matrix given in both orientations (mat: (M, L, Kp), matT: (M, nlat, Lp))."""
+
     @staticmethod
-    def forward(ctx, F, mat, nlat, m_off=0):
-        ctx.mat, ctx.m_off = mat, m_off
-        return legendre_analysis(F, mat, nlat, m_off)
+    def forward(ctx, F, mat, matT, m_off=0):
+        ctx.mat, ctx.m_off, ctx.nlat = mat, m_off, F.shape[1]
+        return legendre_analysis(F, matT, mat.shape[1], m_off)
 
     @staticmethod
     def backward(ctx, gS):
-        return legendre_synthesis(gS.contiguous(), ctx.mat, ctx.m_off), None, None, None
+        return legendre_synthesis(gS.contiguous(), ctx.mat, ctx.nlat, ctx.m_off), None, None, None
 
 
 class SynthesisFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, S, mat, nlat, m_off=0):
-        ctx.mat, ctx.nlat, ctx.m_off = mat, nlat, m_off
-        return legendre_synthesis(S, mat, m_off)
+    def forward(ctx, S, mat, matT, nlat, m_off=0):
+        ctx.matT, ctx.L, ctx.m_off = matT, mat.shape[1], m_off
+        return legendre_synthesis(S, mat, nlat, m_off)
 
     @staticmethod
     def backward(ctx, gF):
-        return legendre_analysis(gF.contiguous(), ctx.mat, ctx.nlat, ctx.m_off), None, None, None
+        return legendre_analysis(gF.contiguous(), ctx.matT, ctx.L, ctx.m_off), None, None, None, None
 
 
 class DhconvFn(torch.autograd.Function):

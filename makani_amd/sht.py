@@ -48,22 +48,29 @@ class _SHTBase(nn.Module):
         self.kp = ops.round4(nlat)
 
     def _padded(self, P):
-        out = np.zeros((self.mmax, self.lmax, self.kp), dtype=np.float32)
-        out[:, :, : self.nlat] = P
-        return torch.from_numpy(out)
+        """(mmax, lmax, nlat) fp64 -> fp32 in both orientations, unit-stride dim zero-padded to a multiple of 4:
+        natural (mmax, lmax, kp) and transposed (mmax, nlat, lp)."""
+        nat = np.zeros((self.mmax, self.lmax, self.kp), dtype=np.float32)
+        nat[:, :, : self.nlat] = P
+        lp = ops.round4(self.lmax)
+        tr = np.zeros((self.mmax, self.nlat, lp), dtype=np.float32)
+        tr[:, :, : self.lmax] = np.transpose(P, (0, 2, 1))
+        return torch.from_numpy(nat), torch.from_numpy(tr)
 
     def extra_repr(self):
         return f"nlat={self.nlat}, nlon={self.nlon}, lmax={self.lmax}, mmax={self.mmax}, grid={self.grid}"
 
 
 class RealSHT(_SHTBase):
-    """Forward transform.  Buffer ``weights``: (mmax, lmax, kp) fp32 =
-    Legendre functions times quadrature weights, latitude padded to a multiple of 4."""
+    """Forward transform.  Buffers ``weights`` (mmax, lmax, kp) / ``weights_t`` (mmax, nlat, lp), fp32 =
+    Legendre functions times quadrature weights in both orientations (unit-stride dim padded to 4)."""
 
     def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="equiangular", norm="ortho", csphase=True):
         super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
         P = _leg.legendre_matrix(self.mmax, self.lmax, self._theta, norm=norm, inverse=False, csphase=csphase)
-        self.register_buffer("weights", self._padded(P * self._wq[None, None, :]), persistent=False)
+        nat, tr = self._padded(P * self._wq[None, None, :])
+        self.register_buffer("weights", nat, persistent=False)        # (mmax, lmax, kp): backward (synthesis-shaped)
+        self.register_buffer("weights_t", tr, persistent=False)       # (mmax, nlat, lp): forward
         c = 2.0 * math.pi / nlon
         self._w = (c, c, c)
 
@@ -72,7 +79,7 @@ class RealSHT(_SHTBase):
         if x4.shape[-2] != self.nlat or x4.shape[-1] != self.nlon:
             raise ValueError(f"expected (..., {self.nlat}, {self.nlon}), got {tuple(x4.shape)}")
         F = ops.RfftFn.apply(x4, self.mmax, ops.round4(x4.shape[1]), self._w)
-        return ops.AnalysisFn.apply(F, self.weights, self.nlat)
+        return ops.AnalysisFn.apply(F, self.weights, self.weights_t)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype not in (torch.float32, torch.bfloat16):
@@ -89,13 +96,15 @@ class InverseRealSHT(_SHTBase):
     def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="equiangular", norm="ortho", csphase=True):
         super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
         P = _leg.legendre_matrix(self.mmax, self.lmax, self._theta, norm=norm, inverse=True, csphase=csphase)
-        self.register_buffer("pct", self._padded(P), persistent=False)
+        nat, tr = self._padded(P)
+        self.register_buffer("pct", nat, persistent=False)            # (mmax, lmax, kp): forward
+        self.register_buffer("pct_t", tr, persistent=False)           # (mmax, nlat, lp): backward (analysis-shaped)
         self._w = (1.0, 2.0, 1.0)
 
     def synthesis(self, S: torch.Tensor, B: int, C: int, out_dtype=torch.float32) -> torch.Tensor:
         """S-layout (lmax, mmax, 2, B*Cp) -> (B, C, nlat, nlon)."""
-        F = ops.SynthesisFn.apply(S, self.pct, self.nlat)
-        return ops.IrfftFn.apply(F, B, C, self.nlat, self.nlon, out_dtype, self._w)
+        F = ops.SynthesisFn.apply(S, self.pct, self.pct_t, self.nlat)
+        return ops.IrfftFn.apply(F, B, C, self.nlon, out_dtype, self._w)
 
     def forward(self, c: torch.Tensor) -> torch.Tensor:
         if c.dtype != torch.complex64:

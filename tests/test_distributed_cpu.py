@@ -35,14 +35,13 @@ class OracleBackend:
         if mmax - 1 == nlon // 2:
             wv[-1] = w[2]
         X = X * wv
-        F = torch.stack([X.real, X.imag], dim=0).permute(3, 0, 1, 2)             # (M, 2, P, nlat)
-        Rp, kp = (P + 3) // 4 * 4, (nlat + 3) // 4 * 4
-        return torch.nn.functional.pad(F, (0, kp - nlat, 0, Rp - P))
+        F = torch.stack([X.real, X.imag], dim=0).permute(3, 2, 0, 1)             # (M, nlat, 2, P)
+        return torch.nn.functional.pad(F, (0, (-P) % 4))
 
     @staticmethod
-    def irfft(F, planes, nlat, nlon, dtype, w):
+    def irfft(F, planes, nlon, dtype, w):
         M = F.shape[0]
-        X = torch.complex(F[:, 0, :planes, :nlat], F[:, 1, :planes, :nlat]).permute(1, 2, 0)   # (P, nlat, M)
+        X = torch.complex(F[:, :, 0, :planes], F[:, :, 1, :planes]).permute(2, 1, 0)   # (P, nlat, M)
         s = torch.full((M,), 2.0, dtype=F.dtype)
         s[0] = 1.0
         wv = torch.full((M,), w[1], dtype=F.dtype)
@@ -55,12 +54,13 @@ class OracleBackend:
         return torch.fft.irfft(X, n=nlon, dim=-1, norm="forward").unsqueeze(0).to(dtype)
 
     @staticmethod
-    def analysis(F, mat, nlat, m_off):
-        return torch.einsum("mlk,mirk->lmir", mat.to(F.dtype), F)
+    def analysis(F, mat, matT, m_off):
+        assert torch.equal(matT[:, :, : mat.shape[1]], mat[:, :, : matT.shape[1]].transpose(1, 2))
+        return torch.einsum("mkl,mkir->lmir", matT[:, :, : mat.shape[1]].to(F.dtype), F)
 
     @staticmethod
-    def synthesis(S, mat, nlat, m_off):
-        return torch.einsum("lmir,mlk->mirk", S, mat.to(S.dtype))
+    def synthesis(S, mat, matT, nlat, m_off):
+        return torch.einsum("lmir,mlk->mkir", S, mat[:, :, :nlat].to(S.dtype))
 
 
 def _s_to_complex(S, B, C):

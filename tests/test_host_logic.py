@@ -43,10 +43,10 @@ def test_argument_validation_without_gpu():
     rc = lib().mk_sgemm_batched(ctypes.byref(g), None)
     assert rc < 0 and b"null" in lib().mk_last_error()
     r = (ctypes.c_int * 2)(4, 3)
-    rc = lib().mk_rfft_rows(ctypes.c_void_p(16), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), r, 2, 1, 1, 4, 8, 25, 5, 8,
+    rc = lib().mk_rfft_rows(ctypes.c_void_p(16), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), r, 2, 1, 1, 4, 8, 25, 5,
                             1.0, 1.0, 1.0, None)
     assert rc < 0 and b"even" in lib().mk_last_error()
-    rc = lib().mk_rfft_rows(ctypes.c_void_p(16), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), r, 2, 1, 1, 4, 8, 26, 5, 8,
+    rc = lib().mk_rfft_rows(ctypes.c_void_p(16), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), r, 2, 1, 1, 4, 8, 26, 5,
                             1.0, 1.0, 1.0, None)
     assert rc < 0 and b"radix product" in lib().mk_last_error()
 
@@ -95,6 +95,8 @@ def test_transform_attributes_and_buffers():
     assert (I.lmax, I.mmax) == (12, 13)                       # torch-harmonics defaults
     assert S.weights.shape == (13, 12, 40) and S.weights.dtype == torch.float32
     assert (S.weights[:, :, 37:] == 0).all()
+    assert S.weights_t.shape == (13, 37, 12) and torch.equal(S.weights_t, S.weights[:, :, :37].transpose(1, 2))
+    assert I.pct.shape == (13, 12, 12) and I.pct_t.shape == (13, 12, 12)
     assert len(S.state_dict()) == 0 and len(I.state_dict()) == 0    # non-persistent buffers
     with pytest.raises(ValueError):
         ma.RealSHT(12, 24, mmax=14)

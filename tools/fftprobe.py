@@ -11,5 +11,5 @@ for nlat, nlon in ((721, 1440), (240, 480)):
     for mmax in (241, 64, 8):
         ms = timeit(lambda: ops.rfft_rows(x, mmax, C, (c, c, c)))
         F = ops.rfft_rows(x, mmax, C, (c, c, c))
-        ms2 = timeit(lambda: ops.irfft_rows(F, 1, C, nlat, nlon, torch.float32, (1.0, 2.0, 1.0)))
+        ms2 = timeit(lambda: ops.irfft_rows(F, 1, C, nlon, torch.float32, (1.0, 2.0, 1.0)))
         print(f"{nlat}x{nlon} mmax={mmax:3d}: rfft {ms:.3f} ms  irfft {ms2:.3f} ms")

@@ -9,5 +9,5 @@ for nlat, nlon in ((721, 1440), (240, 480)):
     x = torch.rand(1, C, nlat, nlon, device=dev)
     for _ in range(3):
         F = ops.rfft_rows(x, 241, C, (c, c, c))
-        y = ops.irfft_rows(F, 1, C, nlat, nlon, torch.float32, (1.0, 2.0, 1.0))
+        y = ops.irfft_rows(F, 1, C, nlon, torch.float32, (1.0, 2.0, 1.0))
 torch.cuda.synchronize()

@@ -32,7 +32,7 @@ def fft():
             nb = C * nlat * (nlon * x.element_size() + mmax * 8)
             print(f"rfft  {nlat}x{nlon} {str(dt)[6:]:9s} {ms:8.3f} ms  {nb/ms/1e6:8.1f} GB/s  ({nb/1e6:.0f} MB)")
             F = ops.rfft_rows(x, mmax, C, (c, c, c))
-            ms = timeit(lambda: ops.irfft_rows(F, 1, C, nlat, nlon, dt, (1.0, 2.0, 1.0)))
+            ms = timeit(lambda: ops.irfft_rows(F, 1, C, nlon, dt, (1.0, 2.0, 1.0)))
             print(f"irfft {nlat}x{nlon} {str(dt)[6:]:9s} {ms:8.3f} ms  {nb/ms/1e6:8.1f} GB/s")
             del x, F
 
@@ -42,12 +42,12 @@ def legendre():
     for nlat, nlon, grid in ((721, 1440, "equiangular"), (240, 480, "legendre-gauss")):
         S = ma.RealSHT(nlat, nlon, lmax=240, mmax=241, grid=grid).to(dev)
         I = ma.InverseRealSHT(nlat, nlon, lmax=240, mmax=241, grid=grid).to(dev)
-        F = torch.randn(241, 2, C, S.kp, device=dev)
-        ms = timeit(lambda: ops.legendre_analysis(F, S.weights, nlat))
+        F = torch.randn(241, nlat, 2, C, device=dev)
+        ms = timeit(lambda: ops.legendre_analysis(F, S.weights_t, 240))
         fl = 4.0 * C * nlat * 240 * 241
         print(f"analysis  K={nlat}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
         Sc = torch.randn(240, 241, 2, C, device=dev)
-        ms = timeit(lambda: ops.legendre_synthesis(Sc, I.pct))
+        ms = timeit(lambda: ops.legendre_synthesis(Sc, I.pct, nlat))
         print(f"synthesis K={nlat}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
 
 
