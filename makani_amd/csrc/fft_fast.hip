@@ -11,13 +11,13 @@
 //   * persistent workgroups own a CONTIGUOUS range of (plane, latitude-group) items, so the
 //     RB-float runs they write to / read from the lat-major F-layout are adjacent in time and
 //     address (they merge in the XCD's L2), and the twiddle table is staged into LDS once.
+#include <stdlib.h>
+
 #include "fft_common.h"
 
 namespace {
 
-constexpr int NT = 256;
-
-template <int ITEMS>
+template <int ITEMS, int NT>
 struct Rounds {
     static constexpr int value = (ITEMS + NT - 1) / NT;
 };
@@ -26,19 +26,19 @@ struct Rounds {
 // its load half and its twiddle + butterfly + store half so that the loads of the NEXT work item can
 // be issued early (software prefetch) and so that load and store may alias the same LDS buffer
 // (all loads of a thread happen before the barrier, all stores after it).
-template <int N2, int R, int RB>
+template <int N2, int R, int RB, int NT>
 struct PassShape {
     static constexpr int NB = N2 / R;
     static constexpr int ITEMS = RB * NB;
-    static constexpr int NR = Rounds<ITEMS>::value;
+    static constexpr int NR = Rounds<ITEMS, NT>::value;
 };
 
-template <int N2, int R, int RB>
-using PassRegs = float2[PassShape<N2, R, RB>::NR][R];
+template <int N2, int R, int RB, int NT>
+using PassRegs = float2[PassShape<N2, R, RB, NT>::NR][R];
 
-template <int N2, int R, int RB, typename LoadFn>
-__device__ __forceinline__ void pass_load(PassRegs<N2, R, RB>& v, LoadFn load, int tid) {
-    using S = PassShape<N2, R, RB>;
+template <int N2, int R, int RB, int NT, typename LoadFn>
+__device__ __forceinline__ void pass_load(PassRegs<N2, R, RB, NT>& v, LoadFn load, int tid) {
+    using S = PassShape<N2, R, RB, NT>;
 #pragma unroll
     for (int q = 0; q < S::NR; ++q) {
         const int idx = tid + q * NT;
@@ -50,11 +50,12 @@ __device__ __forceinline__ void pass_load(PassRegs<N2, R, RB>& v, LoadFn load, i
     }
 }
 
-template <int N2, int R, int NS, int RB, typename StoreFn>
-__device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB>& v, const float2* __restrict__ tw,
+// tp: this pass's twiddles, tp[(r-1)*NS + k] = exp(-2 pi i k r / (NS R)): consecutive lanes (k) read
+// consecutive LDS words
+template <int N2, int R, int NS, int RB, int NT, typename StoreFn>
+__device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB, NT>& v, const float2* __restrict__ tp,
                                                    StoreFn store, int tid) {
-    using S = PassShape<N2, R, RB>;
-    constexpr int TSTEP = 2 * N2 / (NS * R);
+    using S = PassShape<N2, R, RB, NT>;
 #pragma unroll
     for (int q = 0; q < S::NR; ++q) {
         const int idx = tid + q * NT;
@@ -63,7 +64,7 @@ __device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB>& v, const
             const int k = j % NS;
             if (NS > 1) {
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[q][r] = cmul(v[q][r], tw[k * r * TSTEP]);
+                for (int r = 1; r < R; ++r) v[q][r] = cmul(v[q][r], tp[(r - 1) * NS + k]);
             }
             Dft<R>::run(v[q]);
             const int j0 = (j - k) * R + k;
@@ -73,12 +74,12 @@ __device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB>& v, const
     }
 }
 
-template <int N2, int R, int NS, int RB, bool SYNC_BETWEEN, typename LoadFn, typename StoreFn>
-__device__ __forceinline__ void fft_pass(const float2* __restrict__ tw, LoadFn load, StoreFn store, int tid) {
-    float2 v[PassShape<N2, R, RB>::NR][R];
-    pass_load<N2, R, RB>(v, load, tid);
+template <int N2, int R, int NS, int RB, int NT, bool SYNC_BETWEEN, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ tp, LoadFn load, StoreFn store, int tid) {
+    float2 v[PassShape<N2, R, RB, NT>::NR][R];
+    pass_load<N2, R, RB, NT>(v, load, tid);
     if (SYNC_BETWEEN) __syncthreads();
-    pass_compute_store<N2, R, NS, RB>(v, tw, store, tid);
+    pass_compute_store<N2, R, NS, RB, NT>(v, tp, store, tid);
 }
 
 struct ItemRange {
@@ -93,145 +94,285 @@ __device__ __forceinline__ ItemRange my_items(long long nitems) {
     return r;
 }
 
+// LDS row stride (in float2).  The step that moves between the [row][m] LDS image and the
+// [m][row] global image touches LDS with the row index fastest across lanes, so the stride decides its
+// bank pattern (MI355X_MICROARCH.md, LDS): ds_read_b64 works on 32-lane groups over 64 banks, ds_write_b64
+// on 16-lane groups over 32 banks.
+//   forward (reads):  RB = 8 -> stride = 4 mod 8;  RB = 16 -> stride = 2 mod 4
+//   inverse (writes): RB = 8 -> stride = 2 mod 4;  RB = 16 -> stride odd
+__host__ __device__ constexpr int row_stride(int n2, int rb, bool inverse) {
+    int ls = n2 + 1;
+    if (!inverse) {
+        if (rb <= 8) { while (ls % 8 != 4) ++ls; } else { while (ls % 4 != 2) ++ls; }
+    } else {
+        if (rb <= 8) { while (ls % 4 != 2) ++ls; } else { while (ls % 2 != 1) ++ls; }
+    }
+    return ls;
+}
+
+// twiddle tables in LDS: per-pass tables (see pass_compute_store) + U[m] = exp(-2 pi i m / N), m <= N2
+template <int N2, int R1, int R2, int R3>
+struct Tables {
+    static constexpr int T2 = (R2 - 1) * R1;
+    static constexpr int T3 = (R3 > 1) ? (R3 - 1) * R1 * R2 : 0;
+    static constexpr int U = N2 + 1;
+    static constexpr int SIZE = T2 + T3 + U;
+    template <int NT>
+    __device__ static __forceinline__ void fill(float2* t, const float2* __restrict__ tw_g, int tid) {
+        constexpr int N = 2 * N2;
+        for (int q = tid; q < T2; q += NT) {
+            const int r = q / R1 + 1, k = q % R1;
+            t[q] = tw_g[k * r * (N / (R1 * R2))];
+        }
+        for (int q = tid; q < T3; q += NT) {
+            const int r = q / (R1 * R2) + 1, k = q % (R1 * R2);
+            t[T2 + q] = tw_g[k * r * (N / (R1 * R2 * (R3 > 1 ? R3 : 1)))];
+        }
+        for (int q = tid; q < U; q += NT) t[T2 + T3 + q] = tw_g[q];
+    }
+};
+
 // ------------------------------------------------------------------------------------------
-template <int N2, int R1, int R2, int R3, int RB, typename T>
-__global__ __launch_bounds__(NT) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
-                                                       const float2* __restrict__ tw_g, int C, int Cp, long long rows,
-                                                       long long planes, int nlat, int mmax, int ngr, long long nitems,
-                                                       float w_dc, float w_pos, float w_nyq) {
+// Global <-> LDS traffic of both kernels moves 16 bytes per lane:
+//   * x rows are copied whole (contiguous 16-byte vectors, every cache line requested once) into the LDS
+//     work buffer, where the first pass then runs in place like the others; the copy of the NEXT item is
+//     in flight (in registers) during the passes of the current one;
+//   * the F side is touched as float4 = 4 consecutive rows of one (m, latitude, re/im).
+// X[m] of one real row from the N2-point complex FFT Z of its (even, odd) pairs, truncated spectrum weights applied
+template <int N2>
+__device__ __forceinline__ float2 untangle_one(const float2* __restrict__ zrow, const float2* __restrict__ twu, int m,
+                                               float w_dc, float w_pos, float w_nyq) {
+    const int ma = (m == N2) ? 0 : m;
+    const int mb = (m == 0 || m == N2) ? 0 : N2 - m;
+    const float2 A = zrow[ma];
+    const float2 Bc = cconj(zrow[mb]);
+    const float2 u = cadd(A, Bc), t = csub(A, Bc);
+    const float2 wt = cmul(twu[m], t);
+    const float2 X = make_float2(0.5f * (u.x + wt.y), 0.5f * (u.y - wt.x));
+    const bool edge = (m == 0) || (m == N2);
+    const float w = (m == 0) ? w_dc : ((m == N2) ? w_nyq : w_pos);
+    return make_float2(w * X.x, edge ? 0.f : w * X.y);
+}
+
+template <int N2>
+__device__ __forceinline__ float2 weighted_one(int m, float re, float im, float w_dc, float w_pos, float w_nyq) {
+    const bool edge = (m == 0) || (m == N2);
+    const float w = (m == 0) ? w_dc : ((m == N2) ? w_nyq : 0.5f * w_pos);
+    return make_float2(w * re, edge ? 0.f : w * im);
+}
+
+template <typename T>
+struct RowVec;                                  // 16-byte vector of a row
+template <>
+struct RowVec<float> {
+    static constexpr int PAIRS = 2;             // (re, im)-style pairs = float2 slots per vector
+};
+template <>
+struct RowVec<u16> {
+    static constexpr int PAIRS = 4;
+};
+
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, typename T>
+__global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
+                                                            const float2* __restrict__ tw_g, int C, int Cp,
+                                                            long long rows, long long planes, int nlat, int mmax,
+                                                            int ngr, long long nitems, float w_dc, float w_pos,
+                                                            float w_nyq) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
-    constexpr int N = 2 * N2, LS = N2 + 1;
-    __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + N];
+    constexpr int N = 2 * N2, LS = row_stride(N2, RB, false);
+    constexpr int VP = RowVec<T>::PAIRS, VROW = N2 / VP;        // vectors per row
+    static_assert(N2 % VP == 0 && LS % 2 == 0 && RB % 4 == 0, "vector layout");
+    using Tb = Tables<N2, R1, R2, R3>;
+    __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
     float2* buf = smem;
-    float2* tw = smem + RB * LS;
+    float2* tw2 = smem + RB * LS;
+    float2* tw3 = tw2 + Tb::T2;
+    float2* twu = tw3 + Tb::T3;
     const int tid = threadIdx.x;
-    for (int q = tid; q < N; q += NT) tw[q] = tw_g[q];
-    __syncthreads();
+    Tb::template fill<NT>(tw2, tw_g, tid);
 
     const ItemRange it = my_items(nitems);
     auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
     auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
-    // rows of work item `itm` straight from global memory (first pass operands)
-    float2 v1[PassShape<N2, R1, RB>::NR][R1];
-    // work item = one latitude x RB consecutive (batch, channel) planes (k-major F^T layout, see fft.hip)
+    // work item = one latitude x RB consecutive (batch, channel) planes (k-major F layout, see fft.hip)
     const long long rstride = (long long)nlat * N;              // distance between the rows of an item
+    constexpr int NV = (RB * VROW + NT - 1) / NT;
+    uint4 rawv[NV];
     auto prefetch = [&](long long itm) {
         const long long kl_ = itm / ngr;
         const long long p0_ = (itm - kl_ * ngr) * RB;
         const int nr_ = (int)min((long long)RB, planes - p0_);
         const T* xr_ = x + (p0_ * nlat + kl_) * (long long)N;
-        pass_load<N2, R1, RB>(v1, [&](int row, int pos) -> float2 {
-            return row < nr_ ? load_pair<T>(xr_ + (long long)row * rstride + 2 * pos) : make_float2(0.f, 0.f);
-        }, tid);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int idx = tid + q * NT;
+            const int row = idx / VROW, c = idx % VROW;
+            rawv[q] = (row < nr_) ? *reinterpret_cast<const uint4*>(xr_ + (long long)row * rstride + c * (2 * VP))
+                                  : make_uint4(0, 0, 0, 0);
+        }
     };
-    if (it.begin < it.end) prefetch(it.begin);
+    auto commit = [&]() {                                       // registers -> work buffer as float2 pairs
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int idx = tid + q * NT;
+            const int row = idx / VROW, c = idx % VROW;
+            float4* d = reinterpret_cast<float4*>(buf + row * LS + c * VP);
+            const uint4 u = rawv[q];
+            if (idx < RB * VROW) {
+                if constexpr (sizeof(T) == 4) {
+                    d[0] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+                } else {
+                    d[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                    d[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                       __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+                }
+            }
+        }
+    };
+    // 4 consecutive planes map to 4 consecutive F rows unless a quad straddles a batch boundary
+    const bool vec = (C % 4 == 0) || (planes == C);
+    if (it.begin < it.end) {
+        prefetch(it.begin);
+        commit();
+    }
+    __syncthreads();
     for (long long item = it.begin; item < it.end; ++item) {
         const long long klat = item / ngr;
         const long long p0 = (item - klat * ngr) * RB;
         const int nr = (int)min((long long)RB, planes - p0);
 
-        pass_compute_store<N2, R1, 1, RB>(v1, tw, st_lds, tid);
+        if (item + 1 < it.end) prefetch(item + 1);       // in flight during the passes and the untangle step
+        fft_pass<N2, R1, 1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
         __syncthreads();
-        if (item + 1 < it.end) prefetch(item + 1);       // in flight during passes 2, 3 and the untangle step
-        fft_pass<N2, R2, R1, RB, true>(tw, ld_lds, st_lds, tid);
+        fft_pass<N2, R2, R1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
         __syncthreads();
         if constexpr (R3 > 1) {
-            fft_pass<N2, R3, R1 * R2, RB, true>(tw, ld_lds, st_lds, tid);
+            fft_pass<N2, R3, R1 * R2, RB, NT, true>(tw3, ld_lds, st_lds, tid);
             __syncthreads();
         }
 
-        // Hermitian untangle + truncation + weights; lat-major stores (RB consecutive floats)
-        for (int idx = tid; idx < mmax * RB; idx += NT) {
-            const int r = idx % RB, m = idx / RB;
-            if (r >= nr) continue;
-            const int ma = (m == N2) ? 0 : m;
-            const int mb = (m == 0 || m == N2) ? 0 : N2 - m;
-            const float2 A = buf[r * LS + ma];
-            const float2 Bc = cconj(buf[r * LS + mb]);
-            const float2 u = cadd(A, Bc), t = csub(A, Bc);
-            const float2 wt = cmul(tw[m], t);
-            float w = w_pos;
-            float2 X = make_float2(0.5f * (u.x + wt.y), 0.5f * (u.y - wt.x));
-            if (m == 0) {
-                w = w_dc;
-                X.y = 0.f;
-            } else if (m == N2) {
-                w = w_nyq;
-                X.y = 0.f;
+        // Hermitian untangle + truncation + weights
+        if (vec) {
+            for (int idx = tid; idx < mmax * (RB / 4); idx += NT) {
+                const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
+                if (r0 >= nr) continue;
+                const float2* z = buf + r0 * LS;                                    // rows >= nr hold zeros
+                const float2 X0 = untangle_one<N2>(z, twu, m, w_dc, w_pos, w_nyq);
+                const float2 X1 = untangle_one<N2>(z + LS, twu, m, w_dc, w_pos, w_nyq);
+                const float2 X2 = untangle_one<N2>(z + 2 * LS, twu, m, w_dc, w_pos, w_nyq);
+                const float2 X3 = untangle_one<N2>(z + 3 * LS, twu, m, w_dc, w_pos, w_nyq);
+                const long long pr = p0 + r0;
+                float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
+                *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
+                *reinterpret_cast<float4*>(o + rows) = make_float4(X0.y, X1.y, X2.y, X3.y);
             }
-            const long long pr = p0 + r;
-            float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
-            o[0] = w * X.x;
-            o[rows] = w * X.y;
+        } else {
+            for (int idx = tid; idx < mmax * RB; idx += NT) {
+                const int r = idx % RB, m = idx / RB;
+                if (r >= nr) continue;
+                const float2 X = untangle_one<N2>(buf + r * LS, twu, m, w_dc, w_pos, w_nyq);
+                const long long pr = p0 + r;
+                float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
+                o[0] = X.x;
+                o[rows] = X.y;
+            }
         }
         __syncthreads();
+        if (item + 1 < it.end) {
+            commit();
+            __syncthreads();
+        }
     }
 }
 
-template <int N2, int R1, int R2, int R3, int RB, typename T>
-__global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict__ F, T* __restrict__ x,
-                                                        const float2* __restrict__ tw_g, int C, int Cp, long long rows,
-                                                        long long planes, int nlat, int mmax, int ngr, long long nitems,
-                                                        float w_dc, float w_pos, float w_nyq) {
+// MCAP: compile-time bound on mmax (N2/3+1 for the 3x-truncated spectra of the scale-3 model, else N2+1);
+// it sizes the registers that carry the next item's spectrum.
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
+__global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __restrict__ F, T* __restrict__ x,
+                                                             const float2* __restrict__ tw_g, int C, int Cp,
+                                                             long long rows, long long planes, int nlat, int mmax,
+                                                             int ngr, long long nitems, float w_dc, float w_pos,
+                                                             float w_nyq) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
-    constexpr int N = 2 * N2, LS = N2 + 1;
-    __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + N];
+    constexpr int N = 2 * N2, LS = row_stride(N2, RB, true);
+    using Tb = Tables<N2, R1, R2, R3>;
+    __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
     float2* buf = smem;
-    float2* tw = smem + RB * LS;
+    float2* tw2 = smem + RB * LS;
+    float2* tw3 = tw2 + Tb::T2;
+    float2* twu = tw3 + Tb::T3;
     const int tid = threadIdx.x;
-    for (int q = tid; q < N; q += NT) tw[q] = tw_g[q];
+    Tb::template fill<NT>(tw2, tw_g, tid);
     __syncthreads();
 
     const ItemRange it = my_items(nitems);
     const long long rstride = (long long)nlat * N;
-    // weighted half spectrum X'[m], m = 0..N2 (zero beyond mmax) of work item `itm`, prefetched into registers
-    constexpr int NSPEC = ((N2 + 1) * RB + NT - 1) / NT;
-    // register prefetch of the next item's spectrum only where it fits without squeezing the pass
-    // registers (it costs 2*NSPEC VGPRs that stay live across the passes); measured: 480 +36 %, 1440 -14 %
-    constexpr bool PF = NSPEC <= 16;
-    float2 spec[NSPEC];
+    const bool vec = (C % 4 == 0) || (planes == C);
+    // the next item's half spectrum X[m], m < mmax, rides in registers while this one is transformed:
+    // vec: float4 = 4 rows per (m, re/im);  scalar fallback: one (row, m) pair per slot
+    constexpr int NQ4 = (MCAP * (RB / 4) + NT - 1) / NT;
+    constexpr int NQ1 = (MCAP * RB + NT - 1) / NT;
+    float4 sre[NQ4], sim[NQ4];
     auto prefetch = [&](long long itm) {
         const long long kl_ = itm / ngr;
         const long long p0_ = (itm - kl_ * ngr) * RB;
         const int nr_ = (int)min((long long)RB, planes - p0_);
 #pragma unroll
-        for (int q = 0; q < NSPEC; ++q) {
+        for (int q = 0; q < NQ4; ++q) {
             const int idx = tid + q * NT;
-            const int r = idx % RB, m = idx / RB;
-            float2 X = make_float2(0.f, 0.f);
-            if (m < mmax && r < nr_) {
-                const long long pr = p0_ + r;
+            const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (m < mmax && r0 < nr_) {
+                const long long pr = p0_ + r0;
                 const float* sp = F + ((long long)m * nlat + kl_) * 2 * rows + (pr / C) * Cp + (pr % C);
-                X = make_float2(sp[0], sp[rows]);
+                a = *reinterpret_cast<const float4*>(sp);
+                b = *reinterpret_cast<const float4*>(sp + rows);
             }
-            spec[q] = X;
+            sre[q] = a;
+            sim[q] = b;
         }
     };
-    if (PF && it.begin < it.end) prefetch(it.begin);
+    if (vec && it.begin < it.end) prefetch(it.begin);
     for (long long item = it.begin; item < it.end; ++item) {
         const long long klat = item / ngr;
         const long long p0 = (item - klat * ngr) * RB;
         const int nr = (int)min((long long)RB, planes - p0);
         T* xr = x + (p0 * nlat + klat) * (long long)N;
-        if (!PF) prefetch(item);
 
+        // weighted spectrum -> LDS rows, zero beyond mmax (and in rows >= nr)
+        if (vec) {
 #pragma unroll
-        for (int q = 0; q < NSPEC; ++q) {
-            const int idx = tid + q * NT;
-            const int r = idx % RB, m = idx / RB;
-            if (m <= N2) {
-                float2 X = spec[q];
-                if (m == 0)
-                    X = make_float2(w_dc * X.x, 0.f);
-                else if (m == N2)
-                    X = make_float2(w_nyq * X.x, 0.f);
-                else
-                    X = make_float2(0.5f * w_pos * X.x, 0.5f * w_pos * X.y);
-                buf[r * LS + m] = X;
+            for (int q = 0; q < NQ4; ++q) {
+                const int idx = tid + q * NT;
+                const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
+                if (m < mmax) {
+                    const bool live = r0 < nr;
+                    buf[(r0 + 0) * LS + m] = live ? weighted_one<N2>(m, sre[q].x, sim[q].x, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                    buf[(r0 + 1) * LS + m] = live ? weighted_one<N2>(m, sre[q].y, sim[q].y, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                    buf[(r0 + 2) * LS + m] = live ? weighted_one<N2>(m, sre[q].z, sim[q].z, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                    buf[(r0 + 3) * LS + m] = live ? weighted_one<N2>(m, sre[q].w, sim[q].w, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int q = 0; q < NQ1; ++q) {
+                const int idx = tid + q * NT;
+                const int r = idx % RB, m = idx / RB;
+                if (m < mmax) {
+                    float2 X = make_float2(0.f, 0.f);
+                    if (r < nr) {
+                        const long long pr = p0 + r;
+                        const float* sp = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
+                        X = weighted_one<N2>(m, sp[0], sp[rows], w_dc, w_pos, w_nyq);
+                    }
+                    buf[r * LS + m] = X;
+                }
             }
         }
+        for (int idx = tid + mmax * RB; idx < (N2 + 1) * RB; idx += NT) buf[(idx % RB) * LS + idx / RB] = make_float2(0.f, 0.f);
         __syncthreads();
-        if (PF && item + 1 < it.end) prefetch(item + 1);       // in flight during the pre-twiddle and the passes
+        if (vec && item + 1 < it.end) prefetch(item + 1);      // in flight during the pre-twiddle and the passes
 
         // in-place pre-twiddle on the pairs (j, N2-j): Zs[j] = (A + Bc) + i conj(W^j)(A - Bc); store conj(Zs)
         for (int idx = tid; idx < RB * (N2 / 2 + 1); idx += NT) {
@@ -240,12 +381,12 @@ __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict_
             const float2 Xa = buf[row * LS + j], Xb = buf[row * LS + j2];
             {
                 const float2 u = cadd(Xa, cconj(Xb)), t = csub(Xa, cconj(Xb));
-                const float2 wt = cmul(cconj(tw[j]), t);
+                const float2 wt = cmul(cconj(twu[j]), t);
                 buf[row * LS + j] = make_float2(u.x - wt.y, -(u.y + wt.x));
             }
             if (j != 0 && j2 != j) {
                 const float2 u = cadd(Xb, cconj(Xa)), t = csub(Xb, cconj(Xa));
-                const float2 wt = cmul(cconj(tw[j2]), t);
+                const float2 wt = cmul(cconj(twu[j2]), t);
                 buf[row * LS + j2] = make_float2(u.x - wt.y, -(u.y + wt.x));
             }
         }
@@ -253,69 +394,111 @@ __global__ __launch_bounds__(NT) void irfft_fast_kernel(const float* __restrict_
 
         auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
         auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
+        // the last pass writes its rows straight to global memory (staging them through LDS for 16-byte
+        // stores measured 10 % slower: the extra round trip costs more than the narrower stores)
         auto st_global = [&](int row, int pos, float2 val) {
             if (row < nr) store_pair<T>(xr + (long long)row * rstride + 2 * pos, val.x, -val.y);     // conj
         };
-
-        fft_pass<N2, R1, 1, RB, true>(tw, ld_lds, st_lds, tid);
+        fft_pass<N2, R1, 1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
         __syncthreads();
         if constexpr (R3 > 1) {
-            fft_pass<N2, R2, R1, RB, true>(tw, ld_lds, st_lds, tid);
+            fft_pass<N2, R2, R1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
             __syncthreads();
-            fft_pass<N2, R3, R1 * R2, RB, false>(tw, ld_lds, st_global, tid);
+            fft_pass<N2, R3, R1 * R2, RB, NT, false>(tw3, ld_lds, st_global, tid);
         } else {
-            fft_pass<N2, R2, R1, RB, false>(tw, ld_lds, st_global, tid);
+            fft_pass<N2, R2, R1, RB, NT, false>(tw2, ld_lds, st_global, tid);
         }
         __syncthreads();
     }
 }
 
-template <int N2, int R1, int R2, int R3, int RB>
+int fft_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MAKANI_AMD_FFT_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
+int launch_inverse(const float* in, T* out, const float2* tw, int C, int Cp, long long rows, long long planes, int nlat,
+                   int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, hipStream_t s) {
+    auto kern = irfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, MCAP, T>;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), NT, 0) != hipSuccess || n < 1) n = WGS;
+        per_cu = n > 8 ? 8 : n;
+    }
+    long long grid = 256ll * per_cu;            // persistent: every workgroup resident, contiguous item ranges
+    if (grid > nitems) grid = nitems;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems,
+                       w_dc, w_pos, w_nyq);
+    return mk_check_launch("mk_irfft_rows(fast)");
+}
+
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, typename T>
+int launch_forward(const T* in, float* out, const float2* tw, int C, int Cp, long long rows, long long planes, int nlat,
+                   int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, hipStream_t s) {
+    auto kern = rfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, T>;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), NT, 0) != hipSuccess || n < 1) n = WGS;
+        per_cu = n > 8 ? 8 : n;
+    }
+    long long grid = 256ll * per_cu;
+    if (grid > nitems) grid = nitems;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems,
+                       w_dc, w_pos, w_nyq);
+    return mk_check_launch("mk_rfft_rows(fast)");
+}
+
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS>
 int launch(bool inverse, const void* in, void* out, int dtype, const float2* tw, int B, int C, int Cp, int nlat, int mmax,
            float w_dc, float w_pos, float w_nyq, hipStream_t s) {
     const long long planes = (long long)B * C;
     const int ngr = (int)((planes + RB - 1) / RB);
     const long long nitems = (long long)nlat * ngr;
     const long long rows = (long long)B * Cp;
-    // persistent grid: a few workgroups per CU, each owning a contiguous item range
-    constexpr size_t lds = (size_t)(RB * (N2 + 1) + 2 * N2) * 8;
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 6) per_cu = 6;
-    if (per_cu < 1) per_cu = 1;
-    long long grid = 256ll * per_cu;
-    if (grid > nitems) grid = nitems;
-    dim3 g((unsigned)grid), b(NT);
+    MK_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "fft: x and F must be 16-byte aligned");
+    constexpr int M3 = N2 / 3 + 1, MF = N2 + 1;
+#define MK_FFT_TAIL tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq, s
     if (!inverse) {
-        if (dtype == MK_F32)
-            hipLaunchKernelGGL((rfft_fast_kernel<N2, R1, R2, R3, RB, float>), g, b, 0, s, (const float*)in, (float*)out, tw, C,
-                               Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
-        else
-            hipLaunchKernelGGL((rfft_fast_kernel<N2, R1, R2, R3, RB, u16>), g, b, 0, s, (const u16*)in, (float*)out, tw, C,
-                               Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
-    } else {
-        if (dtype == MK_F32)
-            hipLaunchKernelGGL((irfft_fast_kernel<N2, R1, R2, R3, RB, float>), g, b, 0, s, (const float*)in, (float*)out, tw,
-                               C, Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
-        else
-            hipLaunchKernelGGL((irfft_fast_kernel<N2, R1, R2, R3, RB, u16>), g, b, 0, s, (const float*)in, (u16*)out, tw, C,
-                               Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
+        if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, float>((const float*)in, (float*)out, MK_FFT_TAIL);
+        return launch_forward<N2, R1, R2, R3, RB, NT, WGS, u16>((const u16*)in, (float*)out, MK_FFT_TAIL);
     }
-    return mk_check_launch(inverse ? "mk_irfft_rows(fast)" : "mk_rfft_rows(fast)");
+    if (mmax <= M3) {
+        if (dtype == MK_F32) return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, float>((const float*)in, (float*)out, MK_FFT_TAIL);
+        return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, u16>((const float*)in, (u16*)out, MK_FFT_TAIL);
+    }
+    if (dtype == MK_F32) return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, MF, float>((const float*)in, (float*)out, MK_FFT_TAIL);
+    return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, MF, u16>((const float*)in, (u16*)out, MK_FFT_TAIL);
+#undef MK_FFT_TAIL
 }
 
 }  // namespace
+
+#define MK_FFT_ARGS inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s
 
 // returns -1000 if nlon has no specialised kernel (caller falls through to the generic one)
 int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, const float* twiddle, int B, int C, int Cp,
                          int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, void* stream) {
     const float2* tw = reinterpret_cast<const float2*>(twiddle);
     hipStream_t s = (hipStream_t)stream;
+    const int var = fft_variant();
+    //                         N2  radices   RB   NT  WG/CU
     switch (nlon) {
-        case 1440: return launch<720, 10, 9, 8, 8>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
-        case 480: return launch<240, 10, 6, 4, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
-        case 360: return launch<180, 6, 6, 5, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
-        case 128: return launch<64, 4, 4, 4, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
-        case 72: return launch<36, 6, 6, 1, 16>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s);
+        case 1440:
+            if (var == 1) return launch<720, 10, 9, 8, 8, 384, 2>(MK_FFT_ARGS);
+            return launch<720, 10, 9, 8, 8, 256, 2>(MK_FFT_ARGS);
+        case 480:
+            if (var == 1) return launch<240, 10, 6, 4, 16, 384, 3>(MK_FFT_ARGS);
+            return launch<240, 10, 6, 4, 16, 256, 2>(MK_FFT_ARGS);
+        case 360: return launch<180, 6, 6, 5, 16, 256, 3>(MK_FFT_ARGS);
+        case 128: return launch<64, 4, 4, 4, 16, 256, 4>(MK_FFT_ARGS);
+        case 72: return launch<36, 6, 6, 1, 16, 256, 4>(MK_FFT_ARGS);
         default: return -1000;
     }
 }
