@@ -110,12 +110,12 @@ __host__ __device__ constexpr int row_stride(int n2, int rb, bool inverse) {
     return ls;
 }
 
-// twiddle tables in LDS: per-pass tables (see pass_compute_store) + U[m] = exp(-2 pi i m / N), m <= N2
-template <int N2, int R1, int R2, int R3>
+// twiddle tables in LDS: per-pass tables (see pass_compute_store) + U[m] = exp(-2 pi i m / N), m < UN
+template <int N2, int R1, int R2, int R3, int UN>
 struct Tables {
     static constexpr int T2 = (R2 - 1) * R1;
     static constexpr int T3 = (R3 > 1) ? (R3 - 1) * R1 * R2 : 0;
-    static constexpr int U = N2 + 1;
+    static constexpr int U = UN;
     static constexpr int SIZE = T2 + T3 + U;
     template <int NT>
     __device__ static __forceinline__ void fill(float2* t, const float2* __restrict__ tw_g, int tid) {
@@ -172,7 +172,7 @@ struct RowVec<u16> {
     static constexpr int PAIRS = 4;
 };
 
-template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, typename T>
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
 __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
                                                             const float2* __restrict__ tw_g, int C, int Cp,
                                                             long long rows, long long planes, int nlat, int mmax,
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
     constexpr int N = 2 * N2, LS = row_stride(N2, RB, false);
     constexpr int VP = RowVec<T>::PAIRS, VROW = N2 / VP;        // vectors per row
     static_assert(N2 % VP == 0 && LS % 2 == 0 && RB % 4 == 0, "vector layout");
-    using Tb = Tables<N2, R1, R2, R3>;
+    using Tb = Tables<N2, R1, R2, R3, MCAP>;        // mmax <= MCAP
     __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
     float2* buf = smem;
     float2* tw2 = smem + RB * LS;
@@ -296,7 +296,10 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                                                              float w_nyq) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
     constexpr int N = 2 * N2, LS = row_stride(N2, RB, true);
-    using Tb = Tables<N2, R1, R2, R3>;
+    // PRUNED (mmax <= N2/2): the spectrum is zero for mmax <= m <= N2 - mmax ... N2, which the kernel never
+    // touches: no zero fill, the pre-twiddle runs on the loaded registers, the first pass substitutes zeros
+    constexpr bool PRUNED = MCAP <= N2 / 2;
+    using Tb = Tables<N2, R1, R2, R3, PRUNED ? MCAP : N2 + 1>;
     __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
     float2* buf = smem;
     float2* tw2 = smem + RB * LS;
@@ -333,64 +336,91 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
             sim[q] = b;
         }
     };
-    if (vec && it.begin < it.end) prefetch(it.begin);
+    if ((vec || PRUNED) && it.begin < it.end) prefetch(it.begin);
     for (long long item = it.begin; item < it.end; ++item) {
         const long long klat = item / ngr;
         const long long p0 = (item - klat * ngr) * RB;
         const int nr = (int)min((long long)RB, planes - p0);
         T* xr = x + (p0 * nlat + klat) * (long long)N;
 
-        // weighted spectrum -> LDS rows, zero beyond mmax (and in rows >= nr)
-        if (vec) {
+        if constexpr (PRUNED) {
+            // registers -> pre-twiddled pairs (m, N2-m) with X[N2-m] = 0:  Zs[m] and Zs[N2-m] from X[m] alone
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) {
                 const int idx = tid + q * NT;
                 const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
                 if (m < mmax) {
                     const bool live = r0 < nr;
-                    buf[(r0 + 0) * LS + m] = live ? weighted_one<N2>(m, sre[q].x, sim[q].x, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                    buf[(r0 + 1) * LS + m] = live ? weighted_one<N2>(m, sre[q].y, sim[q].y, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                    buf[(r0 + 2) * LS + m] = live ? weighted_one<N2>(m, sre[q].z, sim[q].z, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                    buf[(r0 + 3) * LS + m] = live ? weighted_one<N2>(m, sre[q].w, sim[q].w, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                }
-            }
-        } else {
-#pragma unroll 4
-            for (int q = 0; q < NQ1; ++q) {
-                const int idx = tid + q * NT;
-                const int r = idx % RB, m = idx / RB;
-                if (m < mmax) {
-                    float2 X = make_float2(0.f, 0.f);
-                    if (r < nr) {
-                        const long long pr = p0 + r;
-                        const float* sp = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
-                        X = weighted_one<N2>(m, sp[0], sp[rows], w_dc, w_pos, w_nyq);
+                    const float2 tw = twu[m];
+                    const float re[4] = {sre[q].x, sre[q].y, sre[q].z, sre[q].w};
+                    const float im[4] = {sim[q].x, sim[q].y, sim[q].z, sim[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float2 Xa = live ? weighted_one<N2>(m, re[i], im[i], w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                        const float2 wt = cmul(cconj(tw), Xa);
+                        buf[(r0 + i) * LS + m] = make_float2(Xa.x - wt.y, -(Xa.y + wt.x));
+                        if (m != 0) {
+                            const float2 w2 = cmul(tw, cconj(Xa));
+                            buf[(r0 + i) * LS + N2 - m] = make_float2(Xa.x - w2.y, -(-Xa.y + w2.x));
+                        }
                     }
-                    buf[r * LS + m] = X;
                 }
             }
-        }
-        for (int idx = tid + mmax * RB; idx < (N2 + 1) * RB; idx += NT) buf[(idx % RB) * LS + idx / RB] = make_float2(0.f, 0.f);
-        __syncthreads();
-        if (vec && item + 1 < it.end) prefetch(item + 1);      // in flight during the pre-twiddle and the passes
+            __syncthreads();
+            if (item + 1 < it.end) prefetch(item + 1);         // in flight during the passes
+        } else {
+            // weighted spectrum -> LDS rows, zero beyond mmax (and in rows >= nr)
+            if (vec) {
+    #pragma unroll
+                for (int q = 0; q < NQ4; ++q) {
+                    const int idx = tid + q * NT;
+                    const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
+                    if (m < mmax) {
+                        const bool live = r0 < nr;
+                        buf[(r0 + 0) * LS + m] = live ? weighted_one<N2>(m, sre[q].x, sim[q].x, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                        buf[(r0 + 1) * LS + m] = live ? weighted_one<N2>(m, sre[q].y, sim[q].y, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                        buf[(r0 + 2) * LS + m] = live ? weighted_one<N2>(m, sre[q].z, sim[q].z, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                        buf[(r0 + 3) * LS + m] = live ? weighted_one<N2>(m, sre[q].w, sim[q].w, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                    }
+                }
+            } else {
+    #pragma unroll 4
+                for (int q = 0; q < NQ1; ++q) {
+                    const int idx = tid + q * NT;
+                    const int r = idx % RB, m = idx / RB;
+                    if (m < mmax) {
+                        float2 X = make_float2(0.f, 0.f);
+                        if (r < nr) {
+                            const long long pr = p0 + r;
+                            const float* sp = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
+                            X = weighted_one<N2>(m, sp[0], sp[rows], w_dc, w_pos, w_nyq);
+                        }
+                        buf[r * LS + m] = X;
+                    }
+                }
+            }
+            for (int idx = tid + mmax * RB; idx < (N2 + 1) * RB; idx += NT) buf[(idx % RB) * LS + idx / RB] = make_float2(0.f, 0.f);
+            __syncthreads();
+            if (vec && item + 1 < it.end) prefetch(item + 1);      // in flight during the pre-twiddle and the passes
 
-        // in-place pre-twiddle on the pairs (j, N2-j): Zs[j] = (A + Bc) + i conj(W^j)(A - Bc); store conj(Zs)
-        for (int idx = tid; idx < RB * (N2 / 2 + 1); idx += NT) {
-            const int row = idx / (N2 / 2 + 1), j = idx % (N2 / 2 + 1);
-            const int j2 = N2 - j;                         // partner (j = 0 pairs with N2, j = N2/2 with itself)
-            const float2 Xa = buf[row * LS + j], Xb = buf[row * LS + j2];
-            {
-                const float2 u = cadd(Xa, cconj(Xb)), t = csub(Xa, cconj(Xb));
-                const float2 wt = cmul(cconj(twu[j]), t);
-                buf[row * LS + j] = make_float2(u.x - wt.y, -(u.y + wt.x));
+            // in-place pre-twiddle on the pairs (j, N2-j): Zs[j] = (A + Bc) + i conj(W^j)(A - Bc); store conj(Zs)
+            for (int idx = tid; idx < RB * (N2 / 2 + 1); idx += NT) {
+                const int row = idx / (N2 / 2 + 1), j = idx % (N2 / 2 + 1);
+                const int j2 = N2 - j;                         // partner (j = 0 pairs with N2, j = N2/2 with itself)
+                const float2 Xa = buf[row * LS + j], Xb = buf[row * LS + j2];
+                {
+                    const float2 u = cadd(Xa, cconj(Xb)), t = csub(Xa, cconj(Xb));
+                    const float2 wt = cmul(cconj(twu[j]), t);
+                    buf[row * LS + j] = make_float2(u.x - wt.y, -(u.y + wt.x));
+                }
+                if (j != 0 && j2 != j) {
+                    const float2 u = cadd(Xb, cconj(Xa)), t = csub(Xb, cconj(Xa));
+                    const float2 wt = cmul(cconj(twu[j2]), t);
+                    buf[row * LS + j2] = make_float2(u.x - wt.y, -(u.y + wt.x));
+                }
             }
-            if (j != 0 && j2 != j) {
-                const float2 u = cadd(Xb, cconj(Xa)), t = csub(Xb, cconj(Xa));
-                const float2 wt = cmul(cconj(twu[j2]), t);
-                buf[row * LS + j2] = make_float2(u.x - wt.y, -(u.y + wt.x));
-            }
+            __syncthreads();
         }
-        __syncthreads();
 
         auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
         auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
@@ -399,7 +429,14 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         auto st_global = [&](int row, int pos, float2 val) {
             if (row < nr) store_pair<T>(xr + (long long)row * rstride + 2 * pos, val.x, -val.y);     // conj
         };
-        fft_pass<N2, R1, 1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
+        if constexpr (PRUNED) {
+            const int z0 = mmax, z1 = N2 - mmax;               // never-written (zero) positions, inclusive
+            fft_pass<N2, R1, 1, RB, NT, true>(tw2, [&](int row, int pos) -> float2 {
+                return (pos >= z0 && pos <= z1) ? make_float2(0.f, 0.f) : buf[row * LS + pos];
+            }, st_lds, tid);
+        } else {
+            fft_pass<N2, R1, 1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
+        }
         __syncthreads();
         if constexpr (R3 > 1) {
             fft_pass<N2, R2, R1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
@@ -410,15 +447,6 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         }
         __syncthreads();
     }
-}
-
-int fft_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MAKANI_AMD_FFT_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
 }
 
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
@@ -438,10 +466,10 @@ int launch_inverse(const float* in, T* out, const float2* tw, int C, int Cp, lon
     return mk_check_launch("mk_irfft_rows(fast)");
 }
 
-template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, typename T>
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
 int launch_forward(const T* in, float* out, const float2* tw, int C, int Cp, long long rows, long long planes, int nlat,
                    int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, hipStream_t s) {
-    auto kern = rfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, T>;
+    auto kern = rfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, MCAP, T>;
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
@@ -465,11 +493,16 @@ int launch(bool inverse, const void* in, void* out, int dtype, const float2* tw,
     MK_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "fft: x and F must be 16-byte aligned");
     constexpr int M3 = N2 / 3 + 1, MF = N2 + 1;
 #define MK_FFT_TAIL tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq, s
+    const bool vec = (C % 4 == 0) || (B == 1);
     if (!inverse) {
-        if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, float>((const float*)in, (float*)out, MK_FFT_TAIL);
-        return launch_forward<N2, R1, R2, R3, RB, NT, WGS, u16>((const u16*)in, (float*)out, MK_FFT_TAIL);
+        if (mmax <= M3) {
+            if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, M3, float>((const float*)in, (float*)out, MK_FFT_TAIL);
+            return launch_forward<N2, R1, R2, R3, RB, NT, WGS, M3, u16>((const u16*)in, (float*)out, MK_FFT_TAIL);
+        }
+        if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, MF, float>((const float*)in, (float*)out, MK_FFT_TAIL);
+        return launch_forward<N2, R1, R2, R3, RB, NT, WGS, MF, u16>((const u16*)in, (float*)out, MK_FFT_TAIL);
     }
-    if (mmax <= M3) {
+    if (mmax <= M3 && vec) {      // truncated spectrum (pruned transform; it needs the float4 F access)
         if (dtype == MK_F32) return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, float>((const float*)in, (float*)out, MK_FFT_TAIL);
         return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, u16>((const float*)in, (u16*)out, MK_FFT_TAIL);
     }
@@ -487,15 +520,12 @@ int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, con
                          int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, void* stream) {
     const float2* tw = reinterpret_cast<const float2*>(twiddle);
     hipStream_t s = (hipStream_t)stream;
-    const int var = fft_variant();
     //                         N2  radices   RB   NT  WG/CU
     switch (nlon) {
-        case 1440:
-            if (var == 1) return launch<720, 10, 9, 8, 8, 384, 2>(MK_FFT_ARGS);
-            return launch<720, 10, 9, 8, 8, 256, 2>(MK_FFT_ARGS);
-        case 480:
-            if (var == 1) return launch<240, 10, 6, 4, 16, 384, 3>(MK_FFT_ARGS);
-            return launch<240, 10, 6, 4, 16, 256, 2>(MK_FFT_ARGS);
+        // measured and rejected: 384-thread workgroups (3 waves/SIMD) are 10-25 % slower than 256-thread ones;
+        // forcing 3 workgroups/CU on the forward 1440 kernel spills (2.6x slower)
+        case 1440: return launch<720, 10, 9, 8, 8, 256, 2>(MK_FFT_ARGS);
+        case 480: return launch<240, 10, 6, 4, 16, 256, 2>(MK_FFT_ARGS);
         case 360: return launch<180, 6, 6, 5, 16, 256, 3>(MK_FFT_ARGS);
         case 128: return launch<64, 4, 4, 4, 16, 256, 4>(MK_FFT_ARGS);
         case 72: return launch<36, 6, 6, 1, 16, 256, 4>(MK_FFT_ARGS);
