@@ -382,6 +382,19 @@ def main():
             kernels[k] = dict(launches_per_step=d["launches"] / args.steps, ms_avg=round(d["ms_avg"], 4),
                               ms_per_step=round(d["ms_total"] / args.steps, 3),
                               TFLOPs_dense=round(tf, 2) if tf else None, GBps_algorithmic=round(gb, 1))
+        # HBM traffic per launch of the same kernel from the committed PMC passes (rocprofv3 counters cannot be
+        # collected from inside the timed run; profiles/r01_pmc_hbm_traffic.json says how they were taken)
+        pmc = {}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")) as fh:
+                pmc = json.load(fh)
+        except OSError:
+            pass
+
+        def traffic_of(name):
+            t = pmc.get(name)
+            return t["hbm_bytes"] if isinstance(t, dict) and args.config == "sfno_sc3_layers8_edim384" and msize == 1 else None
+
         if dom_name:
             d = prof[dom_name]
             if d["flops"]:
@@ -393,13 +406,14 @@ def main():
                                  "x6": (PEAK_BF16_MFMA_TF / 6, "bf16 MFMA, 6 limb products per fp32 product"),
                                  "x3": (PEAK_BF16_MFMA_TF / 3, "bf16 MFMA, 3 limb products per fp32 product")}[ops.GEMM_MODE]
                 roofline = dict(kernel=dom_name, bound="mfma", achieved=round(ach, 2), peak=round(peak, 1),
-                                unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+                                unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic_of(dom_name),
+                                algorithmic_bytes=int(d["bytes"] / d["launches"]),
                                 note=f"dense-formulation fp32-equivalent flops per launch / HIP-event launch time; "
                                      f"engine: {eng}; the kernel skips the structurally-zero l<m half (DESIGN.md §4)")
             else:
                 ach = d["bytes"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e9
                 roofline = dict(kernel=dom_name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic_of(dom_name))
         hip_ms = sum(d["ms_total"] for d in prof.values()) / args.steps
         out = {
             "metric": "SFNO train samples/sec at 721x1440x73ch",

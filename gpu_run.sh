@@ -1,9 +1,12 @@
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | tail -4
-timeout 300 python bench.py --steps 10 --warmup 3 2>&1 | tail -1 > gpurun_out/bench_v6.json; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_v6.json').read())
-print(d['ms_per_step'], d['value'], d['hip_kernel_ms_per_step'], d['fwd_sht'])
-for k,v in d['hip_kernels'].items():
-    if 'fft' in k or 'legendre' in k or 'dhconv' in k: print(k, v['ms_avg'], v['ms_per_step'])
-PY
+mkdir -p gpurun_out/pmc7
+R=$GRAFT_REPO_ROOT
+timeout 300 python tools/microbench.py > gpurun_out/pmc7/microbench.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc7 -o $c -- python $R/tools/microbench.py fft legendre dhconv conv > $R/gpurun_out/pmc7/$c.log 2>&1
+  echo "$c rc=$?"
+done
+cd $R
+python tools/pmc_summary.py gpurun_out/pmc7/summary.md $(find gpurun_out/pmc7 -name "*counter_collection.csv") > /dev/null
+find gpurun_out/pmc7 -name "*.csv" -delete
+grep -v amdgpu gpurun_out/pmc7/microbench.log | cut -c1-170
