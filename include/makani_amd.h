@@ -138,6 +138,21 @@ int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int dtype, long 
 int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy, void* gx, float* sums, float* ws, int dtype,
                      long long planes, int channels, long long hw, void* stream);
 
+/* ---- quadrature-weighted L^p plane sums (geometric losses) ---------------------------------
+ * Replace GridQuadrature.forward (makani/utils/grids.py:185-191) and the elementwise chain of
+ * GeometricLpLoss.abs/rel (makani/utils/losses/lp_loss.py:61-107) and their autograd:
+ *   mode 0:  sums[plane][0] = sum_i q[i] * a[plane][i] (* wgt[plane][i])
+ *   mode 1:  sums[plane][0] = sum_i q[i] * |a[plane][i] - b[plane][i]|^p (* wgt[plane][i])     (b NULL = 0)
+ * a, b: (planes, hw) f32 | bf16 independently (prediction bf16, target f32); q: (hw) f32 quadrature weights;
+ * wgt: optional (planes, hw) f32; sums: (planes, 2) f32 (second column 0); ws: planes * mk_quad_lp_chunks(hw) * 2
+ * floats of scratch.  Backward: da = g[plane] * q * wgt * d|d|^p/dd (mode 0: g * q * wgt), db = -da; either may be
+ * NULL; gradients are written in the dtype of the tensor they belong to. */
+int mk_quad_lp_chunks(long long hw);
+int mk_quad_lp_fwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* wgt, const float* q,
+                   float* sums, float* ws, long long planes, long long hw, int mode, float p, void* stream);
+int mk_quad_lp_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* wgt, const float* q,
+                   const float* g, void* da, void* db, long long planes, long long hw, int mode, float p, void* stream);
+
 /* ---- bf16 channel GEMMs (1x1 convolutions on NCHW planes) ---------------------------------
  * Replace nn.Conv2d(kernel_size=1) of MLP / EncoderDecoder / outer_skip / residual_transform
  * (makani/models/common/layers.py:603-643,768-823; makani/models/networks/sfnonet.py:335-338,726-730)

@@ -5,6 +5,8 @@ from .sht import RealSHT, InverseRealSHT
 from .spectral_conv import SpectralConv
 from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv
 from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, SpectralFilterLayer
+from .losses import GeometricLpLoss, GridQuadrature
 
 __all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
-           "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer"]
+           "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer", "GeometricLpLoss",
+           "GridQuadrature"]

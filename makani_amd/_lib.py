@@ -55,6 +55,9 @@ _SIGS = {
     "mk_conv1x1_wgrad": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
     "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
     "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
+    "mk_quad_lp_chunks": ([c_ll], c_int),
+    "mk_quad_lp_fwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),
+    "mk_quad_lp_bwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),
 }
 
 EXPORTS = sorted(list(_SIGS) + ["mk_last_error"])

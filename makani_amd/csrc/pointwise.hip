@@ -331,6 +331,135 @@ __global__ __launch_bounds__(NT) void bias_gelu_bwd(const T* __restrict__ x, con
     }
 }
 
+
+// ---- quadrature-weighted L^p plane sums (geometric losses) -----------------------------------
+//   mode 0:  sum_i q[i] * a[i] (* w[i])                    (GridQuadrature.forward, makani/utils/grids.py:185-191)
+//   mode 1:  sum_i q[i] * |a[i] - b[i]|^p (* w[i])         (GeometricLpLoss, makani/utils/losses/lp_loss.py:61-75)
+// a and b may have different dtypes (prediction bf16 / target f32); 4 elements per lane and step.
+constexpr int LP_UNROLL = 8;
+constexpr long long LP_CHUNK = (long long)NT * 4 * LP_UNROLL;
+
+__device__ __forceinline__ void load4(const float* p, float* v) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+    v[0] = r[0], v[1] = r[1], v[2] = r[2], v[3] = r[3];
+}
+__device__ __forceinline__ void load4(const u16* p, float* v) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(r.x << 16), v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16), v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float* v) {
+    f32x4 r = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = r;
+}
+__device__ __forceinline__ void store4(u16* p, const float* v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                                              (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+}
+__device__ __forceinline__ float lp_pow(float d, float p) {
+    const float ad = fabsf(d);
+    return p == 2.f ? d * d : (p == 1.f ? ad : powf(ad, p));
+}
+__device__ __forceinline__ float lp_pow_grad(float d, float p) {      // d/dd |d|^p  (0 at d = 0 like torch.abs)
+    if (p == 2.f) return 2.f * d;
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    return p == 1.f ? sg : (d == 0.f ? 0.f : p * powf(fabsf(d), p - 1.f) * sg);
+}
+
+template <typename TA, typename TB, typename F>
+__device__ __forceinline__ void lp_for_chunk(long long hw, int chunk, F&& f) {
+    const long long c0 = (long long)chunk * LP_CHUNK;
+    const long long c1 = min(hw, c0 + LP_CHUNK);
+    if ((hw & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < LP_UNROLL; ++u) {
+            const long long e = c0 + ((long long)u * NT + threadIdx.x) * 4;
+            if (e < c1) f(e, true);
+        }
+    } else {
+        for (long long e = c0 + threadIdx.x; e < c1; e += NT) f(e, false);
+    }
+}
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(NT) void quad_lp_fwd(const TA* __restrict__ a, const TB* __restrict__ b,
+                                                  const float* __restrict__ wgt, const float* __restrict__ q,
+                                                  float* __restrict__ ws, long long hw, int chunks, int mode, float p) {
+    __shared__ float red[2 * NT / 64];
+    const long long plane = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const TA* ap = a + plane * hw;
+    const TB* bp = b ? b + plane * hw : nullptr;
+    const float* wp = wgt ? wgt + plane * hw : nullptr;
+    float s1 = 0.f, s2 = 0.f;
+    lp_for_chunk<TA, TB>(hw, chunk, [&](long long e, bool vec) {
+        float va[4], vb[4] = {0.f, 0.f, 0.f, 0.f}, vq[4], vw[4] = {1.f, 1.f, 1.f, 1.f};
+        const int cnt = vec ? 4 : 1;
+        if (vec) {
+            load4(ap + e, va);
+            load4(q + e, vq);
+            if (bp) load4(bp + e, vb);
+            if (wp) load4(wp + e, vw);
+        } else {
+            va[0] = VecIO<TA>::load1(ap + e);
+            vq[0] = q[e];
+            if (bp) vb[0] = VecIO<TB>::load1(bp + e);
+            if (wp) vw[0] = wp[e];
+        }
+        for (int i = 0; i < cnt; ++i) {
+            const float t = mode ? lp_pow(va[i] - vb[i], p) : va[i];
+            s1 += vq[i] * (t * vw[i]);
+        }
+    });
+    block_reduce2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        ws[2 * (long long)blockIdx.x] = s1;
+        ws[2 * (long long)blockIdx.x + 1] = 0.f;
+    }
+}
+
+// da[i] = g[plane] * q[i] * w[i] * (mode ? d|d|^p/dd : 1),  db = -da
+template <typename TA, typename TB>
+__global__ __launch_bounds__(NT) void quad_lp_bwd(const TA* __restrict__ a, const TB* __restrict__ b,
+                                                  const float* __restrict__ wgt, const float* __restrict__ q,
+                                                  const float* __restrict__ g, TA* __restrict__ da, TB* __restrict__ db,
+                                                  long long hw, int chunks, int mode, float p) {
+    const long long plane = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const TA* ap = a + plane * hw;
+    const TB* bp = b ? b + plane * hw : nullptr;
+    const float* wp = wgt ? wgt + plane * hw : nullptr;
+    TA* dap = da ? da + plane * hw : nullptr;
+    TB* dbp = db ? db + plane * hw : nullptr;
+    const float gp = g[plane];
+    lp_for_chunk<TA, TB>(hw, chunk, [&](long long e, bool vec) {
+        float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f}, vq[4], vw[4] = {1.f, 1.f, 1.f, 1.f}, r[4], rn[4];
+        const int cnt = vec ? 4 : 1;
+        if (vec) {
+            if (mode) load4(ap + e, va);
+            load4(q + e, vq);
+            if (bp) load4(bp + e, vb);
+            if (wp) load4(wp + e, vw);
+        } else {
+            if (mode) va[0] = VecIO<TA>::load1(ap + e);
+            vq[0] = q[e];
+            if (bp) vb[0] = VecIO<TB>::load1(bp + e);
+            if (wp) vw[0] = wp[e];
+        }
+        for (int i = 0; i < cnt; ++i) {
+            r[i] = gp * vq[i] * vw[i] * (mode ? lp_pow_grad(va[i] - vb[i], p) : 1.f);
+            rn[i] = -r[i];
+        }
+        if (vec) {
+            if (dap) store4(dap + e, r);
+            if (dbp) store4(dbp + e, rn);
+        } else {
+            if (dap) VecIO<TA>::store1(dap + e, r[0]);
+            if (dbp) VecIO<TB>::store1(dbp + e, rn[0]);
+        }
+    });
+}
+
 template <typename T>
 int chunks_for(long long hw) {
     return (int)((hw + chunk_elems<T>() - 1) / chunk_elems<T>());
@@ -469,4 +598,58 @@ extern "C" int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy
         if (sums) hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);
     }
     return mk_check_launch("mk_bias_gelu_bwd");
+}
+
+extern "C" int mk_quad_lp_chunks(long long hw) { return (int)((hw + LP_CHUNK - 1) / LP_CHUNK); }
+
+#define MK_LP_DISPATCH(KERN, ...)                                                                         \
+    do {                                                                                                  \
+        if (a_dtype == MK_F32 && b_dtype == MK_F32)                                                       \
+            hipLaunchKernelGGL((KERN<float, float>), grid, dim3(NT), 0, s, (const float*)a, (const float*)b, __VA_ARGS__); \
+        else if (a_dtype == MK_F32)                                                                       \
+            hipLaunchKernelGGL((KERN<float, u16>), grid, dim3(NT), 0, s, (const float*)a, (const u16*)b, __VA_ARGS__);     \
+        else if (b_dtype == MK_F32)                                                                       \
+            hipLaunchKernelGGL((KERN<u16, float>), grid, dim3(NT), 0, s, (const u16*)a, (const float*)b, __VA_ARGS__);     \
+        else                                                                                              \
+            hipLaunchKernelGGL((KERN<u16, u16>), grid, dim3(NT), 0, s, (const u16*)a, (const u16*)b, __VA_ARGS__);         \
+    } while (0)
+
+extern "C" int mk_quad_lp_fwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* wgt, const float* q,
+                              float* sums, float* ws, long long planes, long long hw, int mode, float p, void* stream) {
+    int rc = check_common(a, planes, hw, a_dtype, "quad_lp_fwd");
+    if (rc) return rc;
+    MK_REQUIRE(q && sums && ws, "quad_lp_fwd: null pointer");
+    MK_REQUIRE(b_dtype == MK_F32 || b_dtype == MK_BF16, "quad_lp_fwd: bad dtype %d", b_dtype);
+    MK_REQUIRE(mode == 0 || mode == 1, "quad_lp_fwd: mode %d", mode);
+    MK_REQUIRE(mode == 0 || p > 0.f, "quad_lp_fwd: p = %f must be positive", p);
+    if (mode == 0) b = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = mk_quad_lp_chunks(hw);
+    const dim3 grid((unsigned)(planes * ch));
+    MK_LP_DISPATCH(quad_lp_fwd, wgt, q, ws, hw, ch, mode, p);
+    hipLaunchKernelGGL(sum_chunks_final, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, s, ws, sums, planes, ch);
+    return mk_check_launch("mk_quad_lp_fwd");
+}
+
+extern "C" int mk_quad_lp_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* wgt, const float* q,
+                              const float* g, void* da, void* db, long long planes, long long hw, int mode, float p,
+                              void* stream) {
+    int rc = check_common(a, planes, hw, a_dtype, "quad_lp_bwd");
+    if (rc) return rc;
+    MK_REQUIRE(q && g && (da || db), "quad_lp_bwd: null pointer");
+    MK_REQUIRE(b_dtype == MK_F32 || b_dtype == MK_BF16, "quad_lp_bwd: bad dtype %d", b_dtype);
+    MK_REQUIRE(mode == 0 || mode == 1, "quad_lp_bwd: mode %d", mode);
+    MK_REQUIRE(db == nullptr || b != nullptr, "quad_lp_bwd: db without b");
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = mk_quad_lp_chunks(hw);
+    const dim3 grid((unsigned)(planes * ch));
+    if (a_dtype == MK_F32 && b_dtype == MK_F32)
+        hipLaunchKernelGGL((quad_lp_bwd<float, float>), grid, dim3(NT), 0, s, (const float*)a, (const float*)b, wgt, q, g, (float*)da, (float*)db, hw, ch, mode, p);
+    else if (a_dtype == MK_F32)
+        hipLaunchKernelGGL((quad_lp_bwd<float, u16>), grid, dim3(NT), 0, s, (const float*)a, (const u16*)b, wgt, q, g, (float*)da, (u16*)db, hw, ch, mode, p);
+    else if (b_dtype == MK_F32)
+        hipLaunchKernelGGL((quad_lp_bwd<u16, float>), grid, dim3(NT), 0, s, (const u16*)a, (const float*)b, wgt, q, g, (u16*)da, (float*)db, hw, ch, mode, p);
+    else
+        hipLaunchKernelGGL((quad_lp_bwd<u16, u16>), grid, dim3(NT), 0, s, (const u16*)a, (const u16*)b, wgt, q, g, (u16*)da, (u16*)db, hw, ch, mode, p);
+    return mk_check_launch("mk_quad_lp_bwd");
 }

@@ -212,6 +212,25 @@ def transpose(x, sdim, ssizes, cdim, csizes, group, pad_dims=()):
 # --------------------------------------------------------------------------- #
 # local compute backends
 # --------------------------------------------------------------------------- #
+class _ReduceFromSpatialFn(torch.autograd.Function):
+    """``reduce_from_parallel_region(x, "spatial")`` (makani/mpu/mappings.py): SUM all-reduce forward,
+    identity backward."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        y = x.clone()
+        ops._all_reduce_sum(y, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def reduce_from_spatial_region(x):
+    return _ReduceFromSpatialFn.apply(x, spatial_group()) if spatial_size() > 1 else x
+
+
 class HipBackend:
     """Local compute on the HIP library (the product path)."""
 

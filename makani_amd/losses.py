@@ -1,0 +1,184 @@
+"""Drop-in geometric losses on the HIP path.
+
+``GridQuadrature`` mirrors ``makani/utils/grids.py:102-191`` (same constructor, same non-persistent
+``quad_weight`` buffer, ``forward(x)`` = quadrature over the last two axes) and ``GeometricLpLoss`` mirrors
+``makani/utils/losses/lp_loss.py:28-107`` (``abs`` / ``rel`` / ``forward(prd, tar, wgt)`` -> (B, C) norms).
+The elementwise chain ``|prd - tar|^p * wgt * q`` and the plane reduction are ONE HIP kernel
+(``mk_quad_lp_fwd``), its autograd one more (``mk_quad_lp_bwd``); prediction and target may have different
+dtypes (bf16 prediction, fp32 target) without a cast pass.  Spatially distributed quadrature sums over the
+"spatial" group of ``makani_amd.distributed``.
+"""
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib, legendre
+from ._lib import check, dtype_code, lib, ptr, stream
+
+GRID_TO_QUADRATURE_RULE = {
+    "euclidean": "uniform",
+    "equiangular": "naive",
+    "legendre-gauss": "legendre-gauss",
+    "clenshaw-curtiss": "clenshaw-curtiss",
+    "weatherbench2": "weatherbench2",
+}
+
+
+def grid_to_quadrature_rule(grid_type: str) -> str:
+    """``makani/utils/grids.py:27-40``."""
+    if grid_type not in GRID_TO_QUADRATURE_RULE:
+        raise NotImplementedError(f"Grid type {grid_type} does not have a quadrature rule")
+    return GRID_TO_QUADRATURE_RULE[grid_type]
+
+
+def _quad_launch(a, b, wgt, q, mode, p):
+    """sums (planes,) f32 of q * (mode ? |a-b|^p : a) * wgt over the trailing (H, W) plane."""
+    planes = a.numel() // q.numel()
+    hw = q.numel()
+    ch = lib().mk_quad_lp_chunks(hw)
+    sums = torch.empty((planes, 2), dtype=torch.float32, device=a.device)
+    ws = torch.empty((planes * ch * 2,), dtype=torch.float32, device=a.device)
+    check(lib().mk_quad_lp_fwd(ptr(a), dtype_code(a), ptr(b) if b is not None else None,
+                               dtype_code(b) if b is not None else _lib.MK_F32, ptr(wgt) if wgt is not None else None,
+                               ptr(q), ptr(sums), ptr(ws), planes, hw, mode, float(p), stream()), "mk_quad_lp_fwd")
+    return sums[:, 0]
+
+
+def _prep(t, ref_shape=None):
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    if ref_shape is not None and tuple(t.shape) != tuple(ref_shape):
+        t = t.expand(ref_shape)
+    return t.contiguous()
+
+
+class QuadLpFn(torch.autograd.Function):
+    """out[...] = sum_{h,w} q[h,w] * (mode ? |a - b|^p : a) * wgt;  a, b: (..., H, W)."""
+
+    @staticmethod
+    def forward(ctx, a, b, wgt, q, mode, p):
+        if not a.is_cuda:
+            raise RuntimeError("makani_amd losses run on the GPU (HIP) path only")
+        a = _prep(a)
+        b = _prep(b, a.shape) if b is not None else None
+        w = _prep(wgt, a.shape).float() if wgt is not None else None
+        ctx.save_for_backward(a, b, w, q)
+        ctx.meta = (mode, float(p))
+        return _quad_launch(a, b, w, q, mode, p).view(a.shape[:-2])
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, w, q = ctx.saved_tensors
+        mode, p = ctx.meta
+        g = g.contiguous().float().view(-1)
+        need_a, need_b = ctx.needs_input_grad[0], (b is not None and ctx.needs_input_grad[1])
+        da = torch.empty_like(a) if need_a else None
+        db = torch.empty_like(b) if need_b else None
+        if need_a or need_b:
+            check(lib().mk_quad_lp_bwd(ptr(a), dtype_code(a), ptr(b) if b is not None else None,
+                                       dtype_code(b) if b is not None else _lib.MK_F32,
+                                       ptr(w) if w is not None else None, ptr(q), ptr(g),
+                                       ptr(da) if need_a else None, ptr(db) if need_b else None,
+                                       g.numel(), q.numel(), mode, p, stream()), "mk_quad_lp_bwd")
+        return da, db, None, None, None, None
+
+
+def _rule_weights(rule: str, img_shape) -> torch.Tensor:
+    """(H, W) weights summing to 4 pi (before normalisation), ``grids.py:111-144``; same torch-fp32 arithmetic
+    for the closed-form rules so the buffer is bit-identical to the reference's."""
+    H, W = img_shape
+    dlambda = 2 * math.pi / W
+    if rule == "naive":
+        jac = torch.clamp(torch.sin(torch.linspace(0, math.pi, H)), min=0.0)
+        q = ((dlambda * (math.pi / H)) * jac.unsqueeze(1)).tile(1, W)
+        return q * (4.0 * math.pi) / torch.sum(q)
+    if rule in ("clenshaw-curtiss", "legendre-gauss"):
+        _, w = legendre.clenshaw_curtis(H) if rule == "clenshaw-curtiss" else legendre.gauss_legendre(H)
+        return (dlambda * torch.from_numpy(w.copy()).unsqueeze(1)).tile(1, W)
+    if rule == "weatherbench2":
+        lats = torch.linspace(0, math.pi, H)
+        bounds = torch.cat([torch.zeros(1), (lats[:-1] + lats[1:]) / 2, torch.full((1,), math.pi)])
+        jac = torch.cos(bounds[:-1]) - torch.cos(bounds[1:])
+        return (dlambda * jac.unsqueeze(1)).tile(1, W)
+    if rule == "uniform":
+        q = torch.ones((H, W))
+        return 4.0 * math.pi * q / torch.sum(q)
+    raise ValueError(f"Unknown quadrature rule {rule}")
+
+
+class GridQuadrature(nn.Module):
+    def __init__(self, quadrature_rule, img_shape, crop_shape=None, crop_offset=(0, 0), normalize=False, distributed=False):
+        super().__init__()
+        from . import distributed as thd
+        self.distributed = bool(distributed) and thd.is_initialized() and thd.spatial_size() > 1
+        crop_shape = img_shape if crop_shape is None else crop_shape
+        q = _rule_weights(quadrature_rule, img_shape)
+        if normalize:
+            q = q / (4.0 * math.pi)
+        h0, hl = crop_offset[0], crop_shape[0]
+        w0, wl = crop_offset[1], crop_shape[1]
+        if self.distributed:        # this rank's lat/lon shard of the crop (grids.py:150-168)
+            if thd.polar_group_size() > 1:
+                sh = thd.compute_split_shapes(crop_shape[0], thd.polar_group_size())
+                h0, hl = h0 + sum(sh[: thd.polar_group_rank()]), sh[thd.polar_group_rank()]
+            if thd.azimuth_group_size() > 1:
+                sw = thd.compute_split_shapes(crop_shape[1], thd.azimuth_group_size())
+                w0, wl = w0 + sum(sw[: thd.azimuth_group_rank()]), sw[thd.azimuth_group_rank()]
+        q = q[h0:h0 + hl, w0:w0 + wl].contiguous()
+        H, W = q.shape
+        self.register_buffer("quad_weight", q.float().reshape(1, 1, H, W), persistent=False)
+
+    def _reduce(self, quad):
+        if self.distributed:
+            from . import distributed as thd
+            quad = thd.reduce_from_spatial_region(quad.contiguous())
+        return quad
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._reduce(QuadLpFn.apply(x, None, None, self.quad_weight, 0, 1.0).to(x.dtype))
+
+    def lp(self, a, b, wgt, p):
+        """quadrature of |a - b|^p * wgt without materialising the integrand (b None = 0)."""
+        return self._reduce(QuadLpFn.apply(a, b, wgt, self.quad_weight, 1, p))
+
+
+class GeometricLpLoss(nn.Module):
+    """Computes the Lp loss on the sphere (``lp_loss.py:28-107``)."""
+
+    def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
+                 channel_names: List[str], p: Optional[float] = 2.0, relative: Optional[bool] = False,
+                 squared: Optional[bool] = False, jacobian: Optional[str] = "s2",
+                 grid_type: Optional[str] = "equiangular", spatial_distributed: Optional[bool] = False,
+                 eps: Optional[float] = 1.0e-6, **kwargs):
+        super().__init__()
+        self.img_shape, self.crop_shape, self.crop_offset = img_shape, crop_shape, crop_offset
+        self.channel_names = channel_names
+        self.quadrature = GridQuadrature(grid_to_quadrature_rule(grid_type), img_shape=img_shape, crop_shape=crop_shape,
+                                         crop_offset=crop_offset, normalize=True, distributed=spatial_distributed)
+        self.spatial_distributed = self.quadrature.distributed
+        self.p, self.relative, self.squared, self.eps = p, relative, squared, eps
+
+    @property
+    def n_channels(self):
+        return len(self.channel_names)
+
+    def abs(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None):
+        n = prd.shape[0]
+        norms = self.quadrature.lp(prd, tar, wgt, self.p).reshape(n, -1)
+        if not self.squared:
+            norms = norms.pow(1.0 / self.p)
+        return norms
+
+    def rel(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None):
+        n = prd.shape[0]
+        diff = self.quadrature.lp(prd, tar, wgt, self.p).reshape(n, -1)
+        tarn = self.quadrature.lp(tar, None, wgt, self.p).reshape(n, -1)
+        norms = diff / (tarn + self.eps)
+        if not self.squared:
+            norms = norms.pow(1.0 / self.p)
+        return norms
+
+    def forward(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None, **kwargs):
+        return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)

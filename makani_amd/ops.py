@@ -604,16 +604,35 @@ class ConvMmFn(torch.autograd.Function):
         M = weight.shape[0]
         w = weight.view(M, K).to(x.dtype)
         N = H * W
+        # with a residual the product accumulates INTO it (beta = 1, no 88-800 MB copy of the residual first);
+        # autograd is told through mark_dirty, and nothing upstream saves that tensor (it is a norm / GEMM output).
+        # Outputs are allocated in their final shape (never views of a temporary) so that they can be the
+        # in-place target of a later call.
+        inplace = (residual is not None and residual.is_contiguous() and residual.dtype == x.dtype
+                   and not residual._is_view() and not (residual.is_leaf and residual.requires_grad))
+        out = residual if inplace else torch.empty((B, M, H, W), dtype=x.dtype, device=x.device)
         if B == 1:
-            x2 = x.reshape(K, N)
-            y = torch.mm(w, x2) if residual is None else torch.addmm(residual.reshape(M, N), w, x2)
+            x2, o2 = x.reshape(K, N), out.view(M, N)
+            if residual is None:
+                torch.mm(w, x2, out=o2)
+            elif inplace:
+                o2.addmm_(w, x2)
+            else:
+                torch.addmm(residual.reshape(M, N).to(x.dtype), w, x2, out=o2)
         else:
             wb = w.unsqueeze(0).expand(B, -1, -1)
-            x3 = x.reshape(B, K, N)
-            y = torch.bmm(wb, x3) if residual is None else torch.baddbmm(residual.reshape(B, M, N), wb, x3)
+            x3, o3 = x.reshape(B, K, N), out.view(B, M, N)
+            if residual is None:
+                torch.bmm(wb, x3, out=o3)
+            elif inplace:
+                o3.baddbmm_(wb, x3)
+            else:
+                torch.baddbmm(residual.reshape(B, M, N).to(x.dtype), wb, x3, out=o3)
         ctx.save_for_backward(x, weight)
         ctx.has_res = residual is not None
-        return y.view(B, M, H, W)
+        if inplace:
+            ctx.mark_dirty(residual)
+        return out
 
     @staticmethod
     def backward(ctx, gy):

@@ -116,14 +116,56 @@ def contraction_fixtures():
     print(f"contractions.npz: {os.path.getsize(path)/1e6:.2f} MB")
 
 
+def loss_fixtures():
+    """GeometricLpLoss (makani/utils/losses/lp_loss.py:28-107) over every quadrature rule, with crop, p in
+    {1, 1.5, 2}, relative / squared, optional weights: values and input gradients of the reference module."""
+    GeometricLpLoss = ref_shims.import_reference_module("makani.utils.losses.lp_loss").GeometricLpLoss
+
+    cases = [
+        dict(img=(37, 72), crop=(37, 72), off=(0, 0), grid="equiangular", p=2.0, relative=False, squared=True, wgt=False),
+        dict(img=(37, 72), crop=(37, 72), off=(0, 0), grid="equiangular", p=2.0, relative=False, squared=False, wgt=True),
+        dict(img=(24, 48), crop=(24, 48), off=(0, 0), grid="legendre-gauss", p=1.0, relative=True, squared=False, wgt=False),
+        dict(img=(33, 64), crop=(30, 60), off=(2, 3), grid="clenshaw-curtiss", p=1.5, relative=True, squared=True, wgt=False),
+        dict(img=(33, 64), crop=(33, 61), off=(0, 1), grid="weatherbench2", p=3.0, relative=False, squared=False, wgt=False),
+        dict(img=(19, 36), crop=(19, 36), off=(0, 0), grid="euclidean", p=2.0, relative=True, squared=False, wgt=True),
+    ]
+    rec = {"cases": json.dumps(cases)}
+    for i, c in enumerate(cases):
+        torch.manual_seed(100 + i)
+        B, C = 2, 3
+        mod = GeometricLpLoss(img_shape=c["img"], crop_shape=c["crop"], crop_offset=c["off"],
+                              channel_names=[str(k) for k in range(C)], p=c["p"], relative=c["relative"],
+                              squared=c["squared"], grid_type=c["grid"])
+        prd = torch.randn(B, C, *c["crop"], requires_grad=True)
+        tar = torch.randn(B, C, *c["crop"], requires_grad=True)
+        wgt = torch.rand(B, C, *c["crop"]) + 0.5 if c["wgt"] else None
+        out = mod(prd, tar, wgt)
+        g = torch.randn_like(out)
+        (out * g).sum().backward()
+        rec[f"{i}_q"] = _np(mod.quadrature.quad_weight.float())
+        rec[f"{i}_prd"], rec[f"{i}_tar"], rec[f"{i}_g"] = _np(prd), _np(tar), _np(g)
+        if wgt is not None:
+            rec[f"{i}_wgt"] = _np(wgt)
+        rec[f"{i}_out"], rec[f"{i}_dprd"], rec[f"{i}_dtar"] = _np(out), _np(prd.grad), _np(tar.grad)
+    path = os.path.join(OUT, "geometric_lp_loss.npz")
+    np.savez_compressed(path, **rec)
+    print(f"geometric_lp_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
+
 def main():
     if not ref_shims.reference_available():
         raise SystemExit("reference tree not found; golden fixtures can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    contraction_fixtures()
-    spectral_conv_fixtures()
-    sfno_fixtures()
+    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss"]
+    if "contractions" in which:
+        contraction_fixtures()
+    if "spectral_conv" in which:
+        spectral_conv_fixtures()
+    if "sfno" in which:
+        sfno_fixtures()
+    if "loss" in which:
+        loss_fixtures()
 
 
 if __name__ == "__main__":

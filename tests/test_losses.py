@@ -1,0 +1,114 @@
+"""Geometric L^p loss: oracle vs the reference's golden vectors (CPU), the module's
+quadrature buffers vs the same vectors (CPU), HIP kernels vs oracle and golden vectors (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "geometric_lp_loss.npz")
+
+
+def _cases():
+    d = np.load(GOLDEN)
+    return d, json.loads(str(d["cases"]))
+
+
+def test_oracle_loss_matches_reference_golden():
+    from oracle import losses as ol
+    d, cases = _cases()
+    for i, c in enumerate(cases):
+        q = ol.quadrature_weights(ol.GRID_TO_RULE[c["grid"]], c["img"], c["crop"], c["off"], normalize=True)
+        assert np.allclose(q.float().numpy(), d[f"{i}_q"][0, 0], rtol=0, atol=1e-9)
+        prd = torch.tensor(d[f"{i}_prd"], requires_grad=True)
+        tar = torch.tensor(d[f"{i}_tar"], requires_grad=True)
+        w = torch.tensor(d[f"{i}_wgt"]) if c["wgt"] else None
+        out = ol.geometric_lp_loss(prd, tar, q, c["p"], c["relative"], c["squared"], wgt=w)
+        (out * torch.tensor(d[f"{i}_g"])).sum().backward()
+        assert np.allclose(out.detach().numpy(), d[f"{i}_out"], rtol=1e-6, atol=1e-8)
+        assert np.allclose(prd.grad.numpy(), d[f"{i}_dprd"], rtol=1e-5, atol=1e-9)
+        assert np.allclose(tar.grad.numpy(), d[f"{i}_dtar"], rtol=1e-5, atol=1e-9)
+
+
+def test_module_quadrature_buffers_match_reference():
+    """host logic: the (non-persistent) quad_weight buffer equals the reference's for every rule, with crop"""
+    import makani_amd as ma
+    d, cases = _cases()
+    for i, c in enumerate(cases):
+        mod = ma.GeometricLpLoss(img_shape=c["img"], crop_shape=c["crop"], crop_offset=c["off"],
+                                 channel_names=["a", "b", "c"], p=c["p"], relative=c["relative"], squared=c["squared"],
+                                 grid_type=c["grid"])
+        q = mod.quadrature.quad_weight
+        assert q.shape == (1, 1, *c["crop"]) and q.dtype == torch.float32
+        assert np.allclose(q.numpy(), d[f"{i}_q"], rtol=2e-7, atol=1e-12), c["grid"]
+        assert len(mod.state_dict()) == 0 and mod.n_channels == 3
+    with pytest.raises(NotImplementedError):
+        ma.GeometricLpLoss((8, 16), (8, 16), (0, 0), ["a"], grid_type="healpix")
+    with pytest.raises(RuntimeError):                   # no CPU implementation behind the module
+        ma.GeometricLpLoss((8, 16), (8, 16), (0, 0), ["a"])(torch.zeros(1, 1, 8, 16), torch.zeros(1, 1, 8, 16))
+
+
+@pytest.mark.gpu
+def test_hip_loss_matches_reference_golden():
+    import makani_amd as ma
+    d, cases = _cases()
+    dev = torch.device("cuda", 0)
+    for i, c in enumerate(cases):
+        mod = ma.GeometricLpLoss(img_shape=c["img"], crop_shape=c["crop"], crop_offset=c["off"],
+                                 channel_names=["a", "b", "c"], p=c["p"], relative=c["relative"], squared=c["squared"],
+                                 grid_type=c["grid"]).to(dev)
+        prd = torch.tensor(d[f"{i}_prd"], device=dev, requires_grad=True)
+        tar = torch.tensor(d[f"{i}_tar"], device=dev, requires_grad=True)
+        w = torch.tensor(d[f"{i}_wgt"], device=dev) if c["wgt"] else None
+        out = mod(prd, tar, w)
+        (out * torch.tensor(d[f"{i}_g"], device=dev)).sum().backward()
+        assert np.allclose(out.detach().cpu().numpy(), d[f"{i}_out"], rtol=2e-5, atol=1e-7), c
+        assert np.allclose(prd.grad.cpu().numpy(), d[f"{i}_dprd"], rtol=2e-4, atol=1e-8), c
+        assert np.allclose(tar.grad.cpu().numpy(), d[f"{i}_dtar"], rtol=2e-4, atol=1e-8), c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt_prd,dt_tar", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                           (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("H,W,p,relative,squared", [(721, 1440, 2.0, False, True), (37, 73, 1.5, True, False),
+                                                    (24, 48, 1.0, False, False)])
+def test_hip_loss_vs_oracle(dt_prd, dt_tar, H, W, p, relative, squared):
+    """seeded inputs incl. the BASELINE grid, mixed dtypes, odd plane sizes (scalar tail path)"""
+    import makani_amd as ma
+    from oracle import losses as ol
+    torch.manual_seed(H + int(10 * p))
+    dev = torch.device("cuda", 0)
+    B, C = 1, 3
+    prd = torch.randn(B, C, H, W).to(dt_prd)
+    tar = torch.randn(B, C, H, W).to(dt_tar)
+    g = torch.randn(B, C)
+    mod = ma.GeometricLpLoss((H, W), (H, W), (0, 0), ["a"] * C, p=p, relative=relative, squared=squared).to(dev)
+    pd, td = prd.to(dev).requires_grad_(True), tar.to(dev).requires_grad_(True)
+    out = mod(pd, td)
+    (out * g.to(dev)).sum().backward()
+    pr, tr = prd.double().requires_grad_(True), tar.double().requires_grad_(True)
+    q = ol.quadrature_weights("naive", (H, W), normalize=True).double()
+    ref = ol.geometric_lp_loss(pr, tr, q, p, relative, squared)
+    (ref * g.double()).sum().backward()
+    assert out.dtype == torch.float32 and pd.grad.dtype == dt_prd and td.grad.dtype == dt_tar
+    assert torch.allclose(out.cpu().double(), ref.detach(), rtol=2e-5, atol=1e-8)
+    for got, want, dt in ((pd.grad, pr.grad, dt_prd), (td.grad, tr.grad, dt_tar)):
+        tol = 1e-4 if dt == torch.float32 else 1e-2
+        err = (got.cpu().double() - want).norm() / want.norm()
+        assert err < tol, err
+
+
+@pytest.mark.gpu
+def test_hip_grid_quadrature_is_differentiable_sum():
+    import makani_amd as ma
+    dev = torch.device("cuda", 0)
+    quad = ma.GridQuadrature("legendre-gauss", (24, 48), normalize=False).to(dev)
+    x = torch.randn(2, 5, 24, 48, device=dev, requires_grad=True)
+    y = quad(x)
+    ref = torch.sum(x.detach() * quad.quad_weight, dim=(-2, -1))
+    assert y.shape == (2, 5) and torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    y.sum().backward()
+    assert torch.allclose(x.grad, quad.quad_weight.expand_as(x), rtol=1e-6, atol=0)
+    one = quad(torch.ones(1, 1, 24, 48, device=dev))
+    assert abs(one.item() - 4 * np.pi) < 1e-4          # tests/test_grids.py:136-220: the rule integrates 1 to 4 pi
