@@ -413,7 +413,7 @@ def main():
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic_of(dom_name))
         hip_ms = sum(d["ms_total"] for d in prof.values()) / args.steps
         out = {
-            "metric": "SFNO train samples/sec at 721x1440x73ch",
+            "metric": f"SFNO train samples/sec at {H}x{W}x{cfg['inp_chans']}ch",
             "value": dsize * B * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
