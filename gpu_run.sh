@@ -1,4 +1,3 @@
-export MAKANI_AMD_BENCH_BACKEND=gloo
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-sht-metric --config sfno_debug 2>&1 | grep -E '^\{|Error|error' | cut -c1-400
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 4 --steps 2 --warmup 1 --no-cpu-baseline --no-sht-metric --config sfno_debug --parallelism h2w2 2>&1 | grep -E '^\{|Error|error' | cut -c1-400
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 4 --steps 2 --warmup 1 --no-cpu-baseline --no-sht-metric --config sfno_debug --parallelism h2w1 2>&1 | grep -E '^\{|Error|error' | cut -c1-400
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -q --tb=short -x -k "adamw or sfno or train" 2>&1 | tail -3
+for i in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sht-metric 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['hip_kernel_ms_per_step'], d['roofline']['kernel'], d['roofline']['achieved'], len(d['hip_kernels']))"; done

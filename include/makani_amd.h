@@ -176,6 +176,17 @@ int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* part, int M
  * `grad_scale` (device pointer, may be NULL) is that clipping coefficient, applied to g on the fly. */
 int mk_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* grad_scale, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* The same update over `count` tensors (host array of descriptors) in ceil(count / 48) launches: for the ~80 small
+ * tensors of the model, where one launch each costs more in dispatch gaps than in HBM time. */
+typedef struct MkAdamTensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;
+} MkAdamTensor;
+int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_scale, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, void* stream);
 
 #ifdef __cplusplus
 }

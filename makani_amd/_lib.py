@@ -17,6 +17,11 @@ TRI_NONE, TRI_ROW_GE, TRI_K_GE, TRI_ROW_LE, TRI_K_LE = 0, 1, 2, 3, 4
 c_ll, c_int, c_f, c_vp = C.c_longlong, C.c_int, C.c_float, C.c_void_p
 
 
+class MkAdamTensor(C.Structure):
+    """mirrors `struct MkAdamTensor` of include/makani_amd.h"""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong)]
+
+
 class MkGemm(C.Structure):
     _fields_ = [
         ("A", c_vp), ("B", c_vp), ("C", c_vp),
@@ -55,6 +60,7 @@ _SIGS = {
     "mk_conv1x1_wgrad": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
     "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
     "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
+    "mk_adamw_multi": ([c_vp, c_int, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
     "mk_quad_lp_chunks": ([c_ll], c_int),
     "mk_quad_lp_fwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),
     "mk_quad_lp_bwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),

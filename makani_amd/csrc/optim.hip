@@ -45,6 +45,48 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
         }
     }
 }
+
+// ---- many small tensors in one launch ---------------------------------------------------------
+// The SFNO has 8 spectral weights of 70.8 M floats and ~80 tensors of a few hundred to 300 K floats; one
+// launch per small tensor costs more in dispatch gaps and host time than in HBM time.  Up to MULTI_MAX tensors
+// ride in the kernel-argument block; block b works on tensor t with first[t] <= b < first[t+1].
+constexpr int MULTI_MAX = 48;
+constexpr int MULTI_CHUNK = NT * 4 * 4;       // elements per block
+
+struct AdamMulti {
+    float* p[MULTI_MAX];
+    const float* g[MULTI_MAX];
+    float* m[MULTI_MAX];
+    float* v[MULTI_MAX];
+    long long n[MULTI_MAX];
+    int first[MULTI_MAX + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(NT) void adamw_multi_kernel(const AdamMulti a, const float* __restrict__ grad_scale, float lr,
+                                                         float beta1, float beta2, float eps, float weight_decay,
+                                                         float bc1_inv, float bc2_rsqrt) {
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.first[t + 1]) ++t;
+    float* __restrict__ p = a.p[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const long long n = a.n[t];
+    const long long e0 = (long long)((int)blockIdx.x - a.first[t]) * MULTI_CHUNK;
+    const long long e1 = min(n, e0 + MULTI_CHUNK);
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    const float decay = 1.f - lr * weight_decay;
+    const float step = lr * bc1_inv;
+    for (long long i = e0 + threadIdx.x; i < e1; i += NT) {       // small tensors: scalar accesses, any alignment
+        const float gi = g[i] * gs;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] * decay - step * (mi / (sqrtf(vi) * bc2_rsqrt + eps));
+    }
+}
 }  // namespace
 
 extern "C" int mk_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* grad_scale,
@@ -59,4 +101,27 @@ extern "C" int mk_adamw_step(float* p, const float* g, float* m, float* v, long 
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, grad_scale,
                        lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
     return mk_check_launch("mk_adamw_step");
+}
+
+extern "C" int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_scale, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, void* stream) {
+    MK_REQUIRE(tensors && count > 0 && step >= 1, "adamw_multi: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    for (int base = 0; base < count; base += MULTI_MAX) {
+        AdamMulti a;
+        a.count = count - base < MULTI_MAX ? count - base : MULTI_MAX;
+        int blocks = 0;
+        for (int t = 0; t < a.count; ++t) {
+            const MkAdamTensor& s = tensors[base + t];
+            MK_REQUIRE(s.p && s.g && s.m && s.v && s.n > 0, "adamw_multi: tensor %d has a null pointer or no elements", base + t);
+            MK_REQUIRE(s.n < (1ll << 40), "adamw_multi: tensor %d too large for the multi-tensor path", base + t);
+            a.p[t] = s.p, a.g[t] = s.g, a.m[t] = s.m, a.v[t] = s.v, a.n[t] = s.n;
+            a.first[t] = blocks;
+            blocks += (int)((s.n + MULTI_CHUNK - 1) / MULTI_CHUNK);
+        }
+        a.first[a.count] = blocks;
+        hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, a, grad_scale, lr,
+                           beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    }
+    return mk_check_launch("mk_adamw_multi");
 }

@@ -55,6 +55,7 @@ class LaunchProfiler:
 
     def __init__(self):
         self.enabled = False
+        self.only = None           # optional set of launch names to instrument (None = all)
         self.records = []          # (name, start_event, end_event, flops, bytes)
 
     def reset(self):
@@ -82,14 +83,15 @@ class _timed:
         self.name, self.flops, self.nbytes = name, flops, nbytes
 
     def __enter__(self):
-        if PROFILER.enabled:
+        self.on = PROFILER.enabled and (PROFILER.only is None or self.name in PROFILER.only)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if PROFILER.enabled:
+        if self.on:
             self.e1.record()
             PROFILER.records.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
         return False

@@ -1,8 +1,12 @@
 """Fused AdamW + global-norm gradient clipping for the SFNO train step (one HBM pass per
 parameter tensor; the 566 M real numbers of complex64 spectral weights dominate the step)."""
+import ctypes as C
+
 import torch
 
-from ._lib import check, lib, ptr, stream
+from ._lib import MkAdamTensor, check, lib, ptr, stream
+
+SMALL = 1 << 20          # tensors below this many floats share multi-tensor launches
 
 
 def _real(t):
@@ -32,6 +36,8 @@ class FusedAdamW(torch.optim.Optimizer):
             scale = torch.clamp(max_grad_norm / (total + 1e-6), max=1.0).float().reshape(1)
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            small = {}                       # step count -> [descriptors]: one launch per 48 small tensors
+            keep = []                        # python references that must outlive the launches
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -42,9 +48,20 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 pr, gr = _real(p), _real(p.grad)
-                if not (pr.is_contiguous() and gr.is_contiguous()) or pr.dtype != torch.float32:
+                if not (pr.is_contiguous() and gr.is_contiguous()) or pr.dtype != torch.float32 or gr.dtype != torch.float32:
                     raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 parameters and gradients")
-                check(lib().mk_adamw_step(ptr(pr), ptr(gr), ptr(_real(st["exp_avg"])), ptr(_real(st["exp_avg_sq"])),
-                                          pr.numel(), ptr(scale), group["lr"], b1, b2, group["eps"],
-                                          group["weight_decay"], int(st["step"]), stream()), "mk_adamw_step")
+                m, v = _real(st["exp_avg"]), _real(st["exp_avg_sq"])
+                if pr.numel() < SMALL:
+                    small.setdefault(int(st["step"]), []).append(
+                        MkAdamTensor(pr.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), pr.numel()))
+                    keep.append((pr, gr, m, v))
+                else:
+                    check(lib().mk_adamw_step(ptr(pr), ptr(gr), ptr(m), ptr(v), pr.numel(), ptr(scale), group["lr"], b1, b2,
+                                              group["eps"], group["weight_decay"], int(st["step"]), stream()), "mk_adamw_step")
+                # the update goes through raw pointers: tell autograd the parameter changed in place
+                torch.autograd.graph.increment_version(p)
+            for step, descs in small.items():
+                arr = (MkAdamTensor * len(descs))(*descs)
+                check(lib().mk_adamw_multi(C.cast(arr, C.c_void_p), len(descs), ptr(scale), group["lr"], b1, b2, group["eps"],
+                                           group["weight_decay"], step, stream()), "mk_adamw_multi")
         return None

@@ -320,7 +320,9 @@ def test_bias_gelu(dtype, tol, with_bias):
 def test_fused_adamw_matches_torch():
     from makani_amd.optim import FusedAdamW
     torch.manual_seed(3)
-    shapes = [(1, 6, 5, 9), (33,), (7, 13, 1, 1)]
+    # one complex tensor, 60 small tensors (two multi-tensor launches, odd sizes and offsets) and one above the
+    # multi-tensor threshold (single-tensor kernel)
+    shapes = [(1, 6, 5, 9), (33,), (7, 13, 1, 1)] + [(3 + 5 * i,) for i in range(58)] + [(1100, 1024)]
     def make():
         torch.manual_seed(3)
         ps = [torch.nn.Parameter(torch.randn(*shapes[0], dtype=torch.complex64, device=_dev()))]
@@ -340,6 +342,7 @@ def test_fused_adamw_matches_torch():
     for pa, pb in zip(a, b):
         assert rel_l2(pa, pb) < 2e-6
     assert set(oa.state[a[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert a[1]._version > 0                       # raw-pointer updates are visible to autograd's version counter
 
 
 # --------------------------------------------------------------------------- #
