@@ -117,7 +117,7 @@ int mk_complex_to_slayout(const float* in_c64, float* S, int B, int C, int Cp, i
  * Instance norm = nn.InstanceNorm2d(C, eps, affine=True) at makani/models/networks/sfnonet.py:618-620
  * (statistics in fp32 as in makani/mpu/layer_norm.py:147-168); optional fused exact-erf GELU
  * (nn.GELU, sfnonet.py:392-393).  stats: (planes, 2) f32 = {mean, rstd}.
- * Backward: sums (planes, 2) f32 = {sum ga, sum ga * xhat} (dbeta / dgamma per plane),
+ * Backward: sums (2, planes) f32, planar: row 0 = sum ga (dbeta per plane), row 1 = sum ga * xhat (dgamma per plane),
  * gx = rstd*gamma*(ga - mean(ga) - xhat*mean(ga*xhat)), ga = gy * (gelu'(a) if fused).
  * phase 0 = reduce + apply (serial); 1 = reduce only (writes the local `sums`); 2 = apply only with the
  * caller-provided (all-reduced) `sums` and `hw_total` = pixels of the whole plane over all spatial ranks —
@@ -132,7 +132,7 @@ int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const fl
                     long long hw_total, int phase, int fuse_gelu, void* stream);
 /* y = gelu(x + bias[c])  — the bias+activation of the 1x1 convolutions in MLP / EncoderDecoder
  * (makani/models/common/layers.py:603-643,768-823).  bias may be NULL (plain GELU).
- * Backward: gx = gy * gelu'(x + bias[c]); optional sums (planes,2): sums[p][0] = sum gx (bias grad). */
+ * Backward: gx = gy * gelu'(x + bias[c]); optional sums (2, planes): sums[0][p] = sum gx (bias grad). */
 int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int dtype, long long planes, int channels,
                      long long hw, void* stream);
 int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy, void* gx, float* sums, float* ws, int dtype,
@@ -141,10 +141,10 @@ int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy, void* gx,
 /* ---- quadrature-weighted L^p plane sums (geometric losses) ---------------------------------
  * Replace GridQuadrature.forward (makani/utils/grids.py:185-191) and the elementwise chain of
  * GeometricLpLoss.abs/rel (makani/utils/losses/lp_loss.py:61-107) and their autograd:
- *   mode 0:  sums[plane][0] = sum_i q[i] * a[plane][i] (* wgt[plane][i])
- *   mode 1:  sums[plane][0] = sum_i q[i] * |a[plane][i] - b[plane][i]|^p (* wgt[plane][i])     (b NULL = 0)
+ *   mode 0:  sums[0][plane] = sum_i q[i] * a[plane][i] (* wgt[plane][i])
+ *   mode 1:  sums[0][plane] = sum_i q[i] * |a[plane][i] - b[plane][i]|^p (* wgt[plane][i])     (b NULL = 0)
  * a, b: (planes, hw) f32 | bf16 independently (prediction bf16, target f32); q: (hw) f32 quadrature weights;
- * wgt: optional (planes, hw) f32; sums: (planes, 2) f32 (second column 0); ws: planes * mk_quad_lp_chunks(hw) * 2
+ * wgt: optional (planes, hw) f32; sums: (2, planes) f32 (second row 0); ws: planes * mk_quad_lp_chunks(hw) * 2
  * floats of scratch.  Backward: da = g[plane] * q * wgt * d|d|^p/dd (mode 0: g * q * wgt), db = -da; either may be
  * NULL; gradients are written in the dtype of the tensor they belong to. */
 int mk_quad_lp_chunks(long long hw);

@@ -225,8 +225,8 @@ __global__ void sum_chunks_final(const float* __restrict__ ws, float* __restrict
         s1 += (double)ws[2 * (p * chunks + c)];
         s2 += (double)ws[2 * (p * chunks + c) + 1];
     }
-    sums[2 * p] = (float)s1;
-    sums[2 * p + 1] = (float)s2;
+    sums[p] = (float)s1;                 // planar (2, planes): each row is a contiguous per-plane vector
+    sums[planes + p] = (float)s2;
 }
 
 // pass 2: gx = rstd * gamma * (ga - S1/hw - n * S2/hw)
@@ -237,10 +237,11 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
                                                    int channels, long long hw, int chunks, float inv_total) {
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
+    const long long planes = gridDim.x / chunks;
     const int c = (int)(plane % channels);
     const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float m1 = sums[2 * plane] * inv_total, m2 = sums[2 * plane + 1] * inv_total;
+    const float m1 = sums[plane] * inv_total, m2 = sums[planes + plane] * inv_total;
     const float k = rstd * g;
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;

@@ -38,12 +38,12 @@ def _quad_launch(a, b, wgt, q, mode, p):
     planes = a.numel() // q.numel()
     hw = q.numel()
     ch = lib().mk_quad_lp_chunks(hw)
-    sums = torch.empty((planes, 2), dtype=torch.float32, device=a.device)
+    sums = torch.empty((2, planes), dtype=torch.float32, device=a.device)
     ws = torch.empty((planes * ch * 2,), dtype=torch.float32, device=a.device)
     check(lib().mk_quad_lp_fwd(ptr(a), dtype_code(a), ptr(b) if b is not None else None,
                                dtype_code(b) if b is not None else _lib.MK_F32, ptr(wgt) if wgt is not None else None,
                                ptr(q), ptr(sums), ptr(ws), planes, hw, mode, float(p), stream()), "mk_quad_lp_fwd")
-    return sums[:, 0]
+    return sums[0]
 
 
 def _prep(t, ref_shape=None):

@@ -404,6 +404,11 @@ def _ws(planes, hw, dtype, device):
     return torch.empty((planes * ch * 2,), dtype=torch.float32, device=device)
 
 
+def _batch_sum(sums, B, Cc):
+    """(2, B*C) per-plane sums -> (2, C) per-channel sums; a view (no kernel) when B == 1"""
+    return sums if B == 1 else sums.view(2, B, Cc).sum(1)
+
+
 class InstanceNormFn(torch.autograd.Function):
     """nn.InstanceNorm2d(affine) (+ fused exact GELU); fp32 statistics, io in the input dtype."""
 
@@ -434,14 +439,12 @@ class InstanceNormFn(torch.autograd.Function):
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
         gx = torch.empty_like(x)
-        sums = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
         check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(sums),
                                     ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0, stream()), "instnorm_bwd")
-        s = sums.view(B, Cc, 2).sum(0)
-        dgamma = s[:, 1].contiguous() if g is not None else None
-        dbeta = s[:, 0].contiguous() if b is not None else None
-        return gx, dgamma, dbeta, None, None
+        s = _batch_sum(sums, B, Cc)
+        return gx, (s[1] if g is not None else None), (s[0] if b is not None else None), None, None
 
 
 class BiasGeluFn(torch.autograd.Function):
@@ -467,11 +470,11 @@ class BiasGeluFn(torch.autograd.Function):
             gy = gy.to(x.dtype)
         gx = torch.empty_like(x)
         need_b = bf is not None and ctx.needs_input_grad[1]
-        sums = torch.empty((planes, 2), dtype=torch.float32, device=x.device) if need_b else None
+        sums = torch.empty((2, planes), dtype=torch.float32, device=x.device) if need_b else None
         ws = _ws(planes, hw, x.dtype, x.device) if need_b else None
         check(lib().mk_bias_gelu_bwd(ptr(x), ptr(bf), ptr(gy), ptr(gx), ptr(sums), ptr(ws), dtype_code(x), planes, Cc,
                                      hw, stream()), "bias_gelu_bwd")
-        gb = sums.view(B, Cc, 2)[:, :, 0].sum(0) if need_b else None
+        gb = _batch_sum(sums, B, Cc)[0] if need_b else None
         return gx, gb
 
 
@@ -630,7 +633,7 @@ class ConvMmFn(torch.autograd.Function):
                 o3.baddbmm_(wb, x3)
             else:
                 torch.baddbmm(residual.reshape(B, M, N).to(x.dtype), wb, x3, out=o3)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, w if w.dtype != weight.dtype else None)
         ctx.has_res = residual is not None
         if inplace:
             ctx.mark_dirty(residual)
@@ -638,14 +641,15 @@ class ConvMmFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, wc = ctx.saved_tensors
         B, K, H, W = x.shape
         M = weight.shape[0]
         N = H * W
         gy = gy.contiguous()
         gx = gw = gr = None
         if ctx.needs_input_grad[0]:
-            wt = weight.view(M, K).t().to(gy.dtype).contiguous()
+            # W^T as a transposed view of the (already cast) forward operand: the library GEMM takes it as is
+            wt = (wc if wc is not None and wc.dtype == gy.dtype else weight.view(M, K).to(gy.dtype)).t()
             if B == 1:
                 gx = torch.mm(wt, gy.reshape(M, N)).view(B, K, H, W)
             else:
@@ -737,16 +741,16 @@ class DistInstanceNormFn(torch.autograd.Function):
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
         gx = torch.empty_like(x)
-        sums = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
         fg = 1 if fuse_gelu else 0
         hw_total = int(ctx.hw_total[0].item())
         check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), ptr(sums),
                                     ptr(ws), planes, Cc, hw, hw_total, 1, fg, stream()), "instnorm_bwd(reduce)")
-        local = sums.view(B, Cc, 2).sum(0)                        # this rank's share of dgamma / dbeta
+        local = _batch_sum(sums, B, Cc).clone()                   # this rank's share of dgamma / dbeta
         _all_reduce_sum(sums, group)
         check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), ptr(sums),
                                     ptr(ws), planes, Cc, hw, hw_total, 2, fg, stream()), "instnorm_bwd(apply)")
-        dgamma = local[:, 1].contiguous() if g is not None else None
-        dbeta = local[:, 0].contiguous() if b is not None else None
+        dgamma = local[1] if g is not None else None
+        dbeta = local[0] if b is not None else None
         return gx, dgamma, dbeta, None, None, None
