@@ -127,6 +127,10 @@ int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long lo
                       void* stream);
 int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma, const float* beta,
                       long long planes, int channels, long long hw, int fuse_gelu, void* stream);
+/* stats + apply in two launches (the apply kernel finishes the statistics reduction itself and writes `stats` for the
+ * backward): what the serial InstanceNorm2d forward uses. */
+int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, float* ws, const float* gamma, const float* beta,
+                    long long planes, int channels, long long hw, float eps, int fuse_gelu, void* stream);
 int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
                     const float* beta, float* sums, float* ws, long long planes, int channels, long long hw,
                     long long hw_total, int phase, int fuse_gelu, void* stream);
@@ -187,6 +191,11 @@ typedef struct MkAdamTensor {
 } MkAdamTensor;
 int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_scale, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, void* stream);
+/* Global gradient norm and the clipping coefficient of makani/utils/training/training_helpers.py:123-165 over all
+ * `tensors[i].g` (only g and n are read): out[0] = min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0), out[1] = norm.
+ * `partial` needs mk_grad_norm_workspace() floats.  ceil(count / 48) + 1 launches, fixed summation order. */
+long long mk_grad_norm_workspace(const MkAdamTensor* tensors, int count);
+int mk_grad_clip_coef(const MkAdamTensor* tensors, int count, float max_norm, float* partial, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,9 @@ _SIGS = {
     "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
     "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
     "mk_adamw_multi": ([c_vp, c_int, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
+    "mk_instnorm_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_f, c_int, c_vp], c_int),
+    "mk_grad_norm_workspace": ([c_vp, c_int], c_ll),
+    "mk_grad_clip_coef": ([c_vp, c_int, c_f, c_vp, c_vp, c_vp], c_int),
     "mk_quad_lp_chunks": ([c_ll], c_int),
     "mk_quad_lp_fwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),
     "mk_quad_lp_bwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),

@@ -87,6 +87,65 @@ __global__ __launch_bounds__(NT) void adamw_multi_kernel(const AdamMulti a, cons
         p[i] = p[i] * decay - step * (mi / (sqrtf(vi) * bc2_rsqrt + eps));
     }
 }
+
+// ---- global gradient norm -> clipping coefficient, over all tensors in 2-3 launches ---------------
+constexpr int SQ_CHUNK = NT * 4 * 16;         // elements per block
+
+struct SumsqMulti {
+    const float* g[MULTI_MAX];
+    long long n[MULTI_MAX];
+    int first[MULTI_MAX + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(NT) void sumsq_multi_kernel(const SumsqMulti a, float* __restrict__ partial) {
+    __shared__ float red[NT / 64];
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.first[t + 1]) ++t;
+    const float* __restrict__ g = a.g[t];
+    const long long n = a.n[t];
+    const long long e0 = (long long)((int)blockIdx.x - a.first[t]) * SQ_CHUNK;
+    const long long e1 = min(n, e0 + SQ_CHUNK);
+    float s = 0.f;
+    if ((((uintptr_t)g) & 15) == 0) {
+        const long long v1 = e0 + ((e1 - e0) & ~3ll);
+        for (long long i = e0 + (long long)threadIdx.x * 4; i < v1; i += NT * 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(g + i);
+            s += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+        }
+        for (long long i = v1 + threadIdx.x; i < e1; i += NT) s += g[i] * g[i];
+    } else {
+        for (long long i = e0 + threadIdx.x; i < e1; i += NT) s += g[i] * g[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tsum = 0.f;
+        for (int i = 0; i < NT / 64; ++i) tsum += red[i];
+        partial[blockIdx.x] = tsum;
+    }
+}
+
+// out[0] = clip coefficient min(1, max_norm / (norm + 1e-6)), out[1] = norm   (fixed summation order)
+__global__ __launch_bounds__(NT) void clip_coef_kernel(const float* __restrict__ partial, int nparts, float max_norm,
+                                                       float* __restrict__ out) {
+    __shared__ double red[NT];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += NT) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        out[1] = norm;
+        out[0] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    }
+}
 }  // namespace
 
 extern "C" int mk_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* grad_scale,
@@ -124,4 +183,35 @@ extern "C" int mk_adamw_multi(const MkAdamTensor* tensors, int count, const floa
                            beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
     }
     return mk_check_launch("mk_adamw_multi");
+}
+
+extern "C" long long mk_grad_norm_workspace(const MkAdamTensor* tensors, int count) {
+    long long blocks = 0;
+    for (int t = 0; t < count; ++t) blocks += (tensors[t].n + SQ_CHUNK - 1) / SQ_CHUNK;
+    return blocks;
+}
+
+extern "C" int mk_grad_clip_coef(const MkAdamTensor* tensors, int count, float max_norm, float* partial, float* out,
+                                 void* stream) {
+    MK_REQUIRE(tensors && count > 0 && partial && out, "grad_clip_coef: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    long long done = 0;
+    for (int base = 0; base < count; base += MULTI_MAX) {
+        SumsqMulti a;
+        a.count = count - base < MULTI_MAX ? count - base : MULTI_MAX;
+        long long blocks = 0;
+        for (int t = 0; t < a.count; ++t) {
+            const MkAdamTensor& d = tensors[base + t];
+            MK_REQUIRE(d.g && d.n > 0, "grad_clip_coef: tensor %d has no gradient", base + t);
+            a.g[t] = d.g, a.n[t] = d.n;
+            a.first[t] = (int)blocks;
+            blocks += (d.n + SQ_CHUNK - 1) / SQ_CHUNK;
+            MK_REQUIRE(blocks < (1ll << 30), "grad_clip_coef: too many blocks");
+        }
+        a.first[a.count] = (int)blocks;
+        hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, a, partial + done);
+        done += blocks;
+    }
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(NT), 0, s, partial, (int)done, max_norm, out);
+    return mk_check_launch("mk_grad_clip_coef");
 }

@@ -97,6 +97,34 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[
     }
 }
 
+
+// Sum the `chunks` (s1, s2) partial pairs one plane's blocks left in ws; every thread gets the totals.
+// Lets the consumer kernel finish the reduction itself instead of waiting for a tiny finalize launch.
+__device__ __forceinline__ void plane_totals(const float* __restrict__ ws, long long plane, int chunks, double& t1,
+                                             double& t2, double* red /*[2*NT/64]*/) {
+    double a = 0.0, b = 0.0;
+    for (int c = threadIdx.x; c < chunks; c += NT) {
+        a += (double)ws[2 * (plane * chunks + c)];
+        b += (double)ws[2 * (plane * chunks + c) + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[2 * w] = a;
+        red[2 * w + 1] = b;
+    }
+    __syncthreads();
+    t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < NT / 64; ++i) {
+        t1 += red[2 * i];
+        t2 += red[2 * i + 1];
+    }
+}
+
 // ---- instance norm: statistics ---------------------------------------------------
 // partial sums relative to a per-plane pivot (first element) to avoid cancellation in fp32
 template <typename T>
@@ -147,13 +175,31 @@ __global__ void in_stats_final(const T* __restrict__ x, const float* __restrict_
 
 // ---- instance norm: apply (+ GELU) --------------------------------------------------
 template <typename T, bool GELU>
-__global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __restrict__ y,
-                                               const float* __restrict__ stats, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, int channels, long long hw, int chunks) {
+__global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ stats,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               const float* __restrict__ ws, float eps, int channels, long long hw,
+                                               int chunks) {
+    __shared__ double redd[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const int c = (int)(plane % channels);
-    const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
+    float mean, rstd;
+    if (ws) {                    // statistics straight from the partial sums (same arithmetic as in_stats_final)
+        double s1, s2;
+        plane_totals(ws, plane, chunks, s1, s2, redd);
+        const double pivot = (double)VecIO<T>::load1(x + plane * hw);
+        const double m = s1 / (double)hw;
+        double var = s2 / (double)hw - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)(pivot + m);
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (chunk == 0 && threadIdx.x == 0) {
+            stats[2 * plane] = mean;
+            stats[2 * plane + 1] = rstd;
+        }
+    } else {
+        mean = stats[2 * plane], rstd = stats[2 * plane + 1];
+    }
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = rstd * g, sh = b - mean * rstd * g;
     const T* xp = x + plane * hw;
@@ -233,15 +279,29 @@ __global__ void sum_chunks_final(const float* __restrict__ ws, float* __restrict
 template <typename T, bool GELU>
 __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx,
                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, const float* __restrict__ sums,
-                                                   int channels, long long hw, int chunks, float inv_total) {
+                                                   const float* __restrict__ beta, float* __restrict__ sums,
+                                                   const float* __restrict__ ws, int channels, long long hw, int chunks,
+                                                   float inv_total) {
+    __shared__ double redd[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const long long planes = gridDim.x / chunks;
     const int c = (int)(plane % channels);
     const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float m1 = sums[plane] * inv_total, m2 = sums[planes + plane] * inv_total;
+    float t1, t2;
+    if (ws) {                    // finish the reduction of pass 1 here (and publish it for dgamma / dbeta)
+        double d1, d2;
+        plane_totals(ws, plane, chunks, d1, d2, redd);
+        t1 = (float)d1, t2 = (float)d2;
+        if (chunk == 0 && threadIdx.x == 0) {
+            sums[plane] = t1;
+            sums[planes + plane] = t2;
+        }
+    } else {
+        t1 = sums[plane], t2 = sums[planes + plane];
+    }
+    const float m1 = t1 * inv_total, m2 = t2 * inv_total;
     const float k = rstd * g;
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;
@@ -508,27 +568,51 @@ extern "C" int mk_instnorm_stats(const void* x, int dtype, float* stats, float* 
     return mk_check_launch("mk_instnorm_stats");
 }
 
+static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
+                               const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
+                               hipStream_t s);
+
 extern "C" int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma,
                                  const float* beta, long long planes, int channels, long long hw, int fuse_gelu,
                                  void* stream) {
     int rc = check_common(x, planes, hw, dtype, "instnorm_apply");
     if (rc) return rc;
     MK_REQUIRE(y && stats && channels > 0, "instnorm_apply: bad args");
+    return instnorm_apply_impl(x, y, dtype, const_cast<float*>(stats), gamma, beta, nullptr, 0.f, planes, channels, hw,
+                               fuse_gelu, (hipStream_t)stream);
+}
+
+extern "C" int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, float* ws, const float* gamma,
+                               const float* beta, long long planes, int channels, long long hw, float eps, int fuse_gelu,
+                               void* stream) {
+    int rc = check_common(x, planes, hw, dtype, "instnorm_fwd");
+    if (rc) return rc;
+    MK_REQUIRE(y && stats && ws && channels > 0, "instnorm_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MK_F32)
+        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * chunks_for<float>(hw))), dim3(NT), 0, s, (const float*)x, ws, hw, chunks_for<float>(hw));
+    else
+        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * chunks_for<u16>(hw))), dim3(NT), 0, s, (const u16*)x, ws, hw, chunks_for<u16>(hw));
+    return instnorm_apply_impl(x, y, dtype, stats, gamma, beta, ws, eps, planes, channels, hw, fuse_gelu, s);
+}
+
+static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
+                               const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
+                               hipStream_t s) {
     if (dtype == MK_F32) {
         const int ch = chunks_for<float>(hw);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
-            hipLaunchKernelGGL((in_apply<float, true>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<float, true>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
         else
-            hipLaunchKernelGGL((in_apply<float, false>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<float, false>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
     } else {
         const int ch = chunks_for<u16>(hw);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
-            hipLaunchKernelGGL((in_apply<u16, true>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<u16, true>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
         else
-            hipLaunchKernelGGL((in_apply<u16, false>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<u16, false>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
     }
     return mk_check_launch("mk_instnorm_apply");
 }
@@ -547,14 +631,14 @@ extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtyp
     do {                                                                                                               \
         const int ch = chunks_for<T>(hw);                                                                              \
         dim3 g((unsigned)(planes * ch));                                                                               \
-        if (phase != 2) {                                                                                              \
+        if (phase != 2)                                                                                                \
             hipLaunchKernelGGL((in_bwd_partial<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, stats, gamma,    \
                                beta, ws, channels, hw, ch);                                                            \
+        if (phase == 1)                                                                                                \
             hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);                     \
-        }                                                                                                              \
-        if (phase != 1)                                                                                                \
+        if (phase != 1)   /* phase 0: the apply kernel finishes the reduction itself and publishes `sums` */           \
             hipLaunchKernelGGL((in_bwd_apply<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, (T*)gx, stats,     \
-                               gamma, beta, sums, channels, hw, ch, inv_total);                                        \
+                               gamma, beta, sums, phase == 0 ? ws : nullptr, channels, hw, ch, inv_total);             \
     } while (0)
     if (dtype == MK_F32) {
         if (fuse_gelu) IN_BWD(float, true); else IN_BWD(float, false);

@@ -422,10 +422,9 @@ class InstanceNormFn(torch.autograd.Function):
         ws = _ws(planes, hw, x.dtype, x.device)
         g = gamma.float().contiguous() if gamma is not None else None
         b = beta.float().contiguous() if beta is not None else None
-        check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, stream()), "instnorm_stats")
         y = torch.empty_like(x)
-        check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(stats), ptr(g), ptr(b), planes, Cc, hw,
-                                      1 if fuse_gelu else 0, stream()), "instnorm_apply")
+        check(lib().mk_instnorm_fwd(ptr(x), ptr(y), dt, ptr(stats), ptr(ws), ptr(g), ptr(b), planes, Cc, hw, eps,
+                                    1 if fuse_gelu else 0, stream()), "instnorm_fwd")
         ctx.save_for_backward(x, stats, g, b)
         ctx.fuse_gelu = fuse_gelu
         return y

@@ -22,9 +22,22 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()
-    def grad_norm(self):
+    def clip_coef(self, max_grad_norm):
+        """(2,) device tensor: [min(1, max_norm / (||g|| + 1e-6)), ||g||] over all local gradients, 3 launches."""
         grads = [_real(p.grad) for g in self.param_groups for p in g["params"] if p.grad is not None]
-        return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+        if any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+            raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 gradients")
+        arr = (MkAdamTensor * len(grads))(*[MkAdamTensor(None, g.data_ptr(), None, None, g.numel()) for g in grads])
+        nws = lib().mk_grad_norm_workspace(C.cast(arr, C.c_void_p), len(grads))
+        ws = torch.empty((nws,), dtype=torch.float32, device=grads[0].device)
+        out = torch.empty((2,), dtype=torch.float32, device=grads[0].device)
+        check(lib().mk_grad_clip_coef(C.cast(arr, C.c_void_p), len(grads), float(max_grad_norm or 0.0), ptr(ws), ptr(out),
+                                      stream()), "mk_grad_clip_coef")
+        return out
+
+    @torch.no_grad()
+    def grad_norm(self):
+        return self.clip_coef(None)[1]
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm=None, grad_scale=None):
@@ -32,8 +45,7 @@ class FusedAdamW(torch.optim.Optimizer):
         clipping coefficient (1-element device tensor) when the norm needs cross-rank reduction."""
         scale = grad_scale
         if scale is None and max_grad_norm is not None:
-            total = self.grad_norm()
-            scale = torch.clamp(max_grad_norm / (total + 1e-6), max=1.0).float().reshape(1)
+            scale = self.clip_coef(max_grad_norm)[:1]
         for group in self.param_groups:
             b1, b2 = group["betas"]
             small = {}                       # step count -> [descriptors]: one launch per 48 small tensors
