@@ -37,10 +37,13 @@ struct TileStage {
     static constexpr int NV = (ROWS * BK / 4) / NT;  // float4 per thread
     static_assert(NV >= 1, "tile too small");
     f32x4 v[NV];
+    unsigned keep;      // KC: 4 bits per vector = elements inside [klo, khi), applied in store() so that no
+                        // s_waitcnt lands right behind the loads
 
     // base already includes the batch offset.  rs = row stride, ks = k stride (the other one is 1).
     __device__ __forceinline__ void load(const float* __restrict__ base, long long rs, long long ks, int r0, int rmax,
                                          int k0, int klo, int khi, int tid) {
+        keep = 0u;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int f = tid + q * NT;
@@ -50,9 +53,10 @@ struct TileStage {
                 const int k = k0 + kq * 4;
                 if (r0 + row < rmax && k < khi && k + 3 >= klo) {
                     val = *reinterpret_cast<const f32x4*>(base + (long long)(r0 + row) * rs + k);
+                    unsigned m = 0u;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (!in_range(k + e, klo, khi)) val[e] = 0.f;
+                    for (int e = 0; e < 4; ++e) m |= in_range(k + e, klo, khi) ? (1u << e) : 0u;
+                    keep |= m << (4 * q);
                 }
             } else {
                 constexpr int RQ = ROWS / 4;
@@ -76,7 +80,8 @@ struct TileStage {
             if constexpr (KC) {
                 const int row = f >> 2, kq = f & 3;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lds[(kq * 4 + e) * S + row] = v[q][e] * sign;
+                for (int e = 0; e < 4; ++e)
+                    lds[(kq * 4 + e) * S + row] = ((keep >> (4 * q + e)) & 1u) ? v[q][e] * sign : 0.f;
             } else {
                 constexpr int RQ = ROWS / 4;
                 const int kk = f / RQ, rq = f % RQ;

@@ -41,9 +41,12 @@ struct Stage {
     static constexpr int NV = (ROWS * BK / 4) / NT;
     static_assert(NV >= 1, "tile too small");
     f32x4 v[NV];
+    unsigned keep;      // KC: 4 bits per vector = elements inside [klo, khi); applied when the tile is stored, NOT
+                        // on the freshly loaded registers (that would put an s_waitcnt right behind every load)
 
     __device__ __forceinline__ void load(const float* __restrict__ base, long long rs, long long ks, int r0, int rmax,
                                          int k0, int klo, int khi, int tid) {
+        keep = 0u;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int f = tid + q * NT;
@@ -53,9 +56,10 @@ struct Stage {
                 const int k = k0 + kq * 4;
                 if (r0 + row < rmax && k < khi && k + 3 >= klo) {
                     val = *reinterpret_cast<const f32x4*>(base + (long long)(r0 + row) * rs + k);
+                    unsigned m = 0u;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (!in_range(k + e, klo, khi)) val[e] = 0.f;
+                    for (int e = 0; e < 4; ++e) m |= in_range(k + e, klo, khi) ? (1u << e) : 0u;
+                    keep |= m << (4 * q);
                 }
             } else {
                 constexpr int RQ = ROWS / 4;
@@ -86,7 +90,10 @@ struct Stage {
             }
             float r[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = v[q][e] * sign;
+            for (int e = 0; e < 4; ++e) {
+                r[e] = v[q][e] * sign;
+                if constexpr (KC) r[e] = ((keep >> (4 * q + e)) & 1u) ? r[e] : 0.f;
+            }
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 u16 h[4];
@@ -216,7 +223,9 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(const MkGemm p, int tilesM
 }
 
 // ---- complex kernel (planar): block tile 64 x 128, waves 2 x 2, wave tile 32 x 64 ------------
-template <bool A_KC, bool B_KC, int NP>
+// DEPTH = register prefetch distance in k-tiles (2: two staging register sets, the loads of tile kt+2 are issued
+// while tile kt is multiplied)
+template <bool A_KC, bool B_KC, int NP, int DEPTH>
 __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tilesM, int tilesN) {
     constexpr int BM = 64, BN = 128;
     constexpr int PLA = plane_elems<BM, A_KC>(), PLB = plane_elems<BN, B_KC>();
@@ -249,22 +258,21 @@ __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tiles
 
     const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
     const int a_rmax = A_KC ? c.Meff : p.M;
-    Stage<BM, A_KC> sar, sai;
-    Stage<BN, B_KC> sbr, sbi;
-    auto ld = [&](int kt) {
-        sar.load(Ab, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
-        sai.load(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
-        sbr.load(Bb, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
-        sbi.load(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
+    Stage<BM, A_KC> sar[DEPTH], sai[DEPTH];
+    Stage<BN, B_KC> sbr[DEPTH], sbi[DEPTH];
+    auto ld = [&](int d, int kt) {
+        sar[d].load(Ab, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
+        sai[d].load(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
+        sbr[d].load(Bb, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
+        sbi[d].load(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
     };
-    if (kt0 < kt1) ld(kt0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-        sar.template store<NP, PLA>(Are, tid, 1.f);
-        sai.template store<NP, PLA>(Aim, tid, sgn_a);
-        sbr.template store<NP, PLB>(Bre, tid, 1.f);
-        sbi.template store<NP, PLB>(Bim, tid, sgn_b);
+    auto step = [&](int d, int kt) {           // tile kt sits in register set d
+        sar[d].template store<NP, PLA>(Are, tid, 1.f);
+        sai[d].template store<NP, PLA>(Aim, tid, sgn_a);
+        sbr[d].template store<NP, PLB>(Bre, tid, 1.f);
+        sbi[d].template store<NP, PLB>(Bim, tid, sgn_b);
         __syncthreads();
-        if (kt + 1 < kt1) ld(kt + 1);
+        if (kt + DEPTH < kt1) ld(d, kt + DEPTH);
         bf16x8 ar[NP], ai[NP];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
@@ -286,6 +294,15 @@ __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tiles
             cim[n] = mma_split<NP>(ai, br, cim[n]);
         }
         __syncthreads();
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (kt0 + d < kt1) ld(d, kt0 + d);
+    for (int kt = kt0; kt < kt1; kt += DEPTH) {
+        step(0, kt);
+        if constexpr (DEPTH == 2) {
+            if (kt + 1 < kt1) step(1, kt + 1);
+        }
     }
 
     float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
@@ -334,14 +351,17 @@ int launch_cplx(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
     const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
     MK_REQUIRE(nb < (1ll << 31), "xcgemm: grid too large");
     dim3 grid((unsigned)nb), block(NT);
+    // prefetch distance 2 (DEPTH = 2) measured: dgrad -2 %, fwd 0 %, wgrad +2 % -> distance 1
+#define MK_XC_LAUNCH(AK, BK_) hipLaunchKernelGGL((xcgemm_kernel<AK, BK_, NP, 1>), grid, block, 0, s, *g, tm, tn)
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((xcgemm_kernel<true, true, NP>), grid, block, 0, s, *g, tm, tn);
+        MK_XC_LAUNCH(true, true);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((xcgemm_kernel<true, false, NP>), grid, block, 0, s, *g, tm, tn);
+        MK_XC_LAUNCH(true, false);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((xcgemm_kernel<false, true, NP>), grid, block, 0, s, *g, tm, tn);
+        MK_XC_LAUNCH(false, true);
     else
-        hipLaunchKernelGGL((xcgemm_kernel<false, false, NP>), grid, block, 0, s, *g, tm, tn);
+        MK_XC_LAUNCH(false, false);
+#undef MK_XC_LAUNCH
     return mk_check_launch("mk_cgemm_split_batched");
 }
 
