@@ -43,19 +43,55 @@ struct Stage {
     f32x4 v[NV];
     unsigned keep;      // KC: 4 bits per vector = elements inside [klo, khi); applied when the tile is stored, NOT
                         // on the freshly loaded registers (that would put an s_waitcnt right behind every load)
+    // loop-invariant addressing, set up once per tile by init(): pointer of every vector at k = 0 and whether its
+    // row exists.  Inside the k-loop a load is then "pointer + uniform offset" (the 64-bit index arithmetic and the
+    // row checks done per load used to cost as much as a third of the kernel)
+    const float* p0[NV];
+    unsigned ok;
+    long long kstride;  // floats per unit of k
 
-    __device__ __forceinline__ void load(const float* __restrict__ base, long long rs, long long ks, int r0, int rmax,
-                                         int k0, int klo, int khi, int tid) {
+    __device__ __forceinline__ void init(const float* __restrict__ base, long long rs, long long ks, int r0, int rmax,
+                                         int tid) {
+        ok = 0u;
+        kstride = KC ? 1 : ks;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + q * NT;
+            if constexpr (KC) {
+                const int row = f >> 2, kq = f & 3;
+                p0[q] = base + (long long)(r0 + row) * rs + kq * 4;
+                ok |= (r0 + row < rmax ? 1u : 0u) << q;
+            } else {
+                constexpr int RQ = ROWS / 4;
+                const int kk = f / RQ, rq = f % RQ;
+                p0[q] = base + (long long)kk * ks + (r0 + rq * 4);
+                ok |= (r0 + rq * 4 < rmax ? 1u : 0u) << q;
+            }
+        }
+    }
+
+    // tile [k0, k0 + BK) of the operand, zero outside [klo, khi)
+    __device__ __forceinline__ void load(int k0, int klo, int khi, int tid) {
+        const long long koff = (long long)k0 * kstride;                 // uniform
+        if (k0 >= klo && k0 + BK <= khi) {                              // interior tile (uniform branch)
+            keep = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if ((ok >> q) & 1u) val = *reinterpret_cast<const f32x4*>(p0[q] + koff);
+                v[q] = val;
+            }
+            return;
+        }
         keep = 0u;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int f = tid + q * NT;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if constexpr (KC) {
-                const int row = f >> 2, kq = f & 3;
-                const int k = k0 + kq * 4;
-                if (r0 + row < rmax && k < khi && k + 3 >= klo) {
-                    val = *reinterpret_cast<const f32x4*>(base + (long long)(r0 + row) * rs + k);
+                const int k = k0 + (f & 3) * 4;
+                if (((ok >> q) & 1u) && k < khi && k + 3 >= klo) {
+                    val = *reinterpret_cast<const f32x4*>(p0[q] + koff);
                     unsigned m = 0u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) m |= in_range(k + e, klo, khi) ? (1u << e) : 0u;
@@ -63,10 +99,8 @@ struct Stage {
                 }
             } else {
                 constexpr int RQ = ROWS / 4;
-                const int kk = f / RQ, rq = f % RQ;
-                const int k = k0 + kk;
-                const int r = r0 + rq * 4;
-                if (in_range(k, klo, khi) && r < rmax) val = *reinterpret_cast<const f32x4*>(base + (long long)k * ks + r);
+                const int k = k0 + f / RQ;
+                if (((ok >> q) & 1u) && in_range(k, klo, khi)) val = *reinterpret_cast<const f32x4*>(p0[q] + koff);
             }
             v[q] = val;
         }
@@ -176,17 +210,19 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(const MkGemm p, int tilesM
     const int a_rmax = A_KC ? c.Meff : p.M;
     Stage<BM, A_KC> sa;
     Stage<BN, B_KC> sb;
+    sa.init(Ab, p.a_row, p.a_k, c.i0, a_rmax, tid);
+    sb.init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
     if (kt0 < kt1) {
-        sa.load(Ab, p.a_row, p.a_k, c.i0, a_rmax, kt0 * BK, c.klo, c.khi, tid);
-        sb.load(Bb, p.b_col, p.b_k, c.j0, p.N, kt0 * BK, c.klo, c.khi, tid);
+        sa.load(kt0 * BK, c.klo, c.khi, tid);
+        sb.load(kt0 * BK, c.klo, c.khi, tid);
     }
     for (int kt = kt0; kt < kt1; ++kt) {
         sa.template store<NP, PLA>(As, tid, 1.f);
         sb.template store<NP, PLB>(Bs, tid, 1.f);
         __syncthreads();
         if (kt + 1 < kt1) {   // next fp32 tile in flight while this one is multiplied
-            sa.load(Ab, p.a_row, p.a_k, c.i0, a_rmax, (kt + 1) * BK, c.klo, c.khi, tid);
-            sb.load(Bb, p.b_col, p.b_k, c.j0, p.N, (kt + 1) * BK, c.klo, c.khi, tid);
+            sa.load((kt + 1) * BK, c.klo, c.khi, tid);
+            sb.load((kt + 1) * BK, c.klo, c.khi, tid);
         }
         bf16x8 af[2][NP], bfr[2][NP];
 #pragma unroll
@@ -260,11 +296,18 @@ __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tiles
     const int a_rmax = A_KC ? c.Meff : p.M;
     Stage<BM, A_KC> sar[DEPTH], sai[DEPTH];
     Stage<BN, B_KC> sbr[DEPTH], sbi[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        sar[d].init(Ab, p.a_row, p.a_k, c.i0, a_rmax, tid);
+        sai[d].init(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, tid);
+        sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
+        sbi[d].init(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, tid);
+    }
     auto ld = [&](int d, int kt) {
-        sar[d].load(Ab, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
-        sai[d].load(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, kt * BK, c.klo, c.khi, tid);
-        sbr[d].load(Bb, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
-        sbi[d].load(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, kt * BK, c.klo, c.khi, tid);
+        sar[d].load(kt * BK, c.klo, c.khi, tid);
+        sai[d].load(kt * BK, c.klo, c.khi, tid);
+        sbr[d].load(kt * BK, c.klo, c.khi, tid);
+        sbi[d].load(kt * BK, c.klo, c.khi, tid);
     };
     auto step = [&](int d, int kt) {           // tile kt sits in register set d
         sar[d].template store<NP, PLA>(Are, tid, 1.f);
@@ -327,6 +370,7 @@ __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tiles
     }
 }
 
+
 template <int BM, int BN, int NP>
 int launch_real(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
     const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
@@ -352,6 +396,8 @@ int launch_cplx(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
     MK_REQUIRE(nb < (1ll << 31), "xcgemm: grid too large");
     dim3 grid((unsigned)nb), block(NT);
     // prefetch distance 2 (DEPTH = 2) measured: dgrad -2 %, fwd 0 %, wgrad +2 % -> distance 1
+    // measured and rejected: prefetch distance 2 (dgrad -2 %, wgrad +2 %); a wave-specialised variant (4 producer
+    // waves split + stage, 4 consumer waves run the MFMAs, one barrier per k-tile): 15-25 % slower (DESIGN.md par. 10)
 #define MK_XC_LAUNCH(AK, BK_) hipLaunchKernelGGL((xcgemm_kernel<AK, BK_, NP, 1>), grid, block, 0, s, *g, tm, tn)
     if (a_kc && b_kc)
         MK_XC_LAUNCH(true, true);
