@@ -93,21 +93,22 @@ class GradReducer:
             grp, scale = groups[0]
             self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=grp, async_op=True), g, scale))
         else:
-            self.small.setdefault(tuple(id(x[0]) for x in groups), (groups, []))[1].append(g)
+            self.small.setdefault(tuple(id(x[0]) for x in groups), (groups, []))[1].append(p)
 
     def finish(self):
         if not self.active:
             return
-        for groups, grads in self.small.values():
-            flat = torch.cat([g.reshape(-1) for g in grads])
+        for groups, params in self.small.values():
+            flat = torch.cat([(torch.view_as_real(q.grad) if q.grad.is_complex() else q.grad).reshape(-1) for q in params])
             for grp, scale in groups:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=grp)
                 if scale != 1.0:
                     flat.mul_(scale)
             off = 0
-            for g in grads:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
+            for q in params:            # the reduced bucket becomes the gradients (views, no copy-back kernels)
+                n = q.grad.numel() * (2 if q.grad.is_complex() else 1)
+                piece = flat[off:off + n]
+                q.grad = torch.view_as_complex(piece.view(*q.grad.shape, 2)) if q.grad.is_complex() else piece.view_as(q.grad)
                 off += n
         self.small = {}
         for h, g, scale in self.handles:
