@@ -383,7 +383,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         prof = ops.PROFILER.summary()           # timed region: the dominant kernel (or everything with --warmup 0)

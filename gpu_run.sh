@@ -1,5 +1,9 @@
-export MAKANI_AMD_BENCH_BACKEND=gloo
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-sht-metric --config sfno_debug 2>&1 | grep -E '^\{|Error|error' | cut -c1-300
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 4 --steps 2 --warmup 1 --no-cpu-baseline --no-sht-metric --config sfno_debug --parallelism h2w2 2>&1 | grep -E '^\{|Error|error' | cut -c1-300
-unset MAKANI_AMD_BENCH_BACKEND
-timeout 600 python -m pytest tests/test_gpu_distributed.py -m gpu -q -x 2>&1 | tail -2
+mkdir -p gpurun_out/final
+timeout 400 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; tail -c 600 gpurun_out/final/bench.json | head -c 400; echo
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/final -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sht-metric > $GRAFT_REPO_ROOT/gpurun_out/final/bench_traced.log 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/final -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stats.py {} gpurun_out/final/kernel_stats.md > /dev/null
+find gpurun_out/final -name "*.db" -delete
+timeout 300 python tools/microbench.py > gpurun_out/final/microbench.txt 2>&1
+head -5 gpurun_out/final/kernel_stats.md | cut -c1-120
