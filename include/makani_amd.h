@@ -157,6 +157,19 @@ int mk_quad_lp_fwd(const void* a, int a_dtype, const void* b, int b_dtype, const
 int mk_quad_lp_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* wgt, const float* q,
                    const float* g, void* da, void* db, long long planes, long long hw, int mode, float p, void* stream);
 
+/* ---- spectral L^p sums on the S-layout (spectral losses) ------------------------------------
+ * Replace the chain |coeffs|^p * wgt, the m = 0 once / m > 0 twice Parseval sum over m and the sum over l of
+ * SpectralLpLoss.abs/rel (makani/utils/losses/lp_loss.py:141-247) and their autograd, directly on the SHT output:
+ *   partial[b][row] = sum over the 32 (l, m) pairs of block b with l + tri_off >= m of w(m) |c_lm|^p (* wgt[l][m][row])
+ * w(m) = w0 when m + m_off == 0 (global order 0), else w1.  S: (L, M, 2, R) f32; wgt: optional (L, M, R) f32;
+ * partial: (mk_spec_lp_blocks(L, M), R) f32, summed over its first axis by the caller.
+ * Backward: dS = g[row] * w(m) * p * |c|^(p-2) * c (* wgt), exact zeros where l + tri_off < m. */
+long long mk_spec_lp_blocks(int L, int M);
+int mk_spec_lp_fwd(const float* S, const float* wgt, float* partial, int L, int M, long long R, int tri_off, int m_off,
+                   float p, float w0, float w1, void* stream);
+int mk_spec_lp_bwd(const float* S, const float* wgt, const float* g, float* dS, int L, int M, long long R, int tri_off,
+                   int m_off, float p, float w0, float w1, void* stream);
+
 /* ---- bf16 channel GEMMs (1x1 convolutions on NCHW planes) ---------------------------------
  * Replace nn.Conv2d(kernel_size=1) of MLP / EncoderDecoder / outer_skip / residual_transform
  * (makani/models/common/layers.py:603-643,768-823; makani/models/networks/sfnonet.py:335-338,726-730)

@@ -5,8 +5,8 @@ from .sht import RealSHT, InverseRealSHT
 from .spectral_conv import SpectralConv
 from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv
 from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, SpectralFilterLayer
-from .losses import GeometricLpLoss, GridQuadrature
+from .losses import GeometricLpLoss, GridQuadrature, SpectralLpLoss
 
 __all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
            "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer", "GeometricLpLoss",
-           "GridQuadrature"]
+           "GridQuadrature", "SpectralLpLoss"]

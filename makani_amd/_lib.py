@@ -64,6 +64,9 @@ _SIGS = {
     "mk_instnorm_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_f, c_int, c_vp], c_int),
     "mk_grad_norm_workspace": ([c_vp, c_int], c_ll),
     "mk_grad_clip_coef": ([c_vp, c_int, c_f, c_vp, c_vp, c_vp], c_int),
+    "mk_spec_lp_blocks": ([c_int, c_int], c_ll),
+    "mk_spec_lp_fwd": ([c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_int, c_f, c_f, c_f, c_vp], c_int),
+    "mk_spec_lp_bwd": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_int, c_f, c_f, c_f, c_vp], c_int),
     "mk_quad_lp_chunks": ([c_ll], c_int),
     "mk_quad_lp_fwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),
     "mk_quad_lp_bwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),

@@ -100,6 +100,63 @@ __global__ void complex_to_s(const float2* __restrict__ in, float* __restrict__ 
     }
 }
 
+
+// ---- spectral L^p sums on the S-layout ------------------------------------------------------------
+// partial[b][row] = sum over the (l, m) pairs of block b with l >= m of  w(m) * |c|^p (* wgt[l][m][row]),
+// c = S[l][m][0][row] + i S[l][m][1][row];  w(m) = w0 for the global order 0, w1 otherwise.
+constexpr int SP_PAIRS = 32;
+constexpr int SP_NT = 128;
+
+__device__ __forceinline__ float sp_pow(float a2, float p) {      // |c|^p from |c|^2
+    return p == 2.f ? a2 : (a2 > 0.f ? powf(a2, 0.5f * p) : 0.f);
+}
+
+__global__ __launch_bounds__(SP_NT) void spec_lp_partial(const float* __restrict__ S, const float* __restrict__ wgt,
+                                                         float* __restrict__ partial, int L, int M, long long R,
+                                                         int tri_off, int m_off, float p, float w0, float w1) {
+    const long long r = (long long)blockIdx.y * SP_NT + threadIdx.x;
+    if (r >= R) return;
+    const long long pair0 = (long long)blockIdx.x * SP_PAIRS;
+    float acc = 0.f;
+    for (int i = 0; i < SP_PAIRS; ++i) {
+        const long long pr = pair0 + i;
+        if (pr >= (long long)L * M) break;
+        const int l = (int)(pr / M), m = (int)(pr % M);
+        if (l + tri_off < m) continue;                         // structurally zero (never written by the SHT)
+        const float re = S[(pr * 2) * R + r], im = S[(pr * 2 + 1) * R + r];
+        float t = sp_pow(re * re + im * im, p) * ((m + m_off) == 0 ? w0 : w1);
+        if (wgt) t *= wgt[pr * R + r];
+        acc += t;
+    }
+    partial[(long long)blockIdx.x * R + r] = acc;
+}
+
+// dS = g[row] * w(m) * p * |c|^(p-2) * c (* wgt); zeros where l < m
+__global__ __launch_bounds__(SP_NT) void spec_lp_bwd(const float* __restrict__ S, const float* __restrict__ wgt,
+                                                     const float* __restrict__ g, float* __restrict__ dS, int L, int M,
+                                                     long long R, int tri_off, int m_off, float p, float w0, float w1) {
+    const long long r = (long long)blockIdx.y * SP_NT + threadIdx.x;
+    if (r >= R) return;
+    const long long pair0 = (long long)blockIdx.x * SP_PAIRS;
+    const float gr = g[r];
+    for (int i = 0; i < SP_PAIRS; ++i) {
+        const long long pr = pair0 + i;
+        if (pr >= (long long)L * M) break;
+        const int l = (int)(pr / M), m = (int)(pr % M);
+        float dre = 0.f, dim = 0.f;
+        if (l + tri_off >= m) {
+            const float re = S[(pr * 2) * R + r], im = S[(pr * 2 + 1) * R + r];
+            const float a2 = re * re + im * im;
+            float f = p == 2.f ? 2.f : (a2 > 0.f ? p * powf(a2, 0.5f * p - 1.f) : 0.f);
+            f *= gr * ((m + m_off) == 0 ? w0 : w1);
+            if (wgt) f *= wgt[pr * R + r];
+            dre = f * re, dim = f * im;
+        }
+        dS[(pr * 2) * R + r] = dre;
+        dS[(pr * 2 + 1) * R + r] = dim;
+    }
+}
+
 }  // namespace
 
 extern "C" int mk_weight_to_wlayout(const float* w_c64, float* W, int cin, int cout, int cip, int cop, int L, void* stream) {
@@ -131,4 +188,26 @@ extern "C" int mk_complex_to_slayout(const float* in_c64, float* S, int B, int C
     dim3 grid((M + TS - 1) / TS, (Cp + TS - 1) / TS, B * L), block(TS, 8);
     hipLaunchKernelGGL(complex_to_s, grid, block, 0, (hipStream_t)stream, (const float2*)in_c64, S, B, C, Cp, L, M);
     return mk_check_launch("mk_complex_to_slayout");
+}
+
+extern "C" long long mk_spec_lp_blocks(int L, int M) { return ((long long)L * M + SP_PAIRS - 1) / SP_PAIRS; }
+
+extern "C" int mk_spec_lp_fwd(const float* S, const float* wgt, float* partial, int L, int M, long long R, int tri_off,
+                              int m_off, float p, float w0, float w1, void* stream) {
+    MK_REQUIRE(S && partial && L > 0 && M > 0 && R > 0 && p > 0.f, "spec_lp_fwd: bad args");
+    const long long nb = mk_spec_lp_blocks(L, M);
+    MK_REQUIRE(nb < (1ll << 31), "spec_lp_fwd: grid too large");
+    dim3 grid((unsigned)nb, (unsigned)((R + SP_NT - 1) / SP_NT));
+    hipLaunchKernelGGL(spec_lp_partial, grid, dim3(SP_NT), 0, (hipStream_t)stream, S, wgt, partial, L, M, R, tri_off, m_off, p, w0, w1);
+    return mk_check_launch("mk_spec_lp_fwd");
+}
+
+extern "C" int mk_spec_lp_bwd(const float* S, const float* wgt, const float* g, float* dS, int L, int M, long long R,
+                              int tri_off, int m_off, float p, float w0, float w1, void* stream) {
+    MK_REQUIRE(S && g && dS && L > 0 && M > 0 && R > 0 && p > 0.f, "spec_lp_bwd: bad args");
+    const long long nb = mk_spec_lp_blocks(L, M);
+    MK_REQUIRE(nb < (1ll << 31), "spec_lp_bwd: grid too large");
+    dim3 grid((unsigned)nb, (unsigned)((R + SP_NT - 1) / SP_NT));
+    hipLaunchKernelGGL(spec_lp_bwd, grid, dim3(SP_NT), 0, (hipStream_t)stream, S, wgt, g, dS, L, M, R, tri_off, m_off, p, w0, w1);
+    return mk_check_launch("mk_spec_lp_bwd");
 }

@@ -144,6 +144,127 @@ class GridQuadrature(nn.Module):
         return self._reduce(QuadLpFn.apply(a, b, wgt, self.quad_weight, 1, p))
 
 
+def compute_spherical_bandlimit(img_shape, grid_type):
+    """``makani/utils/grids.py:43-55``."""
+    if grid_type == "equiangular":
+        return min((img_shape[0] - 1) // 2, img_shape[1] // 2)
+    if grid_type == "legendre-gauss":
+        return min(img_shape[0] - 1, img_shape[1] // 2)
+    raise NotImplementedError(f"Unknown type {grid_type} not implemented")
+
+
+class SpecLpFn(torch.autograd.Function):
+    """out[row] = sum_{l >= m} w(m) |c_lm|^p (* wgt) over an S-layout tensor (L, M, 2, R)."""
+
+    @staticmethod
+    def forward(ctx, S, wgt, p, w0, w1, tri_off, m_off):
+        S = S.contiguous()
+        L, M, _, R = S.shape
+        nb = lib().mk_spec_lp_blocks(L, M)
+        partial = torch.empty((nb, R), dtype=torch.float32, device=S.device)
+        check(lib().mk_spec_lp_fwd(ptr(S), ptr(wgt) if wgt is not None else None, ptr(partial), L, M, R, tri_off, m_off,
+                                   float(p), float(w0), float(w1), stream()), "mk_spec_lp_fwd")
+        ctx.save_for_backward(S, wgt)
+        ctx.meta = (float(p), float(w0), float(w1), tri_off, m_off)
+        return partial.sum(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        S, wgt = ctx.saved_tensors
+        p, w0, w1, tri_off, m_off = ctx.meta
+        L, M, _, R = S.shape
+        dS = torch.empty_like(S)
+        g = g.contiguous().float()
+        check(lib().mk_spec_lp_bwd(ptr(S), ptr(wgt) if wgt is not None else None, ptr(g), ptr(dS), L, M, R, tri_off, m_off,
+                                   p, w0, w1, stream()), "mk_spec_lp_bwd")
+        return dS, None, None, None, None, None, None
+
+
+class SpectralLpLoss(nn.Module):
+    """Computes the Lp loss in spectral (SH coefficient) space (``lp_loss.py:110-259``, base class
+    ``base_loss.py:345-404``): SHT of the difference on the HIP path, then ONE kernel for
+    ``|c|^p``, the Parseval weights (m = 0 once, m > 0 twice, 1/4pi) and the sum over (l, m) — on the SHT's
+    internal layout, without materialising complex coefficients."""
+
+    def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
+                 channel_names: List[str], grid_type: str, p: Optional[float] = 2.0, relative: Optional[bool] = False,
+                 squared: Optional[bool] = False, spatial_distributed: Optional[bool] = False,
+                 eps: Optional[float] = 1.0e-6, lmax: Optional[int] = None, **kwargs):
+        super().__init__()
+        from . import distributed as thd
+        from .sht import RealSHT
+        self.img_shape, self.crop_shape, self.crop_offset = img_shape, crop_shape, crop_offset
+        self.channel_names = channel_names
+        self.spatial_distributed = bool(spatial_distributed) and thd.is_initialized() and thd.spatial_size() > 1
+        bandlimit = compute_spherical_bandlimit(img_shape, grid_type)
+        if lmax is None or lmax > bandlimit:
+            lmax = bandlimit
+        if self.spatial_distributed:
+            self.sht = thd.DistributedRealSHT(*img_shape, lmax=lmax, mmax=lmax, grid=grid_type)
+            self._l_off, self._m_off = self.sht.l_off, self.sht.m_off
+            l_loc = self.sht.l_shapes[self.sht.comm_rank_polar]
+            m_loc = self.sht.m_shapes[self.sht.comm_rank_azimuth]
+        else:
+            self.sht = RealSHT(*img_shape, lmax=lmax, mmax=lmax, grid=grid_type).float()
+            self._l_off = self._m_off = 0
+            l_loc, m_loc = self.sht.lmax, self.sht.mmax
+        m_weights = 2 * torch.ones(self.sht.mmax, dtype=torch.float32)
+        m_weights[0] = 1.0
+        m_weights = m_weights / (4.0 * math.pi)
+        lm = torch.ones(self.sht.lmax, dtype=torch.float32)[:, None] * m_weights[None, :]
+        lm = lm[self._l_off:self._l_off + l_loc, self._m_off:self._m_off + m_loc].contiguous()
+        self.register_buffer("lm_weights", lm, persistent=False)
+        self.p, self.relative, self.squared, self.eps = p, relative, squared, eps
+
+    @property
+    def n_channels(self):
+        return len(self.channel_names)
+
+    def _s_weights(self, wgt, B, C, L, M, R, device):
+        """broadcastable (B, C, L, M) weights -> (L, M, R) in the S-layout's row order"""
+        if wgt is None:
+            return None
+        w = wgt.to(device=device, dtype=torch.float32).expand(B, C, L, M)
+        Cp = R // B
+        out = torch.zeros((L, M, B, Cp), dtype=torch.float32, device=device)
+        out[:, :, :, :C] = w.permute(2, 3, 0, 1)
+        return out.view(L, M, R)
+
+    def _norm_p(self, x, wgt, w0, w1):
+        """sum_{l,m} w(m) |sht(x)|^p per (b, c)"""
+        if x.dim() != 4:
+            raise ValueError(f"expected (B, C, H, W), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("makani_amd losses run on the GPU (HIP) path only")
+        B, C = x.shape[:2]
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        S = self.sht.analysis(x.contiguous())
+        L, M, _, R = S.shape
+        w3 = self._s_weights(wgt, B, C, L, M, R, x.device)
+        rows = SpecLpFn.apply(S, w3, self.p, w0, w1, self._l_off - self._m_off, self._m_off)
+        out = rows.view(B, R // B)[:, :C]
+        if self.spatial_distributed:
+            from . import distributed as thd
+            out = thd.reduce_from_spatial_region(out.contiguous())
+        return out
+
+    def abs(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None):
+        inv_area = 1.0 / (4.0 * math.pi)
+        normp = self._norm_p(prd - tar, wgt, inv_area, 2.0 * inv_area)
+        return normp if self.squared else normp.pow(1.0 / self.p)
+
+    def rel(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None):
+        normp = self._norm_p(prd - tar, wgt, 1.0, 2.0)
+        tar_normp = self._norm_p(tar, wgt, 1.0, 2.0)
+        if not self.squared:
+            normp, tar_normp = normp.pow(1.0 / self.p), tar_normp.pow(1.0 / self.p)
+        return normp / (tar_normp + self.eps)
+
+    def forward(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None, **kwargs):
+        return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)
+
+
 class GeometricLpLoss(nn.Module):
     """Computes the Lp loss on the sphere (``lp_loss.py:28-107``)."""
 

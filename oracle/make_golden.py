@@ -151,6 +151,36 @@ def loss_fixtures():
     np.savez_compressed(path, **rec)
     print(f"geometric_lp_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
 
+    # SpectralLpLoss (lp_loss.py:110-259) on top of the restated SHT
+    SpectralLpLoss = ref_shims.import_reference_module("makani.utils.losses.lp_loss").SpectralLpLoss
+    scases = [
+        dict(img=(37, 72), grid="equiangular", p=2.0, relative=False, squared=True, wgt=False),
+        dict(img=(37, 72), grid="equiangular", p=2.0, relative=True, squared=False, wgt=False),
+        dict(img=(24, 48), grid="legendre-gauss", p=1.0, relative=False, squared=False, wgt=False),
+        dict(img=(33, 64), grid="equiangular", p=3.0, relative=True, squared=True, wgt=True),
+    ]
+    rec = {"cases": json.dumps(scases)}
+    for i, c in enumerate(scases):
+        torch.manual_seed(200 + i)
+        B, C = 2, 3
+        mod = SpectralLpLoss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0),
+                             channel_names=[str(k) for k in range(C)], grid_type=c["grid"], p=c["p"],
+                             relative=c["relative"], squared=c["squared"])
+        prd = torch.randn(B, C, *c["img"], requires_grad=True)
+        tar = torch.randn(B, C, *c["img"], requires_grad=True)
+        wgt = torch.rand(1, C, mod.sht.lmax, mod.sht.mmax) + 0.5 if c["wgt"] else None
+        out = mod(prd, tar, wgt)
+        g = torch.randn_like(out)
+        (out * g).sum().backward()
+        rec[f"{i}_lm"] = _np(mod.lm_weights)
+        rec[f"{i}_prd"], rec[f"{i}_tar"], rec[f"{i}_g"] = _np(prd), _np(tar), _np(g)
+        if wgt is not None:
+            rec[f"{i}_wgt"] = _np(wgt)
+        rec[f"{i}_out"], rec[f"{i}_dprd"], rec[f"{i}_dtar"] = _np(out), _np(prd.grad), _np(tar.grad)
+    path = os.path.join(OUT, "spectral_lp_loss.npz")
+    np.savez_compressed(path, **rec)
+    print(f"spectral_lp_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
 
 def main():
     if not ref_shims.reference_available():

@@ -112,3 +112,78 @@ def test_hip_grid_quadrature_is_differentiable_sum():
     assert torch.allclose(x.grad, quad.quad_weight.expand_as(x), rtol=1e-6, atol=0)
     one = quad(torch.ones(1, 1, 24, 48, device=dev))
     assert abs(one.item() - 4 * np.pi) < 1e-4          # tests/test_grids.py:136-220: the rule integrates 1 to 4 pi
+
+
+# --------------------------------------------------------------------------- #
+# SpectralLpLoss
+# --------------------------------------------------------------------------- #
+SGOLDEN = os.path.join(os.path.dirname(__file__), "golden", "spectral_lp_loss.npz")
+
+
+def _scases():
+    d = np.load(SGOLDEN)
+    return d, json.loads(str(d["cases"]))
+
+
+def test_oracle_spectral_loss_matches_reference_golden():
+    from oracle import losses as ol
+    d, cases = _scases()
+    for i, c in enumerate(cases):
+        prd = torch.tensor(d[f"{i}_prd"], requires_grad=True)
+        tar = torch.tensor(d[f"{i}_tar"], requires_grad=True)
+        w = torch.tensor(d[f"{i}_wgt"]) if c["wgt"] else None
+        out = ol.spectral_lp_loss(prd, tar, c["img"], c["grid"], c["p"], c["relative"], c["squared"], wgt=w)
+        (out * torch.tensor(d[f"{i}_g"])).sum().backward()
+        assert np.allclose(out.detach().numpy(), d[f"{i}_out"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(prd.grad.numpy(), d[f"{i}_dprd"], rtol=1e-5, atol=1e-10)
+        assert np.allclose(tar.grad.numpy(), d[f"{i}_dtar"], rtol=1e-5, atol=1e-10)
+
+
+def test_spectral_loss_module_attributes_match_reference():
+    import makani_amd as ma
+    d, cases = _scases()
+    for i, c in enumerate(cases):
+        mod = ma.SpectralLpLoss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0), channel_names=["a", "b", "c"],
+                                grid_type=c["grid"], p=c["p"], relative=c["relative"], squared=c["squared"])
+        assert mod.lm_weights.shape == d[f"{i}_lm"].shape and np.allclose(mod.lm_weights.numpy(), d[f"{i}_lm"], rtol=1e-7)
+        assert (mod.sht.lmax, mod.sht.mmax) == d[f"{i}_lm"].shape and len(mod.state_dict()) == 0
+    with pytest.raises(NotImplementedError):
+        ma.SpectralLpLoss((8, 16), (8, 16), (0, 0), ["a"], grid_type="healpix")
+
+
+@pytest.mark.gpu
+def test_hip_spectral_loss_matches_reference_golden():
+    import makani_amd as ma
+    d, cases = _scases()
+    dev = torch.device("cuda", 0)
+    for i, c in enumerate(cases):
+        mod = ma.SpectralLpLoss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0), channel_names=["a", "b", "c"],
+                                grid_type=c["grid"], p=c["p"], relative=c["relative"], squared=c["squared"]).to(dev)
+        prd = torch.tensor(d[f"{i}_prd"], device=dev, requires_grad=True)
+        tar = torch.tensor(d[f"{i}_tar"], device=dev, requires_grad=True)
+        w = torch.tensor(d[f"{i}_wgt"], device=dev) if c["wgt"] else None
+        out = mod(prd, tar, w)
+        (out * torch.tensor(d[f"{i}_g"], device=dev)).sum().backward()
+        assert np.allclose(out.detach().cpu().numpy(), d[f"{i}_out"], rtol=3e-5, atol=1e-7), c
+        for got, want in ((prd.grad, d[f"{i}_dprd"]), (tar.grad, d[f"{i}_dtar"])):
+            err = np.linalg.norm(got.cpu().numpy() - want) / np.linalg.norm(want)
+            assert err < 2e-5, (c, err)
+
+
+@pytest.mark.gpu
+def test_hip_spectral_loss_parseval_fullsize():
+    """size-independent property at the BASELINE grid (tests/test_losses.py:440-452 of the reference): for a
+    band-limited field the spectral L2 norm equals the quadrature L2 norm (Clenshaw-Curtis exact for the integrand)"""
+    import makani_amd as ma
+    dev = torch.device("cuda", 0)
+    H, W, C = 721, 1440, 2
+    torch.manual_seed(11)
+    lmax = 120
+    isht = ma.InverseRealSHT(H, W, lmax=lmax, mmax=lmax, grid="equiangular").to(dev)
+    coef = torch.tril(torch.randn(1, C, lmax, lmax, dtype=torch.complex64, device=dev))
+    x = isht(coef)
+    spec = ma.SpectralLpLoss((H, W), (H, W), (0, 0), ["a"] * C, grid_type="equiangular", p=2.0, squared=True).to(dev)
+    geo = ma.GridQuadrature("clenshaw-curtiss", (H, W), normalize=True).to(dev)
+    a = spec(x, torch.zeros_like(x))
+    b = geo(x * x)
+    assert torch.allclose(a, b, rtol=2e-4), (a, b)
