@@ -366,8 +366,22 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[NA], rb[NA];
-    auto load_tiles = [&](long long n) {
+    // two register sets: the loads of pixel tile kt+2 are issued while tile kt is multiplied (one k-step of 32 MFMAs
+    // = 0.43 us does not cover an HBM round trip under load), tile kt+1 is copied to the other LDS stage after the
+    // MFMAs.  Interior tiles load unconditionally (no per-vector branches).
+    uint4 ra[2][NA], rb[2][NA];
+    const bool rows_full = (m0 + BM <= p.M) && (c0 + BN <= p.K);
+    auto load_tiles = [&](uint4* qa, uint4* qb, long long n) {
+        if (rows_full && n + BK <= nend) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int f = tid + q * NT;
+                const int row = f >> 3, c = f & 7;
+                qa[q] = ld16(Gb + (long long)(m0 + row) * p.N + n + c * 8);
+                qb[q] = ld16(Xb + (long long)(c0 + row) * p.N + n + c * 8);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int f = tid + q * NT;
@@ -377,31 +391,22 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
                 if (m0 + row < p.M) va = ld16(Gb + (long long)(m0 + row) * p.N + n + c * 8);
                 if (c0 + row < p.K) vb = ld16(Xb + (long long)(c0 + row) * p.N + n + c * 8);
             }
-            ra[q] = va;
-            rb[q] = vb;
+            qa[q] = va;
+            qb[q] = vb;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](const uint4* qa, const uint4* qb, int buf) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int f = tid + q * NT;
             const int row = f >> 3, c = f & 7;
-            *reinterpret_cast<uint4*>(As + buf * BM * PA + row * PA + c * 8) = ra[q];
-            *reinterpret_cast<uint4*>(Bs + buf * BN * PA + row * PA + c * 8) = rb[q];
+            *reinterpret_cast<uint4*>(As + buf * BM * PA + row * PA + c * 8) = qa[q];
+            *reinterpret_cast<uint4*>(Bs + buf * BN * PA + row * PA + c * 8) = qb[q];
         }
     };
-
-    const int nk = (int)((nend - nbeg + BK - 1) / BK);
-    if (nk > 0) {
-        load_tiles(nbeg);
-        store_tiles(0);
-    }
-    __syncthreads();
     const int a_off = (wm * 64 + l31) * PA + lh * 8;
     const int b_off = (wn * 64 + l31) * PA + lh * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(nbeg + (long long)(kt + 1) * BK);
+    auto compute = [&](int buf) {
         const u16* Ab = As + buf * BM * PA;
         const u16* Bb = Bs + buf * BN * PA;
 #pragma unroll
@@ -418,7 +423,24 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+    };
+
+    const int nk = (int)((nend - nbeg + BK - 1) / BK);
+    if (nk > 0) load_tiles(ra[0], rb[0], nbeg);
+    if (nk > 1) load_tiles(ra[1], rb[1], nbeg + BK);
+    if (nk > 0) store_tiles(ra[0], rb[0], 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even tile: LDS stage 0, its registers (set 0) are free again
+        if (kt + 2 < nk) load_tiles(ra[0], rb[0], nbeg + (long long)(kt + 2) * BK);
+        compute(0);
+        if (kt + 1 < nk) store_tiles(ra[1], rb[1], 1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd tile: LDS stage 1
+        if (kt + 3 < nk) load_tiles(ra[1], rb[1], nbeg + (long long)(kt + 3) * BK);
+        compute(1);
+        if (kt + 2 < nk) store_tiles(ra[0], rb[0], 0);
         __syncthreads();
     }
 
