@@ -452,6 +452,7 @@ def main():
                        "global_batch": dsize * B, "parallelism": f"dp{dsize}" + (f"_h{ph}w{pw}" if msize > 1 else ""),
                        "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32"},
             "roofline": roofline,
+            "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
             "hip_kernels": kernels,
             "hip_kernel_ms_per_step": round(hip_ms, 2),
             "final_loss": final_loss,
