@@ -46,8 +46,8 @@ __device__ __forceinline__ uint4 ld16(const u16* p) { return *reinterpret_cast<c
 // 0.2 us per wave), interior tiles load without per-vector branches.  Epilogue: the fp32 accumulators cross LDS
 // (64 rows at a time) so that Y, Ypre, G and R are all touched as 16-byte vectors along the pixel axis; direct
 // stores from the MFMA layout would be 2-byte scattered writes (a lane owns one pixel column).
-template <int BM, int BN, int DEPTH, int BKT>
-__global__ __launch_bounds__(NT, 2) void conv_nn_kernel(const ConvNN p, int tilesM, long long tilesN) {
+template <int BM, int BN, int DEPTH, int BKT, int WGS>
+__global__ __launch_bounds__(NT, WGS) void conv_nn_kernel(const ConvNN p, int tilesM, long long tilesN) {
     constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;        // MFMA tiles per wave
     constexpr int BK = BKT;                          // shadows the file-level default
@@ -633,12 +633,24 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     }
     // 128 x 256 tile, BK = 64 with one LDS stage (measured 10-15 % faster at 721x1440 than BK = 32 double-buffered,
     // equal at 240x480; a 128 x 128 tile with two register sets was 10-20 % slower)
-    constexpr int BM = 128, BN = 256;
+    // BK = 64 with one LDS stage (10-15 % faster at 721x1440 than BK = 32 double-buffered).  Tile 128 x 128 with
+    // 3 workgroups / CU on the internal grid (0.118 ms vs 0.128 for 128 x 256 at 240x480, 768 <- 384; the library:
+    // 0.104), 128 x 256 (longer contiguous row segments) on the full-resolution planes; a 4-workgroup build spills.
+    constexpr int BM = 128;
     const int tm = (M + BM - 1) / BM;
-    const long long tn = (N + BN - 1) / BN;
-    const long long nb = (long long)tm * tn * B;
-    MK_REQUIRE(nb < (1ll << 31), "conv1x1_nn: grid too large");
-    hipLaunchKernelGGL((conv_nn_kernel<BM, BN, 1, 64>), dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, p, tm, tn);
+    if (N >= (1ll << 19)) {
+        constexpr int BN = 256;
+        const long long tn = (N + BN - 1) / BN;
+        const long long nb = (long long)tm * tn * B;
+        MK_REQUIRE(nb < (1ll << 31), "conv1x1_nn: grid too large");
+        hipLaunchKernelGGL((conv_nn_kernel<BM, BN, 1, 64, 2>), dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, p, tm, tn);
+    } else {
+        constexpr int BN = 128;
+        const long long tn = (N + BN - 1) / BN;
+        const long long nb = (long long)tm * tn * B;
+        MK_REQUIRE(nb < (1ll << 31), "conv1x1_nn: grid too large");
+        hipLaunchKernelGGL((conv_nn_kernel<BM, BN, 1, 64, 3>), dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, p, tm, tn);
+    }
     return mk_check_launch("mk_conv1x1_nn");
 }
 
