@@ -128,11 +128,14 @@ int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long lo
 int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma, const float* beta,
                       long long planes, int channels, long long hw, int fuse_gelu, void* stream);
 /* stats + apply in two launches (the apply kernel finishes the statistics reduction itself and writes `stats` for the
- * backward): what the serial InstanceNorm2d forward uses. */
+ * backward): what the serial InstanceNorm2d forward uses.  `pre_bias` (channels, may be NULL) folds the bias of the
+ * convolution in front of the norm (the MLP's fc2, makani/models/common/layers.py:768-823) into both passes: the norm
+ * sees (x + pre_bias[c]) rounded to the tensor dtype, exactly the tensor the reference materialises; same in backward. */
 int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, float* ws, const float* gamma, const float* beta,
-                    long long planes, int channels, long long hw, float eps, int fuse_gelu, void* stream);
+                    const float* pre_bias, long long planes, int channels, long long hw, float eps, int fuse_gelu,
+                    void* stream);
 int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
-                    const float* beta, float* sums, float* ws, long long planes, int channels, long long hw,
+                    const float* beta, const float* pre_bias, float* sums, float* ws, long long planes, int channels, long long hw,
                     long long hw_total, int phase, int fuse_gelu, void* stream);
 /* y = gelu(x + bias[c])  — the bias+activation of the 1x1 convolutions in MLP / EncoderDecoder
  * (makani/models/common/layers.py:603-643,768-823).  bias may be NULL (plain GELU).

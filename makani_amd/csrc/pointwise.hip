@@ -125,16 +125,26 @@ __device__ __forceinline__ void plane_totals(const float* __restrict__ ws, long 
     }
 }
 
+// value the norm sees when a per-channel constant `pb` (the bias of the convolution in front of it) is folded in:
+// exactly what the reference materialises, i.e. (x + pb) rounded to the tensor dtype (idempotent for pb = 0)
+template <typename T>
+__device__ __forceinline__ float pre(float v, float pb);
+template <>
+__device__ __forceinline__ float pre<float>(float v, float pb) { return v + pb; }
+template <>
+__device__ __forceinline__ float pre<u16>(float v, float pb) { return bf16_to_f32(f32_to_bf16(v + pb)); }
+
 // ---- instance norm: statistics ---------------------------------------------------
 // partial sums relative to a per-plane pivot (first element) to avoid cancellation in fp32
 template <typename T>
 __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, float* __restrict__ ws, long long hw,
-                                                       int chunks) {
+                                                       int chunks, const float* __restrict__ pre_bias, int channels) {
     __shared__ float red[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const T* xp = x + plane * hw;
-    const float pivot = VecIO<T>::load1(xp);
+    const float pb = pre_bias ? pre_bias[plane % channels] : 0.f;
+    const float pivot = pre<T>(VecIO<T>::load1(xp), pb);
     float s1 = 0.f, s2 = 0.f;
     for_chunk<T>(hw, chunk, [&](long long e, int n, bool vec) {
         float v[VecIO<T>::N];
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
         else
             v[0] = VecIO<T>::load1(xp + e);
         for (int i = 0; i < (vec ? VecIO<T>::N : 1); ++i) {
-            const float d = v[i] - pivot;
+            const float d = pre<T>(v[i], pb) - pivot;
             s1 += d;
             s2 += d * d;
         }
@@ -178,16 +188,17 @@ template <typename T, bool GELU>
 __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ stats,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                const float* __restrict__ ws, float eps, int channels, long long hw,
-                                               int chunks) {
+                                               int chunks, const float* __restrict__ pre_bias) {
     __shared__ double redd[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const int c = (int)(plane % channels);
+    const float pb = pre_bias ? pre_bias[c] : 0.f;
     float mean, rstd;
     if (ws) {                    // statistics straight from the partial sums (same arithmetic as in_stats_final)
         double s1, s2;
         plane_totals(ws, plane, chunks, s1, s2, redd);
-        const double pivot = (double)VecIO<T>::load1(x + plane * hw);
+        const double pivot = (double)pre<T>(VecIO<T>::load1(x + plane * hw), pb);
         const double m = s1 / (double)hw;
         double var = s2 / (double)hw - m * m;
         if (var < 0.0) var = 0.0;
@@ -210,12 +221,12 @@ __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __res
             VecIO<T>::load(xp + e, v);
 #pragma unroll
             for (int i = 0; i < VecIO<T>::N; ++i) {
-                const float a = v[i] * sc + sh;
+                const float a = pre<T>(v[i], pb) * sc + sh;
                 v[i] = GELU ? gelu_f(a) : a;
             }
             VecIO<T>::store(yp + e, v);
         } else {
-            const float a = VecIO<T>::load1(xp + e) * sc + sh;
+            const float a = pre<T>(VecIO<T>::load1(xp + e), pb) * sc + sh;
             VecIO<T>::store1(yp + e, GELU ? gelu_f(a) : a);
         }
     });
@@ -228,11 +239,13 @@ template <typename T, bool GELU>
 __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, const T* __restrict__ gy,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ ws,
-                                                     int channels, long long hw, int chunks) {
+                                                     int channels, long long hw, int chunks,
+                                                     const float* __restrict__ pre_bias) {
     __shared__ float red[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const int c = (int)(plane % channels);
+    const float pb = pre_bias ? pre_bias[c] : 0.f;
     const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const T* xp = x + plane * hw;
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, co
             d[0] = VecIO<T>::load1(gp + e);
         }
         for (int i = 0; i < cnt; ++i) {
-            const float n = (v[i] - mean) * rstd;
+            const float n = (pre<T>(v[i], pb) - mean) * rstd;
             float ga = d[i];
             if (GELU) ga *= gelu_grad_f(n * g + b);
             s1 += ga;
@@ -281,12 +294,13 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ sums,
                                                    const float* __restrict__ ws, int channels, long long hw, int chunks,
-                                                   float inv_total) {
+                                                   float inv_total, const float* __restrict__ pre_bias) {
     __shared__ double redd[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const long long planes = gridDim.x / chunks;
     const int c = (int)(plane % channels);
+    const float pb = pre_bias ? pre_bias[c] : 0.f;
     const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     float t1, t2;
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
             d[0] = VecIO<T>::load1(gp + e);
         }
         for (int i = 0; i < cnt; ++i) {
-            const float n = (v[i] - mean) * rstd;
+            const float n = (pre<T>(v[i], pb) - mean) * rstd;
             float ga = d[i];
             if (GELU) ga *= gelu_grad_f(n * g + b);
             v[i] = k * (ga - m1 - n * m2);
@@ -558,11 +572,11 @@ extern "C" int mk_instnorm_stats(const void* x, int dtype, float* stats, float* 
     const int fb = (int)((planes + 255) / 256);
     if (dtype == MK_F32) {
         const int ch = chunks_for<float>(hw);
-        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch);
+        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch, nullptr, 1);
         hipLaunchKernelGGL(in_stats_final<float>, dim3(fb), dim3(256), 0, s, (const float*)x, ws, stats, planes, hw, ch, eps);
     } else {
         const int ch = chunks_for<u16>(hw);
-        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch);
+        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch, nullptr, 1);
         hipLaunchKernelGGL(in_stats_final<u16>, dim3(fb), dim3(256), 0, s, (const u16*)x, ws, stats, planes, hw, ch, eps);
     }
     return mk_check_launch("mk_instnorm_stats");
@@ -570,7 +584,7 @@ extern "C" int mk_instnorm_stats(const void* x, int dtype, float* stats, float* 
 
 static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
                                const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
-                               hipStream_t s);
+                               const float* pre_bias, hipStream_t s);
 
 extern "C" int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma,
                                  const float* beta, long long planes, int channels, long long hw, int fuse_gelu,
@@ -579,47 +593,48 @@ extern "C" int mk_instnorm_apply(const void* x, void* y, int dtype, const float*
     if (rc) return rc;
     MK_REQUIRE(y && stats && channels > 0, "instnorm_apply: bad args");
     return instnorm_apply_impl(x, y, dtype, const_cast<float*>(stats), gamma, beta, nullptr, 0.f, planes, channels, hw,
-                               fuse_gelu, (hipStream_t)stream);
+                               fuse_gelu, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, float* ws, const float* gamma,
-                               const float* beta, long long planes, int channels, long long hw, float eps, int fuse_gelu,
-                               void* stream) {
+                               const float* beta, const float* pre_bias, long long planes, int channels, long long hw,
+                               float eps, int fuse_gelu, void* stream) {
     int rc = check_common(x, planes, hw, dtype, "instnorm_fwd");
     if (rc) return rc;
     MK_REQUIRE(y && stats && ws && channels > 0, "instnorm_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MK_F32)
-        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * chunks_for<float>(hw))), dim3(NT), 0, s, (const float*)x, ws, hw, chunks_for<float>(hw));
+        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * chunks_for<float>(hw))), dim3(NT), 0, s, (const float*)x, ws, hw, chunks_for<float>(hw), pre_bias, channels);
     else
-        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * chunks_for<u16>(hw))), dim3(NT), 0, s, (const u16*)x, ws, hw, chunks_for<u16>(hw));
-    return instnorm_apply_impl(x, y, dtype, stats, gamma, beta, ws, eps, planes, channels, hw, fuse_gelu, s);
+        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * chunks_for<u16>(hw))), dim3(NT), 0, s, (const u16*)x, ws, hw, chunks_for<u16>(hw), pre_bias, channels);
+    return instnorm_apply_impl(x, y, dtype, stats, gamma, beta, ws, eps, planes, channels, hw, fuse_gelu, pre_bias, s);
 }
 
 static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
                                const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
-                               hipStream_t s) {
+                               const float* pre_bias, hipStream_t s) {
     if (dtype == MK_F32) {
         const int ch = chunks_for<float>(hw);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
-            hipLaunchKernelGGL((in_apply<float, true>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<float, true>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
         else
-            hipLaunchKernelGGL((in_apply<float, false>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<float, false>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
     } else {
         const int ch = chunks_for<u16>(hw);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
-            hipLaunchKernelGGL((in_apply<u16, true>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<u16, true>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
         else
-            hipLaunchKernelGGL((in_apply<u16, false>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch);
+            hipLaunchKernelGGL((in_apply<u16, false>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
     }
     return mk_check_launch("mk_instnorm_apply");
 }
 
 extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats,
-                               const float* gamma, const float* beta, float* sums, float* ws, long long planes,
-                               int channels, long long hw, long long hw_total, int phase, int fuse_gelu, void* stream) {
+                               const float* gamma, const float* beta, const float* pre_bias, float* sums, float* ws,
+                               long long planes, int channels, long long hw, long long hw_total, int phase,
+                               int fuse_gelu, void* stream) {
     int rc = check_common(x, planes, hw, dtype, "instnorm_bwd");
     if (rc) return rc;
     MK_REQUIRE(gy && gx && stats && sums && ws && channels > 0, "instnorm_bwd: bad args");
@@ -633,12 +648,12 @@ extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtyp
         dim3 g((unsigned)(planes * ch));                                                                               \
         if (phase != 2)                                                                                                \
             hipLaunchKernelGGL((in_bwd_partial<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, stats, gamma,    \
-                               beta, ws, channels, hw, ch);                                                            \
+                               beta, ws, channels, hw, ch, pre_bias);                                                  \
         if (phase == 1)                                                                                                \
             hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);                     \
         if (phase != 1)   /* phase 0: the apply kernel finishes the reduction itself and publishes `sums` */           \
             hipLaunchKernelGGL((in_bwd_apply<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, (T*)gx, stats,     \
-                               gamma, beta, sums, phase == 0 ? ws : nullptr, channels, hw, ch, inv_total);             \
+                               gamma, beta, sums, phase == 0 ? ws : nullptr, channels, hw, ch, inv_total, pre_bias);   \
     } while (0)
     if (dtype == MK_F32) {
         if (fuse_gelu) IN_BWD(float, true); else IN_BWD(float, false);

@@ -19,6 +19,7 @@ from . import ops
 
 
 _HIP_NN = os.environ.get("MAKANI_AMD_CONV", "lib") == "hip"
+_DEFER_BIAS = os.environ.get("MAKANI_AMD_DEFER_BIAS", "1") != "0"
 
 
 def hip_conv_eligible(x) -> bool:
@@ -123,6 +124,16 @@ class MLP(nn.Module):
         h = _conv_act(self.fwd[0], self.fwd[1], x)
         return self.fwd[3](h)
 
+    def can_defer_output_bias(self, x) -> bool:
+        """the output bias can ride in the instance norm that follows (no add pass, no reduction for its gradient)"""
+        return (self.fwd[3].bias is not None and not self.checkpointing and _DEFER_BIAS
+                and not (self.fwd[1].is_gelu and hip_conv_eligible(x)))
+
+    def forward_deferred_bias(self, x):
+        """(fc2(act(fc1(x))) WITHOUT the output bias, that bias): for a caller that folds it into its next op"""
+        h = _conv_act(self.fwd[0], self.fwd[1], x)
+        return self.fwd[3].matmul(h), self.fwd[3].bias
+
     def forward(self, x):
         if self.checkpointing and torch.is_grad_enabled():
             return torch.utils.checkpoint.checkpoint(self._run, x, use_reentrant=False)
@@ -181,7 +192,7 @@ class InstanceNorm2d(nn.Module):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
-    def forward(self, x, fuse_gelu=False):
+    def forward(self, x, fuse_gelu=False, pre_bias=None):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError(f"expected (B, {self.num_features}, H, W), got {tuple(x.shape)}")
-        return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu)
+        return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, pre_bias)

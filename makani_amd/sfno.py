@@ -116,9 +116,13 @@ class NeuralOperatorBlock(nn.Module):
         if not fuse:
             x = self.act_layer0(x)
 
-        if hasattr(self, "mlp"):
-            x = self.mlp(x)
-        x = self.norm1(x)
+        if hasattr(self, "mlp") and type(self.norm1) is InstanceNorm2d and self.mlp.can_defer_output_bias(x):
+            x, pb = self.mlp.forward_deferred_bias(x)         # fc2's bias rides in norm1 (same rounding as y + b)
+            x = self.norm1(x, pre_bias=pb)
+        else:
+            if hasattr(self, "mlp"):
+                x = self.mlp(x)
+            x = self.norm1(x)
         x = self.drop_path(x)
 
         if hasattr(self, "outer_skip"):
