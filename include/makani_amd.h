@@ -204,6 +204,7 @@ typedef struct MkAdamTensor {
     float* m;
     float* v;
     long long n;
+    void* p_bf16;   /* optional (mk_adamw_multi only): receives bf16(updated p), the autocast operand of the next step */
 } MkAdamTensor;
 int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_scale, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, void* stream);

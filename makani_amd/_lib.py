@@ -19,7 +19,8 @@ c_ll, c_int, c_f, c_vp = C.c_longlong, C.c_int, C.c_float, C.c_void_p
 
 class MkAdamTensor(C.Structure):
     """mirrors `struct MkAdamTensor` of include/makani_amd.h"""
-    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong)]
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong),
+                ("p_bf16", C.c_void_p)]
 
 
 class MkGemm(C.Structure):

@@ -54,6 +54,7 @@ constexpr int MULTI_MAX = 48;
 constexpr int MULTI_CHUNK = NT * 4 * 4;       // elements per block
 
 struct AdamMulti {
+    u16* pb[MULTI_MAX];          // optional bf16 copy of the updated parameter (the autocast operand of the next step)
     float* p[MULTI_MAX];
     const float* g[MULTI_MAX];
     float* m[MULTI_MAX];
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(NT) void adamw_multi_kernel(const AdamMulti a, cons
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.first[t + 1]) ++t;
     float* __restrict__ p = a.p[t];
+    u16* __restrict__ pb = a.pb[t];
     const float* __restrict__ g = a.g[t];
     float* __restrict__ m = a.m[t];
     float* __restrict__ v = a.v[t];
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(NT) void adamw_multi_kernel(const AdamMulti a, cons
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
-        p[i] = p[i] * decay - step * (mi / (sqrtf(vi) * bc2_rsqrt + eps));
+        const float pn = p[i] * decay - step * (mi / (sqrtf(vi) * bc2_rsqrt + eps));
+        p[i] = pn;
+        if (pb) pb[i] = f32_to_bf16(pn);
     }
 }
 
@@ -174,7 +178,7 @@ extern "C" int mk_adamw_multi(const MkAdamTensor* tensors, int count, const floa
             const MkAdamTensor& s = tensors[base + t];
             MK_REQUIRE(s.p && s.g && s.m && s.v && s.n > 0, "adamw_multi: tensor %d has a null pointer or no elements", base + t);
             MK_REQUIRE(s.n < (1ll << 40), "adamw_multi: tensor %d too large for the multi-tensor path", base + t);
-            a.p[t] = s.p, a.g[t] = s.g, a.m[t] = s.m, a.v[t] = s.v, a.n[t] = s.n;
+            a.p[t] = s.p, a.g[t] = s.g, a.m[t] = s.m, a.v[t] = s.v, a.n[t] = s.n, a.pb[t] = (u16*)s.p_bf16;
             a.first[t] = blocks;
             blocks += (int)((s.n + MULTI_CHUNK - 1) / MULTI_CHUNK);
         }

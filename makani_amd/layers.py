@@ -42,6 +42,7 @@ class PointwiseConv(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 1, 1))
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        ops.want_bf16_shadow(self.weight)
 
     def matmul(self, x, add_to=None):
         """bias-free product; ``add_to`` (same shape as the result) is fused as the GEMM's C input."""

@@ -601,6 +601,23 @@ class ConvGeluConvFn(torch.autograd.Function):
         return gx, gw1, gb1, gw2, gb2
 
 
+def want_bf16_shadow(param):
+    """mark a fp32 parameter whose bf16 copy ``makani_amd.optim.FusedAdamW`` should emit with every update"""
+    param._mk_want_bf16 = True
+
+
+def cast_weight(weight, dtype):
+    """weight in the GEMM dtype: the optimizer's bf16 shadow when it belongs to exactly this version of the
+    parameter (any in-place change through torch bumps ``_version`` and invalidates it), else a cast"""
+    if dtype == weight.dtype:
+        return weight
+    sh = getattr(weight, "_mk_shadow", None)
+    if (sh is not None and dtype == torch.bfloat16 and getattr(weight, "_mk_shadow_version", -1) == weight._version
+            and sh.device == weight.device):
+        return sh
+    return weight.to(dtype)
+
+
 class ConvMmFn(torch.autograd.Function):
     """y = W x (+ residual) with the forward / data-gradient products issued as plain library GEMMs
     (hipBLASLt through torch.mm: measured 2x faster than the round-1 HIP NN kernel on these
@@ -611,7 +628,7 @@ class ConvMmFn(torch.autograd.Function):
     def forward(ctx, x, weight, residual):
         B, K, H, W = x.shape
         M = weight.shape[0]
-        w = weight.view(M, K).to(x.dtype)
+        w = cast_weight(weight, x.dtype).view(M, K)
         N = H * W
         # with a residual the product accumulates INTO it (beta = 1, no 88-800 MB copy of the residual first);
         # autograd is told through mark_dirty, and nothing upstream saves that tensor (it is a norm / GEMM output).

@@ -27,7 +27,7 @@ class FusedAdamW(torch.optim.Optimizer):
         grads = [_real(p.grad) for g in self.param_groups for p in g["params"] if p.grad is not None]
         if any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
             raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 gradients")
-        arr = (MkAdamTensor * len(grads))(*[MkAdamTensor(None, g.data_ptr(), None, None, g.numel()) for g in grads])
+        arr = (MkAdamTensor * len(grads))(*[MkAdamTensor(None, g.data_ptr(), None, None, g.numel(), None) for g in grads])
         nws = lib().mk_grad_norm_workspace(C.cast(arr, C.c_void_p), len(grads))
         ws = torch.empty((nws,), dtype=torch.float32, device=grads[0].device)
         out = torch.empty((2,), dtype=torch.float32, device=grads[0].device)
@@ -50,6 +50,7 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             small = {}                       # step count -> [descriptors]: one launch per 48 small tensors
             keep = []                        # python references that must outlive the launches
+            shadowed = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -64,9 +65,20 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 parameters and gradients")
                 m, v = _real(st["exp_avg"]), _real(st["exp_avg_sq"])
                 if pr.numel() < SMALL:
+                    # parameters that asked for it (ops.want_bf16_shadow) get bf16(p) written by the same kernel: the
+                    # operand the bf16-autocast GEMMs of the next step would otherwise produce with one cast kernel each
+                    shadow = None
+                    if getattr(p, "_mk_want_bf16", False) and pr.dtype == torch.float32:
+                        shadow = getattr(p, "_mk_shadow", None)
+                        if shadow is None or shadow.shape != p.shape or shadow.device != p.device:
+                            shadow = torch.empty_like(p, dtype=torch.bfloat16)
+                            p._mk_shadow = shadow
                     small.setdefault(int(st["step"]), []).append(
-                        MkAdamTensor(pr.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), pr.numel()))
-                    keep.append((pr, gr, m, v))
+                        MkAdamTensor(pr.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), pr.numel(),
+                                     shadow.data_ptr() if shadow is not None else None))
+                    keep.append((pr, gr, m, v, shadow))
+                    if shadow is not None:
+                        shadowed.append(p)
                 else:
                     check(lib().mk_adamw_step(ptr(pr), ptr(gr), ptr(m), ptr(v), pr.numel(), ptr(scale), group["lr"], b1, b2,
                                               group["eps"], group["weight_decay"], int(st["step"]), stream()), "mk_adamw_step")
@@ -76,4 +88,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 arr = (MkAdamTensor * len(descs))(*descs)
                 check(lib().mk_adamw_multi(C.cast(arr, C.c_void_p), len(descs), ptr(scale), group["lr"], b1, b2, group["eps"],
                                            group["weight_decay"], step, stream()), "mk_adamw_multi")
+            for p in shadowed:               # valid for exactly this version of the parameter
+                p._mk_shadow_version = p._version
         return None

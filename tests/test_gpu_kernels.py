@@ -398,3 +398,29 @@ def test_conv_gelu_conv_autograd():
     assert rel_l2(y, yr) < 1e-2
     for d, r in zip(dev_t, ref_t):
         assert rel_l2(d.grad, r.grad) < 2e-2, d.shape
+
+
+def test_bf16_weight_shadow_is_exact_and_invalidated_by_inplace_updates():
+    """FusedAdamW writes bf16(p) for the channel-GEMM weights; the GEMM uses it only for that exact parameter version"""
+    import makani_amd as ma
+    from makani_amd import ops
+    from makani_amd.optim import FusedAdamW
+    torch.manual_seed(4)
+    conv = ma.PointwiseConv(16, 24, bias=False).to(_dev())
+    opt = FusedAdamW(conv.parameters(), lr=1e-2, weight_decay=0.0)
+    x = torch.randn(1, 16, 8, 16, device=_dev())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        conv(x).float().square().mean().backward()
+    assert getattr(conv.weight, "_mk_shadow", None) is None
+    opt.step()
+    sh = conv.weight._mk_shadow
+    assert sh.dtype == torch.bfloat16 and torch.equal(sh, conv.weight.detach().to(torch.bfloat16))
+    assert ops.cast_weight(conv.weight, torch.bfloat16) is sh
+    with torch.no_grad():
+        conv.weight.mul_(2.0)                                   # any in-place change through torch
+    w = ops.cast_weight(conv.weight, torch.bfloat16)
+    assert w is not sh and torch.equal(w, conv.weight.detach().to(torch.bfloat16))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x)
+    ref = torch.einsum("oi,bihw->bohw", conv.weight.detach().view(24, 16).to(torch.bfloat16).float(), x.to(torch.bfloat16).float())
+    assert rel_l2(y, ref) < 1e-2

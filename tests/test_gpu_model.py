@@ -230,3 +230,34 @@ def test_fullsize_sht_vs_oracle_one_channel():
     # the HIP path must be at least as close to the fp64 truth as the fp32 CPU path, and within tolerance of it
     assert rel_l2(c, co64) < TOL_OP
     assert rel_l2(c, co64) < 3 * rel_l2(co, co64) + 1e-6
+
+
+def test_bf16_weight_shadows_do_not_change_training_bitwise():
+    """4 bf16-autocast train steps with FusedAdamW: taking the optimizer's bf16 weight shadows instead of casting
+    the fp32 weights every step must give bit-identical parameters"""
+    import makani_amd as ma
+    from makani_amd.optim import FusedAdamW
+
+    def run(shadow):
+        torch.manual_seed(0)
+        m = ma.SphericalFourierNeuralOperatorNet(inp_shape=(37, 72), out_shape=(37, 72), inp_chans=5, out_chans=5, scale_factor=2,
+                                                 embed_dim=16, num_layers=2, use_mlp=True, mlp_ratio=2.0, operator_type="dhconv",
+                                                 normalization_layer="instance_norm", big_skip=True, pos_embed="none").to(DEV)
+        if not shadow:
+            for p in m.parameters():
+                p._mk_want_bf16 = False
+        opt = FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
+        x, t = torch.rand(1, 5, 37, 72, device=DEV), torch.rand(1, 5, 37, 72, device=DEV)
+        for _ in range(4):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            ((y.float() - t) ** 2).mean().backward()
+            opt.step(max_grad_norm=32.0)
+        return [torch.view_as_real(p.detach()) if p.is_complex() else p.detach() for p in m.parameters()], \
+            sum(getattr(p, "_mk_shadow", None) is not None for p in m.parameters())
+
+    a, na = run(True)
+    b, nb = run(False)
+    assert na > 0 and nb == 0
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
