@@ -1,9 +1,3 @@
-mkdir -p gpurun_out/final2
-timeout 400 python bench.py > gpurun_out/final2/bench.json 2> gpurun_out/final2/bench.err; tail -c 300 gpurun_out/final2/bench.json; echo
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/final2 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sht-metric > $GRAFT_REPO_ROOT/gpurun_out/final2/bench_traced.log 2>&1
-cd $GRAFT_REPO_ROOT
-find gpurun_out/final2 -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stats.py {} gpurun_out/final2/kernel_stats.md > /dev/null
-find gpurun_out/final2 -name "*.db" -delete
-timeout 300 python tools/microbench.py > gpurun_out/final2/microbench.txt 2>&1
-grep '^{' gpurun_out/final2/bench_traced.log | cut -c1-170
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "fft" 2>&1 | tail -2
+MK_FFT480=1 timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "fft" 2>&1 | tail -2
+for v in 0 1; do echo "== fft480 variant $v"; MK_FFT480=$v timeout 120 python tools/microbench.py fft 2>&1 | grep -v amdgpu | grep 240x480 | cut -c1-110; done
