@@ -347,6 +347,12 @@ def main():
     # profiled in full: it yields the per-kernel table and names the dominant HIP kernel; inside the timed region
     # only that kernel carries events (its roofline numbers therefore come from the timed steps).  With
     # --warmup 0 every launch of the timed region is instrumented instead.
+    # Python's cyclic collector is paused for the warm-up and the timed loop: a generation-2 collection over the
+    # autograd graphs stalls the launching thread for ~100 ms (measured with tools/step_times.py: one step of 154 ms
+    # among 54 ms steps), enough to drain the GPU queue.  Reference counting still frees every tensor immediately.
+    import gc
+    gc.collect()
+    gc.disable()
     warm_prof, warm_dom = {}, None
     for i in range(args.warmup):
         last = i == args.warmup - 1
@@ -373,6 +379,7 @@ def main():
     for _ in range(args.steps):
         loss = train_step(model, opt, reducer, inp, tar, loss_fn, amp, clip)
     torch.cuda.synchronize()
+    gc.enable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
