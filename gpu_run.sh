@@ -1,2 +1,3 @@
-for w in 1 2 3; do timeout 300 python bench.py --steps 5 --warmup $w --no-cpu-baseline --no-sht-metric 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('warmup $w', d['ms_per_step'])"; done
+timeout 900 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | tail -2
+for i in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['hip_kernel_ms_per_step'], d['final_loss'], d['fwd_sht'])"; done

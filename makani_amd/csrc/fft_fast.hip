@@ -522,9 +522,11 @@ int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, con
     hipStream_t s = (hipStream_t)stream;
     //                         N2  radices   RB   NT  WG/CU
     switch (nlon) {
-        // measured and rejected: 384-thread workgroups (3 waves/SIMD) are 10-25 % slower than 256-thread ones;
-        // forcing 3 workgroups/CU on the forward 1440 kernel spills (2.6x slower)
-        case 1440: return launch<720, 10, 9, 8, 8, 256, 2>(MK_FFT_ARGS);
+        // measured and rejected: 384-thread workgroups with 8 rows (3 waves/SIMD) 10-25 % slower than 256-thread ones;
+        // forcing 3 workgroups/CU on the 8-row forward 1440 kernel spills (2.6x slower)
+        // 16 rows / 512 threads, one workgroup per CU: the F side is touched in 64-byte runs (8 rows / 256 threads,
+        // two workgroups per CU: 14-16 % slower)
+        case 1440: return launch<720, 10, 9, 8, 16, 512, 1>(MK_FFT_ARGS);
         case 480: return launch<240, 10, 6, 4, 32, 512, 2>(MK_FFT_ARGS);   // 32 rows: whole 128-byte lines on the F side (irfft +7 %)
         case 360: return launch<180, 6, 6, 5, 16, 256, 3>(MK_FFT_ARGS);
         case 128: return launch<64, 4, 4, 4, 16, 256, 4>(MK_FFT_ARGS);
