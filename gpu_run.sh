@@ -1,3 +1,2 @@
-timeout 900 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | tail -2
-for i in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['hip_kernel_ms_per_step'], d['final_loss'], d['fwd_sht'])"; done
+timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -x -k "instance_norm" 2>&1 | tail -2
+for v in 0 1; do echo "== plane path $v"; MAKANI_AMD_NORM_PLANE=$v timeout 120 python tools/microbench.py pointwise 2>&1 | grep -v amdgpu | grep "instnorm" | cut -c1-100; done
