@@ -218,11 +218,13 @@ def _cpu_worker(cfg_name):
     blk = osf.NeuralOperatorBlock(trans, itrans, E, "dhconv", cfg["mlp_ratio"], torch.nn.GELU, False)
     x = torch.rand(1, E, h, w, requires_grad=True)
     blk(x).square().mean().backward()                      # warm-up (thread pools, allocator)
-    x.grad = None
+    reps = 3                                               # ~10-12 s of CPU work in total
     t0 = time.perf_counter()
-    blk(x).square().mean().backward()
-    t = time.perf_counter() - t0
-    print(json.dumps(dict(t_mid=t, threads=threads, cores=cores, h=h, w=w)), flush=True)
+    for _ in range(reps):
+        x.grad = None
+        blk(x).square().mean().backward()
+    t = (time.perf_counter() - t0) / reps
+    print(json.dumps(dict(t_mid=t, threads=threads, cores=cores, h=h, w=w, reps=reps)), flush=True)
 
 
 def cpu_baseline(cfg_name, timeout_s=240):
@@ -243,8 +245,8 @@ def cpu_baseline(cfg_name, timeout_s=240):
     scale = _STAGE_GF["total"] / _STAGE_GF["mid_block"]
     step = rec["t_mid"] * scale
     return dict(value=1.0 / step, unit="samples/s", cores=rec["threads"], kind="port",
-                sample=f"oracle fp32 on {rec['threads']} host threads ({rec['cores']} cores visible): one fwd+bwd of one "
-                       f"internal-grid block ({rec['h']}x{rec['w']}, 384 ch) = {rec['t_mid']:.2f} s, scaled by the step/block "
+                sample=f"oracle fp32 on {rec['threads']} host threads ({rec['cores']} cores visible): fwd+bwd of one "
+                       f"internal-grid block ({rec['h']}x{rec['w']}, 384 ch), mean of {rec.get('reps', 1)} = {rec['t_mid']:.2f} s, scaled by the step/block "
                        f"FLOP ratio {scale:.1f} -> {step:.1f} s per step (optimizer excluded)",
                 ms_per_step=step * 1e3)
 

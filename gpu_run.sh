@@ -1,11 +1,1 @@
-mkdir -p gpurun_out/final3
-timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -2
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 400 python bench.py > gpurun_out/final3/bench.json 2> gpurun_out/final3/bench.err
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/final3 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sht-metric > $GRAFT_REPO_ROOT/gpurun_out/final3/bench_traced.log 2>&1
-cd $GRAFT_REPO_ROOT
-find gpurun_out/final3 -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stats.py {} gpurun_out/final3/kernel_stats.md > /dev/null
-find gpurun_out/final3 -name "*.db" -delete
-timeout 300 python tools/microbench.py > gpurun_out/final3/microbench.txt 2>&1
-grep '^{' gpurun_out/final3/bench_traced.log | cut -c1-170
+timeout 600 python -m pytest tests/test_bench_contract.py -m gpu -q --tb=short 2>&1 | tail -3
