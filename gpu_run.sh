@@ -1,1 +1,1 @@
-timeout 600 python -m pytest tests/test_bench_contract.py -m gpu -q --tb=short 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | tail -3

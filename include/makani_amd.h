@@ -130,12 +130,16 @@ int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, con
 /* stats + apply in two launches (the apply kernel finishes the statistics reduction itself and writes `stats` for the
  * backward): what the serial InstanceNorm2d forward uses.  `pre_bias` (channels, may be NULL) folds the bias of the
  * convolution in front of the norm (the MLP's fc2, makani/models/common/layers.py:768-823) into both passes: the norm
- * sees (x + pre_bias[c]) rounded to the tensor dtype, exactly the tensor the reference materialises; same in backward. */
+ * sees (x + pre_bias[c]) rounded to the tensor dtype, exactly the tensor the reference materialises; same in backward.
+ * `quad` (hw floats, may be NULL; `quad_sum` = their sum Q, 1 on a full grid, < 1 on a crop) switches to
+ * quadrature-weighted statistics mean = sum q x, var = sum q (x - mean)^2: GeometricInstanceNormS2
+ * (makani/models/common/layer_norm.py:30-160); the backward then is
+ * gx_i = rstd gamma (ga_i - q_i (S1 + (n_i - mean rstd (1 - Q)) S2)) with the unweighted sums S1 = sum ga, S2 = sum ga n. */
 int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, float* ws, const float* gamma, const float* beta,
-                    const float* pre_bias, long long planes, int channels, long long hw, float eps, int fuse_gelu,
-                    void* stream);
+                    const float* pre_bias, const float* quad, float quad_sum, long long planes, int channels, long long hw,
+                    float eps, int fuse_gelu, void* stream);
 int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
-                    const float* beta, const float* pre_bias, float* sums, float* ws, long long planes, int channels, long long hw,
+                    const float* beta, const float* pre_bias, const float* quad, float quad_sum, float* sums, float* ws, long long planes, int channels, long long hw,
                     long long hw_total, int phase, int fuse_gelu, void* stream);
 /* y = gelu(x + bias[c])  — the bias+activation of the 1x1 convolutions in MLP / EncoderDecoder
  * (makani/models/common/layers.py:603-643,768-823).  bias may be NULL (plain GELU).

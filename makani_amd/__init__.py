@@ -3,10 +3,10 @@ makani's nn.Module plug-in API.  HIP kernels live in ``csrc/`` behind the C ABI 
 ``include/makani_amd.h``; this package is the host-side mirror of the reference interface."""
 from .sht import RealSHT, InverseRealSHT
 from .spectral_conv import SpectralConv
-from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv
+from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv, GeometricInstanceNormS2
 from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, SpectralFilterLayer
 from .losses import GeometricLpLoss, GridQuadrature, SpectralLpLoss
 
 __all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
            "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer", "GeometricLpLoss",
-           "GridQuadrature", "SpectralLpLoss"]
+           "GridQuadrature", "SpectralLpLoss", "GeometricInstanceNormS2"]

@@ -54,7 +54,7 @@ _SIGS = {
     "mk_pointwise_chunks": ([c_ll, c_int], c_int),
     "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp], c_int),
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
-    "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_ll, c_int, c_int, c_vp], c_int),
+    "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_int, c_ll, c_ll, c_int, c_int, c_vp], c_int),
     "mk_bias_gelu_fwd": ([c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
     "mk_conv1x1_nn": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
     "mk_conv1x1_wgrad_workspace": ([c_int, c_int, c_int, c_ll], c_ll),
@@ -62,7 +62,7 @@ _SIGS = {
     "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
     "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
     "mk_adamw_multi": ([c_vp, c_int, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
-    "mk_instnorm_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_f, c_int, c_vp], c_int),
+    "mk_instnorm_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_ll, c_int, c_ll, c_f, c_int, c_vp], c_int),
     "mk_grad_norm_workspace": ([c_vp, c_int], c_ll),
     "mk_grad_clip_coef": ([c_vp, c_int, c_f, c_vp, c_vp, c_vp], c_int),
     "mk_spec_lp_blocks": ([c_int, c_int], c_ll),

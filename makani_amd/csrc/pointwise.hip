@@ -138,7 +138,8 @@ __device__ __forceinline__ float pre<u16>(float v, float pb) { return bf16_to_f3
 // partial sums relative to a per-plane pivot (first element) to avoid cancellation in fp32
 template <typename T>
 __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, float* __restrict__ ws, long long hw,
-                                                       int chunks, const float* __restrict__ pre_bias, int channels) {
+                                                       int chunks, const float* __restrict__ pre_bias, int channels,
+                                                       const float* __restrict__ q) {
     __shared__ float red[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
@@ -154,8 +155,9 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
             v[0] = VecIO<T>::load1(xp + e);
         for (int i = 0; i < (vec ? VecIO<T>::N : 1); ++i) {
             const float d = pre<T>(v[i], pb) - pivot;
-            s1 += d;
-            s2 += d * d;
+            const float w = q ? q[e + i] : 1.f;           // quadrature weights (sum 1): geometric norm on the sphere
+            s1 += w * d;
+            s2 += w * d * d;
         }
     });
     block_reduce2(s1, s2, red);
@@ -188,7 +190,7 @@ template <typename T, bool GELU>
 __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ stats,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                const float* __restrict__ ws, float eps, int channels, long long hw,
-                                               int chunks, const float* __restrict__ pre_bias) {
+                                               int chunks, const float* __restrict__ pre_bias, float qsum) {
     __shared__ double redd[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
@@ -199,8 +201,16 @@ __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __res
         double s1, s2;
         plane_totals(ws, plane, chunks, s1, s2, redd);
         const double pivot = (double)pre<T>(VecIO<T>::load1(x + plane * hw), pb);
-        const double m = s1 / (double)hw;
-        double var = s2 / (double)hw - m * m;
+        double m, var;
+        if (qsum > 0.f) {        // quadrature weights, Q = sum q (< 1 on a cropped grid): mean = sum q x, var = sum q (x - mean)^2
+            const double Q = (double)qsum;
+            const double mu = s1 + pivot * Q;
+            var = s2 + 2.0 * (pivot - mu) * s1 + (pivot - mu) * (pivot - mu) * Q;
+            m = mu - pivot;
+        } else {
+            m = s1 / (double)hw;
+            var = s2 / (double)hw - m * m;
+        }
         if (var < 0.0) var = 0.0;
         mean = (float)(pivot + m);
         rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -294,7 +304,8 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ sums,
                                                    const float* __restrict__ ws, int channels, long long hw, int chunks,
-                                                   float inv_total, const float* __restrict__ pre_bias) {
+                                                   float inv_total, const float* __restrict__ pre_bias,
+                                                   const float* __restrict__ q, float qsum) {
     __shared__ double redd[2 * NT / 64];
     const long long plane = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
@@ -315,7 +326,8 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
     } else {
         t1 = sums[plane], t2 = sums[planes + plane];
     }
-    const float m1 = t1 * inv_total, m2 = t2 * inv_total;
+    const float m1 = q ? t1 : t1 * inv_total, m2 = q ? t2 : t2 * inv_total;     // weighted: the factor is q[i], applied per element
+    const float cq = q ? mean * rstd * (1.f - qsum) : 0.f;                      // 0 when the weights sum to 1
     const float k = rstd * g;
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;
@@ -334,7 +346,8 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
             const float n = (pre<T>(v[i], pb) - mean) * rstd;
             float ga = d[i];
             if (GELU) ga *= gelu_grad_f(n * g + b);
-            v[i] = k * (ga - m1 - n * m2);
+            const float w = q ? q[e + i] : 1.f;
+            v[i] = k * (ga - w * (m1 + (n - cq) * m2));
         }
         if (vec)
             VecIO<T>::store(op + e, v);
@@ -572,11 +585,11 @@ extern "C" int mk_instnorm_stats(const void* x, int dtype, float* stats, float* 
     const int fb = (int)((planes + 255) / 256);
     if (dtype == MK_F32) {
         const int ch = chunks_for<float>(hw);
-        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch, nullptr, 1);
+        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch, nullptr, 1, nullptr);
         hipLaunchKernelGGL(in_stats_final<float>, dim3(fb), dim3(256), 0, s, (const float*)x, ws, stats, planes, hw, ch, eps);
     } else {
         const int ch = chunks_for<u16>(hw);
-        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch, nullptr, 1);
+        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch, nullptr, 1, nullptr);
         hipLaunchKernelGGL(in_stats_final<u16>, dim3(fb), dim3(256), 0, s, (const u16*)x, ws, stats, planes, hw, ch, eps);
     }
     return mk_check_launch("mk_instnorm_stats");
@@ -584,7 +597,7 @@ extern "C" int mk_instnorm_stats(const void* x, int dtype, float* stats, float* 
 
 static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
                                const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
-                               const float* pre_bias, hipStream_t s);
+                               const float* pre_bias, float qsum, hipStream_t s);
 
 extern "C" int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma,
                                  const float* beta, long long planes, int channels, long long hw, int fuse_gelu,
@@ -593,48 +606,50 @@ extern "C" int mk_instnorm_apply(const void* x, void* y, int dtype, const float*
     if (rc) return rc;
     MK_REQUIRE(y && stats && channels > 0, "instnorm_apply: bad args");
     return instnorm_apply_impl(x, y, dtype, const_cast<float*>(stats), gamma, beta, nullptr, 0.f, planes, channels, hw,
-                               fuse_gelu, nullptr, (hipStream_t)stream);
+                               fuse_gelu, nullptr, 0.f, (hipStream_t)stream);
 }
 
 extern "C" int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, float* ws, const float* gamma,
-                               const float* beta, const float* pre_bias, long long planes, int channels, long long hw,
-                               float eps, int fuse_gelu, void* stream) {
+                               const float* beta, const float* pre_bias, const float* quad, float quad_sum,
+                               long long planes, int channels, long long hw, float eps, int fuse_gelu, void* stream) {
     int rc = check_common(x, planes, hw, dtype, "instnorm_fwd");
     if (rc) return rc;
     MK_REQUIRE(y && stats && ws && channels > 0, "instnorm_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MK_F32)
-        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * chunks_for<float>(hw))), dim3(NT), 0, s, (const float*)x, ws, hw, chunks_for<float>(hw), pre_bias, channels);
+        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * chunks_for<float>(hw))), dim3(NT), 0, s, (const float*)x, ws, hw, chunks_for<float>(hw), pre_bias, channels, quad);
     else
-        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * chunks_for<u16>(hw))), dim3(NT), 0, s, (const u16*)x, ws, hw, chunks_for<u16>(hw), pre_bias, channels);
-    return instnorm_apply_impl(x, y, dtype, stats, gamma, beta, ws, eps, planes, channels, hw, fuse_gelu, pre_bias, s);
+        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * chunks_for<u16>(hw))), dim3(NT), 0, s, (const u16*)x, ws, hw, chunks_for<u16>(hw), pre_bias, channels, quad);
+    MK_REQUIRE(quad == nullptr || quad_sum > 0.f, "instnorm_fwd: quadrature weights need their (positive) sum");
+    return instnorm_apply_impl(x, y, dtype, stats, gamma, beta, ws, eps, planes, channels, hw, fuse_gelu, pre_bias,
+                               quad ? quad_sum : 0.f, s);
 }
 
 static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
                                const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
-                               const float* pre_bias, hipStream_t s) {
+                               const float* pre_bias, float qsum, hipStream_t s) {
     if (dtype == MK_F32) {
         const int ch = chunks_for<float>(hw);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
-            hipLaunchKernelGGL((in_apply<float, true>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
+            hipLaunchKernelGGL((in_apply<float, true>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias, qsum);
         else
-            hipLaunchKernelGGL((in_apply<float, false>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
+            hipLaunchKernelGGL((in_apply<float, false>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias, qsum);
     } else {
         const int ch = chunks_for<u16>(hw);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
-            hipLaunchKernelGGL((in_apply<u16, true>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
+            hipLaunchKernelGGL((in_apply<u16, true>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias, qsum);
         else
-            hipLaunchKernelGGL((in_apply<u16, false>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias);
+            hipLaunchKernelGGL((in_apply<u16, false>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias, qsum);
     }
     return mk_check_launch("mk_instnorm_apply");
 }
 
 extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats,
-                               const float* gamma, const float* beta, const float* pre_bias, float* sums, float* ws,
-                               long long planes, int channels, long long hw, long long hw_total, int phase,
-                               int fuse_gelu, void* stream) {
+                               const float* gamma, const float* beta, const float* pre_bias, const float* quad,
+                               float quad_sum, float* sums, float* ws, long long planes, int channels, long long hw,
+                               long long hw_total, int phase, int fuse_gelu, void* stream) {
     int rc = check_common(x, planes, hw, dtype, "instnorm_bwd");
     if (rc) return rc;
     MK_REQUIRE(gy && gx && stats && sums && ws && channels > 0, "instnorm_bwd: bad args");
@@ -653,7 +668,8 @@ extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtyp
             hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);                     \
         if (phase != 1)   /* phase 0: the apply kernel finishes the reduction itself and publishes `sums` */           \
             hipLaunchKernelGGL((in_bwd_apply<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, (T*)gx, stats,     \
-                               gamma, beta, sums, phase == 0 ? ws : nullptr, channels, hw, ch, inv_total, pre_bias);   \
+                               gamma, beta, sums, phase == 0 ? ws : nullptr, channels, hw, ch, inv_total, pre_bias,    \
+                               quad, quad_sum);                                                                        \
     } while (0)
     if (dtype == MK_F32) {
         if (fuse_gelu) IN_BWD(float, true); else IN_BWD(float, false);

@@ -197,3 +197,34 @@ class InstanceNorm2d(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError(f"expected (B, {self.num_features}, H, W), got {tuple(x.shape)}")
         return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, pre_bias)
+
+
+class GeometricInstanceNormS2(nn.Module):
+    """Instance normalisation with quadrature weights on the sphere
+    (``makani/models/common/layer_norm.py:30-160``): mean = sum_ij q_ij x_ij, var = sum_ij q_ij (x_ij - mean)^2 with the
+    normalised quadrature weights of the grid (``GridQuadrature(..., normalize=True)``), then the usual
+    normalise (+ affine).  Statistics in fp32, output in the input dtype; two HIP passes forward, two backward."""
+
+    def __init__(self, img_shape, crop_shape, crop_offset, grid_type, num_features, eps=1e-05, affine=False):
+        super().__init__()
+        from .losses import GridQuadrature, grid_to_quadrature_rule
+        self.eps, self.affine, self.num_features = eps, affine, num_features
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        self.quadrature = GridQuadrature(grid_to_quadrature_rule(grid_type), img_shape=img_shape, crop_shape=crop_shape,
+                                         crop_offset=crop_offset, normalize=True, distributed=False)
+        self._qsum = float(self.quadrature.quad_weight.double().sum())      # 1 on the full grid, < 1 on a crop
+
+    def forward(self, x):
+        q = self.quadrature.quad_weight
+        if x.dim() != 4 or tuple(x.shape[-2:]) != tuple(q.shape[-2:]):
+            raise ValueError(f"expected (B, C, {q.shape[-2]}, {q.shape[-1]}), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, False, None, q.reshape(-1), self._qsum)

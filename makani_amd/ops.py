@@ -416,7 +416,8 @@ class InstanceNormFn(torch.autograd.Function):
     materialises.  Its gradient is the plane sum of the norm's input gradient, which is exactly zero."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fuse_gelu, pre_bias=None):
+    def forward(ctx, x, gamma, beta, eps, fuse_gelu, pre_bias=None, quad=None, quad_sum=0.0):
+        """quad: (H*W,) fp32 quadrature weights, quad_sum their sum -> area-weighted statistics (GeometricInstanceNormS2)"""
         x = x.contiguous()
         B, Cc, H, W = x.shape
         planes, hw = B * Cc, H * W
@@ -427,15 +428,16 @@ class InstanceNormFn(torch.autograd.Function):
         b = beta.float().contiguous() if beta is not None else None
         pb = pre_bias.float().contiguous() if pre_bias is not None else None
         y = torch.empty_like(x)
-        check(lib().mk_instnorm_fwd(ptr(x), ptr(y), dt, ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(pb), planes, Cc, hw, eps,
-                                    1 if fuse_gelu else 0, stream()), "instnorm_fwd")
-        ctx.save_for_backward(x, stats, g, b, pb)
+        check(lib().mk_instnorm_fwd(ptr(x), ptr(y), dt, ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(pb), ptr(quad), float(quad_sum), planes,
+                                    Cc, hw, eps, 1 if fuse_gelu else 0, stream()), "instnorm_fwd")
+        ctx.save_for_backward(x, stats, g, b, pb, quad)
+        ctx.quad_sum = float(quad_sum)
         ctx.fuse_gelu = fuse_gelu
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, stats, g, b, pb = ctx.saved_tensors
+        x, stats, g, b, pb, quad = ctx.saved_tensors
         B, Cc, H, W = x.shape
         planes, hw = B * Cc, H * W
         gy = gy.contiguous()
@@ -444,11 +446,12 @@ class InstanceNormFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
-        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(sums),
-                                    ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0, stream()), "instnorm_bwd")
+        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(quad),
+                                    ctx.quad_sum, ptr(sums), ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0, stream()),
+              "instnorm_bwd")
         s = _batch_sum(sums, B, Cc)
         gpb = torch.zeros_like(pb) if (pb is not None and ctx.needs_input_grad[5]) else None
-        return gx, (s[1] if g is not None else None), (s[0] if b is not None else None), None, None, gpb
+        return gx, (s[1] if g is not None else None), (s[0] if b is not None else None), None, None, gpb, None, None
 
 
 class BiasGeluFn(torch.autograd.Function):
@@ -766,11 +769,11 @@ class DistInstanceNormFn(torch.autograd.Function):
         ws = _ws(planes, hw, x.dtype, x.device)
         fg = 1 if fuse_gelu else 0
         hw_total = int(ctx.hw_total[0].item())
-        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(sums),
+        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
                                     ptr(ws), planes, Cc, hw, hw_total, 1, fg, stream()), "instnorm_bwd(reduce)")
         local = _batch_sum(sums, B, Cc).clone()                   # this rank's share of dgamma / dbeta
         _all_reduce_sum(sums, group)
-        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(sums),
+        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
                                     ptr(ws), planes, Cc, hw, hw_total, 2, fg, stream()), "instnorm_bwd(apply)")
         dgamma = local[1] if g is not None else None
         dbeta = local[0] if b is not None else None

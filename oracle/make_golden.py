@@ -181,6 +181,36 @@ def loss_fixtures():
     np.savez_compressed(path, **rec)
     print(f"spectral_lp_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
 
+    # GeometricInstanceNormS2 (models/common/layer_norm.py:30-160)
+    S2Norm = ref_shims.import_reference_module("makani.models.common.layer_norm").GeometricInstanceNormS2
+    ncases = [
+        dict(img=(37, 72), crop=(37, 72), off=(0, 0), grid="equiangular", affine=True),
+        dict(img=(24, 48), crop=(24, 48), off=(0, 0), grid="legendre-gauss", affine=False),
+        dict(img=(33, 64), crop=(30, 60), off=(2, 3), grid="clenshaw-curtiss", affine=True),
+    ]
+    rec = {"cases": json.dumps(ncases)}
+    for i, c in enumerate(ncases):
+        torch.manual_seed(300 + i)
+        B, C = 2, 5
+        mod = S2Norm(img_shape=c["img"], crop_shape=c["crop"], crop_offset=c["off"], grid_type=c["grid"], num_features=C,
+                     eps=1e-5, affine=c["affine"])
+        if c["affine"]:
+            with torch.no_grad():
+                mod.weight.copy_(torch.randn(C) + 1.0)
+                mod.bias.copy_(torch.randn(C))
+        x = (torch.randn(B, C, *c["crop"]) * 2 + 1).requires_grad_(True)
+        y = mod(x)
+        g = torch.randn_like(y)
+        (y * g).sum().backward()
+        rec[f"{i}_x"], rec[f"{i}_y"], rec[f"{i}_g"], rec[f"{i}_dx"] = _np(x), _np(y), _np(g), _np(x.grad)
+        rec[f"{i}_q"] = _np(mod.quadrature.quad_weight.float())
+        if c["affine"]:
+            rec[f"{i}_w"], rec[f"{i}_b"] = _np(mod.weight), _np(mod.bias)
+            rec[f"{i}_dw"], rec[f"{i}_db"] = _np(mod.weight.grad), _np(mod.bias.grad)
+    path = os.path.join(OUT, "geometric_instance_norm_s2.npz")
+    np.savez_compressed(path, **rec)
+    print(f"geometric_instance_norm_s2.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
 
 def main():
     if not ref_shims.reference_available():
