@@ -5,8 +5,8 @@ from .sht import RealSHT, InverseRealSHT
 from .spectral_conv import SpectralConv
 from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv, GeometricInstanceNormS2
 from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, SpectralFilterLayer
-from .losses import GeometricLpLoss, GridQuadrature, SpectralLpLoss
+from .losses import GeometricLpLoss, GridQuadrature, SpectralLpLoss, SpectralH1Loss
 
 __all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
            "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer", "GeometricLpLoss",
-           "GridQuadrature", "SpectralLpLoss", "GeometricInstanceNormS2"]
+           "GridQuadrature", "SpectralLpLoss", "SpectralH1Loss", "GeometricInstanceNormS2"]

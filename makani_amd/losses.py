@@ -265,6 +265,37 @@ class SpectralLpLoss(nn.Module):
         return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)
 
 
+class SpectralH1Loss(SpectralLpLoss):
+    """H1 seminorm loss on the sphere (``makani/utils/losses/h1_loss.py:30-180``): the p = 2 spectral loss with every
+    degree weighted by l (l + 1).  Same kernels as ``SpectralLpLoss``; the degree weights ride in its weight operand."""
+
+    def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
+                 channel_names: List[str], grid_type: str, relative: Optional[bool] = False,
+                 squared: Optional[bool] = False, spatial_distributed: Optional[bool] = False,
+                 eps: Optional[float] = 1.0e-6, **kwargs):
+        super().__init__(img_shape, crop_shape, crop_offset, channel_names, grid_type, p=2.0, relative=relative,
+                         squared=squared, spatial_distributed=spatial_distributed, eps=eps)
+        l = torch.arange(self.sht.lmax).float()
+        h1 = (l * (l + 1))[self._l_off:self._l_off + self.lm_weights.shape[0]]
+        self.register_buffer("h1_weights", h1.reshape(1, 1, -1), persistent=False)
+
+    def _norm_p(self, x, wgt, w0, w1):
+        h1 = self.h1_weights.reshape(1, 1, -1, 1)
+        return super()._norm_p(x, h1 if wgt is None else wgt * h1, w0, w1)
+
+    def abs(self, prd, tar, wgt=None):
+        inv_area = 1.0 / (4.0 * math.pi)
+        n2 = self._norm_p(prd - tar, wgt, inv_area, 2.0 * inv_area)
+        return n2 if self.squared else torch.sqrt(n2)
+
+    def rel(self, prd, tar, wgt=None):
+        n2 = self._norm_p(prd - tar, wgt, 1.0, 2.0)
+        t2 = self._norm_p(tar, wgt, 1.0, 2.0)
+        if not self.squared:
+            n2, t2 = torch.sqrt(n2), torch.sqrt(t2)
+        return n2 / (t2 + self.eps)
+
+
 class GeometricLpLoss(nn.Module):
     """Computes the Lp loss on the sphere (``lp_loss.py:28-107``)."""
 

@@ -181,6 +181,34 @@ def loss_fixtures():
     np.savez_compressed(path, **rec)
     print(f"spectral_lp_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
 
+    # SpectralH1Loss (utils/losses/h1_loss.py:30-180)
+    SpectralH1Loss = ref_shims.import_reference_module("makani.utils.losses.h1_loss").SpectralH1Loss
+    hcases = [
+        dict(img=(37, 72), grid="equiangular", relative=False, squared=True, wgt=False),
+        dict(img=(24, 48), grid="legendre-gauss", relative=True, squared=False, wgt=False),
+        dict(img=(33, 64), grid="equiangular", relative=False, squared=False, wgt=True),
+    ]
+    rec = {"cases": json.dumps(hcases)}
+    for i, c in enumerate(hcases):
+        torch.manual_seed(400 + i)
+        B, C = 2, 3
+        mod = SpectralH1Loss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0),
+                             channel_names=[str(k) for k in range(C)], grid_type=c["grid"], relative=c["relative"],
+                             squared=c["squared"])
+        prd = torch.randn(B, C, *c["img"], requires_grad=True)
+        tar = torch.randn(B, C, *c["img"], requires_grad=True)
+        wgt = torch.rand(1, C, mod.sht.lmax, mod.sht.mmax) + 0.5 if c["wgt"] else None
+        out = mod(prd, tar, wgt)
+        g = torch.randn_like(out)
+        (out * g).sum().backward()
+        rec[f"{i}_prd"], rec[f"{i}_tar"], rec[f"{i}_g"] = _np(prd), _np(tar), _np(g)
+        if wgt is not None:
+            rec[f"{i}_wgt"] = _np(wgt)
+        rec[f"{i}_out"], rec[f"{i}_dprd"], rec[f"{i}_dtar"] = _np(out), _np(prd.grad), _np(tar.grad)
+    path = os.path.join(OUT, "spectral_h1_loss.npz")
+    np.savez_compressed(path, **rec)
+    print(f"spectral_h1_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
     # GeometricInstanceNormS2 (models/common/layer_norm.py:30-160)
     S2Norm = ref_shims.import_reference_module("makani.models.common.layer_norm").GeometricInstanceNormS2
     ncases = [

@@ -258,3 +258,51 @@ def test_hip_s2_norm_fullsize_properties():
     assert mean.abs().max().item() < 1e-4 and (var - 1).abs().max().item() < 1e-3
     yb = mod(x.to(torch.bfloat16))
     assert yb.dtype == torch.bfloat16 and (yb.float() - y.float()).abs().max().item() < 0.1
+
+
+# --------------------------------------------------------------------------- #
+# SpectralH1Loss
+# --------------------------------------------------------------------------- #
+HGOLDEN = os.path.join(os.path.dirname(__file__), "golden", "spectral_h1_loss.npz")
+
+
+def test_oracle_h1_loss_matches_reference_golden():
+    from oracle import losses as ol
+    d = np.load(HGOLDEN)
+    for i, c in enumerate(json.loads(str(d["cases"]))):
+        prd = torch.tensor(d[f"{i}_prd"], requires_grad=True)
+        tar = torch.tensor(d[f"{i}_tar"], requires_grad=True)
+        w = torch.tensor(d[f"{i}_wgt"]) if c["wgt"] else None
+        out = ol.spectral_h1_loss(prd, tar, c["img"], c["grid"], c["relative"], c["squared"], wgt=w)
+        (out * torch.tensor(d[f"{i}_g"])).sum().backward()
+        assert np.allclose(out.detach().numpy(), d[f"{i}_out"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(prd.grad.numpy(), d[f"{i}_dprd"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_h1_loss_matches_reference_golden():
+    import makani_amd as ma
+    d = np.load(HGOLDEN)
+    dev = torch.device("cuda", 0)
+    for i, c in enumerate(json.loads(str(d["cases"]))):
+        mod = ma.SpectralH1Loss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0), channel_names=["a", "b", "c"],
+                                grid_type=c["grid"], relative=c["relative"], squared=c["squared"]).to(dev)
+        prd = torch.tensor(d[f"{i}_prd"], device=dev, requires_grad=True)
+        tar = torch.tensor(d[f"{i}_tar"], device=dev, requires_grad=True)
+        w = torch.tensor(d[f"{i}_wgt"], device=dev) if c["wgt"] else None
+        out = mod(prd, tar, w)
+        (out * torch.tensor(d[f"{i}_g"], device=dev)).sum().backward()
+        assert np.allclose(out.detach().cpu().numpy(), d[f"{i}_out"], rtol=5e-5, atol=1e-6), c
+        for got, want in ((prd.grad, d[f"{i}_dprd"]), (tar.grad, d[f"{i}_dtar"])):
+            err = np.linalg.norm(got.cpu().numpy() - want) / np.linalg.norm(want)
+            assert err < 3e-5, (c, err)
+    # H1 = l (l + 1) L2 for a single degree (reference tests/test_losses.py:470-509)
+    lmax = 16
+    isht = ma.InverseRealSHT(33, 64, lmax=lmax, mmax=lmax, grid="equiangular").to(dev)
+    coef = torch.zeros(1, 1, lmax, lmax, dtype=torch.complex64, device=dev)
+    coef[0, 0, 5, 2] = 1.0 + 0.5j
+    x = isht(coef)
+    h1 = ma.SpectralH1Loss((33, 64), (33, 64), (0, 0), ["a"], "equiangular", squared=True).to(dev)
+    l2 = ma.SpectralLpLoss((33, 64), (33, 64), (0, 0), ["a"], "equiangular", p=2.0, squared=True).to(dev)
+    z = torch.zeros_like(x)
+    assert torch.allclose(h1(x, z), 5 * 6 * l2(x, z), rtol=1e-4)
