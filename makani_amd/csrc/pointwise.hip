@@ -128,11 +128,14 @@ __device__ __forceinline__ void plane_totals(const float* __restrict__ ws, long 
 // value the norm sees when a per-channel constant `pb` (the bias of the convolution in front of it) is folded in:
 // exactly what the reference materialises, i.e. (x + pb) rounded to the tensor dtype (idempotent for pb = 0)
 template <typename T>
-__device__ __forceinline__ float pre(float v, float pb);
+__device__ __forceinline__ float pre(float v, float pb, bool on);
 template <>
-__device__ __forceinline__ float pre<float>(float v, float pb) { return v + pb; }
+__device__ __forceinline__ float pre<float>(float v, float pb, bool on) { return on ? v + pb : v; }
 template <>
-__device__ __forceinline__ float pre<u16>(float v, float pb) { return bf16_to_f32(f32_to_bf16(v + pb)); }
+__device__ __forceinline__ float pre<u16>(float v, float pb, bool on) {
+    if (!on) return v;                        // block-uniform: no rounding work when nothing is folded in
+    return bf16_to_f32(f32_to_bf16(v + pb));
+}
 
 // ---- instance norm: statistics ---------------------------------------------------
 // partial sums relative to a per-plane pivot (first element) to avoid cancellation in fp32
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
     const int chunk = blockIdx.x % chunks;
     const T* xp = x + plane * hw;
     const float pb = pre_bias ? pre_bias[plane % channels] : 0.f;
-    const float pivot = pre<T>(VecIO<T>::load1(xp), pb);
+    const float pivot = pre<T>(VecIO<T>::load1(xp), pb, pre_bias != nullptr);
     float s1 = 0.f, s2 = 0.f;
     for_chunk<T>(hw, chunk, [&](long long e, int n, bool vec) {
         float v[VecIO<T>::N];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
         else
             v[0] = VecIO<T>::load1(xp + e);
         for (int i = 0; i < (vec ? VecIO<T>::N : 1); ++i) {
-            const float d = pre<T>(v[i], pb) - pivot;
+            const float d = pre<T>(v[i], pb, pre_bias != nullptr) - pivot;
             const float w = q ? q[e + i] : 1.f;           // quadrature weights (sum 1): geometric norm on the sphere
             s1 += w * d;
             s2 += w * d * d;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __res
     if (ws) {                    // statistics straight from the partial sums (same arithmetic as in_stats_final)
         double s1, s2;
         plane_totals(ws, plane, chunks, s1, s2, redd);
-        const double pivot = (double)pre<T>(VecIO<T>::load1(x + plane * hw), pb);
+        const double pivot = (double)pre<T>(VecIO<T>::load1(x + plane * hw), pb, pre_bias != nullptr);
         double m, var;
         if (qsum > 0.f) {        // quadrature weights, Q = sum q (< 1 on a cropped grid): mean = sum q x, var = sum q (x - mean)^2
             const double Q = (double)qsum;
@@ -231,12 +234,12 @@ __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __res
             VecIO<T>::load(xp + e, v);
 #pragma unroll
             for (int i = 0; i < VecIO<T>::N; ++i) {
-                const float a = pre<T>(v[i], pb) * sc + sh;
+                const float a = pre<T>(v[i], pb, pre_bias != nullptr) * sc + sh;
                 v[i] = GELU ? gelu_f(a) : a;
             }
             VecIO<T>::store(yp + e, v);
         } else {
-            const float a = pre<T>(VecIO<T>::load1(xp + e), pb) * sc + sh;
+            const float a = pre<T>(VecIO<T>::load1(xp + e), pb, pre_bias != nullptr) * sc + sh;
             VecIO<T>::store1(yp + e, GELU ? gelu_f(a) : a);
         }
     });
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, co
             d[0] = VecIO<T>::load1(gp + e);
         }
         for (int i = 0; i < cnt; ++i) {
-            const float n = (pre<T>(v[i], pb) - mean) * rstd;
+            const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
             float ga = d[i];
             if (GELU) ga *= gelu_grad_f(n * g + b);
             s1 += ga;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
             d[0] = VecIO<T>::load1(gp + e);
         }
         for (int i = 0; i < cnt; ++i) {
-            const float n = (pre<T>(v[i], pb) - mean) * rstd;
+            const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
             float ga = d[i];
             if (GELU) ga *= gelu_grad_f(n * g + b);
             const float w = q ? q[e + i] : 1.f;
