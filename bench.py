@@ -68,6 +68,16 @@ class GradReducer:
         self.small = {}
         self.big_bytes = 8 << 20
         self.active = data_size > 1 or spatial_group is not None
+        # RCCL averages inside the collective (ReduceOp.AVG): no scaling pass over the 2.3 GB of gradients afterwards.
+        # Probed once on one element; gloo (CPU tests, N ranks on one GPU) has no AVG and keeps SUM + scale.
+        self.avg = False
+        if data_size > 1:
+            try:
+                probe = torch.ones(1, device=next(model.parameters()).device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=data_group)
+                self.avg = abs(float(probe) - 1.0) < 1e-6
+            except (RuntimeError, ValueError, NotImplementedError):
+                self.avg = False
         if self.active:
             for name, p in model.named_parameters():
                 p.register_post_accumulate_grad_hook(lambda q, n=name: self._hook(q, n))
@@ -91,7 +101,10 @@ class GradReducer:
             return
         if g.numel() * g.element_size() >= self.big_bytes and len(groups) == 1:
             grp, scale = groups[0]
-            self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=grp, async_op=True), g, scale))
+            op = dist.ReduceOp.SUM
+            if self.avg and grp is self.data_group:
+                op, scale = dist.ReduceOp.AVG, 1.0
+            self.handles.append((dist.all_reduce(g, op=op, group=grp, async_op=True), g, scale))
         else:
             self.small.setdefault(tuple(id(x[0]) for x in groups), (groups, []))[1].append(p)
 
@@ -101,6 +114,9 @@ class GradReducer:
         for groups, params in self.small.values():
             flat = torch.cat([(torch.view_as_real(q.grad) if q.grad.is_complex() else q.grad).reshape(-1) for q in params])
             for grp, scale in groups:
+                if self.avg and grp is self.data_group:
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=grp)
+                    continue
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=grp)
                 if scale != 1.0:
                     flat.mul_(scale)
@@ -263,6 +279,11 @@ def main():
     ap.add_argument("--parallelism", default=os.environ.get("MAKANI_AMD_PARALLELISM", "dp"),
                     help="'dp' (default: one sample per GPU, weak scaling) or 'hHwW' e.g. h4w2: spatial model "
                          "parallelism over H x W GPUs per model instance (strong scaling), remaining ranks data parallel")
+    ap.add_argument("--multistep-count", type=int, default=1,
+                    help="autoregressive rollout length per sample (makani's --multistep_count, BASELINE configs[4]); "
+                         "1 = the headline single-step metric")
+    ap.add_argument("--multistep-checkpoint", action="store_true",
+                    help="recompute each rollout step's network call in backward (makani's --multistep_checkpoint)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -332,11 +353,15 @@ def main():
     B = 1
     model = build_model(args.config, device, seed=333)            # same seed on every rank -> same init
     opt = make_optimizer(model)
+    net = model
+    if args.multistep_count > 1:                                   # makani/models/stepper.py:176-345
+        from makani_amd.stepper import MultiStepWrapper
+        net = MultiStepWrapper(model, n_future=args.multistep_count - 1, multistep_checkpoint=args.multistep_checkpoint).train()
     reducer = GradReducer(model, data_group, dsize, spatial_group if msize > 1 else None, w_group if pw > 1 else None)
     torch.manual_seed(333 + d_idx)                                 # DummyLoader: fixed U[0,1) tensors on device
     inp = torch.rand(B, cfg["inp_chans"], H, W, device=device)
-    tar = torch.rand(B, cfg["out_chans"], H, W, device=device)
-    loss_fn = make_loss(H, W, cfg["out_chans"], device, msize > 1)
+    tar = torch.rand(B, cfg["out_chans"] * args.multistep_count, H, W, device=device)
+    loss_fn = make_loss(H, W, cfg["out_chans"] * args.multistep_count, device, msize > 1)
     if msize > 1:                                                  # this rank's lat/lon shard (dataloaders shard likewise)
         lat0, lon0 = sum(model.trans_down.lat_shapes[:ih]), sum(model.trans_down.lon_shapes[:iw])
         hl, wl = model.inp_shape_loc
@@ -362,7 +387,7 @@ def main():
             torch.cuda.synchronize()
             ops.PROFILER.reset()
             ops.PROFILER.enabled = True
-        train_step(model, opt, reducer, inp, tar, loss_fn, amp, clip)
+        train_step(net, opt, reducer, inp, tar, loss_fn, amp, clip)
         if last:
             torch.cuda.synchronize()
             ops.PROFILER.enabled = False
@@ -379,7 +404,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(model, opt, reducer, inp, tar, loss_fn, amp, clip)
+        loss = train_step(net, opt, reducer, inp, tar, loss_fn, amp, clip)
     torch.cuda.synchronize()
     gc.enable()
     if world > 1:
@@ -459,7 +484,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.config, "grid": f"{H}x{W}", "channels": cfg["inp_chans"],
                        "global_batch": dsize * B, "parallelism": f"dp{dsize}" + (f"_h{ph}w{pw}" if msize > 1 else ""),
-                       "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32"},
+                       "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32",
+                       "multistep_count": args.multistep_count,
+                       "multistep_checkpoint": bool(args.multistep_checkpoint)},
             "roofline": roofline,
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
             "hip_kernels": kernels,
@@ -467,7 +494,7 @@ def main():
             "final_loss": final_loss,
         }
         if world == 1 and not args.no_sht_metric and args.config == "sfno_sc3_layers8_edim384":
-            del model, opt
+            del model, net, opt
             torch.cuda.empty_cache()
             print("[bench] train loop done; measuring fwd SHT", file=sys.stderr, flush=True)
             out["fwd_sht"] = sht_bandwidth(device)

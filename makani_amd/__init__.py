@@ -6,7 +6,8 @@ from .spectral_conv import SpectralConv
 from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv, GeometricInstanceNormS2
 from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, SpectralFilterLayer
 from .losses import GeometricLpLoss, GridQuadrature, SpectralLpLoss, SpectralH1Loss
+from .stepper import MultiStepWrapper, SingleStepWrapper
 
 __all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
            "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer", "GeometricLpLoss",
-           "GridQuadrature", "SpectralLpLoss", "SpectralH1Loss", "GeometricInstanceNormS2"]
+           "GridQuadrature", "SpectralLpLoss", "SpectralH1Loss", "GeometricInstanceNormS2", "MultiStepWrapper", "SingleStepWrapper"]

@@ -230,7 +230,9 @@ def loss_fixtures():
         y = mod(x)
         g = torch.randn_like(y)
         (y * g).sum().backward()
-        rec[f"{i}_x"], rec[f"{i}_y"], rec[f"{i}_g"], rec[f"{i}_dx"] = _np(x), _np(y), _np(g), _np(x.grad)
+        rec[f"{i}_x"], rec[f"{i}_y"], rec[f"{i}_g"] = _np(x), _np(y), _np(g)
+        if x.grad is not None:                 # push-forward mode detaches the input of step 0 as well
+            rec[f"{i}_dx"] = _np(x.grad)
         rec[f"{i}_q"] = _np(mod.quadrature.quad_weight.float())
         if c["affine"]:
             rec[f"{i}_w"], rec[f"{i}_b"] = _np(mod.weight), _np(mod.bias)
@@ -240,12 +242,57 @@ def loss_fixtures():
     print(f"geometric_instance_norm_s2.npz: {os.path.getsize(path)/1e6:.2f} MB")
 
 
+def stepper_fixtures():
+    """MultiStepWrapper rollouts (makani/models/stepper.py:176-345) of the reference around a small convolution:
+    outputs in train / eval mode and the gradients of input and weights, for history windows, push-forward mode and
+    rollout checkpointing.  The preprocessor runs with every optional stage off (history_normalization_mode "none")."""
+    stepper = ref_shims.import_reference_module("makani.models.stepper")
+    ParamsBase = ref_shims.import_reference_module("makani.utils.YParams").ParamsBase
+    cases = [
+        dict(n_history=0, n_future=0, push_forward=False, ckpt=False),
+        dict(n_history=0, n_future=3, push_forward=False, ckpt=False),
+        dict(n_history=0, n_future=2, push_forward=True, ckpt=False),
+        dict(n_history=1, n_future=2, push_forward=False, ckpt=True),
+        dict(n_history=2, n_future=3, push_forward=False, ckpt=False),
+        dict(n_history=2, n_future=1, push_forward=True, ckpt=True),
+    ]
+    rec = {"cases": json.dumps(cases)}
+    B, C, H, W = 2, 3, 8, 16
+    for i, c in enumerate(cases):
+        p = ParamsBase()
+        for k, v in dict(img_shape_x=H, img_shape_y=W, img_shape_x_resampled=H, img_shape_y_resampled=W,
+                         n_history=c["n_history"], history_normalization_mode="none", n_future=c["n_future"],
+                         channel_names=[f"c{j}" for j in range(C)], batch_size=B, multistep_checkpoint=c["ckpt"],
+                         multistep={"push_forward": c["push_forward"]}).items():
+            p[k] = v
+        torch.manual_seed(500 + i)
+        cin = (c["n_history"] + 1) * C
+        net = torch.nn.Sequential(torch.nn.Conv2d(cin, 5, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(5, C, 1)).double()
+        wrap = stepper.MultiStepWrapper(p, lambda: net)
+        x = torch.randn(B, cin, H, W, dtype=torch.float64, requires_grad=True)
+        wrap.train()
+        y = wrap(x)
+        g = torch.randn_like(y)
+        (y * g).sum().backward()
+        rec[f"{i}_x"], rec[f"{i}_y"], rec[f"{i}_g"] = _np(x), _np(y), _np(g)
+        if x.grad is not None:                 # push-forward mode detaches the input of step 0 as well
+            rec[f"{i}_dx"] = _np(x.grad)
+        for j, q in enumerate(net.parameters()):
+            rec[f"{i}_p{j}"], rec[f"{i}_dp{j}"] = _np(q), _np(q.grad)
+        wrap.eval()
+        with torch.no_grad():
+            rec[f"{i}_y_eval"] = _np(wrap(x))
+    path = os.path.join(OUT, "multistep_rollout.npz")
+    np.savez_compressed(path, **rec)
+    print(f"multistep_rollout.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
+
 def main():
     if not ref_shims.reference_available():
         raise SystemExit("reference tree not found; golden fixtures can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss"]
+    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss", "stepper"]
     if "contractions" in which:
         contraction_fixtures()
     if "spectral_conv" in which:
@@ -254,6 +301,8 @@ def main():
         sfno_fixtures()
     if "loss" in which:
         loss_fixtures()
+    if "stepper" in which:
+        stepper_fixtures()
 
 
 if __name__ == "__main__":

@@ -28,3 +28,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_multistep_rollout_runs():
+    """--multistep-count 3 --multistep-checkpoint (makani's multistep flags, BASELINE configs[4] shape of work)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "sfno_debug", "--steps", "2", "--warmup", "1",
+                          "--no-sht-metric", "--no-cpu-baseline", "--multistep-count", "3", "--multistep-checkpoint"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["multistep_count"] == 3 and d["config"]["multistep_checkpoint"] is True
+    assert d["value"] > 0 and d["final_loss"] == d["final_loss"]

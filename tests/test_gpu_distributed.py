@@ -101,3 +101,42 @@ def _worker(rank, world, port, h, w):
 def test_spatial_parallel_sfno_matches_serial(h, w):
     world = h * w
     mp.spawn(_worker, args=(world, _free_port(), h, w), nprocs=world, join=True)
+
+
+def _worker_rccl(rank, world, port):
+    """RCCL itself on the one GPU of the box (world size 1): the collectives bench.py's GradReducer issues —
+    an async in-place all-reduce on the real view of a complex gradient, and ReduceOp.AVG (or its fallback)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import bench
+        model = torch.nn.Module()
+        model.c = torch.nn.Parameter(torch.randn(1200, 1024, dtype=torch.complex64, device=dev))     # 9.8 MB: async path
+        model.a = torch.nn.Parameter(torch.randn(7, 5, device=dev))
+        red = bench.GradReducer(model, dist.group.WORLD, 1)
+        red.active, red.data_size = True, 1          # one rank: mean over the group == the local gradient
+        for name, p in model.named_parameters():
+            p.register_post_accumulate_grad_hook(lambda q, n=name: red._hook(q, n))
+        red._groups_for = lambda name: [(dist.group.WORLD, 1.0)]
+        (torch.view_as_real(model.c).sum() * 3.0 + model.a.sum() * 2.0).backward()
+        assert len(red.handles) == 1
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(model.c.grad), torch.full((1200, 1024, 2), 3.0, device=dev))
+        assert torch.equal(model.a.grad, torch.full((7, 5), 2.0, device=dev))
+        t = torch.full((4,), 5.0, device=dev)
+        try:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            assert torch.equal(t, torch.full((4,), 5.0, device=dev))
+        except RuntimeError:
+            pass                                      # GradReducer then keeps SUM + scale
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_of_the_grad_reducer_world1():
+    mp.spawn(_worker_rccl, args=(1, _free_port()), nprocs=1, join=True)

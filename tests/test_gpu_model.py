@@ -261,3 +261,73 @@ def test_bf16_weight_shadows_do_not_change_training_bitwise():
     b, nb = run(False)
     assert na > 0 and nb == 0
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def _grads(m):
+    return [torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad for p in m.parameters()]
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_activation_checkpointing_is_exact(amp):
+    """checkpointing_level 3 (every block recomputed in backward, sfnonet.py:857-864) and level 1 (encoder / decoder)
+    reproduce the plain run: output and input gradient bit for bit (the HIP autograd functions are deterministic and
+    stateless).  Parameter gradients agree to rounding only: a checkpointed MLP keeps its output bias in the GEMM
+    epilogue instead of folding it into the following norm, so that bias gradient is summed by a different kernel."""
+    import makani_amd as ma
+    cfg = dict(inp_shape=(37, 72), out_shape=(37, 72), inp_chans=5, out_chans=5, scale_factor=2, embed_dim=16, num_layers=3,
+               mlp_ratio=2.0)
+    x, g = torch.rand(2, 5, 37, 72, device=DEV), torch.randn(2, 5, 37, 72, device=DEV)
+    res = []
+    for level in (0, 1, 3):
+        torch.manual_seed(3)
+        m = ma.SphericalFourierNeuralOperatorNet(checkpointing_level=level, **cfg).to(DEV)
+        xs = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = m(xs)
+        (y.float() * g).sum().backward()
+        res.append((y.detach(), xs.grad, _grads(m), [n for n, _ in m.named_parameters()]))
+    for y, gx, gp, names in res[1:]:
+        assert torch.equal(y, res[0][0]) and torch.equal(gx, res[0][1])
+        bad = {n: rel_l2(a, b) for n, a, b in zip(names, gp, res[0][2]) if not rel_l2(a, b) < 1e-5}
+        assert not bad, bad
+
+
+def test_rollout_checkpointing_is_exact_and_matches_manual_unroll():
+    """makani_amd.stepper.MultiStepWrapper around the HIP SFNO (bf16 autocast): a 3-step rollout equals the hand-
+    unrolled y1 = f(x), y2 = f(y1), y3 = f(y2); rollout checkpointing (stepper.py:262-265) changes no bit of the
+    output or of any gradient; push-forward mode cuts the gradient between steps"""
+    import makani_amd as ma
+    from makani_amd.stepper import MultiStepWrapper
+    cfg = dict(inp_shape=(37, 72), out_shape=(37, 72), inp_chans=4, out_chans=4, scale_factor=2, embed_dim=16, num_layers=2,
+               mlp_ratio=2.0)
+    torch.manual_seed(5)
+    m = ma.SphericalFourierNeuralOperatorNet(**cfg).to(DEV)
+    x, g = torch.rand(1, 4, 37, 72, device=DEV), torch.randn(1, 12, 37, 72, device=DEV)
+
+    def run(fn):
+        m.zero_grad(set_to_none=True)
+        xs = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fn(xs)
+        (y.float() * g).sum().backward()
+        return y.detach(), xs.grad, [t.clone() for t in _grads(m)]
+
+    def unrolled(xs):
+        y1 = m(xs)
+        y2 = m(y1)
+        return torch.cat([y1, y2, m(y2)], dim=1)
+
+    ref = run(unrolled)
+    plain = run(MultiStepWrapper(m, n_future=2).train())
+    ckpt = run(MultiStepWrapper(m, n_future=2, multistep_checkpoint=True).train())
+    for got in (plain, ckpt):
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))
+    pf = MultiStepWrapper(m, n_future=2, push_forward=True).train()
+    m.zero_grad(set_to_none=True)
+    xs = x.clone().requires_grad_(True)
+    y = pf(xs)
+    assert torch.equal(y[:, :4], m(x))
+    (y * g).sum().backward()
+    assert xs.grad is None
+    assert MultiStepWrapper(m, n_future=2).eval()(x).shape == (1, 4, 37, 72)
