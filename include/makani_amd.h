@@ -177,6 +177,32 @@ int mk_spec_lp_fwd(const float* S, const float* wgt, float* partial, int L, int 
 int mk_spec_lp_bwd(const float* S, const float* wgt, const float* g, float* dS, int L, int M, long long R, int tri_off,
                    int m_off, float p, float w0, float w1, void* stream);
 
+/* ---- spectral contractions that are not matrix products over l --------------------------------
+ * Activations x, y, gy: S-layout (L, M, 2, R) f32; position (l, m) is live when m <= l + tri_off, dead positions
+ * are written as exact zeros and never read.
+ *
+ * mk_spec_sep_mul / mk_spec_sep_wgrad: the separable operators _contract_sep_lmwise ("bgixy,gixy->bgixy") and
+ *   _contract_sep_lwise ("bgixy,gix->bgixy") (makani/models/common/contractions.py:26-31) and their autograd.
+ *   R = B*Cp, Cp % 4 == 0.  w, gw: the weight in S-layout (L, Mw, 2, Cp), Mw = M (lm-wise) or 1 (l-wise).
+ *     sep_mul:   y = x * w            (conj_w = 0: forward)      y = x * conj(w)   (conj_w = 1: input gradient of gy)
+ *     sep_wgrad: gw[l][mw][c] = sum_b (and sum over live m when Mw == 1) conj(x) * gy
+ *
+ * mk_spec_diag_apply / mk_spec_diag_wgrad: the dense diagonal operator _contract_lmwise ("bgixy,gioxy->bgoxy",
+ *   contractions.py:17-18) for ONE group.  w_c64 / gw_c64: the group's slice of the PARAMETER, (Cin, Cout, L, M)
+ *   complex64, read and written in place (every weight byte crosses HBM exactly once, coalesced along (l, m)).
+ *   x: Cin channels inside rows of stride x_ld per batch entry (R_x = B*x_ld), y likewise with y_ld; pointers may be
+ *   offset to a group's first channel.
+ *     diag_apply dgrad = 0: y[p][b][o] = sum_i x[p][b][i] * w[i][o][p]; channels [Cout, Cout + y_pad) are zeroed
+ *                dgrad = 1: x is gy (Cout channels), y is gx[p][b][i] = sum_o gy[p][b][o] * conj(w[i][o][p])
+ *     diag_wgrad: gw[i][o][p] = sum_b conj(x[p][b][i]) * gy[p][b][o] */
+int mk_spec_sep_mul(const float* x, const float* w, float* y, int L, int M, int Mw, int B, int Cp, int tri_off, int conj_w,
+                    void* stream);
+int mk_spec_sep_wgrad(const float* x, const float* gy, float* gw, int L, int M, int Mw, int B, int Cp, int tri_off, void* stream);
+int mk_spec_diag_apply(const float* x, const float* w_c64, float* y, int L, int M, int B, int Cin, int Cout, int x_ld, int y_ld,
+                       int y_pad, int tri_off, int dgrad, void* stream);
+int mk_spec_diag_wgrad(const float* x, const float* gy, float* gw_c64, int L, int M, int B, int Cin, int Cout, int x_ld, int y_ld,
+                       int tri_off, void* stream);
+
 /* ---- bf16 channel GEMMs (1x1 convolutions on NCHW planes) ---------------------------------
  * Replace nn.Conv2d(kernel_size=1) of MLP / EncoderDecoder / outer_skip / residual_transform
  * (makani/models/common/layers.py:603-643,768-823; makani/models/networks/sfnonet.py:335-338,726-730)

@@ -51,6 +51,10 @@ _SIGS = {
     "mk_wlayout_to_weight_grad": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_slayout_to_complex": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_complex_to_slayout": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_spec_sep_mul": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_spec_sep_wgrad": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_spec_diag_apply": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_spec_diag_wgrad": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_pointwise_chunks": ([c_ll, c_int], c_int),
     "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp], c_int),
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),

@@ -224,50 +224,57 @@ def wlayout_to_weight_grad(gW: torch.Tensor, cin: int, cout: int) -> torch.Tenso
     return torch.view_as_complex(out)
 
 
-def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int, tri_off: int = 0) -> torch.Tensor:
-    """T[l][m][ri][b][o] = sum_i S[l][m][.][b][i] * W[l][.][i][o]   (complex; rows m <= l only)."""
+def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int, tri_off: int = 0, out=None, grp=None) -> torch.Tensor:
+    """T[l][m][ri][b][o] = sum_i S[l][m][.][b][i] * W[l][.][i][o]   (complex; rows m <= l only).
+    ``grp = (first input channel, first output channel, x_ld, y_ld)`` runs one channel group of a grouped operator:
+    S and ``out`` then hold all groups (x_ld / y_ld channels per batch entry), W this group's matrices."""
     L, M, _, R = S.shape
     Lw, _, cip, cop = W.shape
-    assert Lw == L and R == B * cip
-    Ro = B * cop
-    T = torch.empty((L, M, 2, Ro), dtype=torch.float32, device=S.device)
-    g = _gemm(A=S.data_ptr(), B=W.data_ptr(), C=T.data_ptr(),
-              a_batch=M * 2 * R, a_inner=cip, a_row=2 * R, a_k=1, a_im=R,
+    a_off, c_off, xld, yld = grp if grp is not None else (0, 0, cip, cop)
+    assert Lw == L and R == B * xld
+    Ro = B * yld
+    T = out if out is not None else torch.empty((L, M, 2, Ro), dtype=torch.float32, device=S.device)
+    g = _gemm(A=S.data_ptr() + 4 * a_off, B=W.data_ptr(), C=T.data_ptr() + 4 * c_off,
+              a_batch=M * 2 * R, a_inner=xld, a_row=2 * R, a_k=1, a_im=R,
               b_batch=2 * cip * cop, b_inner=0, b_col=1, b_k=cop, b_im=cip * cop,
-              c_batch=M * 2 * Ro, c_inner=cop, c_row=2 * Ro, c_im=Ro,
+              c_batch=M * 2 * Ro, c_inner=yld, c_row=2 * Ro, c_im=Ro,
               M=M, N=cop, K=cin, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off)
     # dense-formulation work: 8 * B * Cin * Cout * L * M flops (complex MAC = 8 real flops)
     with _timed("dhconv_fwd", flops=8.0 * B * cin * cop * L * M,
-                nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
+                nbytes=4.0 * (2 * B * cip * L * M + 2 * B * cop * L * M + 2 * cip * cop * L)):
         _run_gemm(g, True, "dhconv_fwd")
     return T
 
 
-def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int, tri_off: int = 0) -> torch.Tensor:
+def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int, tri_off: int = 0, out=None, grp=None) -> torch.Tensor:
     """gS[l][m][b][i] = sum_o gT[l][m][b][o] * conj(W[l][i][o])."""
     L, M, _, Ro = gT.shape
     _, _, cip, cop = W.shape
-    R = B * cip
-    gS = torch.empty((L, M, 2, R), dtype=torch.float32, device=gT.device)
-    g = _gemm(A=gT.data_ptr(), B=W.data_ptr(), C=gS.data_ptr(),
-              a_batch=M * 2 * Ro, a_inner=cop, a_row=2 * Ro, a_k=1, a_im=Ro,
+    a_off, c_off, xld, yld = grp if grp is not None else (0, 0, cip, cop)      # (input ch., output ch., x_ld, y_ld)
+    assert Ro == B * yld
+    R = B * xld
+    gS = out if out is not None else torch.empty((L, M, 2, R), dtype=torch.float32, device=gT.device)
+    g = _gemm(A=gT.data_ptr() + 4 * c_off, B=W.data_ptr(), C=gS.data_ptr() + 4 * a_off,
+              a_batch=M * 2 * Ro, a_inner=yld, a_row=2 * Ro, a_k=1, a_im=Ro,
               b_batch=2 * cip * cop, b_inner=0, b_col=cop, b_k=1, b_im=cip * cop,
-              c_batch=M * 2 * R, c_inner=cip, c_row=2 * R, c_im=R,
+              c_batch=M * 2 * R, c_inner=xld, c_row=2 * R, c_im=R,
               M=M, N=cin, K=cout, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off, conj_b=1)
     with _timed("dhconv_dgrad", flops=8.0 * B * cin * cout * L * M,
-                nbytes=4.0 * (2 * R * L * M + 2 * Ro * L * M + 2 * cip * cop * L)):
+                nbytes=4.0 * (2 * B * cip * L * M + 2 * B * cop * L * M + 2 * cip * cop * L)):
         _run_gemm(g, True, "dhconv_dgrad")
     return gS
 
 
-def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0) -> torch.Tensor:
-    """gW[l][i][o] = sum_{b, m <= l} conj(S[l][m][b][i]) * gT[l][m][b][o]."""
+def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0, grp=None) -> torch.Tensor:
+    """gW[l][i][o] = sum_{b, m <= l} conj(S[l][m][b][i]) * gT[l][m][b][o].
+    ``grp = (first input channel, first output channel, group inputs, group outputs)`` for one group of a grouped operator."""
     L, M, _, R = S.shape
     Ro = gT.shape[-1]
-    cip, cop = R // B, Ro // B
+    xld, yld = R // B, Ro // B
+    a_off, c_off, cip, cop = grp if grp is not None else (0, 0, xld, yld)
     gW = torch.empty((L, 2, cip, cop), dtype=torch.float32, device=S.device)
     for b in range(B):
-        g = _gemm(A=S.data_ptr() + 4 * b * cip, B=gT.data_ptr() + 4 * b * cop, C=gW.data_ptr(),
+        g = _gemm(A=S.data_ptr() + 4 * (b * xld + a_off), B=gT.data_ptr() + 4 * (b * yld + c_off), C=gW.data_ptr(),
                   a_batch=M * 2 * R, a_row=1, a_k=2 * R, a_im=R,
                   b_batch=M * 2 * Ro, b_col=1, b_k=2 * Ro, b_im=Ro,
                   c_batch=2 * cip * cop, c_row=cop, c_im=cip * cop,
@@ -371,6 +378,146 @@ class DhconvFn(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[1]:
             gw = wlayout_to_weight_grad(dhconv_wgrad(S, gT, B, tri_off), cin, cout)
+        return gS, gw, None, None
+
+
+def _addr(t, off_floats=0):
+    """device address of element ``off_floats`` of an fp32 GPU tensor (channel-group slices of the S-layout)"""
+    if not t.is_cuda:
+        raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+    return C.c_void_p(t.data_ptr() + 4 * off_floats)
+
+
+class GroupedDhconvFn(torch.autograd.Function):
+    """``_contract_lwise`` with num_groups > 1: ``einsum("bgixy,giox->bgoxy")`` as G runs of the same MFMA engine on
+    channel slices of the S-layout (group sizes must be multiples of 4: the slices start on 16-byte boundaries)."""
+
+    @staticmethod
+    def forward(ctx, S, weight, B, tri_off=0):
+        G, cgi, cgo, L = weight.shape
+        cin, cout = G * cgi, G * cgo
+        Ws = [weight_to_wlayout(weight[g:g + 1]) for g in range(G)]
+        T = torch.empty((L, S.shape[1], 2, B * cout), dtype=torch.float32, device=S.device)
+        for g in range(G):
+            dhconv_fwd(S, Ws[g], B, cgi, tri_off, out=T, grp=(g * cgi, g * cgo, cin, cout))
+        ctx.save_for_backward(S, *Ws)
+        ctx.meta = (B, G, cgi, cgo, tri_off)
+        return T
+
+    @staticmethod
+    def backward(ctx, gT):
+        S, *Ws = ctx.saved_tensors
+        B, G, cgi, cgo, tri_off = ctx.meta
+        cin, cout = G * cgi, G * cgo
+        gT = gT.contiguous()
+        gS = gw = None
+        if ctx.needs_input_grad[0]:
+            gS = torch.empty_like(S)
+            for g in range(G):
+                dhconv_dgrad(gT, Ws[g], B, cgi, cgo, tri_off, out=gS, grp=(g * cgi, g * cgo, cin, cout))
+        if ctx.needs_input_grad[1]:
+            gw = torch.cat([wlayout_to_weight_grad(dhconv_wgrad(S, gT, B, tri_off, grp=(g * cgi, g * cgo, cgi, cgo)), cgi, cgo)
+                            for g in range(G)], dim=0)
+        return gS, gw, None, None
+
+
+class WeightToSFn(torch.autograd.Function):
+    """complex64 weight (C, L, Mw) -> S-layout (L, Mw, 2, round4(C)) and back for its gradient (no triangle mask: the
+    contraction kernels already write exact zeros at dead positions, in shard-local or global indexing alike)"""
+
+    @staticmethod
+    def forward(ctx, w3):
+        ctx.C = w3.shape[0]
+        return complex_to_s(w3.unsqueeze(0))
+
+    @staticmethod
+    def backward(ctx, gS):
+        L, Mw = gS.shape[:2]
+        return s_to_complex(gS.contiguous(), 1, ctx.C, l_off=Mw, m_off=0)[0]
+
+
+class SepContractFn(torch.autograd.Function):
+    """``_contract_sep_lmwise`` / ``_contract_sep_lwise`` (makani/models/common/contractions.py:26-31) on the S-layout:
+    y[l][m][b][c] = x[l][m][b][c] * w[l][m or 0][c]; one streaming kernel each for y, gx and gw."""
+
+    @staticmethod
+    def forward(ctx, S, Ws, B, tri_off=0):
+        L, M, _, R = S.shape
+        Lw, Mw, _, Cp = Ws.shape
+        assert Lw == L and Mw in (1, M) and R == B * Cp
+        S = S.contiguous()
+        y = torch.empty_like(S)
+        with _timed("spec_sep_mul", nbytes=4.0 * (4 * R * L * M + 2 * Cp * L * Mw)):
+            check(lib().mk_spec_sep_mul(ptr(S), ptr(Ws), ptr(y), L, M, Mw, B, Cp, tri_off, 0, stream()), "spec_sep_mul")
+        ctx.save_for_backward(S, Ws)
+        ctx.meta = (B, tri_off)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        S, Ws = ctx.saved_tensors
+        B, tri_off = ctx.meta
+        L, M, _, R = S.shape
+        _, Mw, _, Cp = Ws.shape
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(S)
+            with _timed("spec_sep_mul", nbytes=4.0 * (4 * R * L * M + 2 * Cp * L * Mw)):
+                check(lib().mk_spec_sep_mul(ptr(gy), ptr(Ws), ptr(gx), L, M, Mw, B, Cp, tri_off, 1, stream()), "spec_sep_mul")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(Ws)
+            with _timed("spec_sep_wgrad", nbytes=4.0 * (4 * R * L * M + 2 * Cp * L * Mw)):
+                check(lib().mk_spec_sep_wgrad(ptr(S), ptr(gy), ptr(gw), L, M, Mw, B, Cp, tri_off, stream()), "spec_sep_wgrad")
+        return gx, gw, None, None
+
+
+class DiagContractFn(torch.autograd.Function):
+    """``_contract_lmwise`` (contractions.py:17-18), ``einsum("bgixy,gioxy->bgoxy")``: one Cin/G x Cout/G matrix per
+    (l, m).  The weight is streamed once from its parameter layout (G, Cin/G, Cout/G, L, M) — no re-layout, and its
+    gradient is written straight into that layout."""
+
+    @staticmethod
+    def forward(ctx, S, weight, B, tri_off=0):
+        G, cgi, cgo, L, M = weight.shape
+        cin, cout = G * cgi, G * cgo
+        cip, cop = round4(cin), round4(cout)
+        S = S.contiguous()
+        assert S.shape == (L, M, 2, B * cip)
+        wr = torch.view_as_real(weight.detach().contiguous())
+        T = torch.empty((L, M, 2, B * cop), dtype=torch.float32, device=S.device)
+        nb = 4.0 * (2 * B * cgi * L * M + 2 * B * cgo * L * M + 2 * cgi * cgo * L * M)
+        for g in range(G):
+            with _timed("spec_diag_fwd", flops=8.0 * B * cgi * cgo * L * M, nbytes=nb):
+                check(lib().mk_spec_diag_apply(_addr(S, g * cgi), _addr(wr[g]), _addr(T, g * cgo), L, M, B, cgi, cgo,
+                                               cip, cop, cop - cout if g == G - 1 else 0, tri_off, 0, stream()), "spec_diag_apply")
+        ctx.save_for_backward(S, wr)
+        ctx.meta = (B, tri_off)
+        return T
+
+    @staticmethod
+    def backward(ctx, gT):
+        S, wr = ctx.saved_tensors
+        B, tri_off = ctx.meta
+        G, cgi, cgo, L, M, _ = wr.shape
+        cin, cout = G * cgi, G * cgo
+        cip, cop = round4(cin), round4(cout)
+        gT = gT.contiguous()
+        gS = gw = None
+        nb = 4.0 * (2 * B * cgi * L * M + 2 * B * cgo * L * M + 2 * cgi * cgo * L * M)
+        if ctx.needs_input_grad[0]:
+            gS = torch.empty_like(S)
+            for g in range(G):
+                with _timed("spec_diag_dgrad", flops=8.0 * B * cgi * cgo * L * M, nbytes=nb):
+                    check(lib().mk_spec_diag_apply(_addr(gT, g * cgo), _addr(wr[g]), _addr(gS, g * cgi), L, M, B, cgi,
+                                                   cgo, cop, cip, cip - cin if g == G - 1 else 0, tri_off, 1, stream()), "spec_diag_apply")
+        if ctx.needs_input_grad[1]:
+            gwr = torch.empty_like(wr)
+            for g in range(G):
+                with _timed("spec_diag_wgrad", flops=8.0 * B * cgi * cgo * L * M, nbytes=nb):
+                    check(lib().mk_spec_diag_wgrad(_addr(S, g * cgi), _addr(gT, g * cgo), _addr(gwr[g]), L, M, B, cgi,
+                                                   cgo, cip, cop, tri_off, stream()), "spec_diag_wgrad")
+            gw = torch.view_as_complex(gwr)
         return gS, gw, None, None
 
 

@@ -72,23 +72,44 @@ class SpectralConv(nn.Module):
             weight_shape += [self.modes_lat_local]
         else:
             raise ValueError(f"Unsupported operator type f{operator_type}")
-        if operator_type != "dhconv" or separable or num_groups != 1:
-            raise NotImplementedError(
-                "the HIP contraction implements operator_type='dhconv', separable=False, num_groups=1 "
-                "(the configuration of every BASELINE config)"
-            )
+        if separable and in_channels != out_channels:
+            raise ValueError(f"separable operators keep the channel count: in_channels ({in_channels}) != out_channels ({out_channels})")
+        if operator_type == "dhconv" and not separable and num_groups > 1 and (
+                (in_channels // num_groups) % 4 or (out_channels // num_groups) % 4):
+            raise NotImplementedError("grouped dhconv on the MFMA engine needs group sizes that are multiples of 4 "
+                                      f"(got {in_channels // num_groups} -> {out_channels // num_groups})")
 
+        # same initialisation as the reference (spectral_convolution.py:184-193), including its broadcast of the
+        # per-l scale against the LAST weight axis (which is m for the "diagonal" operator)
         scale = math.sqrt(gain / (in_channels // num_groups)) * torch.ones(self.modes_lat_local, dtype=torch.complex64)
         scale[0] *= math.sqrt(2.0)
         self.weight = nn.Parameter(scale * torch.randn(*weight_shape, dtype=torch.complex64))
-        self.weight.is_shared_mp = ["matmul", "w"]
-        self.weight.sharded_dims_mp = [None for _ in weight_shape]
-        self.weight.sharded_dims_mp[-1] = "h"
+        if operator_type == "dhconv":
+            self.weight.is_shared_mp = ["matmul", "w"]
+            self.weight.sharded_dims_mp = [None for _ in weight_shape]
+            self.weight.sharded_dims_mp[-1] = "h"
+        else:
+            self.weight.is_shared_mp = ["matmul"]
+            self.weight.sharded_dims_mp = [None for _ in weight_shape]
+            self.weight.sharded_dims_mp[-1] = "w"
+            self.weight.sharded_dims_mp[-2] = "h"
 
         if bias:
             self.bias = nn.Parameter(torch.zeros(1, out_channels, 1, 1))
             self.bias.is_shared_mp = ["model"]
             self.bias.sharded_dims_mp = [None, None, None, None]
+
+    def _contract(self, S, B):
+        """the four contractions of makani/models/common/contractions.py:17-54 on the S-layout"""
+        w = self.weight
+        if self.separable:                                   # "bgixy,gixy->bgixy" / "bgixy,gix->bgixy"
+            w3 = w.reshape(self.in_channels, self.modes_lat_local, -1)          # (C, L, M) or (C, L, 1)
+            return ops.SepContractFn.apply(S, ops.WeightToSFn.apply(w3), B, self._tri_off)
+        if self.operator_type == "diagonal":                  # "bgixy,gioxy->bgoxy"
+            return ops.DiagContractFn.apply(S, w, B, self._tri_off)
+        if self.num_groups > 1:                               # "bgixy,giox->bgoxy", G > 1
+            return ops.GroupedDhconvFn.apply(S, w, B, self._tri_off)
+        return ops.DhconvFn.apply(S, w, B, self._tri_off)
 
     def forward(self, x):
         if x.dim() != 4:
@@ -99,7 +120,7 @@ class SpectralConv(nn.Module):
         S = self.forward_transform.analysis(x)                    # fp32 coefficients, bf16 read fused
         if self.scale_residual:
             residual = self.inverse_transform.synthesis(S, B, C, out_dtype=dtype)
-        T = ops.DhconvFn.apply(S, self.weight, B, self._tri_off)
+        T = self._contract(S, B)
         y = self.inverse_transform.synthesis(T, B, self.out_channels, out_dtype=dtype)
         if hasattr(self, "bias"):
             y = y + self.bias.to(dtype=y.dtype)

@@ -81,12 +81,20 @@ def spectral_conv_fixtures():
         (33, 64, "equiangular", 12, 24, "legendre-gauss", 12, 13, 8, 8, 1, "dhconv"),   # down-sampling (block 0)
         (12, 24, "legendre-gauss", 33, 64, "equiangular", 12, 13, 8, 8, 2, "dhconv"),   # up-sampling (last block)
         (12, 24, "legendre-gauss", 12, 24, "legendre-gauss", 12, 12, 6, 4, 2, "diagonal"),  # lmax == mmax: the reference init only broadcasts then
+        # (..., num_groups, separable): the remaining contractions of contractions.py:17-54
+        (12, 24, "legendre-gauss", 12, 24, "legendre-gauss", 12, 12, 6, 10, 2, "diagonal", 2, False),
+        (12, 24, "legendre-gauss", 12, 24, "legendre-gauss", 12, 12, 7, 7, 2, "diagonal", 1, True),
+        (33, 64, "equiangular", 33, 64, "equiangular", 16, 17, 6, 6, 2, "dhconv", 2, True),
+        (33, 64, "equiangular", 12, 24, "legendre-gauss", 12, 13, 8, 16, 2, "dhconv", 2, False),
+        (12, 24, "legendre-gauss", 33, 64, "equiangular", 12, 13, 12, 12, 1, "dhconv", 3, False),
     ]
-    for idx, (h0, w0, g0, h1, w1, g1, lmax, mmax, cin, cout, B, op) in enumerate(cases):
+    for idx, case in enumerate(cases):
+        h0, w0, g0, h1, w1, g1, lmax, mmax, cin, cout, B, op = case[:12]
+        groups, separable = case[12:] if len(case) > 12 else (1, False)
         torch.manual_seed(100 + idx)
         fwd = th.RealSHT(h0, w0, lmax=lmax, mmax=mmax, grid=g0).float()
         inv = th.InverseRealSHT(h1, w1, lmax=lmax, mmax=mmax, grid=g1).float()
-        layer = sc.SpectralConv(fwd, inv, cin, cout, operator_type=op, bias=False, gain=2.0)
+        layer = sc.SpectralConv(fwd, inv, cin, cout, num_groups=groups, operator_type=op, separable=separable, bias=False, gain=2.0)
         x = torch.randn(B, cin, h0, w0, requires_grad=True)
         y, res = layer(x)
         gy = torch.randn_like(y)
@@ -94,7 +102,7 @@ def spectral_conv_fixtures():
         ((y * gy).sum() + (res * gr).sum()).backward()
         p = f"case{idx}/"
         rec[p + "meta"] = np.array(json.dumps(dict(h0=h0, w0=w0, g0=g0, h1=h1, w1=w1, g1=g1, lmax=lmax, mmax=mmax,
-                                                  cin=cin, cout=cout, B=B, op=op)))
+                                                  cin=cin, cout=cout, B=B, op=op, groups=groups, separable=separable)))
         rec[p + "x"], rec[p + "w"], rec[p + "y"], rec[p + "res"] = _np(x), _np(layer.weight), _np(y), _np(res)
         rec[p + "gy"], rec[p + "gr"], rec[p + "gx"], rec[p + "gw"] = _np(gy), _np(gr), _np(x.grad), _np(layer.weight.grad)
     rec["ncases"] = np.array(len(cases))

@@ -30,6 +30,16 @@ def contract_lmwise(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return torch.einsum("bgixy,gioxy->bgoxy", x, w)
 
 
+def contract_sep_lmwise(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``makani/models/common/contractions.py:26-27`` (separable diagonal)."""
+    return torch.einsum("bgixy,gixy->bgixy", x, w)
+
+
+def contract_sep_lwise(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``makani/models/common/contractions.py:30-31`` (separable dhconv)."""
+    return torch.einsum("bgixy,gix->bgixy", x, w)
+
+
 class SpectralConv(nn.Module):
     """``makani/models/common/spectral_convolution.py:116-264``."""
 
@@ -40,8 +50,7 @@ class SpectralConv(nn.Module):
             raise ValueError("in_channels must be divisible by num_groups")
         if out_channels % num_groups != 0:
             raise ValueError("out_channels must be divisible by num_groups")
-        if separable:
-            raise NotImplementedError("separable contraction is outside the oracle's scope")
+        self.separable = separable
         self.forward_transform = forward_transform
         self.inverse_transform = inverse_transform
         self.in_channels, self.out_channels, self.num_groups = in_channels, out_channels, num_groups
@@ -51,7 +60,9 @@ class SpectralConv(nn.Module):
             forward_transform.nlon != inverse_transform.nlon
         ) or (forward_transform.grid != inverse_transform.grid)
         self.operator_type = operator_type
-        shape = [num_groups, in_channels // num_groups, out_channels // num_groups]
+        shape = [num_groups, in_channels // num_groups]
+        if not separable:
+            shape += [out_channels // num_groups]
         if operator_type == "diagonal":
             shape += [self.modes_lat, self.modes_lon]
         elif operator_type == "dhconv":
@@ -77,7 +88,10 @@ class SpectralConv(nn.Module):
         B, C, H, W = x.shape
         x = x.reshape(B, self.num_groups, C // self.num_groups, H, W)
         w = self.weight.to(x.dtype)
-        xp = contract_lwise(x, w) if self.operator_type == "dhconv" else contract_lmwise(x, w)
+        if self.separable:      # dispatch of contractions.py:35-54
+            xp = contract_sep_lwise(x, w) if self.operator_type == "dhconv" else contract_sep_lmwise(x, w)
+        else:
+            xp = contract_lwise(x, w) if self.operator_type == "dhconv" else contract_lmwise(x, w)
         x = xp.reshape(B, self.out_channels, H, W).contiguous()
         x = self.inverse_transform(x).to(dtype)
         if hasattr(self, "bias"):

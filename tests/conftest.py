@@ -37,12 +37,15 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+def _real64(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach().cpu()
+    if t.is_complex():               # BEFORE any dtype cast: .double() on a complex tensor drops the imaginary part
+        t = torch.view_as_real(t.resolve_conj())
+    return t.double()
+
+
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
-    a = a.detach().double().cpu()
-    b = b.detach().double().cpu()
-    if a.is_complex():
-        a = torch.view_as_real(a)
-    if b.is_complex():
-        b = torch.view_as_real(b)
+    a, b = _real64(a), _real64(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
     den = b.norm().item()
     return (a - b).norm().item() / (den if den > 0 else 1.0)

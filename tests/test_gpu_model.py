@@ -89,33 +89,49 @@ def test_sht_leading_dims_and_errors():
         ma.RealSHT(12, 24)(torch.randn(1, 1, 12, 24))       # CPU tensor: no fallback
 
 
-def test_spectral_conv_matches_reference_golden():
+def _spectral_conv_cases():
+    g = load_golden("spectral_conv.npz")
+    return [(i, json.loads(str(g[f"case{i}/meta"]))) for i in range(int(g["ncases"]))]
+
+
+@pytest.mark.parametrize("i,m", _spectral_conv_cases(),
+                         ids=[f"{m['op']}{'-sep' if m.get('separable') else ''}-g{m.get('groups', 1)}-{i}" for i, m in _spectral_conv_cases()])
+def test_spectral_conv_matches_reference_golden(i, m):
+    """every contraction of makani/models/common/contractions.py:17-54 behind SpectralConv — dhconv (G = 1 and
+    grouped), diagonal (dense, grouped), and both separable forms — against the reference module's own outputs,
+    input gradients and weight gradients, incl. the residual resampling path"""
     import makani_amd as ma
     g = load_golden("spectral_conv.npz")
-    ran = 0
-    for i in range(int(g["ncases"])):
-        p = f"case{i}/"
-        m = json.loads(str(g[p + "meta"]))
-        if m["op"] != "dhconv":
-            with pytest.raises(NotImplementedError):
-                ma.SpectralConv(ma.RealSHT(m["h0"], m["w0"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g0"]),
-                                ma.InverseRealSHT(m["h1"], m["w1"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g1"]),
-                                m["cin"], m["cout"], operator_type=m["op"])
-            continue
-        fwd = ma.RealSHT(m["h0"], m["w0"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g0"])
-        inv = ma.InverseRealSHT(m["h1"], m["w1"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g1"])
-        layer = ma.SpectralConv(fwd, inv, m["cin"], m["cout"], operator_type=m["op"]).to(DEV)
-        with torch.no_grad():
-            layer.weight.copy_(torch.from_numpy(g[p + "w"]))
-        x = torch.from_numpy(g[p + "x"]).to(DEV).requires_grad_(True)
-        y, res = layer(x)
-        ((y * torch.from_numpy(g[p + "gy"]).to(DEV)).sum() + (res * torch.from_numpy(g[p + "gr"]).to(DEV)).sum()).backward()
-        assert rel_l2(y, torch.from_numpy(g[p + "y"])) < TOL_OP, i
-        assert rel_l2(res, torch.from_numpy(g[p + "res"])) < TOL_OP, i
-        assert rel_l2(x.grad, torch.from_numpy(g[p + "gx"])) < 2 * TOL_OP, i
-        assert rel_l2(layer.weight.grad, torch.from_numpy(g[p + "gw"])) < 2 * TOL_OP, i
-        ran += 1
-    assert ran == 3
+    p = f"case{i}/"
+    fwd = ma.RealSHT(m["h0"], m["w0"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g0"])
+    inv = ma.InverseRealSHT(m["h1"], m["w1"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g1"])
+    layer = ma.SpectralConv(fwd, inv, m["cin"], m["cout"], num_groups=m.get("groups", 1), operator_type=m["op"],
+                            separable=m.get("separable", False)).to(DEV)
+    assert layer.weight.shape == g[p + "w"].shape
+    with torch.no_grad():
+        layer.weight.copy_(torch.from_numpy(g[p + "w"]))
+    x = torch.from_numpy(g[p + "x"]).to(DEV).requires_grad_(True)
+    y, res = layer(x)
+    ((y * torch.from_numpy(g[p + "gy"]).to(DEV)).sum() + (res * torch.from_numpy(g[p + "gr"]).to(DEV)).sum()).backward()
+    assert rel_l2(y, torch.from_numpy(g[p + "y"])) < TOL_OP
+    assert rel_l2(res, torch.from_numpy(g[p + "res"])) < TOL_OP
+    assert rel_l2(x.grad, torch.from_numpy(g[p + "gx"])) < 2 * TOL_OP
+    assert rel_l2(layer.weight.grad, torch.from_numpy(g[p + "gw"])) < 2 * TOL_OP
+
+
+def test_spectral_conv_constructor_errors():
+    import makani_amd as ma
+    fwd, inv = ma.RealSHT(12, 24, lmax=12, mmax=12, grid="legendre-gauss"), ma.InverseRealSHT(12, 24, lmax=12, mmax=12, grid="legendre-gauss")
+    with pytest.raises(ValueError):
+        ma.SpectralConv(fwd, inv, 6, 4, num_groups=4)
+    with pytest.raises(ValueError):
+        ma.SpectralConv(fwd, inv, 6, 4, operator_type="nope")
+    with pytest.raises(ValueError):
+        ma.SpectralConv(fwd, inv, 6, 4, separable=True)
+    with pytest.raises(NotImplementedError):
+        ma.SpectralConv(fwd, inv, 6, 6, num_groups=2)               # grouped dhconv: group sizes must be multiples of 4
+    with pytest.raises(ValueError):
+        ma.SpectralConv(fwd, ma.InverseRealSHT(12, 24, lmax=10, mmax=12, grid="legendre-gauss"), 4, 4)
 
 
 def _load_model(name, cls):
@@ -271,8 +287,9 @@ def _grads(m):
 def test_activation_checkpointing_is_exact(amp):
     """checkpointing_level 3 (every block recomputed in backward, sfnonet.py:857-864) and level 1 (encoder / decoder)
     reproduce the plain run: output and input gradient bit for bit (the HIP autograd functions are deterministic and
-    stateless).  Parameter gradients agree to rounding only: a checkpointed MLP keeps its output bias in the GEMM
-    epilogue instead of folding it into the following norm, so that bias gradient is summed by a different kernel."""
+    stateless), and so do all parameter gradients but one: the MLP's output bias sits directly in front of an instance
+    norm, so its gradient is mathematically zero and what is computed is rounding noise — a checkpointed MLP keeps
+    that bias in the GEMM epilogue instead of folding it into the norm, which sums the noise in a different order."""
     import makani_amd as ma
     cfg = dict(inp_shape=(37, 72), out_shape=(37, 72), inp_chans=5, out_chans=5, scale_factor=2, embed_dim=16, num_layers=3,
                mlp_ratio=2.0)
@@ -288,8 +305,13 @@ def test_activation_checkpointing_is_exact(amp):
         res.append((y.detach(), xs.grad, _grads(m), [n for n, _ in m.named_parameters()]))
     for y, gx, gp, names in res[1:]:
         assert torch.equal(y, res[0][0]) and torch.equal(gx, res[0][1])
-        bad = {n: rel_l2(a, b) for n, a, b in zip(names, gp, res[0][2]) if not rel_l2(a, b) < 1e-5}
-        assert not bad, bad
+        scale = max(float(t.abs().max()) for t in res[0][2])
+        for n, a, b in zip(names, gp, res[0][2]):
+            if n.endswith("mlp.fwd.3.bias"):
+                tol = (1e-2 if amp else 1e-4) * scale       # bf16: the rounding of each gradient element does not cancel in the sum
+                assert float(a.abs().max()) < tol and float(b.abs().max()) < tol, n
+            else:
+                assert torch.equal(a, b), n
 
 
 def test_rollout_checkpointing_is_exact_and_matches_manual_unroll():

@@ -118,8 +118,22 @@ def test_spectral_conv_interface_and_errors():
         ma.SpectralConv(f, i, 8, 6, operator_type="bogus")
     with pytest.raises(ValueError):
         ma.SpectralConv(ma.RealSHT(33, 64, lmax=10, mmax=13), i, 8, 6)
-    with pytest.raises(NotImplementedError):
+    # "diagonal": the reference initialises with a per-l scale broadcast against the last (m) axis
+    # (spectral_convolution.py:184-193), which only works for lmax == mmax; mirrored, including the failure
+    with pytest.raises(RuntimeError):
         ma.SpectralConv(f, i, 8, 6, operator_type="diagonal")
+    f2 = ma.RealSHT(12, 24, lmax=12, mmax=12, grid="legendre-gauss")
+    i2 = ma.InverseRealSHT(12, 24, lmax=12, mmax=12, grid="legendre-gauss")
+    d = ma.SpectralConv(f2, i2, 8, 6, num_groups=2, operator_type="diagonal")
+    assert d.weight.shape == (2, 4, 3, 12, 12)
+    assert d.weight.is_shared_mp == ["matmul"] and d.weight.sharded_dims_mp == [None, None, None, "h", "w"]
+    assert ma.SpectralConv(f2, i2, 8, 8, num_groups=2, operator_type="diagonal", separable=True).weight.shape == (2, 4, 12, 12)
+    assert ma.SpectralConv(f2, i2, 8, 8, num_groups=2, operator_type="dhconv", separable=True).weight.shape == (2, 4, 12)
+    assert ma.SpectralConv(f2, i2, 8, 16, num_groups=2).weight.shape == (2, 4, 8, 12)
+    with pytest.raises(ValueError):
+        ma.SpectralConv(f2, i2, 8, 6, separable=True)                    # separable operators keep the channel count
+    with pytest.raises(NotImplementedError):
+        ma.SpectralConv(f2, i2, 6, 6, num_groups=2)                      # grouped dhconv: group sizes % 4
 
 
 @pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz"])

@@ -25,7 +25,8 @@ def test_spectral_conv_matches_reference():
         m = json.loads(str(g[p + "meta"]))
         fwd = osht.RealSHT(m["h0"], m["w0"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g0"]).float()
         inv = osht.InverseRealSHT(m["h1"], m["w1"], lmax=m["lmax"], mmax=m["mmax"], grid=m["g1"]).float()
-        layer = osf.SpectralConv(fwd, inv, m["cin"], m["cout"], operator_type=m["op"])
+        layer = osf.SpectralConv(fwd, inv, m["cin"], m["cout"], num_groups=m.get("groups", 1), operator_type=m["op"],
+                                 separable=m.get("separable", False))
         with torch.no_grad():
             layer.weight.copy_(torch.from_numpy(g[p + "w"]))
         x = torch.from_numpy(g[p + "x"]).requires_grad_(True)
