@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) diag_kernel(const float* __restrict__ x, 
         __syncthreads();
         if (live) {
             const int kn = min(DK, K - k0);
+#pragma unroll 4                                   // 16 independent 8-byte weight loads in flight per lane
             for (int kk = 0; kk < kn; ++kk) {
                 const float xr = xs[0][kk][lane], xi = xs[1][kk][lane];
                 const float2* wp = w + (long long)(k0 + kk) * wk + p;

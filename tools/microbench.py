@@ -95,6 +95,37 @@ def conv():
               f" || wgrad hip {ms3:7.3f} ms ({fl/ms3/1e9:6.0f} TF) | torch {ms4:7.3f} ms ({fl/ms4/1e9:6.0f} TF)")
 
 
+def spectral():
+    """the HBM-streaming contractions (csrc/spectral_pointwise.hip): algorithmic bytes = activations in + out + weights once"""
+    L, M = 240, 241
+    for C in (64, 128):                       # diagonal: one C x C complex matrix per (l, m); 1.9 / 7.6 GB of weights
+        S = torch.randn(L, M, 2, C, device=dev)
+        w = torch.randn(1, C, C, L, M, dtype=torch.complex64, device=dev)
+        wr = torch.view_as_real(w)
+        T = torch.empty_like(S)
+        gw = torch.empty_like(wr)
+        nb = 8.0 * C * C * L * M + 2 * 8.0 * C * L * M
+        live = 0.5 * 8.0 * C * C * L * M + 2 * 8.0 * C * L * M          # the l < m half of the weights is never read
+        ms = timeit(lambda: ops.check(ops.lib().mk_spec_diag_apply(ops.ptr(S), ops.ptr(wr), ops.ptr(T), L, M, 1, C, C, C, C, 0, 0, 0, ops.stream())))
+        print(f"diag fwd   C={C:3d}: {ms:7.3f} ms  {nb/ms/1e6:7.1f} GB/s dense  ({live/ms/1e6:7.1f} GB/s touched)")
+        ms = timeit(lambda: ops.check(ops.lib().mk_spec_diag_apply(ops.ptr(S), ops.ptr(wr), ops.ptr(T), L, M, 1, C, C, C, C, 0, 0, 1, ops.stream())))
+        print(f"diag dgrad C={C:3d}: {ms:7.3f} ms  {nb/ms/1e6:7.1f} GB/s dense  ({live/ms/1e6:7.1f} GB/s touched)")
+        ms = timeit(lambda: ops.check(ops.lib().mk_spec_diag_wgrad(ops.ptr(S), ops.ptr(T), ops.ptr(gw), L, M, 1, C, C, C, C, 0, ops.stream())))
+        print(f"diag wgrad C={C:3d}: {ms:7.3f} ms  {nb/ms/1e6:7.1f} GB/s (gradient written in full)")
+        del S, w, wr, T, gw
+    C = 384
+    S = torch.randn(L, M, 2, C, device=dev)
+    T = torch.empty_like(S)
+    for Mw in (M, 1):
+        Ws = torch.randn(L, Mw, 2, C, device=dev)
+        gW = torch.empty_like(Ws)
+        nb = 4.0 * (4 * C * L * M + 2 * C * L * Mw)
+        ms = timeit(lambda: ops.check(ops.lib().mk_spec_sep_mul(ops.ptr(S), ops.ptr(Ws), ops.ptr(T), L, M, Mw, 1, C, 0, 0, ops.stream())))
+        print(f"sep mul   Mw={Mw:3d}: {ms:7.3f} ms  {nb/ms/1e6:7.1f} GB/s dense")
+        ms = timeit(lambda: ops.check(ops.lib().mk_spec_sep_wgrad(ops.ptr(S), ops.ptr(T), ops.ptr(gW), L, M, Mw, 1, C, 0, ops.stream())))
+        print(f"sep wgrad Mw={Mw:3d}: {ms:7.3f} ms  {nb/ms/1e6:7.1f} GB/s dense")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fft", "legendre", "dhconv", "pointwise"]
     for w in which:
