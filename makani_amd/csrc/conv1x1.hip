@@ -24,7 +24,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int NT = 256;
-constexpr int BK = 32;
 
 struct ConvNN {
     const u16* A;        // (M, lda) weights, k contiguous, lda % 8 == 0, zero beyond K
@@ -284,148 +283,6 @@ __global__ __launch_bounds__(NT, WGS) void conv_nn_kernel(const ConvNN p, int ti
 }
 
 // ------------------------------------------------------------------------------------------
-// X-stationary variant for K <= 384 (every SFNO channel GEMM except the 768 -> 384 ones): one workgroup
-// owns BN = 128 pixels, stages the WHOLE activation tile X[0:K][n0:n0+128] in LDS once (<= 123 KB), and
-// sweeps all output-channel tiles over it, streaming the weights (L2-resident) through a small LDS tile.
-// HBM traffic is exactly one read of X and one write of Y per GEMM, whatever M is.
-template <int BN>
-__global__ __launch_bounds__(NT, 1) void conv_xs_kernel(const ConvNN p, long long tilesN, int kp32) {
-    constexpr int BM = 128;
-    constexpr int PA = BK + 8;
-    constexpr int PB = BN + 32;
-    constexpr int MAXX = 24;                      // uint4 per thread for the X tile (K <= 384, BN = 128)
-    extern __shared__ __attribute__((aligned(16))) u16 dsm[];
-    u16* Xs = dsm;                                // [kp32][PB]
-    u16* As = dsm + (size_t)kp32 * PB;            // [BM][PA]
-
-    const long long bid = blockIdx.x;
-    const int b = (int)(bid / tilesN);
-    const long long n0 = (bid % tilesN) * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const u16* Xb = p.X + (long long)b * p.K * p.N;
-
-    // ---- stage the activation tile: all loads in flight at once, then one pass of LDS writes ----
-    {
-        constexpr int CPR = BN / 8;               // 16-byte chunks per row
-        const int nchunk = kp32 * CPR;
-        uint4 xr[MAXX];
-#pragma unroll
-        for (int q = 0; q < MAXX; ++q) {
-            const int f = tid + q * NT;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (f < nchunk) {
-                const int kk = f / CPR, c = f % CPR;
-                if (kk < p.K && n0 + c * 8 < p.N) v = ld16(Xb + (long long)kk * p.N + n0 + c * 8);
-            }
-            xr[q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < MAXX; ++q) {
-            const int f = tid + q * NT;
-            if (f < nchunk) {
-                const int kk = f / CPR, c = f % CPR;
-                *reinterpret_cast<uint4*>(Xs + kk * PB + c * 8) = xr[q];
-            }
-        }
-    }
-
-    const int tilesM = (p.M + BM - 1) / BM;
-    const int nk = kp32 / BK;
-    const int nsteps = tilesM * nk;
-    uint4 ra[2];
-    auto load_a = [&](int step) {
-        const int mt = step / nk, kt = step % nk;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int f = tid + q * NT;
-            const int row = f >> 2, c = f & 3;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (mt * BM + row < p.M && kt * BK + c * 8 < p.lda) v = ld16(p.A + (long long)(mt * BM + row) * p.lda + kt * BK + c * 8);
-            ra[q] = v;
-        }
-    };
-    auto store_a = [&]() {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int f = tid + q * NT;
-            const int row = f >> 2, c = f & 3;
-            *reinterpret_cast<uint4*>(As + row * PA + c * 8) = ra[q];
-        }
-    };
-
-    const int s = lane & 15, g1 = (lane >> 4) & 1;
-    const int a_off = (wm * 64 + l31) * PA + lh * 8;
-    const int b_off = (lh * 8 + (s >> 2)) * PB + wn * 64 + g1 * 16 + (s & 3) * 4;
-    const long long plane = (long long)b * p.M * p.N;
-
-    f32x16 acc[2][2];
-    load_a(0);
-    for (int step = 0; step < nsteps; ++step) {
-        const int mt = step / nk, kt = step % nk;
-        if (kt == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
-        store_a();
-        __syncthreads();                      // also orders the X tile stores before the first reads
-        if (step + 1 < nsteps) load_a(step + 1);
-        const u16* Bb = Xs + (kt * BK) * PB;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(As + a_off + i * 32 * PA + ks * 16));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const u16* q0 = Bb + b_off + (ks * 16) * PB + j * 32;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * PB));
-                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bfr[j] = __builtin_bit_cast(bf16x8, v);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-        if (kt == nk - 1) {                   // epilogue of this output-channel tile
-            const int m0 = mt * BM;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m >= p.M) continue;
-                    const float bv = p.bias ? p.bias[m] : 0.f;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const long long n = n0 + wn * 64 + j * 32 + l31;
-                        if (n >= p.N) continue;
-                        const long long o = plane + (long long)m * p.N + n;
-                        float v = acc[i][j][r] + bv;
-                        if (p.act) {
-                            if (p.Ypre) p.Ypre[o] = f32_to_bf16(v);
-                            v = gelu_f(v);
-                        }
-                        if (p.G) v *= gelu_grad_f(bf16_to_f32(p.G[o]));
-                        if (p.R) v += bf16_to_f32(p.R[o]);
-                        p.Y[o] = f32_to_bf16(v);
-                    }
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // wgrad: part[s][m][k] = sum_{n in split s} G[b][m][n] X[b][k][n];   tile 128 (m) x 128 (k-channel)
 struct ConvWg {
     const u16* G;   // (B, M, N)
@@ -591,17 +448,6 @@ __global__ void reduce_splits(const float* __restrict__ part, float* __restrict_
     out[i] = s;
 }
 
-bool use_xs() {
-    static int v = -1;
-    if (v < 0) {
-        // opt-in: measured 25-40 % SLOWER than the tiled kernel (1 workgroup / CU cannot hide the latency
-        // of the weight stream) — kept as a recorded experiment, see DESIGN.md §5
-        const char* e = getenv("MAKANI_AMD_CONV_XS");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
-
 }  // namespace
 
 extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, const float* bias, const void* R,
@@ -612,25 +458,6 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     MK_REQUIRE((N % 8) == 0, "conv1x1_nn: pixel count %lld must be a multiple of 8", N);
     MK_REQUIRE((((uintptr_t)A | (uintptr_t)X) & 15) == 0, "conv1x1_nn: operands must be 16-byte aligned");
     ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
-    if (K <= 384 && use_xs()) {        // X-stationary: one read of X, one write of Y
-        constexpr int BNX = 128;
-        const int kp32 = (K + BK - 1) / BK * BK;
-        const long long tnx = (N + BNX - 1) / BNX;
-        const size_t lds = ((size_t)kp32 * (BNX + 32) + 128 * (BK + 8)) * sizeof(u16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xs_kernel<BNX>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) {
-                mk_set_error("conv1x1_nn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-                return (int)e;
-            }
-            attr_set = true;
-        }
-        MK_REQUIRE(tnx * B < (1ll << 31), "conv1x1_nn: grid too large");
-        hipLaunchKernelGGL((conv_xs_kernel<BNX>), dim3((unsigned)(tnx * B)), dim3(NT), lds, (hipStream_t)stream, p, tnx, kp32);
-        return mk_check_launch("mk_conv1x1_nn(xs)");
-    }
     // 128 x 256 tile, BK = 64 with one LDS stage (measured 10-15 % faster at 721x1440 than BK = 32 double-buffered,
     // equal at 240x480; a 128 x 128 tile with two register sets was 10-20 % slower)
     // BK = 64 with one LDS stage (10-15 % faster at 721x1440 than BK = 32 double-buffered).  Tile 128 x 128 with
