@@ -219,7 +219,7 @@ class GeometricInstanceNormS2(nn.Module):
                                          crop_offset=crop_offset, normalize=True, distributed=False)
         self._qsum = float(self.quadrature.quad_weight.double().sum())      # 1 on the full grid, < 1 on a crop
 
-    def forward(self, x):
+    def forward(self, x, fuse_gelu=False):
         q = self.quadrature.quad_weight
         if x.dim() != 4 or tuple(x.shape[-2:]) != tuple(q.shape[-2:]):
             raise ValueError(f"expected (B, C, {q.shape[-2]}, {q.shape[-1]}), got {tuple(x.shape)}")
@@ -227,4 +227,4 @@ class GeometricInstanceNormS2(nn.Module):
             raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
-        return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, False, None, q.reshape(-1), self._qsum)
+        return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, None, q.reshape(-1), self._qsum)

@@ -20,7 +20,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from . import distributed as thd
-from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv
+from .layers import MLP, EncoderDecoder, GeometricInstanceNormS2, InstanceNorm2d, PointwiseConv
 from .sht import InverseRealSHT, RealSHT
 from .spectral_conv import SpectralConv
 
@@ -108,7 +108,7 @@ class NeuralOperatorBlock(nn.Module):
     def forward(self, x):
         x, residual = self.filter(x)
 
-        fuse = (self.act_is_gelu and isinstance(self.norm0, (InstanceNorm2d, thd.DistributedInstanceNorm2d))
+        fuse = (self.act_is_gelu and isinstance(self.norm0, (InstanceNorm2d, GeometricInstanceNormS2, thd.DistributedInstanceNorm2d))
                 and not hasattr(self, "inner_skip"))
         x = self.norm0(x, fuse_gelu=True) if fuse else self.norm0(x)
         if hasattr(self, "inner_skip"):
@@ -175,10 +175,19 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 norm = partial(thd.DistributedInstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True)
             else:
                 norm = partial(InstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True, track_running_stats=False)
+        elif normalization_layer == "instance_norm_s2":        # sfnonet.py:620-645
+            if self.spatial_parallel:
+                raise NotImplementedError("DistributedGeometricInstanceNormS2 is not implemented: use instance_norm with h x w parallelism")
+            norm = partial(GeometricInstanceNormS2, img_shape=(self.h, self.w), crop_shape=(self.h, self.w), crop_offset=(0, 0),
+                           grid_type=model_grid_type, num_features=embed_dim, eps=1e-6, affine=True)
+            norm_out = partial(GeometricInstanceNormS2, img_shape=self.out_shape, crop_shape=self.out_shape, crop_offset=(0, 0),
+                               grid_type=model_grid_type, num_features=embed_dim, eps=1e-6, affine=True)
         elif normalization_layer == "none":
             norm = nn.Identity
         else:
             raise NotImplementedError(f"Error, normalization {normalization_layer} not implemented.")
+        if normalization_layer != "instance_norm_s2":
+            norm_out = norm
 
         self.blocks = nn.ModuleList([])
         for i in range(num_layers):
@@ -187,7 +196,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 self.trans_down if first else self.trans,
                 self.itrans_up if last else self.itrans,
                 embed_dim, filter_type=filter_type, operator_type=operator_type, mlp_ratio=mlp_ratio,
-                mlp_drop_rate=mlp_drop_rate, path_drop_rate=0.0, act_layer=act, norm_layer=(norm, norm),
+                mlp_drop_rate=mlp_drop_rate, path_drop_rate=0.0, act_layer=act,
+                norm_layer=(norm, norm) if (first or not last) else (norm_out, norm_out),       # sfnonet.py:668-673
                 inner_skip="none", outer_skip="linear", use_mlp=use_mlp, rank=rank, separable=separable,
                 complex_activation=complex_activation, spectral_layers=spectral_layers, bias=bias,
                 checkpointing_level=checkpointing_level))

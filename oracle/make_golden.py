@@ -69,6 +69,14 @@ def sfno_fixtures():
              embed_dim=16, mlp_ratio=2),
         batch=2, seed=334, name="sfno_small_37x72.npz",
     )
+    # output grid != input grid (the big skip is resampled through trans_down -> itrans_up, sfnonet.py:886-891) and
+    # quadrature-weighted instance norms (normalization_layer "instance_norm_s2", sfnonet.py:620-645)
+    _run_model(
+        SFNO,
+        dict(inp_shape=(33, 64), out_shape=(25, 48), inp_chans=4, out_chans=3, num_layers=3, scale_factor=2,
+             embed_dim=12, mlp_ratio=2, normalization_layer="instance_norm_s2"),
+        batch=2, seed=335, name="sfno_s2norm_resample_33x64.npz",
+    )
 
 
 def spectral_conv_fixtures():

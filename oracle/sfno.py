@@ -147,17 +147,39 @@ def _encdec(num_layers, inp, out, hidden, act, gain=1.0):
     return _Seq(*mods)
 
 
+class GeometricInstanceNormS2(nn.Module):
+    """``makani/models/common/layer_norm.py:30-160`` (serial): instance norm with normalised quadrature weights."""
+
+    def __init__(self, img_shape, grid_type, num_features, eps=1e-6):
+        super().__init__()
+        from . import losses as _ol
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("quad_weight", _ol.quadrature_weights(_ol.GRID_TO_RULE[grid_type], tuple(img_shape), normalize=True),
+                             persistent=False)
+
+    def forward(self, x):
+        from . import losses as _ol
+        return _ol.geometric_instance_norm_s2(x, self.quad_weight, self.weight, self.bias, self.eps)
+
+
+def _instance_norm(embed_dim):
+    return nn.InstanceNorm2d(embed_dim, eps=1e-6, affine=True, track_running_stats=False)
+
+
 class NeuralOperatorBlock(nn.Module):
     """``makani/models/networks/sfnonet.py:169-408`` with the SFNO settings
     ``inner_skip="none"``, ``outer_skip="linear"``, ``use_mlp=True``."""
 
-    def __init__(self, fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias):
+    def __init__(self, fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias, norm_layer=None):
         super().__init__()
-        self.norm0 = nn.InstanceNorm2d(embed_dim, eps=1e-6, affine=True, track_running_stats=False)
+        norm_layer = norm_layer or (lambda: _instance_norm(embed_dim), lambda: _instance_norm(embed_dim))
+        self.norm0 = norm_layer[0]()
         gain = 2.0 if act != nn.Identity else 1.0
         self.filter = _Filter(fwd, inv, embed_dim, operator_type, bias, gain)
         self.act_layer0 = act()
-        self.norm1 = nn.InstanceNorm2d(embed_dim, eps=1e-6, affine=True, track_running_stats=False)
+        self.norm1 = norm_layer[1]()
         gain = 1.0
         self.outer_skip = nn.Conv2d(embed_dim, embed_dim, 1, 1, bias=False)
         gain /= 2.0
@@ -177,14 +199,14 @@ class NeuralOperatorBlock(nn.Module):
 class SphericalFourierNeuralOperatorNet(nn.Module):
     """``makani/models/networks/sfnonet.py:411-934`` restricted to the
     BASELINE configuration family: ``spectral_transform="sht"``,
-    ``filter_type="linear"``, ``normalization_layer="instance_norm"``,
+    ``filter_type="linear"``, ``normalization_layer`` "instance_norm" / "instance_norm_s2" / "none",
     ``pos_embed="none"``, drop rates 0, serial (no model parallelism)."""
 
     def __init__(self, model_grid_type="equiangular", sht_grid_type="legendre-gauss", operator_type="dhconv",
                  inp_shape=(721, 1440), out_shape=(721, 1440), scale_factor=8, inp_chans=2, out_chans=2,
                  embed_dim=32, num_layers=4, mlp_ratio=2.0, encoder_ratio=1, decoder_ratio=1,
                  activation_function="gelu", encoder_layers=1, hard_thresholding_fraction=1.0, max_modes=None,
-                 big_skip=True, bias=False, **kwargs):
+                 big_skip=True, bias=False, normalization_layer="instance_norm", **kwargs):
         super().__init__()
         self.inp_shape, self.out_shape = tuple(inp_shape), tuple(out_shape)
         self.inp_chans, self.out_chans, self.embed_dim, self.big_skip = inp_chans, out_chans, embed_dim, big_skip
@@ -201,11 +223,22 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         self.itrans = InverseRealSHT(self.h, self.w, lmax=ml, mmax=mm, grid=sht_grid_type)
         act = {"relu": nn.ReLU, "gelu": nn.GELU, "silu": nn.SiLU}[activation_function]
         self.encoder = _encdec(encoder_layers, inp_chans, embed_dim, int(encoder_ratio * embed_dim), act)
+        # norm layers per block position, sfnonet.py:609-673
+        if normalization_layer == "instance_norm":
+            n_inp = n_mid = n_out = lambda: _instance_norm(embed_dim)
+        elif normalization_layer == "instance_norm_s2":
+            n_inp = n_mid = lambda: GeometricInstanceNormS2((self.h, self.w), model_grid_type, embed_dim)
+            n_out = lambda: GeometricInstanceNormS2(tuple(out_shape), model_grid_type, embed_dim)
+        elif normalization_layer == "none":
+            n_inp = n_mid = n_out = nn.Identity
+        else:
+            raise NotImplementedError(f"Error, normalization {normalization_layer} not implemented.")
         self.blocks = nn.ModuleList()
         for i in range(num_layers):
             fwd = self.trans_down if i == 0 else self.trans
             inv = self.itrans_up if i == num_layers - 1 else self.itrans
-            self.blocks.append(NeuralOperatorBlock(fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias))
+            norms = (n_inp, n_mid) if i == 0 else ((n_out, n_out) if i == num_layers - 1 else (n_mid, n_mid))
+            self.blocks.append(NeuralOperatorBlock(fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias, norm_layer=norms))
         self.decoder = _encdec(encoder_layers, embed_dim, out_chans, int(decoder_ratio * embed_dim), act,
                                gain=0.5 if big_skip else 1.0)
         if big_skip:

@@ -143,7 +143,7 @@ def _load_model(name, cls):
     return g, kwargs, model
 
 
-@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz"])
+@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz"])
 def test_sfno_matches_reference_golden_fp32(name):
     import makani_amd as ma
     g, kwargs, model = _load_model(name, ma.SphericalFourierNeuralOperatorNet)

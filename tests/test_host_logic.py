@@ -136,7 +136,7 @@ def test_spectral_conv_interface_and_errors():
         ma.SpectralConv(f2, i2, 6, 6, num_groups=2)                      # grouped dhconv: group sizes % 4
 
 
-@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz"])
+@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz"])
 def test_sfno_state_dict_is_reference_compatible(name):
     import makani_amd as ma
     g = load_golden(name)
@@ -150,7 +150,10 @@ def test_sfno_state_dict_is_reference_compatible(name):
     model.load_state_dict(sd, strict=True)
     for n, p in model.named_parameters():
         # annotations the reference sets (layers.py:613,633,780-784; mpu/layer_norm.py:121-122; sfnonet.py:727)
-        if any(t in n for t in ("encoder", "decoder", "mlp", "norm", "residual_transform")):
+        tags = ("encoder", "decoder", "mlp", "norm", "residual_transform")
+        if kwargs.get("normalization_layer") == "instance_norm_s2":          # models/common/layer_norm.py:30-160 sets none
+            tags = tuple(t for t in tags if t != "norm")
+        if any(t in n for t in tags):
             assert p.is_shared_mp == ["spatial"], n
 
 

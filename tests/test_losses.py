@@ -243,6 +243,41 @@ def test_hip_s2_norm_matches_reference_golden():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hip_s2_norm_fused_gelu_matches_oracle(dtype):
+    """norm + exact GELU in one pass (what the SFNO block uses for normalization_layer="instance_norm_s2"), forward and
+    all gradients, against gelu(oracle S2 norm) in fp64"""
+    import makani_amd as ma
+    from oracle import losses as ol
+    dev = torch.device("cuda", 0)
+    B, C, H, W = 2, 5, 33, 64
+    torch.manual_seed(9)
+    mod = ma.GeometricInstanceNormS2((H, W), (H, W), (0, 0), "equiangular", num_features=C, eps=1e-6, affine=True).to(dev)
+    with torch.no_grad():
+        mod.weight.copy_(torch.rand(C) + 0.5)
+        mod.bias.copy_(torch.randn(C) * 0.3)
+    x0 = (torch.randn(B, C, H, W) * 2 + 1).to(dtype)
+    g0 = torch.randn(B, C, H, W).to(dtype)
+    x = x0.to(dev).requires_grad_(True)
+    y = mod(x, fuse_gelu=True)
+    assert y.dtype == dtype
+    (y.float() * g0.to(dev).float()).sum().backward()
+    q = ol.quadrature_weights("naive", (H, W), normalize=True).double()
+    xr = x0.double().requires_grad_(True)
+    wr, br = mod.weight.detach().cpu().double().requires_grad_(True), mod.bias.detach().cpu().double().requires_grad_(True)
+    mean = (xr * q).sum((-2, -1), keepdim=True)
+    var = ((xr - mean) ** 2 * q).sum((-2, -1), keepdim=True)
+    yr = torch.nn.functional.gelu((xr - mean) / torch.sqrt(var + 1e-6) * wr.view(1, -1, 1, 1) + br.view(1, -1, 1, 1))
+    (yr * g0.double()).sum().backward()
+
+    def rel(a, b):
+        return ((a.detach().cpu().double() - b.detach()).norm() / b.detach().norm()).item()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel(y, yr) < tol and rel(x.grad, xr.grad) < tol
+    assert rel(mod.weight.grad, wr.grad) < tol and rel(mod.bias.grad, br.grad) < tol
+
+
+@pytest.mark.gpu
 def test_hip_s2_norm_fullsize_properties():
     """BASELINE grid, bf16: quadrature-weighted mean 0 / variance 1 of the output, and a constant field maps to beta"""
     import makani_amd as ma

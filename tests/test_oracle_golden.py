@@ -38,7 +38,7 @@ def test_spectral_conv_matches_reference():
         assert rel_l2(layer.weight.grad, torch.from_numpy(g[p + "gw"])) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz"])
+@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz"])
 def test_sfno_matches_reference(name):
     g = load_golden(name)
     kwargs = json.loads(str(g["kwargs"]))
@@ -51,4 +51,9 @@ def test_sfno_matches_reference(name):
     assert rel_l2(y, torch.from_numpy(g["y"])) < 1e-6
     assert rel_l2(x.grad, torch.from_numpy(g["gx"])) < 1e-5
     for k, p in model.named_parameters():
+        if k.endswith("mlp.fwd.3.bias"):
+            # a per-channel constant in front of an instance norm has exactly zero gradient: both sides hold round-off
+            wmax = float(np.abs(g["grad/" + k.replace("bias", "weight")]).max())
+            assert p.grad.abs().max().item() < 1e-3 * max(wmax, 1e-3) and np.abs(g["grad/" + k]).max() < 1e-3 * max(wmax, 1e-3), k
+            continue
         assert rel_l2(p.grad, torch.from_numpy(g["grad/" + k])) < 2e-5, k
