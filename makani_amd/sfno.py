@@ -9,8 +9,9 @@ It can be named in a makani yaml as ``nettype: "makani_amd/sfno.py:SphericalFour
 
 Scope: the serial (one GPU per model instance) configuration family of
 BASELINE.json — ``spectral_transform="sht"``, ``filter_type="linear"``,
-``operator_type="dhconv"``, ``normalization_layer in {"instance_norm", "none"}``,
-``pos_embed="none"``, all drop rates 0.  Anything else raises ``NotImplementedError``.
+every ``operator_type`` / ``separable`` combination of ``SpectralConv``, ``normalization_layer in {"instance_norm",
+"instance_norm_s2", "none"}``, ``pos_embed in {"none", "direct", "frequency"}``, all drop rates 0.  Anything else
+raises ``NotImplementedError`` (``ValueError`` where the reference raises one).
 """
 import math
 from functools import partial
@@ -148,8 +149,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         super().__init__()
         if spectral_transform != "sht":
             raise NotImplementedError("only spectral_transform='sht' is implemented")
-        if pos_embed not in ("none", "None", None):
-            raise NotImplementedError("pos_embed must be 'none' on the accelerated path")
+        if pos_embed not in ("none", "None", None, "direct", "frequency"):
+            raise ValueError("Unknown position embedding type")
         if pos_drop_rate > 0.0 or path_drop_rate > 0.0 or mlp_drop_rate > 0.0:
             raise NotImplementedError("drop rates must be 0 on the accelerated path")
 
@@ -211,6 +212,40 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             self.residual_transform.weight.sharded_dims_mp = [None, None, None, None]
             nn.init.normal_(self.residual_transform.weight, mean=0.0, std=math.sqrt(0.5 / inp_chans))
 
+        # learned position embedding (sfnonet.py:732-764)
+        if pos_embed == "direct":
+            self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, self.inp_shape_loc[0], self.inp_shape_loc[1]))
+            self.pos_embed.is_shared_mp = []
+            self.pos_embed.sharded_dims_mp = [None, None, "h", "w"]
+            self.pos_embed.type = "direct"
+            with torch.no_grad():
+                nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        elif pos_embed == "frequency":
+            if self.spatial_parallel:
+                lmax_loc = self.itrans_up.l_shapes[self.itrans_up.comm_rank_polar]
+                mmax_loc = self.itrans_up.m_shapes[self.itrans_up.comm_rank_azimuth]
+            else:
+                lmax_loc, mmax_loc = self.itrans_up.lmax, self.itrans_up.mmax
+            rcoeffs = nn.Parameter(torch.tril(torch.randn(1, embed_dim, lmax_loc, mmax_loc), diagonal=0))
+            ccoeffs = nn.Parameter(torch.tril(torch.randn(1, embed_dim, lmax_loc, mmax_loc - 1), diagonal=-1))
+            with torch.no_grad():
+                nn.init.trunc_normal_(rcoeffs, std=0.02)
+                nn.init.trunc_normal_(ccoeffs, std=0.02)
+            self.pos_embed = nn.ParameterList([rcoeffs, ccoeffs])
+            self.pos_embed.type = "frequency"
+            self.pos_embed.is_shared_mp = []
+            self.pos_embed.sharded_dims_mp = [None, None, "h", "w"]
+
+    def _add_pos_embed(self, x):
+        """sfnonet.py:898-911: the embedding is either the parameter itself or synthesised from learned coefficients by
+        the HIP inverse SHT (fp32), then added in the activation dtype"""
+        if self.pos_embed.type == "frequency":
+            pe = torch.stack([self.pos_embed[0], nn.functional.pad(self.pos_embed[1], (1, 0), "constant", 0)], dim=-1)
+            pe = self.itrans_up(torch.view_as_complex(pe))
+        else:
+            pe = self.pos_embed
+        return x + pe.to(dtype=x.dtype)
+
     def _init_spectral_transforms(self, model_grid_type, sht_grid_type, hard_thresholding_fraction, max_modes):
         if max_modes is not None:
             modes_lat, modes_lon = max_modes
@@ -257,6 +292,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             x = checkpoint(self.encoder, x, use_reentrant=False)
         else:
             x = self.encoder(x)
+        if hasattr(self, "pos_embed"):
+            x = self._add_pos_embed(x)
         x = self.pos_drop(x)
         x = self._forward_features(x)
         if self.checkpointing_level >= 1 and torch.is_grad_enabled():

@@ -77,6 +77,14 @@ def sfno_fixtures():
              embed_dim=12, mlp_ratio=2, normalization_layer="instance_norm_s2"),
         batch=2, seed=335, name="sfno_s2norm_resample_33x64.npz",
     )
+    # learned position embeddings (sfnonet.py:732-764,898-911)
+    for i, pe in enumerate(("direct", "frequency")):
+        _run_model(
+            SFNO,
+            dict(inp_shape=(19, 36), out_shape=(19, 36), inp_chans=2, out_chans=2, num_layers=2, scale_factor=2,
+                 embed_dim=8, mlp_ratio=2, pos_embed=pe),
+            batch=1, seed=336 + i, name=f"sfno_posembed_{pe}_19x36.npz",
+        )
 
 
 def spectral_conv_fixtures():

@@ -206,7 +206,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                  inp_shape=(721, 1440), out_shape=(721, 1440), scale_factor=8, inp_chans=2, out_chans=2,
                  embed_dim=32, num_layers=4, mlp_ratio=2.0, encoder_ratio=1, decoder_ratio=1,
                  activation_function="gelu", encoder_layers=1, hard_thresholding_fraction=1.0, max_modes=None,
-                 big_skip=True, bias=False, normalization_layer="instance_norm", **kwargs):
+                 big_skip=True, bias=False, normalization_layer="instance_norm", pos_embed="none", **kwargs):
         super().__init__()
         self.inp_shape, self.out_shape = tuple(inp_shape), tuple(out_shape)
         self.inp_chans, self.out_chans, self.embed_dim, self.big_skip = inp_chans, out_chans, embed_dim, big_skip
@@ -244,6 +244,29 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         if big_skip:
             self.residual_transform = nn.Conv2d(inp_chans, out_chans, 1, bias=False)
             nn.init.normal_(self.residual_transform.weight, std=math.sqrt(0.5 / inp_chans))
+        # learned position embedding, sfnonet.py:732-764
+        if pos_embed == "direct":
+            self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, *self.inp_shape))
+            self.pos_embed.type = "direct"
+            nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        elif pos_embed == "frequency":
+            rc = nn.Parameter(torch.tril(torch.randn(1, embed_dim, ml, mm), diagonal=0))
+            cc = nn.Parameter(torch.tril(torch.randn(1, embed_dim, ml, mm - 1), diagonal=-1))
+            nn.init.trunc_normal_(rc, std=0.02)
+            nn.init.trunc_normal_(cc, std=0.02)
+            self.pos_embed = nn.ParameterList([rc, cc])
+            self.pos_embed.type = "frequency"
+        elif pos_embed not in ("none", "None", None):
+            raise ValueError("Unknown position embedding type")
+
+    def _pos_embed(self, x):
+        """sfnonet.py:898-911"""
+        if self.pos_embed.type == "frequency":
+            pe = torch.stack([self.pos_embed[0], F.pad(self.pos_embed[1], (1, 0), "constant", 0)], dim=-1)
+            pe = self.itrans_up(torch.view_as_complex(pe))
+        else:
+            pe = self.pos_embed
+        return x + pe.to(dtype=x.dtype)
 
     def forward(self, x):
         if self.big_skip:
@@ -252,6 +275,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             else:
                 residual = x
         x = self.encoder(x)
+        if hasattr(self, "pos_embed"):
+            x = self._pos_embed(x)
         for blk in self.blocks:
             x = blk(x)
         x = self.decoder(x)

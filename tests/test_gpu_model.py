@@ -9,6 +9,9 @@ import numpy as np
 import pytest
 import torch
 
+SFNO_GOLDEN = ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz",
+               "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz"]
+
 from conftest import load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -143,7 +146,7 @@ def _load_model(name, cls):
     return g, kwargs, model
 
 
-@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz"])
+@pytest.mark.parametrize("name", SFNO_GOLDEN)
 def test_sfno_matches_reference_golden_fp32(name):
     import makani_amd as ma
     g, kwargs, model = _load_model(name, ma.SphericalFourierNeuralOperatorNet)

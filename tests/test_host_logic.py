@@ -10,6 +10,9 @@ import numpy as np
 import pytest
 import torch
 
+SFNO_GOLDEN = ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz",
+               "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz"]
+
 from conftest import ROOT, load_golden
 
 
@@ -136,7 +139,7 @@ def test_spectral_conv_interface_and_errors():
         ma.SpectralConv(f2, i2, 6, 6, num_groups=2)                      # grouped dhconv: group sizes % 4
 
 
-@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz"])
+@pytest.mark.parametrize("name", SFNO_GOLDEN)
 def test_sfno_state_dict_is_reference_compatible(name):
     import makani_amd as ma
     g = load_golden(name)
@@ -163,8 +166,13 @@ def test_no_cpu_fallback():
                                                  num_layers=2, inp_chans=2, out_chans=2)
     with pytest.raises(RuntimeError, match="GPU"):
         model(torch.randn(1, 2, 16, 32))
+    with pytest.raises(ValueError):
+        ma.SphericalFourierNeuralOperatorNet(pos_embed="bogus", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2)
     with pytest.raises(NotImplementedError):
-        ma.SphericalFourierNeuralOperatorNet(pos_embed="direct")
+        ma.SphericalFourierNeuralOperatorNet(normalization_layer="layer_norm", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2)
+    pe = ma.SphericalFourierNeuralOperatorNet(pos_embed="frequency", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2, embed_dim=8)
+    assert [tuple(p.shape) for p in pe.pos_embed] == [(1, 8, 8, 9), (1, 8, 8, 8)] and pe.pos_embed.type == "frequency"
+    assert pe.no_weight_decay() == {"pos_embed", "cls_token"}
     with pytest.raises(NotImplementedError):
         ma.SphericalFourierNeuralOperatorNet(filter_type="non-linear", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2)
     with pytest.raises(ValueError):

@@ -6,6 +6,9 @@ import numpy as np
 import pytest
 import torch
 
+SFNO_GOLDEN = ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz",
+               "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz"]
+
 from conftest import load_golden, rel_l2
 from oracle import sfno as osf
 from oracle import sht as osht
@@ -38,7 +41,7 @@ def test_spectral_conv_matches_reference():
         assert rel_l2(layer.weight.grad, torch.from_numpy(g[p + "gw"])) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz"])
+@pytest.mark.parametrize("name", SFNO_GOLDEN)
 def test_sfno_matches_reference(name):
     g = load_golden(name)
     kwargs = json.loads(str(g["kwargs"]))
