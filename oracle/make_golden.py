@@ -77,6 +77,22 @@ def sfno_fixtures():
              embed_dim=12, mlp_ratio=2, normalization_layer="instance_norm_s2"),
         batch=2, seed=335, name="sfno_s2norm_resample_33x64.npz",
     )
+    # non-default constructor options in one go: deeper encoder / decoder, SiLU, no big skip, truncated spectrum,
+    # SpectralConv bias, no normalisation  /  ReLU, no MLP, explicit max_modes, wider encoder
+    _run_model(
+        SFNO,
+        dict(inp_shape=(24, 48), out_shape=(24, 48), inp_chans=3, out_chans=2, num_layers=2, scale_factor=2, embed_dim=8,
+             mlp_ratio=2, activation_function="silu", encoder_layers=2, big_skip=False, hard_thresholding_fraction=0.75,
+             bias=True, normalization_layer="none"),
+        batch=2, seed=340, name="sfno_options_a_24x48.npz",
+    )
+    _run_model(
+        SFNO,
+        dict(inp_shape=(24, 48), out_shape=(24, 48), inp_chans=3, out_chans=3, num_layers=3, scale_factor=3, embed_dim=8,
+             activation_function="relu", use_mlp=False, max_modes=(6, 7), encoder_ratio=2, decoder_ratio=2,
+             model_grid_type="legendre-gauss", sht_grid_type="equiangular"),
+        batch=1, seed=341, name="sfno_options_b_24x48.npz",
+    )
     # learned position embeddings (sfnonet.py:732-764,898-911)
     for i, pe in enumerate(("direct", "frequency")):
         _run_model(

@@ -172,7 +172,7 @@ class NeuralOperatorBlock(nn.Module):
     """``makani/models/networks/sfnonet.py:169-408`` with the SFNO settings
     ``inner_skip="none"``, ``outer_skip="linear"``, ``use_mlp=True``."""
 
-    def __init__(self, fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias, norm_layer=None):
+    def __init__(self, fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias, norm_layer=None, use_mlp=True):
         super().__init__()
         norm_layer = norm_layer or (lambda: _instance_norm(embed_dim), lambda: _instance_norm(embed_dim))
         self.norm0 = norm_layer[0]()
@@ -184,13 +184,15 @@ class NeuralOperatorBlock(nn.Module):
         self.outer_skip = nn.Conv2d(embed_dim, embed_dim, 1, 1, bias=False)
         gain /= 2.0
         nn.init.normal_(self.outer_skip.weight, std=math.sqrt(gain / embed_dim))
-        self.mlp = _mlp(embed_dim, int(embed_dim * mlp_ratio), act, gain)
+        if use_mlp:
+            self.mlp = _mlp(embed_dim, int(embed_dim * mlp_ratio), act, gain)
 
     def forward(self, x):
         x, residual = self.filter(x)
         x = self.norm0(x)
         x = self.act_layer0(x)
-        x = self.mlp(x)
+        if hasattr(self, "mlp"):
+            x = self.mlp(x)
         x = self.norm1(x)
         x = x + self.outer_skip(residual)
         return x
@@ -206,7 +208,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                  inp_shape=(721, 1440), out_shape=(721, 1440), scale_factor=8, inp_chans=2, out_chans=2,
                  embed_dim=32, num_layers=4, mlp_ratio=2.0, encoder_ratio=1, decoder_ratio=1,
                  activation_function="gelu", encoder_layers=1, hard_thresholding_fraction=1.0, max_modes=None,
-                 big_skip=True, bias=False, normalization_layer="instance_norm", pos_embed="none", **kwargs):
+                 big_skip=True, bias=False, normalization_layer="instance_norm", pos_embed="none", use_mlp=True, **kwargs):
         super().__init__()
         self.inp_shape, self.out_shape = tuple(inp_shape), tuple(out_shape)
         self.inp_chans, self.out_chans, self.embed_dim, self.big_skip = inp_chans, out_chans, embed_dim, big_skip
@@ -238,7 +240,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             fwd = self.trans_down if i == 0 else self.trans
             inv = self.itrans_up if i == num_layers - 1 else self.itrans
             norms = (n_inp, n_mid) if i == 0 else ((n_out, n_out) if i == num_layers - 1 else (n_mid, n_mid))
-            self.blocks.append(NeuralOperatorBlock(fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias, norm_layer=norms))
+            self.blocks.append(NeuralOperatorBlock(fwd, inv, embed_dim, operator_type, mlp_ratio, act, bias, norm_layer=norms,
+                                                   use_mlp=use_mlp))
         self.decoder = _encdec(encoder_layers, embed_dim, out_chans, int(decoder_ratio * embed_dim), act,
                                gain=0.5 if big_skip else 1.0)
         if big_skip:

@@ -11,7 +11,8 @@ import pytest
 import torch
 
 SFNO_GOLDEN = ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz",
-               "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz"]
+               "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz", "sfno_options_a_24x48.npz",
+               "sfno_options_b_24x48.npz"]
 
 from conftest import ROOT, load_golden
 
