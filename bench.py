@@ -134,6 +134,49 @@ class GradReducer:
         self.handles = []
 
 
+def parse_parallelism(par):
+    """'dp' -> (1, 1); 'hHwW' -> (H, W)"""
+    if par == "dp":
+        return 1, 1
+    import re
+    mt = re.fullmatch(r"h(\d+)w(\d+)", par)
+    if not mt:
+        raise SystemExit(f"--parallelism {par!r}: expected 'dp' or 'hHwW'")
+    return int(mt.group(1)), int(mt.group(2))
+
+
+def build_groups(world, rank, ph, pw):
+    """Process-group tree world -> data x (h x w) (makani/utils/comm.py:114-201): model instance d owns the ranks
+    [d*h*w, (d+1)*h*w), laid out h-major; every rank creates every group (torch.distributed requires it) and keeps its
+    own.  Returns (d_idx, ih, iw, data_group, spatial_group, h_group, w_group); groups of size 1 are None."""
+    msize = ph * pw
+    dsize = world // msize
+    d_idx, m_idx = rank // msize, rank % msize
+    ih, iw = m_idx // pw, m_idx % pw
+    data_group = spatial_group = h_group = w_group = None
+    if world > 1:
+        for d in range(dsize):
+            base = d * msize
+            if msize > 1:
+                g = dist.new_group(list(range(base, base + msize)))
+                if d == d_idx:
+                    spatial_group = g
+                for j in range(pw):
+                    g = dist.new_group([base + i * pw + j for i in range(ph)])
+                    if d == d_idx and j == iw:
+                        h_group = g
+                for i in range(ph):
+                    g = dist.new_group([base + i * pw + j for j in range(pw)])
+                    if d == d_idx and i == ih:
+                        w_group = g
+        if dsize > 1:
+            for m in range(msize):
+                g = dist.new_group([d * msize + m for d in range(dsize)])
+                if m == m_idx:
+                    data_group = g
+    return d_idx, ih, iw, data_group, spatial_group, h_group, w_group
+
+
 def build_model(cfg_name, device, seed):
     import makani_amd as ma
     torch.manual_seed(seed)
@@ -310,41 +353,12 @@ def main():
     import makani_amd.distributed as thd
 
     # ---- process-group tree: world -> data x (h x w), as makani/utils/comm.py:114-201 ----
-    par = args.parallelism
-    ph = pw = 1
-    if par != "dp":
-        import re
-        mt = re.fullmatch(r"h(\d+)w(\d+)", par)
-        if not mt:
-            raise SystemExit(f"--parallelism {par!r}: expected 'dp' or 'hHwW'")
-        ph, pw = int(mt.group(1)), int(mt.group(2))
+    ph, pw = parse_parallelism(args.parallelism)
     msize = ph * pw
     if world % msize:
         raise SystemExit(f"world size {world} is not a multiple of h*w = {msize}")
     dsize = world // msize
-    d_idx, m_idx = rank // msize, rank % msize
-    ih, iw = m_idx // pw, m_idx % pw
-    data_group = spatial_group = h_group = w_group = None
-    if world > 1:
-        for d in range(dsize):
-            base = d * msize
-            if msize > 1:
-                g = dist.new_group(list(range(base, base + msize)))
-                if d == d_idx:
-                    spatial_group = g
-                for j in range(pw):
-                    g = dist.new_group([base + i * pw + j for i in range(ph)])
-                    if d == d_idx and j == iw:
-                        h_group = g
-                for i in range(ph):
-                    g = dist.new_group([base + i * pw + j for j in range(pw)])
-                    if d == d_idx and i == ih:
-                        w_group = g
-        if dsize > 1:
-            for m in range(msize):
-                g = dist.new_group([d * msize + m for d in range(dsize)])
-                if m == m_idx:
-                    data_group = g
+    d_idx, ih, iw, data_group, spatial_group, h_group, w_group = build_groups(world, rank, ph, pw)
     if msize > 1:
         thd.init(h_group if ph > 1 else None, w_group if pw > 1 else None, spatial_group)
 

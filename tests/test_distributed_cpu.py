@@ -170,3 +170,65 @@ def _worker_dp(rank, world, port):
 
 def test_data_parallel_grad_reducer_world2():
     mp.spawn(_worker_dp, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _worker_tree(rank, world, port, ph, pw):
+    """bench.build_groups (makani/utils/comm.py:114-201) + GradReducer with model-parallel groups: spectral weights
+    (l-sharded over h) are summed over "w" only, everything else over "spatial", then averaged over "data"
+    (makani/mpu/mappings.py:460-523)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        msize = ph * pw
+        dsize = world // msize
+        d_idx, ih, iw, data_g, spatial_g, h_g, w_g = bench.build_groups(world, rank, ph, pw)
+        assert (d_idx, ih, iw) == (rank // msize, (rank % msize) // pw, (rank % msize) % pw)
+        assert (spatial_g is None) == (msize == 1) and (data_g is None) == (dsize == 1)
+        assert (h_g is None) == (msize == 1) and (w_g is None) == (msize == 1)
+        if msize > 1:
+            assert dist.get_world_size(spatial_g) == msize and dist.get_world_size(h_g) == ph and dist.get_world_size(w_g) == pw
+            assert dist.get_process_group_ranks(h_g) == [d_idx * msize + i * pw + iw for i in range(ph)]
+            assert dist.get_process_group_ranks(w_g) == [d_idx * msize + ih * pw + j for j in range(pw)]
+        if dsize > 1:
+            assert dist.get_process_group_ranks(data_g) == [d * msize + rank % msize for d in range(dsize)]
+
+        model = torch.nn.Module()
+        model.blocks = torch.nn.ModuleList([torch.nn.Module()])
+        model.blocks[0].filter = torch.nn.Module()
+        model.blocks[0].filter.filter = torch.nn.Module()
+        model.blocks[0].filter.filter.weight = torch.nn.Parameter(torch.zeros(1, 3, 3, 4, dtype=torch.complex64))
+        model.enc = torch.nn.Parameter(torch.zeros(6))
+        red = bench.GradReducer(model, data_g, dsize, spatial_g if msize > 1 else None, w_g if pw > 1 else None)
+        w = model.blocks[0].filter.filter.weight
+        ((torch.view_as_real(w).sum() + model.enc.sum()) * float(rank + 1)).backward()
+        red.finish()
+        r1 = lambda ranks: sum(r + 1 for r in ranks)
+        spatial = [d_idx * msize + k for k in range(msize)]
+        wranks = [d_idx * msize + ih * pw + j for j in range(pw)]
+        # expected: mean over data of (sum over the model-parallel group) of (rank + 1)
+        def over_data(fn):
+            tot = 0.0
+            for d in range(dsize):
+                tot += fn(d)
+            return tot / dsize
+        exp_enc = over_data(lambda d: r1([d * msize + k for k in range(msize)]))
+        exp_w = over_data(lambda d: r1([d * msize + ih * pw + j for j in range(pw)]) if pw > 1 else float(d * msize + rank % msize + 1))
+        assert torch.allclose(model.enc.grad, torch.full((6,), exp_enc)), (rank, model.enc.grad, exp_enc)
+        assert torch.allclose(torch.view_as_real(w.grad), torch.full((1, 3, 3, 4, 2), exp_w)), (rank, w.grad.flatten()[0], exp_w)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ph,pw", [(2, 1, 1), (4, 2, 1), (4, 1, 2), (4, 2, 2)])
+def test_group_tree_and_model_parallel_grad_reduction(world, ph, pw):
+    mp.spawn(_worker_tree, args=(world, _free_port(), ph, pw), nprocs=world, join=True)
+
+
+def test_parse_parallelism():
+    import bench
+    assert bench.parse_parallelism("dp") == (1, 1) and bench.parse_parallelism("h4w2") == (4, 2)
+    with pytest.raises(SystemExit):
+        bench.parse_parallelism("tp8")
