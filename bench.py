@@ -134,6 +134,87 @@ class GradReducer:
         self.handles = []
 
 
+def kernel_family(name):
+    """Launch names of the channel GEMMs carry their shape (``conv1x1_wgrad_m384_k768_n115200``): one kernel symbol,
+    nine shapes per step.  The family is what rocprofv3 aggregates under one kernel name."""
+    import re
+    return re.sub(r"_m\d+_k\d+_n\d+$", "", name)
+
+
+def dominant_family(summary):
+    """(family, member launch names) with the largest accumulated time in a LaunchProfiler summary"""
+    fam = {}
+    for k, d in summary.items():
+        fam.setdefault(kernel_family(k), []).append(k)
+    if not fam:
+        return None, []
+    best = max(fam, key=lambda f: sum(summary[k]["ms_total"] for k in fam[f]))
+    return best, sorted(fam[best])
+
+
+def kernel_table(warm_prof, prof, steps):
+    """per launch name: launches/step, mean duration, ms/step, dense TFLOP/s, algorithmic GB/s.  Numbers come from the
+    timed region where a kernel was instrumented there, else from the fully profiled last warm-up step."""
+    table, table_steps = (warm_prof, 1) if warm_prof else (prof, steps)
+    kernels = {}
+    for k, d in sorted(table.items(), key=lambda kv: -kv[1]["ms_total"]):
+        nsteps = table_steps
+        if k in prof:
+            d, nsteps = prof[k], steps
+        tf = d["flops"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e12 if d["flops"] else None
+        gb = d["bytes"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e9
+        kernels[k] = dict(launches_per_step=d["launches"] / nsteps, ms_avg=round(d["ms_avg"], 4),
+                          ms_per_step=round(d["ms_total"] / nsteps, 3),
+                          TFLOPs_dense=round(tf, 2) if tf else None, GBps_algorithmic=round(gb, 1))
+    return kernels
+
+
+def roofline_of(family, members, prof, gemm_mode, traffic):
+    """The ``roofline`` object for one kernel family: algorithmic flops / bytes per launch (summed over the family's
+    launches in ``prof``) over its mean launch duration.  Bound: HBM for kernels without matrix work; for the bf16
+    channel GEMMs whichever roof the shape mix sits under (arithmetic intensity vs 2500 TF / 8 TB/s = 312 flop/B);
+    the fp32 spectral GEMMs are priced against the matrix rate of the engine they run on."""
+    ds = [prof[m] for m in members if m in prof]
+    launches = sum(d["launches"] for d in ds)
+    if not launches:
+        return None
+    ms_avg = sum(d["ms_total"] for d in ds) / launches
+    flops = sum(d["flops"] for d in ds) / launches
+    nbytes = sum(d["bytes"] for d in ds) / launches
+    tf = flops / (ms_avg * 1e-3) / 1e12
+    gb = nbytes / (ms_avg * 1e-3) / 1e9
+    base = dict(kernel=family, launches=launches, ms_avg=round(ms_avg, 4), algorithmic_bytes=int(nbytes),
+                algorithmic_flops=int(flops), traffic=traffic)
+    if len(members) > 1:
+        base["shapes"] = members
+    if not flops:
+        return dict(base, bound="hbm", achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gb / PEAK_HBM_GBS, 4))
+    if family.startswith("conv1x1"):
+        if flops / (PEAK_BF16_MFMA_TF * 1e12) < nbytes / (PEAK_HBM_GBS * 1e9):      # below the ridge: HBM is the roof
+            return dict(base, bound="hbm", achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=round(gb / PEAK_HBM_GBS, 4), TFLOPs=round(tf, 1),
+                        note=f"bf16 channel GEMM, {flops / nbytes:.0f} flop/B < 312 flop/B ridge: HBM-bound; "
+                             f"{tf:.0f} TF = {tf / PEAK_BF16_MFMA_TF:.3f} of the bf16 MFMA peak")
+        return dict(base, bound="mfma", achieved=round(tf, 2), peak=PEAK_BF16_MFMA_TF, unit="TFLOP/s",
+                    frac=round(tf / PEAK_BF16_MFMA_TF, 4), GBps=round(gb, 1), note="bf16 MFMA")
+    peak, eng = {"fp32": (PEAK_F32_MFMA_TF, "exact-fp32 MFMA"),
+                 "x6": (PEAK_BF16_MFMA_TF / 6, "bf16 MFMA, 6 limb products per fp32 product"),
+                 "x3": (PEAK_BF16_MFMA_TF / 3, "bf16 MFMA, 3 limb products per fp32 product")}[gemm_mode]
+    return dict(base, bound="mfma", achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
+                note=f"dense-formulation fp32-equivalent flops per launch / HIP-event launch time; engine: {eng}; "
+                     f"the kernel skips the structurally-zero l<m half (DESIGN.md §4)")
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 counters cannot be collected from inside the timed
+    run; profiles/r01_pmc_hbm_traffic.json says how they were taken)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
+            return {k: v["hbm_bytes"] for k, v in json.load(fh).items() if isinstance(v, dict) and "hbm_bytes" in v}
+    except (OSError, ValueError):
+        return {}
+
+
 def parse_parallelism(par):
     """'dp' -> (1, 1); 'hHwW' -> (H, W)"""
     if par == "dp":
@@ -394,7 +475,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    warm_prof, warm_dom = {}, None
+    warm_prof, dom_family, dom_members = {}, None, []
     for i in range(args.warmup):
         last = i == args.warmup - 1
         if last:
@@ -406,13 +487,12 @@ def main():
             torch.cuda.synchronize()
             ops.PROFILER.enabled = False
             warm_prof = ops.PROFILER.summary()
-            if warm_prof:
-                warm_dom = max(warm_prof, key=lambda k: warm_prof[k]["ms_total"])
+            dom_family, dom_members = dominant_family(warm_prof)
     torch.cuda.synchronize()
 
     ops.PROFILER.reset()
     ops.PROFILER.enabled = True
-    ops.PROFILER.only = {warm_dom} if warm_dom else None      # HIP events on the dominant kernel only (see above)
+    ops.PROFILER.only = set(dom_members) if dom_members else None      # HIP events on the dominant kernel only (see above)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -435,53 +515,22 @@ def main():
 
     if rank == 0:
         prof = ops.PROFILER.summary()           # timed region: the dominant kernel (or everything with --warmup 0)
-        # dominant HIP kernel = largest accumulated time among our launches
-        dom_name = warm_dom if warm_dom in prof else (max(prof, key=lambda k: prof[k]["ms_total"]) if prof else None)
-        roofline = None
-        kernels = {}
-        table, table_steps = (warm_prof, 1) if warm_prof else (prof, args.steps)
-        for k, d in sorted(table.items(), key=lambda kv: -kv[1]["ms_total"]):
-            if k in prof:                        # timed-region numbers where we have them
-                d, nsteps = prof[k], args.steps
-            else:
-                nsteps = table_steps
-            tf = d["flops"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e12 if d["flops"] else None
-            gb = d["bytes"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e9
-            kernels[k] = dict(launches_per_step=d["launches"] / nsteps, ms_avg=round(d["ms_avg"], 4),
-                              ms_per_step=round(d["ms_total"] / nsteps, 3),
-                              TFLOPs_dense=round(tf, 2) if tf else None, GBps_algorithmic=round(gb, 1))
-        # HBM traffic per launch of the same kernel from the committed PMC passes (rocprofv3 counters cannot be
-        # collected from inside the timed run; profiles/r01_pmc_hbm_traffic.json says how they were taken)
-        pmc = {}
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")) as fh:
-                pmc = json.load(fh)
-        except OSError:
-            pass
-
-        def traffic_of(name):
-            t = pmc.get(name)
-            return t["hbm_bytes"] if isinstance(t, dict) and args.config == "sfno_sc3_layers8_edim384" and msize == 1 else None
-
-        if dom_name:
-            d = prof[dom_name]
-            if d["flops"]:
-                ach = d["flops"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e12
-                if dom_name.startswith("conv1x1"):
-                    peak, eng = PEAK_BF16_MFMA_TF, "bf16 MFMA"
-                else:   # fp32 spectral GEMM: peak of the engine it runs on, in fp32-equivalent flops
-                    peak, eng = {"fp32": (PEAK_F32_MFMA_TF, "exact-fp32 MFMA"),
-                                 "x6": (PEAK_BF16_MFMA_TF / 6, "bf16 MFMA, 6 limb products per fp32 product"),
-                                 "x3": (PEAK_BF16_MFMA_TF / 3, "bf16 MFMA, 3 limb products per fp32 product")}[ops.GEMM_MODE]
-                roofline = dict(kernel=dom_name, bound="mfma", achieved=round(ach, 2), peak=round(peak, 1),
-                                unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic_of(dom_name),
-                                algorithmic_bytes=int(d["bytes"] / d["launches"]),
-                                note=f"dense-formulation fp32-equivalent flops per launch / HIP-event launch time; "
-                                     f"engine: {eng}; the kernel skips the structurally-zero l<m half (DESIGN.md §4)")
-            else:
-                ach = d["bytes"] / d["launches"] / (d["ms_avg"] * 1e-3) / 1e9
-                roofline = dict(kernel=dom_name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic_of(dom_name))
+        # dominant HIP kernel = the kernel family with the largest accumulated time among our launches (what the
+        # rocprofv3 --stats table of the same command shows on top); its numbers come from the timed steps
+        if not (dom_family and any(m in prof for m in dom_members)):
+            dom_family, dom_members = dominant_family(prof)
+        kernels = kernel_table(warm_prof, prof, args.steps)
+        pmc = load_pmc_traffic() if (args.config == "sfno_sc3_layers8_edim384" and msize == 1) else {}
+        roofline = roofline_of(dom_family, dom_members, prof, ops.GEMM_MODE, pmc.get(dom_family)) if dom_family else None
+        # the runners-up, from the fully profiled warm-up step (one launch set, not an average over the timed steps)
+        others = []
+        if warm_prof:
+            fams = {}
+            for k in warm_prof:
+                fams.setdefault(kernel_family(k), []).append(k)
+            rank_f = sorted(fams, key=lambda f: -sum(warm_prof[k]["ms_total"] for k in fams[f]))
+            for f in [f for f in rank_f if f != dom_family][:4]:
+                others.append(roofline_of(f, sorted(fams[f]), warm_prof, ops.GEMM_MODE, pmc.get(f)))
         hip_ms = sum(v["ms_per_step"] for v in kernels.values())
         out = {
             "metric": f"SFNO train samples/sec at {H}x{W}x{cfg['inp_chans']}ch",
@@ -502,6 +551,7 @@ def main():
                        "multistep_count": args.multistep_count,
                        "multistep_checkpoint": bool(args.multistep_checkpoint)},
             "roofline": roofline,
+            "roofline_runners_up": others,
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
             "hip_kernels": kernels,
             "hip_kernel_ms_per_step": round(hip_ms, 2),

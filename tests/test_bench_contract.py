@@ -40,3 +40,52 @@ def test_bench_multistep_rollout_runs():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["multistep_count"] == 3 and d["config"]["multistep_checkpoint"] is True
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
+
+
+def _rec(launches, ms_avg, flops_per, bytes_per):
+    return dict(launches=launches, ms_avg=ms_avg, ms_total=launches * ms_avg, flops=launches * flops_per, bytes=launches * bytes_per)
+
+
+def test_roofline_report_on_a_synthetic_profile():
+    """the pure reporting functions of bench.py: the dominant kernel is chosen per kernel FAMILY (the nine shapes of the
+    channel-GEMM weight gradient are one kernel symbol in the rocprofv3 table), priced against the roof it sits under"""
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = {
+        "conv1x1_wgrad_m384_k768_n115200": _rec(70, 0.129, 2.0 * 384 * 768 * 115200, 2.0 * 115200 * (384 + 768)),
+        "conv1x1_wgrad_m384_k384_n1038240": _rec(30, 0.539, 2.0 * 384 * 384 * 1038240, 2.0 * 1038240 * (384 + 384)),
+        "dhconv_dgrad": _rec(80, 0.330, 68.23e9, 638.5e6),
+        "rfft_1440": _rec(30, 0.55, 0.0, 1331e6),
+    }
+    assert bench.kernel_family("conv1x1_wgrad_m384_k768_n115200") == "conv1x1_wgrad"
+    assert bench.kernel_family("legendre_analysis_k240") == "legendre_analysis_k240"
+    fam, members = bench.dominant_family(prof)
+    assert fam == "dhconv_dgrad" and members == ["dhconv_dgrad"]          # 26.4 ms vs 9.0 + 16.2 = 25.2 ms
+    prof["conv1x1_wgrad_m768_k384_n115200"] = _rec(70, 0.127, 2.0 * 384 * 768 * 115200, 2.0 * 115200 * (384 + 768))
+    fam, members = bench.dominant_family(prof)
+    assert fam == "conv1x1_wgrad" and len(members) == 3
+
+    r = bench.roofline_of(fam, members, prof, "x6", None)
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes"):
+        assert k in r, k
+    assert r["kernel"] == "conv1x1_wgrad" and r["shapes"] == members and r["traffic"] is None
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0          # 250-330 flop/B: under the ridge
+    tot_b = sum(prof[m]["bytes"] for m in members)
+    tot_ms = sum(prof[m]["ms_total"] for m in members)
+    assert abs(r["achieved"] - tot_b / tot_ms / 1e6) < 0.1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+    d = bench.roofline_of("dhconv_dgrad", ["dhconv_dgrad"], prof, "x6", 473456640)
+    assert d["bound"] == "mfma" and abs(d["peak"] - 2500.0 / 6) < 0.1 and d["traffic"] == 473456640
+    assert abs(d["achieved"] - 68.23e9 / 0.330e-3 / 1e12) < 0.01 and "shapes" not in d
+    assert abs(bench.roofline_of("dhconv_dgrad", ["dhconv_dgrad"], prof, "fp32", None)["peak"] - 157.3) < 1e-6
+    f = bench.roofline_of("rfft_1440", ["rfft_1440"], prof, "x6", 1527091200)
+    assert f["bound"] == "hbm" and abs(f["achieved"] - 1331e6 / 0.55e-3 / 1e9) < 0.1
+    assert bench.roofline_of("nothing", ["nothing"], prof, "x6", None) is None
+
+    t = bench.kernel_table({}, prof, 10)
+    assert t["dhconv_dgrad"]["launches_per_step"] == 8 and abs(t["dhconv_dgrad"]["ms_per_step"] - 2.64) < 1e-9
+    warm = {"adamw": _rec(8, 0.39, 0.0, 1.98e9), **{k: _rec(v["launches"] // 10, v["ms_avg"], v["flops"] / v["launches"], v["bytes"] / v["launches"]) for k, v in prof.items()}}
+    t = bench.kernel_table(warm, {"dhconv_dgrad": prof["dhconv_dgrad"]}, 10)
+    assert t["adamw"]["launches_per_step"] == 8 and t["dhconv_dgrad"]["launches_per_step"] == 8
+    pm = bench.load_pmc_traffic()
+    assert pm.get("dhconv_dgrad", 0) > 0 and all(isinstance(v, (int, float)) for v in pm.values())
