@@ -16,7 +16,7 @@ no noise), and what remains is the part that decides the cost of a rollout on th
   ``bench.py --multistep-count 4``: 88.5 GB peak and 203 ms per 4-step sample without, 33.4 GB and 276 ms with
   checkpointing — on 288 GB of HBM the plain rollout is the faster default, checkpointing buys batch size.
   The HIP autograd functions hold no private RNG state and write their saved tensors only once, so recomputation is
-  bit-identical to the first forward (``tests/test_gpu_model.py::test_rollout_checkpointing_is_exact``).
+  bit-identical to the first forward (``tests/test_gpu_model.py::test_rollout_checkpointing_is_exact_and_matches_manual_unroll``).
 
 Evaluation mode performs ONE step (``stepper.py:286-313``): inference drives the rollout itself.
 """
