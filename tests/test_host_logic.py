@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -185,3 +186,30 @@ def test_product_never_imports_oracle():
     for path in glob.glob(os.path.join(ROOT, "makani_amd", "**", "*.py"), recursive=True):
         src = open(path).read()
         assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), path
+
+
+def test_network_registers_with_the_reference_model_registry():
+    """boundary B3 against the reference's own registry code (makani/models/model_registry.py:36-119): registration by
+    class and by the "file.py:Class" string of the yaml `nettype` key; runs where the reference tree is present"""
+    from oracle import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip("reference tree not present")
+    mr = ref_shims.import_reference_module("makani.models.model_registry")
+    import makani_amd as ma
+    sys.path.insert(0, ROOT)
+    import makani_plugin
+    for n in ("SFNO_mi355x", "SFNO_mi355x_file"):
+        mr._model_registry.pop(n, None)
+    makani_plugin.register("SFNO_mi355x")
+    assert "SFNO_mi355x" in mr.list_models() and mr._model_registry["SFNO_mi355x"] is ma.SphericalFourierNeuralOperatorNet
+    with pytest.raises(ValueError):
+        makani_plugin.register("SFNO_mi355x")                       # name already in use
+    mr.register_model(os.path.join(ROOT, "makani_plugin.py") + ":SphericalFourierNeuralOperatorNet", "SFNO_mi355x_file")
+    cls = mr._model_registry["SFNO_mi355x_file"]
+    assert cls.__name__ == "SphericalFourierNeuralOperatorNet"
+    # constructed the way get_model does (model_registry.py:201,228-235): shapes + channels + the yaml's keys, unknown ones ignored
+    net = cls(inp_shape=(16, 32), out_shape=(16, 32), inp_chans=3, out_chans=3, scale_factor=2, embed_dim=8, num_layers=2,
+              nettype="SFNO_mi355x_file", lr=1e-3, losses=[{"type": "l2"}])
+    assert isinstance(net, ma.SphericalFourierNeuralOperatorNet) or type(net).__name__ == "SphericalFourierNeuralOperatorNet"
+    for n in ("SFNO_mi355x", "SFNO_mi355x_file"):
+        mr._model_registry.pop(n, None)
