@@ -213,3 +213,41 @@ def test_network_registers_with_the_reference_model_registry():
     assert isinstance(net, ma.SphericalFourierNeuralOperatorNet) or type(net).__name__ == "SphericalFourierNeuralOperatorNet"
     for n in ("SFNO_mi355x", "SFNO_mi355x_file"):
         mr._model_registry.pop(n, None)
+
+
+def test_reference_get_model_builds_and_drives_the_network():
+    """the reference's own get_model (model_registry.py:123-262) constructs the registered MI355X network from a
+    yaml-shaped parameter set (every yaml key arrives as a constructor kwarg), wraps it in its MultiStepWrapper +
+    Preprocessor2D, and the wrapped forward reaches the HIP path (which refuses CPU tensors: there is no fallback)"""
+    from oracle import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip("reference tree not present")
+    mr = ref_shims.import_reference_module("makani.models.model_registry")
+    ParamsBase = ref_shims.import_reference_module("makani.utils.YParams").ParamsBase
+    import makani_amd as ma
+    sys.path.insert(0, ROOT)
+    import makani_plugin
+    mr._model_registry.pop("SFNO_mi355x", None)
+    makani_plugin.register("SFNO_mi355x")
+    p = ParamsBase()
+    cfg = dict(nettype="SFNO_mi355x", model_grid_type="equiangular", sht_grid_type="legendre-gauss", filter_type="linear",
+               scale_factor=2, embed_dim=8, num_layers=2, complex_activation="real", normalization_layer="instance_norm",
+               hard_thresholding_fraction=1.0, use_mlp=True, mlp_mode="serial", mlp_ratio=2, separable=False,
+               operator_type="dhconv", activation_function="gelu", pos_embed="none",
+               losses=[{"type": "l2", "channel_weights": "auto"}], lr=1e-3, batch_size=2, weight_decay=0.0,
+               img_shape_x=16, img_shape_y=32, img_shape_x_resampled=16, img_shape_y_resampled=32, N_in_channels=3,
+               N_out_channels=3, n_history=0, n_future=2, history_normalization_mode="none", channel_names=["a", "b", "c"])
+    for k, v in cfg.items():
+        p[k] = v
+    try:
+        m = mr.get_model(p, multistep=True)
+        assert type(m).__name__ == "MultiStepWrapper" and isinstance(m.model, ma.SphericalFourierNeuralOperatorNet)
+        assert (m.model.inp_shape, m.model.out_shape, m.model.inp_chans, m.model.out_chans) == ((16, 32), (16, 32), 3, 3)
+        assert m.model.embed_dim == 8 and len(m.model.blocks) == 2 and m.n_future == 2
+        m.train()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m(torch.rand(2, 3, 16, 32))
+        s = mr.get_model(p, multistep=False)
+        assert type(s).__name__ == "SingleStepWrapper" and isinstance(s.model, ma.SphericalFourierNeuralOperatorNet)
+    finally:
+        mr._model_registry.pop("SFNO_mi355x", None)
