@@ -251,3 +251,26 @@ def test_reference_get_model_builds_and_drives_the_network():
         assert type(s).__name__ == "SingleStepWrapper" and isinstance(s.model, ma.SphericalFourierNeuralOperatorNet)
     finally:
         mr._model_registry.pop("SFNO_mi355x", None)
+
+
+def test_reference_spectral_conv_accepts_the_hip_transforms():
+    """boundary B1: the reference's own SpectralConv (spectral_convolution.py:116-211) built around makani_amd's
+    transform objects reads the attributes it needs (nlat / nlon / lmax / mmax / grid) and ends up with the same
+    configuration as makani_amd.SpectralConv around the same objects"""
+    from oracle import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip("reference tree not present")
+    sc = ref_shims.import_reference_module("makani.models.common.spectral_convolution")
+    import makani_amd as ma
+    f = ma.RealSHT(33, 64, lmax=12, mmax=13, grid="equiangular").float()
+    i = ma.InverseRealSHT(12, 24, lmax=12, mmax=13, grid="legendre-gauss").float()
+    torch.manual_seed(0)
+    ref = sc.SpectralConv(f, i, 8, 6, operator_type="dhconv", bias=True, gain=2.0)
+    torch.manual_seed(0)
+    own = ma.SpectralConv(f, i, 8, 6, operator_type="dhconv", bias=True, gain=2.0)
+    assert ref.weight.shape == own.weight.shape and torch.equal(ref.weight, own.weight)          # same init stream
+    assert (ref.modes_lat, ref.modes_lon, ref.scale_residual) == (own.modes_lat, own.modes_lon, own.scale_residual) == (12, 13, True)
+    assert (ref.modes_lat_local, ref.modes_lon_local, ref.nlat_local, ref.nlon_local) == (12, 13, 12, 24)
+    assert ref.weight.is_shared_mp == own.weight.is_shared_mp and ref.weight.sharded_dims_mp == own.weight.sharded_dims_mp
+    assert list(ref.state_dict().keys()) == [k for k in own.state_dict().keys() if not k.startswith(("forward_transform", "inverse_transform"))] \
+        or list(ref.state_dict().keys()) == list(own.state_dict().keys())
