@@ -319,6 +319,7 @@ class DistributedRealSHT(RealSHT, _DistBase):
         S = transpose(S, 0, self.l_shapes, 3, ph, polar_group(), pad_dims=(3,))        # (L_loc, M_loc, 2, round4(P))
         return S
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from .sht import _as4d
         x4, lead = _as4d(x, 2)
@@ -355,6 +356,7 @@ class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
         x = transpose(x, 3, self.lon_shapes, 1, pw, azimuth_group())                  # (1, P, hl, wl)
         return x.reshape(B, C, hl, wl)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, c: torch.Tensor) -> torch.Tensor:
         from .sht import _as4d
         c4, lead = _as4d(c, 2)
@@ -378,6 +380,7 @@ class DistributedInstanceNorm2d(nn.Module):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x, fuse_gelu=False):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError(f"expected (B, {self.num_features}, H, W), got {tuple(x.shape)}")

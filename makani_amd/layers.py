@@ -58,6 +58,7 @@ class PointwiseConv(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             return ops.ConvMmFn.apply(x.contiguous(), self.weight, add_to)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x, add_to=None):
         if hip_conv_eligible(x):
             xb = x.to(torch.bfloat16)
@@ -77,6 +78,7 @@ class _Act(nn.Module):
         self.is_gelu = act_layer is nn.GELU
         self.act = None if self.is_gelu else act_layer()
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
         return ops.BiasGeluFn.apply(x, None) if self.is_gelu else self.act(x)
 
@@ -130,11 +132,13 @@ class MLP(nn.Module):
         return (self.fwd[3].bias is not None and not self.checkpointing and _DEFER_BIAS
                 and not (self.fwd[1].is_gelu and hip_conv_eligible(x)))
 
+    @torch.compiler.disable(recursive=True)
     def forward_deferred_bias(self, x):
         """(fc2(act(fc1(x))) WITHOUT the output bias, that bias): for a caller that folds it into its next op"""
         h = _conv_act(self.fwd[0], self.fwd[1], x)
         return self.fwd[3].matmul(h), self.fwd[3].bias
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
         if self.checkpointing and torch.is_grad_enabled():
             return torch.utils.checkpoint.checkpoint(self._run, x, use_reentrant=False)
@@ -163,6 +167,7 @@ class EncoderDecoder(nn.Module):
         mods.append(c)
         self.fwd = nn.Sequential(*mods)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
         mods = list(self.fwd)
         if len(mods) == 3 and mods[1].is_gelu and hip_conv_eligible(x):
@@ -193,6 +198,7 @@ class InstanceNorm2d(nn.Module):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x, fuse_gelu=False, pre_bias=None):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError(f"expected (B, {self.num_features}, H, W), got {tuple(x.shape)}")
@@ -219,6 +225,7 @@ class GeometricInstanceNormS2(nn.Module):
                                          crop_offset=crop_offset, normalize=True, distributed=False)
         self._qsum = float(self.quadrature.quad_weight.double().sum())      # 1 on the full grid, < 1 on a crop
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x, fuse_gelu=False):
         q = self.quadrature.quad_weight
         if x.dim() != 4 or tuple(x.shape[-2:]) != tuple(q.shape[-2:]):

@@ -136,6 +136,7 @@ class GridQuadrature(nn.Module):
             quad = thd.reduce_from_spatial_region(quad.contiguous())
         return quad
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._reduce(QuadLpFn.apply(x, None, None, self.quad_weight, 0, 1.0).to(x.dtype))
 
@@ -261,6 +262,7 @@ class SpectralLpLoss(nn.Module):
             normp, tar_normp = normp.pow(1.0 / self.p), tar_normp.pow(1.0 / self.p)
         return normp / (tar_normp + self.eps)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None, **kwargs):
         return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)
 
@@ -332,5 +334,6 @@ class GeometricLpLoss(nn.Module):
             norms = norms.pow(1.0 / self.p)
         return norms
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None, **kwargs):
         return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)

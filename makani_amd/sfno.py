@@ -38,6 +38,7 @@ class SpectralFilterLayer(nn.Module):
         self.filter = SpectralConv(forward_transform, inverse_transform, embed_dim, embed_dim,
                                    operator_type=operator_type, separable=separable, bias=bias, gain=gain)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
         return self.filter(x)
 
@@ -106,6 +107,7 @@ class NeuralOperatorBlock(nn.Module):
         if final_activation:
             self.act_layer1 = act_layer()
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
         x, residual = self.filter(x)
 
@@ -281,6 +283,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 x = blk(x)
         return x
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
         if self.big_skip:
             if self.out_shape != self.inp_shape:

@@ -81,6 +81,7 @@ class RealSHT(_SHTBase):
         F = ops.RfftFn.apply(x4, self.mmax, ops.round4(x4.shape[1]), self._w)
         return ops.AnalysisFn.apply(F, self.weights, self.weights_t)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError(f"RealSHT (HIP) supports float32 / bfloat16 input, got {x.dtype}")
@@ -106,6 +107,7 @@ class InverseRealSHT(_SHTBase):
         F = ops.SynthesisFn.apply(S, self.pct, self.pct_t, self.nlat)
         return ops.IrfftFn.apply(F, B, C, self.nlon, out_dtype, self._w)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, c: torch.Tensor) -> torch.Tensor:
         if c.dtype != torch.complex64:
             raise TypeError(f"InverseRealSHT (HIP) supports complex64 input, got {c.dtype}")

@@ -111,6 +111,7 @@ class SpectralConv(nn.Module):
             return ops.GroupedDhconvFn.apply(S, w, B, self._tri_off)
         return ops.DhconvFn.apply(S, w, B, self._tri_off)
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
         if x.dim() != 4:
             raise ValueError(f"expected (B, C, H, W), got {tuple(x.shape)}")

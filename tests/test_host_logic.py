@@ -274,3 +274,20 @@ def test_reference_spectral_conv_accepts_the_hip_transforms():
     assert ref.weight.is_shared_mp == own.weight.is_shared_mp and ref.weight.sharded_dims_mp == own.weight.sharded_dims_mp
     assert list(ref.state_dict().keys()) == [k for k in own.state_dict().keys() if not k.startswith(("forward_transform", "inverse_transform"))] \
         or list(ref.state_dict().keys()) == list(own.state_dict().keys())
+
+
+def test_modules_opt_out_of_torch_compile():
+    """makani compiles the model when jit_mode == "inductor" (utils/training/deterministic_trainer.py:316-319).  The HIP
+    path is launched through a C ABI that dynamo cannot trace, so every public module forward is marked
+    torch.compiler.disable (as the reference marks its own untraceable parts, sfnonet.py:765,840): a compiled wrapper
+    simply runs the eager HIP path."""
+    import makani_amd as ma
+    net = ma.SphericalFourierNeuralOperatorNet(inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2, embed_dim=8, num_layers=2,
+                                               inp_chans=2, out_chans=2)
+    mods = [net, net.blocks[0], net.blocks[0].filter.filter, net.trans, net.itrans, net.encoder, net.blocks[0].mlp, net.blocks[0].norm0,
+            ma.GeometricLpLoss(img_shape=(16, 32), crop_shape=(16, 32), crop_offset=(0, 0), channel_names=["a", "b"], p=2.0)]
+    for m in mods:
+        assert getattr(m.forward, "_torchdynamo_disable", False), type(m).__name__
+    compiled = torch.compile(net)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):       # reaches the HIP entry point, not a dynamo error
+        compiled(torch.randn(1, 2, 16, 32))
