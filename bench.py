@@ -19,6 +19,7 @@ import sys
 import time
 
 os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver (already exported on the boxes)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
