@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmakani_amd.so")
+# MAKANI_AMD_LIB: a variant of the library built by tools/ab.py (same-box A/B measurements); default: the in-tree build
+LIB_PATH = os.environ.get("MAKANI_AMD_LIB") or os.path.join(_HERE, "libmakani_amd.so")
 
 MK_F32, MK_BF16 = 0, 1
 TRI_NONE, TRI_ROW_GE, TRI_K_GE, TRI_ROW_LE, TRI_K_LE = 0, 1, 2, 3, 4

@@ -24,9 +24,13 @@ def _stale(obj, src):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    """Compile every csrc/*.hip to an object and link the shared library."""
-    objdir = os.path.join(HERE, "build")
+def build(force=False, verbose=True, defines=(), tag=None):
+    """Compile every csrc/*.hip to an object and link the shared library.
+    ``tag`` / ``defines``: a variant build (``libmakani_amd_<tag>.so``, objects under ``build_<tag>/``) compiled with extra
+    ``-D`` options — what tools/ab.py uses for A/B measurements inside one GPU call; the default build is untouched."""
+    objdir = os.path.join(HERE, "build" + (f"_{tag}" if tag else ""))
+    LIB = os.path.join(HERE, f"libmakani_amd_{tag}.so") if tag else globals()["LIB"]
+    FLAGS = globals()["FLAGS"] + [d if d.startswith("-D") else "-D" + d for d in defines]
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for src in sources():
@@ -49,5 +53,6 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else None
+    print(build(force="--force" in argv, defines=[a for a in argv if a.startswith("-D")], tag=tag))
