@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import comm as _comm
 from . import legendre as _leg
 from . import ops
 from .sht import RealSHT, InverseRealSHT
@@ -69,6 +70,18 @@ def spatial_size() -> int:
 
 def is_initialized() -> bool:
     return _INIT
+
+
+def ensure_initialized() -> bool:
+    """``sfnonet.py:786-789``: when the process-group tree (``makani_amd.comm``: built by ``comm.init(h, w)`` or adopted
+    from ``makani.utils.comm``) names a split ``spatial`` group and nobody called ``init`` yet, do it from the tree's
+    ``h`` / ``w`` groups.  Returns whether spatial model parallelism is active."""
+    if not _INIT:
+        _comm.autodetect()
+        if _comm.get_size("spatial") > 1:
+            init(_comm.get_group("h") if _comm.get_size("h") > 1 else None,
+                 _comm.get_group("w") if _comm.get_size("w") > 1 else None, _comm.get_group("spatial"))
+    return _INIT and spatial_size() > 1
 
 
 def polar_group():
@@ -385,3 +398,177 @@ class DistributedInstanceNorm2d(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError(f"expected (B, {self.num_features}, H, W), got {tuple(x.shape)}")
         return ops.DistInstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, spatial_group())
+
+
+# --------------------------------------------------------------------------- #
+# gradient reduction (makani/mpu/mappings.py:321-525) and the sharded gradient norm
+# (makani/utils/training/training_helpers.py:123-165)
+# --------------------------------------------------------------------------- #
+def _real(g):
+    return torch.view_as_real(g) if g.is_complex() else g
+
+
+class GradReducer:
+    """The reductions of makani's communication hook (``mappings.py:460-523``) issued from post-accumulate-grad hooks
+    so that they overlap with the rest of backward:
+
+      * MEAN over the ``data`` group for every parameter;
+      * SUM over every model-parallel group named in ``param.is_shared_mp`` (a parameter without the annotation counts
+        as shared over ``model``, ``mappings.py:398-401``): the l-sharded dhconv weights carry ``["matmul", "w"]``, the
+        pointwise weights and norm parameters ``["spatial"]``, a position embedding ``[]``.
+
+    A gradient of >= ``big_bytes`` is all-reduced on its own as soon as it is final (the eight 283 MB spectral weights are
+    natural large xGMI messages); when it belongs to several groups the later stages are chained in ``finish()`` without
+    any copy.  Smaller gradients are flattened into one bucket per reduction signature; the reduced bucket then BECOMES
+    the gradients (views), so nothing is copied back.  ``finish()`` runs automatically at the end of ``backward()``
+    (autograd engine callback, the mechanism DDP uses) and is idempotent, so calling it explicitly is harmless."""
+
+    def __init__(self, model, comm=None, big_bytes=8 << 20):
+        self.comm = comm or _comm
+        self.big_bytes = big_bytes
+        self.pending = []          # (work, real-view gradient, remaining stages)
+        self.small = {}            # signature -> (stages, [params])
+        self._armed = False
+        self.plan = {}
+        data_size = self.comm.get_size("data")
+        names = [n for n in self.comm.get_comm_names() if n != "data" and self.comm.get_size(n) > 1]
+        # "model" and "spatial" may be the same ranks under two names (no matmul parallelism): reduce once
+        seen_members = {}
+        self._avg = False
+        if data_size > 1:
+            self._avg = self._probe_avg(self.comm.get_group("data"), next(model.parameters()).device)
+        for pname, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            shared = getattr(p, "is_shared_mp", None)
+            if shared is None:
+                shared = ["model"]
+            stages, used = [], set()
+            for n in names:
+                if n in shared:
+                    g = self.comm.get_group(n)
+                    if id(g) in used:
+                        continue
+                    used.add(id(g))
+                    stages.append((g, "sum", 1.0))
+            if data_size > 1:
+                stages.append((self.comm.get_group("data"), "avg" if self._avg else "sum", 1.0 if self._avg else 1.0 / data_size))
+            self.plan[pname] = stages
+            if stages:
+                p.register_post_accumulate_grad_hook(lambda q, st=tuple(stages): self._hook(q, st))
+        self.active = any(self.plan.values())
+
+    @staticmethod
+    def _probe_avg(group, device):
+        """RCCL averages inside the collective (ReduceOp.AVG): no scaling pass afterwards.  gloo has no AVG."""
+        try:
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+            return abs(float(probe) - 1.0) < 1e-6
+        except (RuntimeError, ValueError, NotImplementedError):
+            return False
+
+    @staticmethod
+    def _issue(t, stage):
+        g, kind, _ = stage
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG if kind == "avg" else dist.ReduceOp.SUM, group=g, async_op=True)
+
+    def _arm(self):
+        if not self._armed:
+            self._armed = True
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(self.finish)
+
+    def _hook(self, p, stages):
+        self._arm()
+        g = _real(p.grad)
+        if g.numel() * g.element_size() >= self.big_bytes and g.is_contiguous():
+            self.pending.append([self._issue(g, stages[0]), g, list(stages)])
+        else:
+            self.small.setdefault(tuple((id(s[0]), s[1]) for s in stages), (stages, []))[1].append(p)
+
+    def finish(self):
+        self._armed = False
+        for stages, params in self.small.values():
+            params = sorted(params, key=lambda q: not q.grad.is_complex())     # complex first: their views need even offsets
+            flat = torch.cat([_real(q.grad).reshape(-1) for q in params])
+            for st in stages:
+                self._issue(flat, st).wait()
+                if st[2] != 1.0:
+                    flat.mul_(st[2])
+            off = 0
+            for q in params:            # the reduced bucket becomes the gradients (views, no copy-back kernels)
+                n = _real(q.grad).numel()
+                piece = flat[off:off + n]
+                q.grad = torch.view_as_complex(piece.view(*q.grad.shape, 2)) if q.grad.is_complex() else piece.view_as(q.grad)
+                off += n
+        self.small = {}
+        while self.pending:
+            nxt = []
+            for work, g, stages in self.pending:
+                work.wait()
+                if stages[0][2] != 1.0:
+                    g.mul_(stages[0][2])
+                if len(stages) > 1:
+                    nxt.append([self._issue(g, stages[1]), g, stages[1:]])
+            self.pending = nxt
+
+
+class GradReduceWrapper(nn.Module):
+    """What ``init_gradient_reduction_hooks`` returns: the model under ``.module`` (as DDP exposes it) with the
+    reductions armed; ``backward()`` alone completes them."""
+
+    def __init__(self, module, reducer):
+        super().__init__()
+        self.module = module
+        self.reducer = reducer
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def init_gradient_reduction_hooks(model, device=None, reduction_buffer_count=1, broadcast_buffers=True,
+                                  find_unused_parameters=False, gradient_as_bucket_view=True, static_graph=False,
+                                  verbose=None, comm=None):
+    """Signature and semantics of ``makani/mpu/mappings.py:321-525``: returns the model unchanged when
+    ``torch.distributed`` is not initialised, otherwise a wrapper (``.module`` = the model) whose backward pass performs
+    the data-parallel mean and the per-group sums of the ``is_shared_mp`` annotations.  The DDP-specific knobs are
+    accepted for call compatibility; buffers are never broadcast (sharded Legendre buffers legitimately differ)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return model
+    c = comm or _comm
+    if not c.is_initialized():
+        c.autodetect()
+    red = GradReducer(model, c)
+    if verbose:
+        for n, st in red.plan.items():
+            print(f"[grad reduction] {n}: {[(k, dist.get_world_size(g)) for g, k, _ in st]}")
+    return GradReduceWrapper(model, red)
+
+
+def total_grad_norm(model, comm=None):
+    """Global 2-norm of the gradients with sharded parameters counted once (``training_helpers.py:123-160``): the
+    squared norms of parameters sharded over a model-parallel group (``sharded_dims_mp``) are summed over that group,
+    replicated parameters count once."""
+    c = comm or _comm
+    groups = {}
+    for p in model.parameters():
+        if p.grad is None:
+            continue
+        key = tuple(g for g in getattr(p, "sharded_dims_mp", []) if g is not None and c.get_size(g) > 1)
+        groups.setdefault(key, []).append(_real(p.grad))
+    partials = []
+    for key, grads in groups.items():
+        part = torch.stack(torch._foreach_norm(grads)).square().sum()
+        for g in key:
+            ops._all_reduce_sum(part.view(1), c.get_group(g))
+        partials.append(part)
+    if not partials:
+        return torch.zeros(())
+    return torch.stack(partials).sum().sqrt()
+
+
+def clip_coefficient(model, max_norm, comm=None):
+    """(1,) fp32 device tensor ``min(1, max_norm / (||g|| + 1e-6))`` for ``FusedAdamW.step(grad_scale=...)``"""
+    total = total_grad_norm(model, comm)
+    return torch.clamp(max_norm / (total + 1e-6), max=1.0).float().reshape(1)

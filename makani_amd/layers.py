@@ -44,8 +44,10 @@ class PointwiseConv(nn.Module):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         ops.want_bf16_shadow(self.weight)
 
-    def matmul(self, x, add_to=None):
-        """bias-free product; ``add_to`` (same shape as the result) is fused as the GEMM's C input."""
+    def matmul(self, x, add_to=None, add_to_is_fresh=False):
+        """bias-free product; ``add_to`` (same shape as the result) is fused as the GEMM's C input.  The product is
+        accumulated INTO ``add_to`` only when the caller states that no autograd node saved that tensor
+        (``add_to_is_fresh``: it is the output of an instance norm or of a GEMM of this package)."""
         B, C, H, W = x.shape
         if C != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {C}")
@@ -56,15 +58,15 @@ class PointwiseConv(nn.Module):
             x = x.to(dt)
             add_to = add_to.to(dt) if add_to is not None else None
         with torch.autocast(device_type="cuda", enabled=False):
-            return ops.ConvMmFn.apply(x.contiguous(), self.weight, add_to)
+            return ops.ConvMmFn.apply(x.contiguous(), self.weight, add_to, add_to_is_fresh)
 
     @torch.compiler.disable(recursive=True)
-    def forward(self, x, add_to=None):
+    def forward(self, x, add_to=None, add_to_is_fresh=False):
         if hip_conv_eligible(x):
             xb = x.to(torch.bfloat16)
             r = add_to.to(torch.bfloat16) if add_to is not None else None
             return ops.Conv1x1Fn.apply(xb, self.weight, self.bias, r)
-        y = self.matmul(x, add_to)
+        y = self.matmul(x, add_to, add_to_is_fresh)
         if self.bias is not None:
             y = y + self.bias.to(y.dtype).view(1, -1, 1, 1)
         return y

@@ -112,7 +112,7 @@ class GridQuadrature(nn.Module):
     def __init__(self, quadrature_rule, img_shape, crop_shape=None, crop_offset=(0, 0), normalize=False, distributed=False):
         super().__init__()
         from . import distributed as thd
-        self.distributed = bool(distributed) and thd.is_initialized() and thd.spatial_size() > 1
+        self.distributed = bool(distributed) and thd.ensure_initialized()
         crop_shape = img_shape if crop_shape is None else crop_shape
         q = _rule_weights(quadrature_rule, img_shape)
         if normalize:
@@ -196,7 +196,7 @@ class SpectralLpLoss(nn.Module):
         from .sht import RealSHT
         self.img_shape, self.crop_shape, self.crop_offset = img_shape, crop_shape, crop_offset
         self.channel_names = channel_names
-        self.spatial_distributed = bool(spatial_distributed) and thd.is_initialized() and thd.spatial_size() > 1
+        self.spatial_distributed = bool(spatial_distributed) and thd.ensure_initialized()
         bandlimit = compute_spherical_bandlimit(img_shape, grid_type)
         if lmax is None or lmax > bandlimit:
             lmax = bandlimit

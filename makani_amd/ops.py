@@ -758,12 +758,14 @@ def want_bf16_shadow(param):
 
 def cast_weight(weight, dtype):
     """weight in the GEMM dtype: the optimizer's bf16 shadow when it belongs to exactly this version of the
-    parameter (any in-place change through torch bumps ``_version`` and invalidates it), else a cast"""
+    parameter (any in-place change through torch bumps ``_version``, re-pointing ``param.data`` changes the storage
+    address: both invalidate it), else a cast.  In-place writes THROUGH ``param.data`` (``p.data.mul_()``) bypass the
+    version counter and are not supported while shadows are in use; ``load_state_dict`` / ``copy_`` / optimizers are."""
     if dtype == weight.dtype:
         return weight
     sh = getattr(weight, "_mk_shadow", None)
     if (sh is not None and dtype == torch.bfloat16 and getattr(weight, "_mk_shadow_version", -1) == weight._version
-            and sh.device == weight.device):
+            and getattr(weight, "_mk_shadow_ptr", 0) == weight.data_ptr() and sh.device == weight.device):
         return sh
     return weight.to(dtype)
 
@@ -775,16 +777,18 @@ class ConvMmFn(torch.autograd.Function):
     (mk_conv1x1_wgrad: 1.1-3.7x faster than the library on these huge-K shapes)."""
 
     @staticmethod
-    def forward(ctx, x, weight, residual):
+    def forward(ctx, x, weight, residual, residual_is_fresh=False):
         B, K, H, W = x.shape
         M = weight.shape[0]
         w = cast_weight(weight, x.dtype).view(M, K)
         N = H * W
-        # with a residual the product accumulates INTO it (beta = 1, no 88-800 MB copy of the residual first);
-        # autograd is told through mark_dirty, and nothing upstream saves that tensor (it is a norm / GEMM output).
+        # with a residual the product may accumulate INTO it (beta = 1, no 88-800 MB copy of the residual first), which
+        # autograd is told through mark_dirty.  That is only legal when no upstream node saved that tensor for its own
+        # backward (a ReLU saves its output, an instance norm or a GEMM of this package does not), which this function
+        # cannot see: the caller has to vouch for it with ``residual_is_fresh``; otherwise the output is a new tensor.
         # Outputs are allocated in their final shape (never views of a temporary) so that they can be the
         # in-place target of a later call.
-        inplace = (residual is not None and residual.is_contiguous() and residual.dtype == x.dtype
+        inplace = (residual_is_fresh and residual is not None and residual.is_contiguous() and residual.dtype == x.dtype
                    and not residual._is_view() and not (residual.is_leaf and residual.requires_grad))
         out = residual if inplace else torch.empty((B, M, H, W), dtype=x.dtype, device=x.device)
         if B == 1:
@@ -832,7 +836,7 @@ class ConvMmFn(torch.autograd.Function):
                 gw = torch.einsum("bmn,bkn->mk", gy.reshape(B, M, N).float(), x.reshape(B, K, N).float()).view_as(weight).to(weight.dtype)
         if ctx.has_res and ctx.needs_input_grad[2]:
             gr = gy
-        return gx, gw, gr
+        return gx, gw, gr, None
 
 
 # --------------------------------------------------------------------------- #

@@ -88,6 +88,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 arr = (MkAdamTensor * len(descs))(*descs)
                 check(lib().mk_adamw_multi(C.cast(arr, C.c_void_p), len(descs), ptr(scale), group["lr"], b1, b2, group["eps"],
                                            group["weight_decay"], step, stream()), "mk_adamw_multi")
-            for p in shadowed:               # valid for exactly this version of the parameter
+            for p in shadowed:               # valid for exactly this version (and storage) of the parameter
                 p._mk_shadow_version = p._version
+                p._mk_shadow_ptr = p.data_ptr()
         return None

@@ -63,61 +63,41 @@ class NeuralOperatorBlock(nn.Module):
             self.input_shape_loc = (forward_transform.nlat, forward_transform.nlon)
             self.output_shape_loc = (inverse_transform.nlat, inverse_transform.nlon)
 
+        # The SFNO builds every block with inner_skip="none" and outer_skip="linear" (sfnonet.py:680-700); those are the
+        # two wirings of this boundary class.  Submodules are created in the reference's order (norm0, filter, norm1,
+        # outer_skip, mlp) because that order IS the RNG stream of the initialisation.
+        if inner_skip not in ("none", None):
+            raise NotImplementedError(f"inner_skip={inner_skip!r}: the SFNO path uses inner_skip='none'")
+        if outer_skip not in ("linear", "none", None):
+            raise NotImplementedError(f"outer_skip={outer_skip!r}: the SFNO path uses outer_skip='linear' (or none)")
+        has_act = act_layer is not nn.Identity
         self.norm0 = norm_layer[0]()
-        gain_factor = 1.0 if act_layer == nn.Identity else 2.0
-
-        if inner_skip == "linear":
-            self.inner_skip = PointwiseConv(embed_dim, embed_dim, bias=False)
-            gain_factor /= 2.0
-            nn.init.normal_(self.inner_skip.weight, std=math.sqrt(gain_factor / embed_dim))
-        elif inner_skip == "identity":
-            self.inner_skip = nn.Identity()
-            gain_factor /= 2.0
-        elif inner_skip == "none":
-            pass
-        else:
-            raise ValueError(f"Unknown skip connection type {inner_skip}")
-
         self.filter = SpectralFilterLayer(forward_transform, inverse_transform, embed_dim, filter_type, operator_type,
                                           hidden_size_factor=mlp_ratio, rank=rank, separable=separable,
                                           complex_activation=complex_activation, spectral_layers=spectral_layers,
-                                          bias=bias, drop_rate=path_drop_rate, gain=gain_factor)
+                                          bias=bias, drop_rate=path_drop_rate, gain=2.0 if has_act else 1.0)
         self.act_is_gelu = act_layer is nn.GELU
         self.act_layer0 = act_layer()
         self.norm1 = norm_layer[1]()
-
-        gain_factor = 2.0 if (final_activation and act_layer != nn.Identity) else 1.0
+        gain = 2.0 if (final_activation and has_act) else 1.0
         if outer_skip == "linear":
+            gain /= 2.0                                  # the block's two branches share the output variance
             self.outer_skip = PointwiseConv(embed_dim, embed_dim, bias=False)
-            gain_factor /= 2.0
-            nn.init.normal_(self.outer_skip.weight, std=math.sqrt(gain_factor / embed_dim))
-        elif outer_skip == "identity":
-            self.outer_skip = nn.Identity()
-            gain_factor /= 2.0
-        elif outer_skip == "none" or outer_skip is None:
-            pass
-        else:
-            raise ValueError(f"Unknown skip connection type {outer_skip}")
-
+            nn.init.normal_(self.outer_skip.weight, std=math.sqrt(gain / embed_dim))
         if use_mlp:
             self.mlp = MLP(in_features=embed_dim, hidden_features=int(embed_dim * mlp_ratio), act_layer=act_layer,
-                           drop_rate=mlp_drop_rate, drop_type="features", checkpointing=(checkpointing_level >= 2),
-                           gain=gain_factor)
-        self.drop_path = nn.Identity()
+                           drop_rate=mlp_drop_rate, drop_type="features", checkpointing=(checkpointing_level >= 2), gain=gain)
         if final_activation:
             self.act_layer1 = act_layer()
 
     @torch.compiler.disable(recursive=True)
     def forward(self, x):
         x, residual = self.filter(x)
-
-        fuse = (self.act_is_gelu and isinstance(self.norm0, (InstanceNorm2d, GeometricInstanceNormS2, thd.DistributedInstanceNorm2d))
-                and not hasattr(self, "inner_skip"))
-        x = self.norm0(x, fuse_gelu=True) if fuse else self.norm0(x)
-        if hasattr(self, "inner_skip"):
-            x = x + self.inner_skip(residual)
-        if not fuse:
-            x = self.act_layer0(x)
+        norms = (InstanceNorm2d, GeometricInstanceNormS2, thd.DistributedInstanceNorm2d)
+        if self.act_is_gelu and isinstance(self.norm0, norms):
+            x = self.norm0(x, fuse_gelu=True)                 # norm + exact GELU in one pass over the plane
+        else:
+            x = self.act_layer0(self.norm0(x))
 
         if hasattr(self, "mlp") and type(self.norm1) is InstanceNorm2d and self.mlp.can_defer_output_bias(x):
             x, pb = self.mlp.forward_deferred_bias(x)         # fc2's bias rides in norm1 (same rounding as y + b)
@@ -126,13 +106,12 @@ class NeuralOperatorBlock(nn.Module):
             if hasattr(self, "mlp"):
                 x = self.mlp(x)
             x = self.norm1(x)
-        x = self.drop_path(x)
 
         if hasattr(self, "outer_skip"):
-            if isinstance(self.outer_skip, PointwiseConv):
-                x = self.outer_skip(residual, add_to=x)        # skip GEMM accumulates into x (beta = 1)
-            else:
-                x = x + self.outer_skip(residual)
+            # the skip GEMM accumulates into x (beta = 1) when x is a tensor nobody saved for backward: the output of
+            # a norm kernel or of the MLP's last GEMM (+ bias); an activation output (ReLU saves it) is not
+            fresh = hasattr(self, "mlp") or isinstance(self.norm1, norms)
+            x = self.outer_skip(residual, add_to=x, add_to_is_fresh=fresh)
         if hasattr(self, "act_layer1"):
             x = self.act_layer1(x)
         return x
@@ -254,9 +233,11 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         else:
             modes_lat = int(self.h * hard_thresholding_fraction)
             modes_lon = int((self.w // 2 + 1) * hard_thresholding_fraction)
-        # spatial (h x w) model parallelism when makani_amd.distributed.init() set up split groups
-        # (the reference tests comm.get_size("spatial") > 1, sfnonet.py:786-805)
-        self.spatial_parallel = thd.is_initialized() and thd.spatial_size() > 1
+        # spatial (h x w) model parallelism, decided as the reference does (sfnonet.py:786-805): the process-group tree
+        # says so (makani_amd.comm, filled by comm.init(h, w) or adopted from makani.utils.comm when makani's driver
+        # constructs this plug-in) and the transform layer is initialised from its "h" / "w" groups on first use.
+        # An explicit makani_amd.distributed.init(...) by the caller is honoured as well.
+        self.spatial_parallel = thd.ensure_initialized()
         sht, isht = (thd.DistributedRealSHT, thd.DistributedInverseRealSHT) if self.spatial_parallel else (RealSHT, InverseRealSHT)
         self.trans_down = sht(*self.inp_shape, lmax=modes_lat, mmax=modes_lon, grid=model_grid_type).float()
         self.itrans_up = isht(*self.out_shape, lmax=modes_lat, mmax=modes_lon, grid=model_grid_type).float()
@@ -304,5 +285,5 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         else:
             x = self.decoder(x)
         if self.big_skip:
-            x = self.residual_transform(residual, add_to=x)
+            x = self.residual_transform(residual, add_to=x, add_to_is_fresh=True)      # x: output of the decoder's last GEMM
         return x

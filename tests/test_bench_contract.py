@@ -42,6 +42,47 @@ def test_bench_multistep_rollout_runs():
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
 
 
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_headline_split_and_secondary_dp():
+    """``python bench.py --gpus 2`` (no torchrun): the script spawns its two ranks, measures the north-star split
+    (h2w1, strong scaling) and then data parallelism as ``secondary``.  Functional run on ONE GPU: both ranks share
+    cuda:0 and exchange through gloo (host-staged)."""
+    env = dict(os.environ, MAKANI_AMD_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "sfno_debug", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "dp1_h2w1", d["config"]
+    assert d["config"]["global_batch"] == 1 and d["value"] > 0 and "note" not in d
+    s = d["secondary"]
+    assert s["parallelism"] == "dp2" and s["scaling"] == "weak" and s["global_batch"] == 2 and s["value"] > 0
+    assert d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_bench_rank_launched_by_torchrun_form():
+    """the driver's form: ``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`` — every rank's copy
+    of the script starts its own worker per phase on a fresh rendezvous port; rank 0 prints the line"""
+    env = dict(os.environ, MAKANI_AMD_BENCH_BACKEND="gloo")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config",
+                          "sfno_debug", "--steps", "2", "--warmup", "1", "--parallelism", "h1w2", "--no-secondary"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp1_h1w2" and "secondary" not in d
+
+
 def _rec(launches, ms_avg, flops_per, bytes_per):
     return dict(launches=launches, ms_avg=ms_avg, ms_total=launches * ms_avg, flops=launches * flops_per, bytes=launches * bytes_per)
 

@@ -3,7 +3,8 @@
    transform, forward and backward — the pattern of the reference's
    tests/distributed/tests_distributed_layers.py:69-223.  Local compute is injected from the CPU oracle
    (test-only backend); on a GPU the same schedule runs on the HIP kernels.
- * the data-parallel gradient reducer of bench.py averages gradients (incl. complex ones)."""
+ * the process-group tree (makani_amd.comm) and the gradient reductions / sharded gradient norm of
+   makani_amd.distributed (data-parallel mean, per-group sums from the is_shared_mp annotations)."""
 import math
 import os
 import socket
@@ -150,20 +151,27 @@ def _worker_dp(rank, world, port):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import bench
+        import makani_amd.comm as mcomm
+        import makani_amd.distributed as thd
+        mcomm.init(1, 1)
+        assert mcomm.get_size("data") == world and mcomm.get_size("spatial") == 1 and not thd.ensure_initialized()
         torch.manual_seed(0)
         model = torch.nn.Module()
         model.a = torch.nn.Parameter(torch.randn(5, 3))
         model.c = torch.nn.Parameter(torch.randn(4, 2, dtype=torch.complex64))
         model.big = torch.nn.Parameter(torch.randn(3 * 1024 * 1024))          # > 8 MB: async path
-        red = bench.GradReducer(model, dist.group.WORLD, world)
-        loss = (model.a.sum() * (rank + 1)) + (torch.view_as_real(model.c).sum() * (rank + 2)) + model.big.sum() * rank
-        loss.backward()
-        red.finish()
-        mean = sum(range(1, world + 1)) / world
-        assert torch.allclose(model.a.grad, torch.full_like(model.a, mean))
-        assert torch.allclose(torch.view_as_real(model.c.grad), torch.full((4, 2, 2), mean + 1.0))
-        assert torch.allclose(model.big.grad, torch.full_like(model.big, (world - 1) / 2))
+        model.forward = lambda: (model.a.sum() * (rank + 1)) + (torch.view_as_real(model.c).sum() * (rank + 2)) + model.big.sum() * rank
+        net = thd.init_gradient_reduction_hooks(model, torch.device("cpu"))
+        assert net.module is model
+        for it in range(2):                     # the reductions complete inside backward(), every step
+            for p in model.parameters():
+                p.grad = None
+            net().backward()
+            mean = sum(range(1, world + 1)) / world
+            assert torch.allclose(model.a.grad, torch.full_like(model.a, mean))
+            assert torch.allclose(torch.view_as_real(model.c.grad), torch.full((4, 2, 2), mean + 1.0))
+            assert torch.allclose(model.big.grad, torch.full_like(model.big, (world - 1) / 2))
+            assert not net.reducer.pending and not net.reducer.small
     finally:
         dist.destroy_process_group()
 
@@ -173,62 +181,125 @@ def test_data_parallel_grad_reducer_world2():
 
 
 def _worker_tree(rank, world, port, ph, pw):
-    """bench.build_groups (makani/utils/comm.py:114-201) + GradReducer with model-parallel groups: spectral weights
-    (l-sharded over h) are summed over "w" only, everything else over "spatial", then averaged over "data"
-    (makani/mpu/mappings.py:460-523)"""
+    """makani_amd.comm.init (makani/utils/comm.py:114-201) + the gradient reductions of makani/mpu/mappings.py:460-523
+    driven by the is_shared_mp annotations: dhconv weights (["matmul", "w"], l-sharded over h) are summed over "w" only,
+    ["spatial"] / un-annotated parameters over the whole model instance, a position embedding ([]) over nothing; then
+    the data-parallel mean.  Also the sharded gradient norm (training_helpers.py:123-160)."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import bench
+        import makani_amd.comm as mcomm
+        import makani_amd.distributed as thd
         msize = ph * pw
         dsize = world // msize
-        d_idx, ih, iw, data_g, spatial_g, h_g, w_g = bench.build_groups(world, rank, ph, pw)
+        d_idx, ih, iw = mcomm.init(ph, pw)
         assert (d_idx, ih, iw) == (rank // msize, (rank % msize) // pw, (rank % msize) % pw)
-        assert (spatial_g is None) == (msize == 1) and (data_g is None) == (dsize == 1)
-        assert (h_g is None) == (msize == 1) and (w_g is None) == (msize == 1)
-        if msize > 1:
-            assert dist.get_world_size(spatial_g) == msize and dist.get_world_size(h_g) == ph and dist.get_world_size(w_g) == pw
-            assert dist.get_process_group_ranks(h_g) == [d_idx * msize + i * pw + iw for i in range(ph)]
-            assert dist.get_process_group_ranks(w_g) == [d_idx * msize + ih * pw + j for j in range(pw)]
+        assert (mcomm.get_size("h"), mcomm.get_size("w"), mcomm.get_size("spatial"), mcomm.get_size("data")) == (ph, pw, msize, dsize)
+        assert (mcomm.get_rank("h"), mcomm.get_rank("w"), mcomm.get_rank("data")) == (ih, iw, d_idx)
+        assert (mcomm.get_group("spatial") is None) == (msize == 1) and (mcomm.get_group("data") is None) == (dsize == 1)
+        if ph > 1:
+            assert dist.get_process_group_ranks(mcomm.get_group("h")) == [d_idx * msize + i * pw + iw for i in range(ph)]
+        if pw > 1:
+            assert dist.get_process_group_ranks(mcomm.get_group("w")) == [d_idx * msize + ih * pw + j for j in range(pw)]
         if dsize > 1:
-            assert dist.get_process_group_ranks(data_g) == [d * msize + rank % msize for d in range(dsize)]
+            assert dist.get_process_group_ranks(mcomm.get_group("data")) == [d * msize + rank % msize for d in range(dsize)]
+        assert thd.ensure_initialized() == (msize > 1)       # the transform layer initialises itself from the tree
+        assert thd.polar_group_size() == ph and thd.azimuth_group_size() == pw
 
         model = torch.nn.Module()
-        model.blocks = torch.nn.ModuleList([torch.nn.Module()])
-        model.blocks[0].filter = torch.nn.Module()
-        model.blocks[0].filter.filter = torch.nn.Module()
-        model.blocks[0].filter.filter.weight = torch.nn.Parameter(torch.zeros(1, 3, 3, 4, dtype=torch.complex64))
+        model.w = torch.nn.Parameter(torch.zeros(1, 3, 3, 4, dtype=torch.complex64))
+        model.w.is_shared_mp, model.w.sharded_dims_mp = ["matmul", "w"], [None, None, None, "h"]
         model.enc = torch.nn.Parameter(torch.zeros(6))
-        red = bench.GradReducer(model, data_g, dsize, spatial_g if msize > 1 else None, w_g if pw > 1 else None)
-        w = model.blocks[0].filter.filter.weight
-        ((torch.view_as_real(w).sum() + model.enc.sum()) * float(rank + 1)).backward()
-        red.finish()
+        model.enc.is_shared_mp = ["spatial"]
+        model.plain = torch.nn.Parameter(torch.zeros(2))                   # no annotation: shared over "model"
+        model.pos = torch.nn.Parameter(torch.zeros(3))
+        model.pos.is_shared_mp, model.pos.sharded_dims_mp = [], [None]
+        model.forward = lambda: (torch.view_as_real(model.w).sum() + model.enc.sum() + model.plain.sum() + model.pos.sum()) * float(rank + 1)
+        net = thd.init_gradient_reduction_hooks(model, torch.device("cpu"))
+        net().backward()
         r1 = lambda ranks: sum(r + 1 for r in ranks)
-        spatial = [d_idx * msize + k for k in range(msize)]
-        wranks = [d_idx * msize + ih * pw + j for j in range(pw)]
-        # expected: mean over data of (sum over the model-parallel group) of (rank + 1)
-        def over_data(fn):
-            tot = 0.0
-            for d in range(dsize):
-                tot += fn(d)
-            return tot / dsize
-        exp_enc = over_data(lambda d: r1([d * msize + k for k in range(msize)]))
-        exp_w = over_data(lambda d: r1([d * msize + ih * pw + j for j in range(pw)]) if pw > 1 else float(d * msize + rank % msize + 1))
-        assert torch.allclose(model.enc.grad, torch.full((6,), exp_enc)), (rank, model.enc.grad, exp_enc)
-        assert torch.allclose(torch.view_as_real(w.grad), torch.full((1, 3, 3, 4, 2), exp_w)), (rank, w.grad.flatten()[0], exp_w)
+
+        def over_data(fn):          # expected: mean over data of (sum over the model-parallel group) of (rank + 1)
+            return sum(fn(d) for d in range(dsize)) / dsize
+        exp_sp = over_data(lambda d: r1([d * msize + k for k in range(msize)]))
+        exp_w = over_data(lambda d: r1([d * msize + ih * pw + j for j in range(pw)]))
+        exp_pos = over_data(lambda d: float(d * msize + rank % msize + 1))
+        assert torch.allclose(model.enc.grad, torch.full((6,), exp_sp)), (rank, model.enc.grad, exp_sp)
+        assert torch.allclose(model.plain.grad, torch.full((2,), exp_sp))
+        assert torch.allclose(torch.view_as_real(model.w.grad), torch.full((1, 3, 3, 4, 2), exp_w)), (rank, model.w.grad.flatten()[0], exp_w)
+        assert torch.allclose(model.pos.grad, torch.full((3,), exp_pos))
+        # sharded norm: ||w||^2 summed over h (each h-rank holds another l-shard), everything else counted once
+        sq_w = sum(72 * over_data(lambda d, i=i: r1([d * msize + i * pw + j for j in range(pw)])) ** 2 for i in range(ph))
+        exp_norm = math.sqrt(sq_w + 6 * exp_sp ** 2 + 2 * exp_sp ** 2 + 3 * exp_pos ** 2)
+        assert abs(float(thd.total_grad_norm(model)) - exp_norm) < 1e-3 * exp_norm
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,ph,pw", [(2, 1, 1), (4, 2, 1), (4, 1, 2), (4, 2, 2)])
+@pytest.mark.parametrize("world,ph,pw", [(2, 1, 1), (4, 2, 1), (4, 1, 2), (4, 2, 2), (8, 2, 2)])
 def test_group_tree_and_model_parallel_grad_reduction(world, ph, pw):
     mp.spawn(_worker_tree, args=(world, _free_port(), ph, pw), nprocs=world, join=True)
+
+
+def _worker_ragged(rank, world, port, h, w, C):
+    """BASELINE configs[2] / [4] split sizes at the real grid: 721 x 1440, lmax 240, mmax 241 over h = 4 (lat
+    [181, 181, 181, 178], l [60] * 4) and w = 2 (lon [720, 720], m [121, 120]), reduced channel count"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd.comm as mcomm
+        import makani_amd.distributed as thd
+        from oracle import sht as osht
+        _, ih, iw = mcomm.init(h, w)
+        assert thd.ensure_initialized()
+        thd.set_backend(OracleBackend)
+        nlat, nlon, lmax, mmax, B = 721, 1440, 240, 241, 1
+        fwd = thd.DistributedRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid="equiangular")
+        inv = thd.DistributedInverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid="equiangular")
+        if h == 4:
+            assert fwd.lat_shapes == [181, 181, 181, 178] and fwd.l_shapes == [60, 60, 60, 60]
+        if w == 2:
+            assert fwd.lon_shapes == [720, 720] and fwd.m_shapes == [121, 120]
+        lat0, lon0 = sum(fwd.lat_shapes[:ih]), sum(fwd.lon_shapes[:iw])
+        l0, m0 = sum(fwd.l_shapes[:ih]), sum(fwd.m_shapes[:iw])
+        hl, wl, ll, ml = fwd.lat_shapes[ih], fwd.lon_shapes[iw], fwd.l_shapes[ih], fwd.m_shapes[iw]
+        torch.manual_seed(7)
+        x = torch.randn(B, C, nlat, nlon, dtype=torch.float64)
+        xl = x[..., lat0:lat0 + hl, lon0:lon0 + wl].clone().requires_grad_(True)
+        c = _s_to_complex(fwd.analysis(xl), B, C)
+        So = osht.RealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid="equiangular")
+        xs = x.clone().requires_grad_(True)
+        cref = So(xs)
+        assert (c - cref[..., l0:l0 + ll, m0:m0 + ml]).abs().max().item() < 1e-6
+        G = torch.randn(B, C, lmax, mmax, dtype=torch.complex128)
+        (torch.view_as_real(c) * torch.view_as_real(G[..., l0:l0 + ll, m0:m0 + ml])).sum().backward()
+        (torch.view_as_real(cref) * torch.view_as_real(G)).sum().backward()
+        gref = xs.grad[..., lat0:lat0 + hl, lon0:lon0 + wl]
+        assert (xl.grad - gref).abs().max().item() < 1e-6 * max(1.0, gref.abs().max().item())
+        coef = torch.tril(torch.randn(B, C, lmax, mmax, dtype=torch.complex128))
+        y = inv.synthesis(_complex_to_s(coef[..., l0:l0 + ll, m0:m0 + ml].clone()), B, C, out_dtype=torch.float64)
+        yref = osht.InverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid="equiangular")(coef)
+        assert y.shape == (B, C, hl, wl)
+        assert (y - yref[..., lat0:lat0 + hl, lon0:lon0 + wl]).abs().max().item() < 1e-6 * yref.abs().max().item()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w,C", [(4, 1, 6), (4, 2, 5)])
+def test_distributed_sht_ragged_config3_splits(h, w, C):
+    """h = 4 (BASELINE configs[2]) and h4 w2 (configs[4]) at 721 x 1440 with ragged plane counts (6 planes over 4 ranks ->
+    [1, 1, 1, 3]; 5 over 2 -> [3, 2])"""
+    mp.spawn(_worker_ragged, args=(h * w, _free_port(), h, w, C), nprocs=h * w, join=True)
 
 
 def test_parse_parallelism():
     import bench
     assert bench.parse_parallelism("dp") == (1, 1) and bench.parse_parallelism("h4w2") == (4, 2)
+    assert [bench.default_parallelism(n) for n in (1, 2, 4, 8)] == ["dp", "h2w1", "h4w1", "h4w2"]
     with pytest.raises(SystemExit):
         bench.parse_parallelism("tp8")

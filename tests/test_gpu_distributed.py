@@ -103,36 +103,65 @@ def test_spatial_parallel_sfno_matches_serial(h, w):
     mp.spawn(_worker, args=(world, _free_port(), h, w), nprocs=world, join=True)
 
 
+class _OneRankTree:
+    """a process-group tree that names the (one-rank) world as a split "spatial" group: every gradient takes the SUM
+    stage of the reducer, which over one rank is the identity"""
+
+    @staticmethod
+    def get_comm_names():
+        return ["spatial", "data"]
+
+    @staticmethod
+    def get_size(name):
+        return 2 if name == "spatial" else 1
+
+    @staticmethod
+    def get_group(name):
+        return dist.group.WORLD if name == "spatial" else None
+
+    @staticmethod
+    def is_initialized():
+        return True
+
+
 def _worker_rccl(rank, world, port):
-    """RCCL itself on the one GPU of the box (world size 1): the collectives bench.py's GradReducer issues —
-    an async in-place all-reduce on the real view of a complex gradient, and ReduceOp.AVG (or its fallback)."""
+    """RCCL itself on the one GPU of the box (world size 1): the collectives makani_amd.distributed.GradReducer issues —
+    an async in-place all-reduce on the real view of a complex gradient, the flattened small-gradient bucket whose
+    pieces become the gradients, and ReduceOp.AVG (or its fallback)."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
-        import bench
+        import makani_amd.distributed as thd
         model = torch.nn.Module()
         model.c = torch.nn.Parameter(torch.randn(1200, 1024, dtype=torch.complex64, device=dev))     # 9.8 MB: async path
         model.a = torch.nn.Parameter(torch.randn(7, 5, device=dev))
-        red = bench.GradReducer(model, dist.group.WORLD, 1)
-        red.active, red.data_size = True, 1          # one rank: mean over the group == the local gradient
-        for name, p in model.named_parameters():
-            p.register_post_accumulate_grad_hook(lambda q, n=name: red._hook(q, n))
-        red._groups_for = lambda name: [(dist.group.WORLD, 1.0)]
-        (torch.view_as_real(model.c).sum() * 3.0 + model.a.sum() * 2.0).backward()
-        assert len(red.handles) == 1
-        red.finish()
+        model.sc = torch.nn.Parameter(torch.randn(3, 3, dtype=torch.complex64, device=dev))            # small complex: bucket
+        for p in model.parameters():
+            p.is_shared_mp = ["spatial"]
+        red = thd.GradReducer(model, comm=_OneRankTree)
+        assert red.active and all(len(st) == 1 for st in red.plan.values())
+        (torch.view_as_real(model.c).sum() * 3.0 + model.a.sum() * 2.0 + torch.view_as_real(model.sc).sum() * 5.0).backward()
+        assert not red.pending and not red.small                    # finished by the autograd engine callback
         torch.cuda.synchronize()
         assert torch.equal(torch.view_as_real(model.c.grad), torch.full((1200, 1024, 2), 3.0, device=dev))
         assert torch.equal(model.a.grad, torch.full((7, 5), 2.0, device=dev))
+        assert torch.equal(torch.view_as_real(model.sc.grad), torch.full((3, 3, 2), 5.0, device=dev))
+        assert thd.GradReducer._probe_avg(dist.group.WORLD, dev) in (True, False)
         t = torch.full((4,), 5.0, device=dev)
         try:
             dist.all_reduce(t, op=dist.ReduceOp.AVG)
             assert torch.equal(t, torch.full((4,), 5.0, device=dev))
         except RuntimeError:
             pass                                      # GradReducer then keeps SUM + scale
+        # the all-to-all primitive of the distributed transforms on the RCCL branch (one rank: a copy)
+        send = [torch.arange(12.0, device=dev).view(3, 4)]
+        recv = [torch.empty(3, 4, device=dev)]
+        thd._exchange(recv, send, dist.group.WORLD)
+        torch.cuda.synchronize()
+        assert torch.equal(recv[0], send[0])
         dist.barrier()
     finally:
         dist.destroy_process_group()

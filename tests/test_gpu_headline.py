@@ -1,0 +1,176 @@
+"""GPU parity at the BASELINE config-2 shapes (sfno_sc3_layers8_edim384: C = 384, internal grid 240 x 480,
+L = 240, M = 241, full grid 721 x 1440 = 1 038 240 pixels) against the CPU oracle — the shapes the benchmark runs,
+not toy stand-ins.  Each case is sized so the CPU side finishes in seconds on the GPU box's host cores."""
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+E, H, W, L, M = 384, 240, 480, 240, 241
+NPIX_FULL = 721 * 1440
+
+# fp32 ops <= 1e-5, fp32 end to end <= 1e-4, bf16 autocast <= 2e-2
+TOL_OP, TOL_E2E, TOL_BF16 = 1e-5, 1e-4, 2e-2
+
+
+def _threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(n, 64)))
+
+
+# --------------------------------------------------------------------------- #
+# (i) one NeuralOperatorBlock at 240 x 480 x 384: forward, input gradient, every parameter gradient
+# --------------------------------------------------------------------------- #
+@pytest.fixture(scope="module")
+def block_pair():
+    import makani_amd as ma
+    from makani_amd.sfno import NeuralOperatorBlock
+    from makani_amd.layers import InstanceNorm2d
+    from functools import partial
+    from oracle import sfno as osf
+    from oracle import sht as osht
+    _threads()
+    torch.manual_seed(333)
+    ot, oi = (osht.RealSHT(H, W, lmax=L, mmax=M, grid="legendre-gauss").float(),
+              osht.InverseRealSHT(H, W, lmax=L, mmax=M, grid="legendre-gauss").float())
+    oblk = osf.NeuralOperatorBlock(ot, oi, E, "dhconv", 2, torch.nn.GELU, False)
+    with torch.no_grad():                      # non-trivial affine parameters and biases (the initial ones are 1 / 0)
+        for n, p in oblk.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0.0, 0.1)
+            elif n.startswith("norm"):
+                p.normal_(1.0, 0.2)
+    norm = partial(InstanceNorm2d, num_features=E, eps=1e-6, affine=True, track_running_stats=False)
+    t, i = ma.RealSHT(H, W, lmax=L, mmax=M, grid="legendre-gauss"), ma.InverseRealSHT(H, W, lmax=L, mmax=M, grid="legendre-gauss")
+    blk = NeuralOperatorBlock(t, i, E, filter_type="linear", operator_type="dhconv", mlp_ratio=2, act_layer=torch.nn.GELU,
+                              norm_layer=(norm, norm), inner_skip="none", outer_skip="linear", use_mlp=True)
+    blk.load_state_dict(oblk.state_dict(), strict=True)
+    blk = blk.to(DEV)
+    x = torch.rand(1, E, H, W) - 0.5
+    g = torch.randn(1, E, H, W)
+    xo = x.clone().requires_grad_(True)
+    yo = oblk(xo)
+    (yo * g).sum().backward()
+    ref = dict(y=yo.detach(), gx=xo.grad, grads={n: p.grad for n, p in oblk.named_parameters()})
+    return blk, x, g, ref
+
+
+def _check_block(blk, x, g, ref, amp, tol):
+    blk.zero_grad(set_to_none=True)
+    xd = x.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = blk(xd)
+    (y.float() * g.to(DEV)).sum().backward()
+    errs = {"y": rel_l2(y.float(), ref["y"]), "gx": rel_l2(xd.grad, ref["gx"])}
+    gmax = max(float(v.abs().max()) for v in ref["grads"].values())
+    for n, p in blk.named_parameters():
+        r = ref["grads"][n]
+        e = rel_l2(p.grad, r)
+        a = float((torch.view_as_real(p.grad.detach().cpu()) - torch.view_as_real(r)).abs().max()) if r.is_complex() \
+            else float((p.grad.detach().cpu().float() - r).abs().max())
+        errs[n] = e
+        # a per-channel constant in front of an instance norm (mlp.fwd.3.bias) has an exactly-zero gradient: round-off on
+        # both sides, accepted on the absolute scale of the model's largest gradient entry (as in test_gpu_model.py)
+        assert e < 2 * tol or a < 1e-4 * gmax * (100 if amp else 1), (n, e, a, gmax)
+    assert errs["y"] < tol and errs["gx"] < tol, errs
+    return errs
+
+
+def test_block_240x480x384_fp32_matches_oracle(block_pair):
+    blk, x, g, ref = block_pair
+    errs = _check_block(blk, x, g, ref, amp=False, tol=TOL_E2E)
+    print("block 240x480x384 fp32 rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
+def test_block_240x480x384_bf16_autocast_matches_oracle(block_pair):
+    """the benchmark's precision (bf16 autocast, fp32 spectral path) against the fp32 oracle at the stated 2e-2 gate"""
+    blk, x, g, ref = block_pair
+    errs = _check_block(blk, x, g, ref, amp=True, tol=TOL_BF16)
+    print("block 240x480x384 bf16 rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
+def test_block_240x480x384_hip_channel_gemm_matches_oracle(block_pair, monkeypatch):
+    """the same block with every forward / data-gradient channel GEMM on the hand-written HIP kernel and its fused
+    bias+GELU / gelu' / skip epilogues (MAKANI_AMD_CONV=hip), bf16 autocast"""
+    from makani_amd import layers
+    blk, x, g, ref = block_pair
+    monkeypatch.setattr(layers, "_HIP_NN", True)
+    errs = _check_block(blk, x, g, ref, amp=True, tol=TOL_BF16)
+    print("block 240x480x384 bf16 (HIP channel GEMM) rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
+# --------------------------------------------------------------------------- #
+# (ii) channel-GEMM weight gradient at 1 038 240 pixels (the dominant kernel, in the regime of its pixel split)
+# --------------------------------------------------------------------------- #
+def _wgrad_ref(g, x, chunk=1 << 16):
+    """fp64 einsum over every pixel, accumulated chunk by chunk on the host"""
+    Mm, K = g.shape[1], x.shape[1]
+    out = torch.zeros(Mm, K, dtype=torch.float64)
+    g2, x2 = g.reshape(Mm, -1), x.reshape(K, -1)
+    for n0 in range(0, g2.shape[1], chunk):
+        out += g2[:, n0:n0 + chunk].double() @ x2[:, n0:n0 + chunk].double().t()
+    return out
+
+
+@pytest.mark.parametrize("Mm,K", [(384, 384), (768, 384), (384, 768), (73, 384), (384, 73), (73, 73)])
+def test_conv1x1_wgrad_fullres(Mm, K):
+    from makani_amd import ops
+    _threads()
+    torch.manual_seed(Mm * 7 + K)
+    g = (torch.randn(1, Mm, 721, 1440) * 0.5).bfloat16()
+    x = (torch.rand(1, K, 721, 1440) - 0.3).bfloat16()          # non-zero mean: the partial sums do not cancel
+    dW = ops.conv1x1_wgrad(g.to(DEV), x.to(DEV))
+    ref = _wgrad_ref(g, x)
+    assert dW.shape == (Mm, K) and dW.dtype == torch.float32
+    e = rel_l2(dW, ref)
+    assert e < TOL_OP, e
+
+
+@pytest.mark.parametrize("Mm,K", [(768, 384), (384, 768), (384, 384), (73, 384)])
+def test_conv1x1_nn_fullres(Mm, K):
+    """forward / data-gradient channel GEMM (HIP kernel) at 1 038 240 pixels against an fp64 product of the same bf16
+    operands; the result is stored in bf16, hence the 4e-3 bound (one rounding)"""
+    from makani_amd import ops
+    _threads()
+    torch.manual_seed(Mm + K)
+    x = (torch.rand(1, K, 721, 1440) - 0.5).bfloat16()
+    w = (torch.randn(Mm, K) / math.sqrt(K)).bfloat16()
+    y, _ = ops.conv1x1_nn(ops.pad_weight_bf16(w.to(DEV)), K, x.to(DEV))
+    xs = x.reshape(K, -1)
+    ref = torch.empty(Mm, NPIX_FULL, dtype=torch.float32)
+    for n0 in range(0, NPIX_FULL, 1 << 17):
+        ref[:, n0:n0 + (1 << 17)] = (w.double() @ xs[:, n0:n0 + (1 << 17)].double()).float()
+    assert rel_l2(y.reshape(Mm, -1).float(), ref) < 4e-3
+
+
+# --------------------------------------------------------------------------- #
+# (iii) dhconv at C = 384, L = 240, M = 241 against _contract_lwise (contractions.py:23-24)
+# --------------------------------------------------------------------------- #
+def test_dhconv_c384_l240_m241_matches_contract_lwise():
+    from makani_amd import ops
+    from oracle import sfno as osf
+    _threads()
+    torch.manual_seed(5)
+    tri = torch.tril(torch.ones(L, M))
+    x = torch.randn(1, E, L, M, dtype=torch.complex64) * tri            # SHT coefficients vanish for m > l
+    w = torch.randn(1, E, E, L, dtype=torch.complex64) / math.sqrt(E)
+    gy = torch.randn(1, E, L, M, dtype=torch.complex64) * tri
+    xo = x.to(torch.complex128).requires_grad_(True)
+    wo = w.to(torch.complex128).requires_grad_(True)
+    yo = osf.contract_lwise(xo.unsqueeze(1), wo)[:, 0]
+    torch.view_as_real(yo).mul(torch.view_as_real(gy.to(torch.complex128))).sum().backward()
+
+    xd = x.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    S = ops.ComplexToSFn.apply(xd)
+    T = ops.DhconvFn.apply(S, wd, 1)
+    y = ops.SToComplexFn.apply(T, 1, E)
+    torch.view_as_real(y).mul(torch.view_as_real(gy.to(DEV))).sum().backward()
+    assert rel_l2(y, yo) < TOL_OP
+    assert rel_l2(xd.grad.cpu() * tri, xo.grad * tri) < TOL_OP
+    assert rel_l2(wd.grad, wo.grad) < TOL_OP

@@ -356,3 +356,31 @@ def test_rollout_checkpointing_is_exact_and_matches_manual_unroll():
     (y * g).sum().backward()
     assert xs.grad is None
     assert MultiStepWrapper(m, n_future=2).eval()(x).shape == (1, 4, 37, 72)
+
+
+def test_relu_without_norm_and_mlp_backward_matches_oracle():
+    """activation_function="relu", normalization_layer="none", use_mlp=False: the tensor the skip GEMM would accumulate
+    into is a ReLU output, which ReLU's backward saved — the product must go to a new tensor (it used to be written in
+    place and backward raised).  fp32 against the oracle, and bf16 autocast just runs."""
+    import makani_amd as ma
+    from oracle import sfno as osf
+    cfg = dict(inp_shape=(24, 48), out_shape=(24, 48), inp_chans=3, out_chans=3, scale_factor=2, embed_dim=8, num_layers=2,
+               activation_function="relu", normalization_layer="none", use_mlp=False, big_skip=True)
+    torch.manual_seed(9)
+    oracle = osf.SphericalFourierNeuralOperatorNet(**cfg)
+    model = ma.SphericalFourierNeuralOperatorNet(**cfg)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.to(DEV)
+    x, g = torch.randn(2, 3, 24, 48), torch.randn(2, 3, 24, 48)
+    xd = x.to(DEV).requires_grad_(True)
+    y = model(xd)
+    (y * g.to(DEV)).sum().backward()
+    xo = x.clone().requires_grad_(True)
+    yo = oracle(xo)
+    (yo * g).sum().backward()
+    assert rel_l2(y, yo) < TOL_E2E and rel_l2(xd.grad, xo.grad) < TOL_E2E
+    for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        assert rel_l2(p.grad, q.grad) < 2 * TOL_E2E, k
+    model.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        model(x.to(DEV)).float().square().mean().backward()
