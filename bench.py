@@ -210,8 +210,9 @@ def _host_cores():
 
 def _cpu_worker(cfg_name, mode):
     """child process: the oracle (the reference's model code restated over the restated torch-harmonics SHT), fp32, on
-    the host cores.  mode "block": forward+backward of ONE internal-grid block (a few seconds; also used to pick the
-    thread count); mode "step": ONE full train step (forward + backward + AdamW) of the whole network at 721 x 1440."""
+    the host cores.  Always: forward and forward+backward of ONE internal-grid block (seconds; also picks the thread
+    count).  mode "fwd" (default): one FORWARD pass of the whole network at 721 x 1440.  mode "step": one full train
+    step (forward + backward + clip + AdamW) of the whole network — minutes of host time, opt-in."""
     from oracle import sfno as osf
     from oracle import sht as osht
     cores = _host_cores()
@@ -224,29 +225,39 @@ def _cpu_worker(cfg_name, mode):
     itrans = osht.InverseRealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid="legendre-gauss").float()
     blk = osf.NeuralOperatorBlock(trans, itrans, E, "dhconv", cfg["mlp_ratio"], torch.nn.GELU, False)
     x = torch.rand(1, E, h, w, requires_grad=True)
-    # thread count: torch's intra-op pools stop scaling well before a 2-socket host is full; take the best of a few
+    # thread count: torch's intra-op pools stop scaling long before a two-socket host is full (and collapse when
+    # oversubscribed), so the better of 32 and 64 threads is used, measured on the block
     best = None
-    for threads in sorted({min(cores, t) for t in (32, 64, 128, cores)}):
+    for threads in sorted({min(cores, t) for t in (32, 64)}):
         torch.set_num_threads(threads)
         blk(x).square().mean().backward()                  # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
+        with torch.no_grad():
+            blk(x)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
         x.grad = None
         blk(x).square().mean().backward()
-        t = time.perf_counter() - t0
-        if best is None or t < best[0]:
-            best = (t, threads)
-    t_blk, threads = best
-    rec = dict(t_mid=t_blk, threads=threads, cores=cores, h=h, w=w, reps=1)
+        t_fb = time.perf_counter() - t0
+        if best is None or t_fb < best[0]:
+            best = (t_fb, t_f, threads)
+    t_fb, t_f, threads = best
+    rec = dict(t_mid=t_fb, t_mid_fwd=t_f, threads=threads, cores=cores, h=h, w=w, reps=1)
     print(json.dumps(rec), flush=True)
-    if mode != "step":
-        return
     del blk, x, trans, itrans
     torch.set_num_threads(threads)
     keys = ("inp_shape", "out_shape", "inp_chans", "out_chans", "scale_factor", "embed_dim", "num_layers", "mlp_ratio",
             "operator_type", "model_grid_type", "sht_grid_type")
     model = osf.SphericalFourierNeuralOperatorNet(**{k: cfg[k] for k in keys if k in cfg})
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
     inp, tar = torch.rand(1, cfg["inp_chans"], H, W), torch.rand(1, cfg["out_chans"], H, W)
+    if mode != "step":
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            y = model(inp)
+            rec.update(t_fwd=time.perf_counter() - t0, out_mean=float(y.mean()))
+        print(json.dumps(rec), flush=True)
+        return
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
     t0 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
     loss = (model(inp) - tar).square().mean()
@@ -257,43 +268,56 @@ def _cpu_worker(cfg_name, mode):
     print(json.dumps(rec), flush=True)
 
 
-def cpu_baseline(cfg_name, timeout_s=420):
-    """Reference-equivalent CPU path, timed in a child process on this host's cores, fp32 (kind "port": the oracle).
-    Measured: ONE full train step (forward + backward + clip + AdamW) of the whole 721 x 1440 network, no warm-up step
-    (a second one would double the minutes this adds to the run).  If the full step cannot run here (host RAM, time
-    limit) the fallback is one internal-grid block's forward+backward scaled by the step/block FLOP ratio — and the
-    ``sample`` string says which of the two was reported."""
+def cpu_baseline(cfg_name, timeout_s=240):
+    """Reference-equivalent CPU path, timed in a child process on this host's cores, fp32 (kind "port": the oracle), on
+    a bounded sample (about 30 s of host time): ONE forward pass of the whole network at 721 x 1440, measured, times the
+    (forward+backward)/forward ratio measured on one internal-grid block; the optimizer is excluded (which favours the
+    CPU number).  MAKANI_AMD_CPU_BASELINE=step measures one full train step instead (minutes; a first attempt on the GPU
+    box's host did not finish within 420 s).  If the whole-network pass cannot run (host RAM, time limit) the fallback is
+    the block measurement scaled by the step/block FLOP ratio; ``sample`` says which one was reported."""
     import subprocess
     if cfg_name != "sfno_sc3_layers8_edim384":
         return None
-    mode = os.environ.get("MAKANI_AMD_CPU_BASELINE", "step")
+    mode = os.environ.get("MAKANI_AMD_CPU_BASELINE", "fwd")
+    if mode == "step":
+        timeout_s = max(timeout_s, 1500)
     recs, err = [], None
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name, "--cpu-mode", mode],
-                             capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
-        recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
-        if out.returncode != 0:
-            err = f"exit code {out.returncode}"
-    except subprocess.TimeoutExpired as e:
-        recs = [json.loads(l) for l in (e.stdout or b"").decode().splitlines() if l.startswith("{")]
-        err = f"time limit {timeout_s} s"
+        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name, "--cpu-mode", mode],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        try:
+            so, _ = pr.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            so, _ = pr.communicate()
+            err = f"time limit {timeout_s} s"
+        recs = [json.loads(l) for l in (so or "").splitlines() if l.startswith("{")]
+        if pr.returncode not in (0, None) and err is None:
+            err = f"exit code {pr.returncode}"
     except Exception as e:   # never stall the GPU benchmark
         err = type(e).__name__
     if not recs:
         return dict(value=None, unit="samples/s", cores=None, kind="port", sample=f"CPU baseline unavailable: {err}")
     rec = recs[-1]
+    who = f"oracle fp32 on {rec['threads']} host threads ({rec['cores']} cores visible; the faster of 32 / 64 threads on one block)"
     if "t_step" in rec:
         return dict(value=1.0 / rec["t_step"], unit="samples/s", cores=rec["threads"], kind="port",
-                    sample=f"oracle fp32 on {rec['threads']} host threads ({rec['cores']} cores visible; thread count = the "
-                           f"fastest of a short sweep on one block): ONE measured full train step (fwd + bwd + clip + AdamW) "
-                           f"of the whole network at 721x1440, B=1 = {rec['t_step']:.1f} s",
-                    ms_per_step=rec["t_step"] * 1e3, measured="full step")
+                    sample=f"{who}: ONE measured full train step (fwd + bwd + clip + AdamW) of the whole network at 721x1440, "
+                           f"B=1 = {rec['t_step']:.1f} s", ms_per_step=rec["t_step"] * 1e3, measured="full step")
+    if "t_fwd" in rec:
+        ratio = rec["t_mid"] / rec["t_mid_fwd"]
+        step = rec["t_fwd"] * ratio
+        return dict(value=1.0 / step, unit="samples/s", cores=rec["threads"], kind="port",
+                    sample=f"{who}: ONE measured forward pass of the whole network at 721x1440, B=1 = {rec['t_fwd']:.1f} s, times the "
+                           f"measured (fwd+bwd)/fwd ratio of one internal-grid block ({rec['t_mid']:.2f} s / {rec['t_mid_fwd']:.2f} s = "
+                           f"{ratio:.2f}) -> {step:.1f} s per step; optimizer excluded",
+                    ms_per_step=step * 1e3, measured="full-size forward x block bwd/fwd ratio")
     scale = _STAGE_GF["total"] / _STAGE_GF["mid_block"]
     step = rec["t_mid"] * scale
     return dict(value=1.0 / step, unit="samples/s", cores=rec["threads"], kind="port",
-                sample=f"oracle fp32 on {rec['threads']} host threads ({rec['cores']} cores visible): the full step did not "
-                       f"complete ({err}); fwd+bwd of one internal-grid block ({rec['h']}x{rec['w']}, 384 ch) = {rec['t_mid']:.2f} s, "
-                       f"scaled by the step/block FLOP ratio {scale:.1f} -> {step:.1f} s per step (optimizer excluded)",
+                sample=f"{who}: the whole-network pass did not complete ({err}); fwd+bwd of one internal-grid block "
+                       f"({rec['h']}x{rec['w']}, 384 ch) = {rec['t_mid']:.2f} s, scaled by the step/block FLOP ratio {scale:.1f} -> "
+                       f"{step:.1f} s per step (optimizer excluded)",
                 ms_per_step=step * 1e3, measured="one block, extrapolated")
 
 
@@ -579,7 +603,7 @@ def main():
                     help="recompute each rollout step's network call in backward (makani's --multistep_checkpoint)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-mode", default="step", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-mode", default="fwd", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         _cpu_worker(args.cpu_worker, args.cpu_mode)

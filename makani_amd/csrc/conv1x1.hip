@@ -40,6 +40,58 @@ struct ConvNN {
 
 __device__ __forceinline__ uint4 ld16(const u16* p) { return *reinterpret_cast<const uint4*>(p); }
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// ---- LDS-DMA (buffer_load ... lds) as inline assembly -------------------------------------------------------------
+// The ring kernels below keep one or two stages of LDS-DMA in flight across barriers and wait for them with counted
+// s_waitcnt vmcnt(N).  hipcc's own wait-count pass knows the builtin form of these loads and puts a full
+// s_waitcnt vmcnt(0) in front of the next LDS read (it cannot tell which stage a ds_read touches), which drains the
+// ring at every step; as inline assembly the loads are outside its bookkeeping and the kernel counts them itself.
+// One statement = 3 or 4 pieces of 1 KB (64 lanes x 16 B) to LDS addresses lds0 + i * STEP; M0 (the DMA destination
+// base) is written and restored inside the statement; s_nop 4 covers an SGPR operand written by the instruction just
+// before, s_nop 0 the M0 write -> DMA read hazard.
+__device__ __forceinline__ v4i_t make_rsrc(const void* ptr) {      // raw buffer, stride 0: voffset >= 2^31 reads zeros
+    const unsigned long long a = (unsigned long long)ptr;
+    v4i_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    r[2] = (int)0x80000000u;
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const void* ptr) { return (unsigned)(unsigned long long)(lds_void_t*)ptr; }
+
+template <int STEP>
+__device__ __forceinline__ void dma4(unsigned lds0, v4i_t rs, unsigned soff, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_nop 4\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds0), "s"(rs), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "i"(STEP)
+        : "memory", "scc");
+}
+template <int STEP>
+__device__ __forceinline__ void dma3(unsigned lds0, v4i_t rs, unsigned soff, unsigned v0, unsigned v1, unsigned v2) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_nop 4\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds0), "s"(rs), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "i"(STEP)
+        : "memory", "scc");
+}
+
 // ------------------------------------------------------------------------------------------
 // Main loop: LDS double buffer + TWO register sets (loads run two k-tiles ahead: one k-tile is only 16 MFMAs =
 // 0.2 us per wave), interior tiles load without per-vector branches.  Epilogue: the fp32 accumulators cross LDS
@@ -283,6 +335,268 @@ __global__ __launch_bounds__(NT, WGS) void conv_nn_kernel(const ConvNN p, int ti
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward / data-gradient channel GEMM, ring version (K a multiple of 64, M >= 192): a persistent grid of 512-thread
+// workgroups, one per CU, walks over (pixel tile, channel slab) pairs.  Tile = BM (256 or 192) output channels x 256
+// pixels; both operands stream through a two-stage LDS ring filled by LDS-DMA (a stage = BM x 64 weights + 64 x 256
+// activations = 56-64 KB, so that much is in flight per CU while the other stage is multiplied):
+//   weights     rows of 128 B (64 k), chunk index XOR (row >> 1) & 7      -> conflict-free ds_read_b128 fragments
+//   activations rows of 512 B (256 pixels of one input channel), chunk index XOR (k & 3) << 2
+//                                                                          -> conflict-free ds_read_b64_tr_b16 fragments
+// (the XOR is applied to the per-lane source address; the DMA destination is lane-linear).
+// The product is formed transposed, D[pixel][channel] (activation fragment as the MFMA's first operand), so that a lane
+// owns ONE output channel and runs of 4 consecutive pixels: bias is a per-lane scalar and the accumulators go to a
+// 32 KB bf16 staging image in LDS with 8-byte stores; from there every thread handles whole 16-byte pixel vectors of
+// one channel row (epilogue math, coalesced 512-byte row segments to global memory).
+// The first two stages of the next tile are requested before the epilogue of the current one starts.
+template <int TM>                // TM = 32-row channel tiles per wave (BM = 2 * TM * 32)
+__global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, int tilesM, long long tilesN, long long ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TN = 2;                               // 8 waves = 2 (channels) x 4 (pixels); wave tile (TM*32) x 64
+    constexpr int BM = 2 * TM * 32, BN = 256, BK = 64;
+    constexpr int ASZ = BM * 128, XSZ = BK * BN * 2, STAGE = ASZ + XSZ;
+    constexpr int NIA = BM / 64, NIX = 4, NI = NIA + NIX;     // LDS-DMA instructions per wave and stage
+    constexpr int EROWS = 64;                           // staging image: 64 channel rows x 256 pixels bf16 = 32 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + EROWS * 512];
+    unsigned char* const stg = smem + 2 * STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nk = p.K / BK;
+    const unsigned rowbytes = (unsigned)(p.N * 2);
+
+    // ---- DMA addressing ----
+    // weights: instruction i fills row group rg = wave + 8 i (8 rows x 128 B); lane -> (row = lane >> 3, physical chunk = lane & 7)
+    const int ca_log = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    // activations: instruction j fills rows kk = 2 (wave + 8 j) + (lane >> 5); lane -> physical chunk lane & 31 of a 512-byte row
+    const int kx3 = (2 * (wave & 1) + (lane >> 5)) & 3;                 // kk & 3, the same for every j
+    const int cx_log = (lane & 31) ^ (kx3 << 2);
+    unsigned voffx[NIX];
+#pragma unroll
+    for (int j = 0; j < NIX; ++j) voffx[j] = (unsigned)(2 * (wave + 8 * j) + (lane >> 5)) * rowbytes + (unsigned)cx_log * 16u;
+    const v4i_t rsA = make_rsrc(p.A);
+    const unsigned lds_w = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;    // this wave's 1 KB slot of a row-group stripe
+
+    // ---- fragment addressing ----
+    const int swa = (l31 >> 1) & 7;
+    int aoff[4];                                        // weight fragment (MFMA second operand): row l31 of a 32-row tile, chunk ks*2 + lh
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) aoff[ks] = (wm * TM * 32 + l31) * 128 + (((ks * 2 + lh) ^ swa) * 16);
+    const int s15 = lane & 15, g1 = (lane >> 4) & 1;
+    int xoff[TN];                                       // activation fragment (first operand): transpose read, rows ks*16 + lh*8 + (s15>>2) [+4]
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        xoff[j] = ASZ + (lh * 8 + (s15 >> 2)) * 512 + ((((wn * TN + j) ^ ((s15 >> 2) & 3)) * 4 + g1 * 2 + ((s15 & 3) >> 1)) * 16) + (s15 & 1) * 8;
+
+    const long long first = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned voffa[NIA];
+    unsigned voffx_t[NIX];
+    v4i_t rsX = rsA;
+    int m0 = 0, bcur = -1;
+    long long n0 = 0;
+
+    auto setup_tile = [&](long long t) {                // per-tile DMA addresses (tiles of one pixel range are consecutive ids)
+        const int tm = (int)(t % tilesM);
+        const long long tnb = t / tilesM;
+        const int b = (int)(tnb / tilesN);
+        m0 = tm * BM;
+        n0 = (tnb % tilesN) * BN;
+        if (b != bcur) {
+            bcur = b;
+            rsX = make_rsrc(p.X + (long long)b * p.K * p.N);
+        }
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int row = min(m0 + (wave + 8 * i) * 8 + (lane >> 3), p.M - 1);     // rows past M: any valid row (never stored)
+            voffa[i] = (unsigned)row * (unsigned)(p.lda * 2) + (unsigned)ca_log * 16u;
+        }
+        // pixels past N (last pixel tile): re-read the last valid chunk of the row (those columns are never stored)
+        const int cmax = (int)((min(p.N, n0 + BN) - n0) / 8) - 1;
+#pragma unroll
+        for (int j = 0; j < NIX; ++j) voffx_t[j] = voffx[j] - (unsigned)max(0, cx_log - cmax) * 16u;
+    };
+    auto issue = [&](int kt, int stage) {
+        const unsigned dst = lds_w + stage * STAGE;
+        const unsigned soffa = (unsigned)(kt * BK * 2);
+        const unsigned soffx = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(((long long)kt * BK * p.N + n0) * 2));
+        if constexpr (NIA == 4) dma4<8192>(dst, rsA, soffa, voffa[0], voffa[1], voffa[2], voffa[3]);
+        else dma3<8192>(dst, rsA, soffa, voffa[0], voffa[1], voffa[2]);
+        dma4<8192>(dst + ASZ, rsX, soffx, voffx_t[0], voffx_t[1], voffx_t[2], voffx_t[3]);
+    };
+
+    f32x16 acc[TM][TN];
+    auto compute = [&](int stage) {
+        const unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[TM], xf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(sb + aoff[ks] + i * 4096));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned char* q0 = sb + xoff[j] + ks * 16 * 512;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 512));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                xf[j] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[j], af[i], acc[i][j], 0, 0, 0);     // D[pixel][channel]
+        }
+    };
+
+    long long t = first;
+    if (t < ntiles) {
+        setup_tile(t);
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+    }
+    for (; t < ntiles; t += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int cm0 = m0;                               // coordinates of the tile being multiplied (setup_tile moves on below)
+        const long long cn0 = n0;
+        const int cb = bcur;
+        // this lane's bias values, fetched and WAITED FOR here: the wait hipcc emits in front of the first use of an
+        // ordinary load is a full vmcnt drain as far as the hardware counter is concerned (the DMA pieces are not in its
+        // books); at this point that drain coincides with the wait for the tile's first stage, in the epilogue it would
+        // stall on the next tile's prefetch
+        float bvr[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = cm0 + (wm * TM + i) * 32 + l31;
+            bvr[i] = (p.bias && mrow < p.M) ? p.bias[mrow] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(bvr[i]));
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt == 0 || kt + 1 >= nk) wait_vmcnt<0>(); else wait_vmcnt<NI>();     // kt == 0 also drains the previous tile's stores
+            __builtin_amdgcn_s_barrier();
+            compute(kt & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2, kt & 1);
+        }
+        // next tile: its first two stages fly during this tile's epilogue.  With a fused multiplicand / residual the
+        // epilogue has loads of its own, and the wait in front of their first use drains the whole counter (see above):
+        // there the prefetch is issued in the last round, after those loads have been consumed
+        const bool have_next = t + gridDim.x < ntiles;
+        const bool epi_loads = p.G || p.R;
+        if (have_next) setup_tile(t + gridDim.x);
+        if (have_next && !epi_loads) {
+            issue(0, 0);                                  // (both stages are free: the k-loop ended with a barrier)
+            if (nk > 1) issue(1, 1);
+        }
+
+        // ---- epilogue: TM rounds of 64 channel rows (32 per wave row) through the staging image ----
+        const long long plane = (long long)cb * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // (a) this thread's four 8-pixel vectors of the round and the operands it has to fetch for them
+            long long off[4];
+            bool live[4];
+            uint4 gq[4], rq[4];
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int idx = tid + 512 * u4;
+                const int row = idx >> 5, ch = idx & 31;
+                const int m = cm0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+                const long long n = cn0 + ch * 8;
+                live[u4] = m < p.M && n < p.N;
+                off[u4] = plane + (long long)m * p.N + n;
+                gq[u4] = rq[u4] = make_uint4(0, 0, 0, 0);
+                if (live[u4] && p.G) gq[u4] = ld16(p.G + off[u4]);
+                if (live[u4] && p.R) rq[u4] = ld16(p.R + off[u4]);
+            }
+            // (b) accumulators (+ bias) -> bf16 -> staging image
+            const float bv = bvr[i];
+            const int lrow = wm * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int px = (wn * TN + j) * 32 + 8 * q + 4 * lh;           // 4 consecutive pixels of this lane's channel
+                    uint2 u;
+                    u.x = (uint32_t)f32_to_bf16(acc[i][j][4 * q] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 1] + bv) << 16);
+                    u.y = (uint32_t)f32_to_bf16(acc[i][j][4 * q + 2] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 3] + bv) << 16);
+                    *reinterpret_cast<uint2*>(stg + lrow * 512 + (((px >> 3) ^ (lrow & 15)) * 16) + ((px >> 2) & 1) * 8) = u;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (epi_loads) {
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) {          // consume the fetched operands here (one wait), then the prefetch may go
+                    asm volatile("" : "+v"(gq[u4].x), "+v"(gq[u4].y), "+v"(gq[u4].z), "+v"(gq[u4].w));
+                    asm volatile("" : "+v"(rq[u4].x), "+v"(rq[u4].y), "+v"(rq[u4].z), "+v"(rq[u4].w));
+                }
+                if (i == TM - 1 && have_next) {
+                    issue(0, 0);
+                    if (nk > 1) issue(1, 1);
+                }
+            }
+            // (c) staging image -> epilogue math -> 16-byte stores
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int idx = tid + 512 * u4;
+                const int row = idx >> 5, ch = idx & 31;
+                const uint4 raw = *reinterpret_cast<const uint4*>(stg + row * 512 + ((ch ^ (row & 15)) * 16));
+                if (live[u4]) {
+                    const long long o = off[u4];
+                    if (!p.act && !p.G && !p.R) {
+                        *reinterpret_cast<uint4*>(p.Y + o) = raw;
+                    } else {
+                        if (p.act && p.Ypre) *reinterpret_cast<uint4*>(p.Ypre + o) = raw;
+                        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] = __uint_as_float(w[e] << 16);
+                            v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+                        }
+                        if (p.act) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                        }
+                        if (p.G) {
+                            const uint32_t gw[4] = {gq[u4].x, gq[u4].y, gq[u4].z, gq[u4].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[2 * e] *= gelu_grad_f(__uint_as_float(gw[e] << 16));
+                                v[2 * e + 1] *= gelu_grad_f(__uint_as_float(gw[e] & 0xffff0000u));
+                            }
+                        }
+                        if (p.R) {
+                            const uint32_t rw[4] = {rq[u4].x, rq[u4].y, rq[u4].z, rq[u4].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[2 * e] += __uint_as_float(rw[e] << 16);
+                                v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                            }
+                        }
+                        uint4 out;
+                        out.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        out.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        out.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                        out.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                        *reinterpret_cast<uint4*>(p.Y + o) = out;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // the staging image is free for the next round
+        }
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad: part[s][m][k] = sum_{n in split s} G[b][m][n] X[b][k][n];   tile 128 (m) x 128 (k-channel)
 struct ConvWg {
     const u16* G;   // (B, M, N)
@@ -440,11 +754,181 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad, ring version: one 512-thread workgroup per CU owns an output tile that spans the WHOLE smaller channel
+// dimension (TQ = 384 rows of operand Q) and a 256- or 192-row slab of the other operand (P), so every pixel of P is
+// read from memory exactly once and Q's pixels are shared by only 2-3 co-scheduled workgroups (the 128 x 128 tiles above
+// re-read each operand 3-6 times; measured 1.67x the algorithmic HBM bytes).  Both operands stream through a two-stage
+// LDS ring filled by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass); a stage holds
+// (TP + TQ) rows x 64 pixels = 72-80 KB, i.e. 72-80 KB per CU are in flight at any time while the other stage is
+// multiplied.  LDS rows are 128 bytes (one cache line of one channel); the 16-byte chunk index of a row is XOR-swizzled
+// with (row >> 1) & 7 — applied to the per-lane SOURCE address, the DMA destination is lane-linear — which makes the
+// ds_read_b128 fragment reads conflict-free.
+struct ConvWgR {
+    const u16* P;    // (B, RP, N)   slab operand
+    const u16* Q;    // (B, RQ, N)   operand held in full (RQ <= TQ)
+    float* part;     // (S, M, K) fp32 partials in OUTPUT orientation
+    int RP, RQ, B, S, slabs;
+    int ldo;         // row length of the output (= K)
+    long long N;
+    long long chunk;   // pixels per split (multiple of 64)
+};
+
+
+// SWAP = false: P = G (rows m), Q = X (rows k): tile D[p][q] = out[m][k]
+// SWAP = true : P = X (rows k), Q = G (rows m): MFMA operands exchanged so that D[q][p] = out[m][k]
+// (either way the lanes of an accumulator row run along k, the contiguous output index)
+template <int WP, int WQ, int WTP, int WTQ, bool SWAP>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // buffer resources / LDS-DMA builtins exist in the device pass only (the host pass just needs the stub)
+    static_assert(WP * WQ == 8, "8 waves");
+    constexpr int TP = WP * WTP * 32, TQ = WQ * WTQ * 32;
+    constexpr int BK = 64;                              // pixels per stage: one 128-byte line per row
+    constexpr int STAGE = (TP + TQ) * 128;              // bytes
+    constexpr int NI = (TP + TQ) / 64;                  // LDS-DMA instructions per wave and stage (8 rows each)
+    constexpr int NIP = TP / 64;                        // the first NIP of them fetch P rows
+    static_assert(TP % 64 == 0 && TQ == 384, "row groups; Q is fetched by 2 x 3 DMA pieces per wave");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);   // the slabs of one pixel split are neighbours on one XCD (share Q in L2)
+    const int slab = bid % p.slabs;
+    const int sp = bid / p.slabs;
+    const int splits_per_b = p.S / p.B;
+    const int b = sp / splits_per_b;
+    const long long nbeg = (long long)(sp % splits_per_b) * p.chunk;
+    const long long nend = min(p.N, nbeg + p.chunk);
+    const int nk = nbeg < nend ? (int)((nend - nbeg + BK - 1) / BK) : 0;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave / WQ, wq = wave % WQ;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- LDS-DMA addressing: instruction i of this wave fills row group rg = wave + 8 i (8 rows x 128 B) ----
+    // lane -> (row in group = lane >> 3, physical chunk = lane & 7); it fetches the LOGICAL chunk c = phys ^ swizzle(row)
+    const int c_log = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    const unsigned rowbytes = (unsigned)(p.N * 2);
+    unsigned voff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int rg = wave + 8 * i;
+        int row;
+        if (i < NIP) row = min(slab * TP + rg * 8 + (lane >> 3), p.RP - 1);           // rows past the operand: any valid row
+        else row = min((rg - TP / 8) * 8 + (lane >> 3), p.RQ - 1);                    // (their products are never stored)
+        voff[i] = (unsigned)row * rowbytes + (unsigned)c_log * 16u;
+    }
+    // raw buffers (stride 0, 2^31 records): a lane whose voffset is >= 2^31 reads zeros — used for the ragged last pixel tile
+    const v4i_t rsP = make_rsrc(p.P + (long long)b * p.RP * p.N);
+    const v4i_t rsQ = make_rsrc(p.Q + (long long)b * p.RQ * p.N);
+    const unsigned lds_w = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;
+
+    auto issue = [&](int kt, int stage) {
+        const long long n = nbeg + (long long)kt * BK;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(n * 2));
+        const unsigned dst = lds_w + stage * STAGE;
+        unsigned v[NI];
+        // ragged last pixel tile of the plane (at most once per workgroup): chunks past nend get a voffset beyond the
+        // buffer's 2^31 records and come back as zeros
+        const bool ok = n + BK <= nend || n + c_log * 8 < nend;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = ok ? voff[i] : 0xC0000000u;
+        if constexpr (NIP == 4) dma4<8192>(dst, rsP, soff, v[0], v[1], v[2], v[3]);
+        else dma3<8192>(dst, rsP, soff, v[0], v[1], v[2]);
+        dma3<8192>(dst + NIP * 8192, rsQ, soff, v[NIP], v[NIP + 1], v[NIP + 2]);
+        dma3<8192>(dst + (NIP + 3) * 8192, rsQ, soff, v[NIP + 3], v[NIP + 4], v[NIP + 5]);
+    };
+
+    // ---- fragment addressing: lane (l31, lh) reads row l31 of a 32-row tile, logical chunk ks*2 + lh ----
+    const int swz = (l31 >> 1) & 7;
+    int pa[4], qa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int ch = ((ks * 2 + lh) ^ swz) * 16;
+        pa[ks] = (wp * WTP * 32 + l31) * 128 + ch;
+        qa[ks] = (TP + wq * WTQ * 32 + l31) * 128 + ch;
+    }
+
+    f32x16 acc[WTP][WTQ];
+#pragma unroll
+    for (int i = 0; i < WTP; ++i)
+#pragma unroll
+        for (int j = 0; j < WTQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int stage) {
+        const unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 pf[WTP], qf[WTQ];
+#pragma unroll
+            for (int i = 0; i < WTP; ++i) pf[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(sb + pa[ks] + i * 4096));
+#pragma unroll
+            for (int j = 0; j < WTQ; ++j) qf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(sb + qa[ks] + j * 4096));
+#pragma unroll
+            for (int i = 0; i < WTP; ++i)
+#pragma unroll
+                for (int j = 0; j < WTQ; ++j)
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nk > 0) issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<NI>(); else wait_vmcnt<0>();      // this wave's share of stage kt has landed ...
+        __builtin_amdgcn_s_barrier();                                   // ... and so has everybody else's
+        compute(kt & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my fragment reads have RETURNED (a raw s_barrier does not wait) ...
+        __builtin_amdgcn_s_barrier();                                   // ... and everybody's: the stage may be overwritten
+        if (kt + 2 < nk) issue(kt + 2, kt & 1);
+    }
+
+    // ---- partial tile -> part[sp] in output orientation (lanes along k) ----
+    float* out = p.part + (long long)sp * ((long long)(SWAP ? p.RQ : p.RP) * p.ldo);
+#pragma unroll
+    for (int i = 0; i < WTP; ++i)
+#pragma unroll
+        for (int j = 0; j < WTQ; ++j) {
+            const int prow0 = slab * TP + (wp * WTP + i) * 32, qrow0 = (wq * WTQ + j) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                // not swapped: D rows = p (m), lanes = q (k);  swapped: D rows = q (m), lanes = p (k)
+                const int m = SWAP ? qrow0 + rr : prow0 + rr;
+                const int k = SWAP ? prow0 + l31 : qrow0 + l31;
+                const bool ok = SWAP ? (m < p.RQ && k < p.RP) : (m < p.RP && k < p.RQ);
+                if (ok) out[(long long)m * p.ldo + k] = acc[i][j][r];
+            }
+        }
+#endif
+}
+
 __global__ void reduce_splits(const float* __restrict__ part, float* __restrict__ out, long long n, int S, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = accumulate ? out[i] : 0.f;
     for (int k = 0; k < S; ++k) s += part[(long long)k * n + i];
+    out[i] = s;
+}
+
+// n % 4 == 0: four consecutive outputs per thread, eight splits in flight
+__global__ void reduce_splits4(const float4* __restrict__ part, float4* __restrict__ out, long long n4, int S, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + u) * n4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+    }
+    for (; k < S; ++k) {
+        const float4 v = part[(long long)k * n4 + i];
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
     out[i] = s;
 }
 
@@ -458,6 +942,19 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     MK_REQUIRE((N % 8) == 0, "conv1x1_nn: pixel count %lld must be a multiple of 8", N);
     MK_REQUIRE((((uintptr_t)A | (uintptr_t)X) & 15) == 0, "conv1x1_nn: operands must be 16-byte aligned");
     ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
+    static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
+    if (!force_tile && (K % 64) == 0 && M >= 192 && (long long)K * N * 2 < (1ll << 31) && (long long)M * lda * 2 < (1ll << 31) && N >= 256) {
+        // ring kernel: persistent grid, one 512-thread workgroup per CU
+        const bool big = (M % 256 == 0) || M > 576;
+        const int bm = big ? 256 : 192;
+        const int tm = (M + bm - 1) / bm;
+        const long long tn = (N + 255) / 256;
+        const long long nt = (long long)tm * tn * B;
+        const unsigned grid = (unsigned)(nt < 256 ? nt : 256);
+        if (big) hipLaunchKernelGGL((conv_nn_ring_kernel<4>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tm, tn, nt);
+        else hipLaunchKernelGGL((conv_nn_ring_kernel<3>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, tm, tn, nt);
+        return mk_check_launch("mk_conv1x1_nn");
+    }
     // 128 x 256 tile, BK = 64 with one LDS stage (measured 10-15 % faster at 721x1440 than BK = 32 double-buffered,
     // equal at 240x480; a 128 x 128 tile with two register sets was 10-20 % slower)
     // BK = 64 with one LDS stage (10-15 % faster at 721x1440 than BK = 32 double-buffered).  Tile 128 x 128 with
@@ -481,31 +978,103 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     return mk_check_launch("mk_conv1x1_nn");
 }
 
-extern "C" long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N) {
-    // number of fp32 elements the caller must provide as `part`
+// ---- host-side plan of the weight gradient -------------------------------------------------
+namespace {
+struct WgPlan {
+    bool ring;          // ring kernel (big tiles) or the 128 x 128 tile kernel
+    bool swap;          // ring: P = X, Q = G
+    int tp;             // ring: slab height (256 / 192)
+    int slabs;
+    long long S;        // pixel splits (all batch entries)
+    long long chunk;    // pixels per split
+};
+
+int wgrad_kernel_choice() {      // MAKANI_AMD_WGRAD=tile forces the 128 x 128 tile kernel (A/B measurements)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MAKANI_AMD_WGRAD");
+        v = (e && e[0] == 't') ? 1 : 0;
+    }
+    return v;
+}
+
+WgPlan wgrad_plan(int M, int K, int B, long long N) {
+    WgPlan pl{};
+    const int big = M > K ? M : K, small = M > K ? K : M;
+    // ring kernel: the smaller channel count fits one 384-row tile, the other one is cut into slabs; 32-bit byte
+    // offsets inside one batch entry; at least a few pixel tiles per split
+    const bool ok = wgrad_kernel_choice() == 0 && big <= 384 * 4 && big >= 96 && (long long)big * N * 2 < (1ll << 31) && N >= 2048;
+    if (ok && (small <= 384)) {
+        pl.ring = true;
+        int q, pr;                                   // rows of Q (held in full) and of P (slabs)
+        if (big <= 384) { q = big; pr = small; } else { q = small; pr = big; }
+        // Q = X (k) unless that puts the larger operand in P's place the wrong way round
+        const bool q_is_x = (K == q) && !(M == q && M > K);
+        pl.swap = !q_is_x;
+        pl.tp = (pr > 192 && pr % 256 != 192 && (pr % 192 != 0 || pr % 256 == 0)) ? 256 : 192;
+        if (pr <= 192) pl.tp = 192;
+        pl.slabs = (pr + pl.tp - 1) / pl.tp;
+        long long per_b = 256 / ((long long)pl.slabs * B);
+        if (per_b < 1) per_b = 1;
+        const long long maxs = (N + 1023) / 1024;    // at least 16 pixel tiles per split
+        if (per_b > maxs) per_b = maxs;
+        long long chunk = ((N + per_b - 1) / per_b + 63) / 64 * 64;
+        per_b = (N + chunk - 1) / chunk;             // no empty splits
+        pl.chunk = chunk;
+        pl.S = per_b * B;
+        return pl;
+    }
     const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
     long long per_b = 1024 / ((long long)tiles * B);
     if (per_b < 1) per_b = 1;
-    const long long maxs = (N + 2047) / 2048;      // at least 2048 pixels per split
+    const long long maxs = (N + 2047) / 2048;        // at least 2048 pixels per split
     if (per_b > maxs) per_b = maxs;
-    return per_b * B * (long long)M * K;
+    long long chunk = (N + per_b - 1) / per_b;
+    chunk = (chunk + 127) / 128 * 128;
+    pl.chunk = chunk;
+    pl.S = per_b * B;
+    return pl;
+}
+}  // namespace
+
+extern "C" long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N) {
+    // number of fp32 elements the caller must provide as `part`
+    return wgrad_plan(M, K, B, N).S * (long long)M * K;
 }
 
 extern "C" int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* part, int M, int K, int B, long long N,
                                 int accumulate, void* stream) {
     MK_REQUIRE(G && X && dW && part, "conv1x1_wgrad: null pointer");
     MK_REQUIRE(M > 0 && K > 0 && B > 0 && N > 0 && (N % 8) == 0, "conv1x1_wgrad: bad shape");
-    const int tm = (M + 127) / 128, tk = (K + 127) / 128;
-    const long long S = mk_conv1x1_wgrad_workspace(M, K, B, N) / ((long long)M * K);
-    const long long per_b = S / B;
-    long long chunk = (N + per_b - 1) / per_b;
-    chunk = (chunk + 127) / 128 * 128;
-    ConvWg p{(const u16*)G, (const u16*)X, part, M, K, B, (int)S, N, chunk};
+    const WgPlan pl = wgrad_plan(M, K, B, N);
     hipStream_t s = (hipStream_t)stream;
-    // BK = 128 / one LDS stage and BK = 64 / two stages + two register sets measure the same (+-2 %) on the 384/768
-    // channel shapes; the former is 8 % faster on the 73-channel ones and needs 36 fewer VGPRs
-    hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3((unsigned)(tm * tk * S)), dim3(NT), 0, s, p, tm, tk);
+    if (pl.ring) {
+        ConvWgR p{};
+        p.P = (const u16*)(pl.swap ? X : G);
+        p.Q = (const u16*)(pl.swap ? G : X);
+        p.RP = pl.swap ? K : M;
+        p.RQ = pl.swap ? M : K;
+        p.part = part, p.B = B, p.S = (int)pl.S, p.slabs = pl.slabs, p.ldo = K, p.N = N, p.chunk = pl.chunk;
+        const dim3 grid((unsigned)(pl.slabs * pl.S)), blk(512);
+        if (pl.tp == 256) {
+            if (pl.swap) hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 4, 4, 3, true>), grid, blk, 0, s, p);
+            else hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 4, 4, 3, false>), grid, blk, 0, s, p);
+        } else {
+            if (pl.swap) hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 4, 3, 3, true>), grid, blk, 0, s, p);
+            else hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 4, 3, 3, false>), grid, blk, 0, s, p);
+        }
+    } else {
+        const int tm = (M + 127) / 128, tk = (K + 127) / 128;
+        ConvWg p{(const u16*)G, (const u16*)X, part, M, K, B, (int)pl.S, N, pl.chunk};
+        // BK = 128 / one LDS stage and BK = 64 / two stages + two register sets measure the same (+-2 %) on the 384/768
+        // channel shapes; the former is 8 % faster on the 73-channel ones and needs 36 fewer VGPRs
+        hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3((unsigned)(tm * tk * pl.S)), dim3(NT), 0, s, p, tm, tk);
+    }
     const long long n = (long long)M * K;
-    hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dW, n, (int)S, accumulate);
+    if (n % 4 == 0 && (((uintptr_t)part | (uintptr_t)dW) & 15) == 0)
+        hipLaunchKernelGGL(reduce_splits4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float4*)part, (float4*)dW,
+                           n / 4, (int)pl.S, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dW, n, (int)pl.S, accumulate);
     return mk_check_launch("mk_conv1x1_wgrad");
 }

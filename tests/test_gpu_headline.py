@@ -74,9 +74,12 @@ def _check_block(blk, x, g, ref, amp, tol):
         a = float((torch.view_as_real(p.grad.detach().cpu()) - torch.view_as_real(r)).abs().max()) if r.is_complex() \
             else float((p.grad.detach().cpu().float() - r).abs().max())
         errs[n] = e
-        # a per-channel constant in front of an instance norm (mlp.fwd.3.bias) has an exactly-zero gradient: round-off on
-        # both sides, accepted on the absolute scale of the model's largest gradient entry (as in test_gpu_model.py)
-        assert e < 2 * tol or a < 1e-4 * gmax * (100 if amp else 1), (n, e, a, gmax)
+        # a per-channel constant in front of an instance norm (mlp.fwd.3.bias) has an exactly-zero gradient: what both
+        # sides hold is round-off.  fp32: accepted on the absolute scale of the model's largest gradient entry (as in
+        # test_gpu_model.py); bf16: the sum over 115 200 bf16-rounded gradient pixels is noise of no fixed scale — skipped
+        if amp and n.endswith("mlp.fwd.3.bias"):
+            continue
+        assert e < 2 * tol or a < 1e-4 * gmax, (n, e, a, gmax)
     assert errs["y"] < tol and errs["gx"] < tol, errs
     return errs
 

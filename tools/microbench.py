@@ -79,20 +79,69 @@ def pointwise():
 
 
 def conv():
-    for (M, K, H, W) in ((384, 384, 721, 1440), (768, 384, 721, 1440), (384, 768, 721, 1440), (768, 384, 240, 480),
-                         (384, 768, 240, 480), (384, 384, 240, 480), (384, 73, 721, 1440), (73, 384, 721, 1440)):
-        x = torch.randn(1, K, H, W, device=dev).bfloat16()
+    """forward / data-gradient channel GEMM: HIP kernel (MAKANI_AMD_CONV_NN=tile: the 128-row tile kernel instead of the
+    ring kernel) against the library GEMM, plain and with the fused epilogues; each result checked against fp32"""
+    per_step = {(768, 384, 721): 2, (384, 768, 721): 2, (384, 384, 721): 8, (768, 384, 240): 14, (384, 768, 240): 14, (384, 384, 240): 14}
+    tot_hip = tot_lib = 0.0
+    for (M, K, H, W) in ((768, 384, 721, 1440), (384, 768, 721, 1440), (384, 384, 721, 1440), (768, 384, 240, 480),
+                         (384, 768, 240, 480), (384, 384, 240, 480), (73, 384, 721, 1440), (384, 73, 721, 1440)):
+        torch.manual_seed(M + K)
+        x = (torch.rand(1, K, H, W, device=dev) - 0.5).bfloat16()
         w = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
+        bias = torch.randn(M, device=dev)
         A = ops.pad_weight_bf16(w)
         fl = 2.0 * M * K * H * W
         nb = 2.0 * H * W * (M + K)
-        ms = timeit(lambda: ops.conv1x1_nn(A, K, x))
-        ms2 = timeit(lambda: torch.mm(w, x.view(K, H * W)))
-        g = torch.randn(1, M, H, W, device=dev).bfloat16()
-        ms3 = timeit(lambda: ops.conv1x1_wgrad(g, x))
-        ms4 = timeit(lambda: torch.mm(g.view(M, H * W), x.view(K, H * W).t()))
-        print(f"conv M={M} K={K} {H}x{W}: nn hip {ms:7.3f} ms ({fl/ms/1e9:6.0f} TF, {nb/ms/1e6:6.0f} GB/s) | torch.mm {ms2:7.3f} ms ({fl/ms2/1e9:6.0f} TF)"
-              f" || wgrad hip {ms3:7.3f} ms ({fl/ms3/1e9:6.0f} TF) | torch {ms4:7.3f} ms ({fl/ms4/1e9:6.0f} TF)")
+        ref = torch.mm(w.float(), x.view(K, -1).float())
+        y, _ = ops.conv1x1_nn(A, K, x)
+        err = ((y.view(M, -1).float() - ref).norm() / ref.norm()).item()
+        gsrc = torch.randn(1, M, H, W, device=dev).bfloat16()
+        res = torch.randn(1, M, H, W, device=dev).bfloat16()
+        y2, pre = ops.conv1x1_nn(A, K, x, bias=bias, act=True, want_pre=True, residual=res)
+        pre_ref = (ref + bias[:, None]).bfloat16().float()
+        ref2 = torch.nn.functional.gelu(pre_ref) + res.view(M, -1).float()
+        err2 = ((y2.view(M, -1).float() - ref2).norm() / ref2.norm()).item()
+        errp = ((pre.view(M, -1).float() - pre_ref).norm() / pre_ref.norm()).item()
+        del ref2, pre_ref, y2, pre
+        ms = timeit(lambda: ops.conv1x1_nn(A, K, x), reps=20, warm=3)
+        ms_b = timeit(lambda: ops.conv1x1_nn(A, K, x, bias=bias, act=True, want_pre=True), reps=20, warm=3)
+        ms_g = timeit(lambda: ops.conv1x1_nn(A, K, x, gelu_grad_of=gsrc), reps=20, warm=3)
+        ms_r = timeit(lambda: ops.conv1x1_nn(A, K, x, residual=res), reps=20, warm=3)
+        out = torch.empty(M, H * W, device=dev, dtype=torch.bfloat16)
+        ms2 = timeit(lambda: torch.mm(w, x.view(K, H * W), out=out), reps=20, warm=3)
+        n = per_step.get((M, K, H), 0)
+        tot_hip += n * ms
+        tot_lib += n * ms2
+        print(f"conv M={M:3d} K={K:3d} {H}x{W}: hip {ms:7.3f} ms ({fl/ms/1e9:5.0f} TF, {nb/ms/1e6:5.0f} GB/s) | lib {ms2:7.3f} ms ({fl/ms2/1e9:5.0f} TF)"
+              f" | +bias+gelu+pre {ms_b:6.3f}  *gelu'(G) {ms_g:6.3f}  +R {ms_r:6.3f} | rel err {err:.1e} fused {err2:.1e} pre {errp:.1e}")
+        del x, gsrc, res, ref, out
+    print(f"fwd+dgrad GEMMs of the step at these shapes: hip {tot_hip:.2f} ms, library {tot_lib:.2f} ms")
+
+
+def wgrad():
+    """channel-GEMM weight gradient: the nine shapes of the train step (+ ragged / batched ones), checked against an fp32
+    GEMM of the same bf16 operands, then timed.  MAKANI_AMD_WGRAD=tile selects the 128 x 128 tile kernel."""
+    shapes = [(768, 384, 1, 721, 1440), (384, 768, 1, 721, 1440), (384, 384, 1, 721, 1440), (384, 73, 1, 721, 1440),
+              (73, 384, 1, 721, 1440), (73, 73, 1, 721, 1440), (768, 384, 1, 240, 480), (384, 768, 1, 240, 480),
+              (384, 384, 1, 240, 480), (384, 200, 2, 91, 184), (300, 384, 1, 37, 72), (768, 384, 2, 60, 124)]
+    per_step = {(768, 384, 721): 1, (384, 768, 721): 1, (384, 384, 721): 3, (384, 73, 721): 1, (73, 384, 721): 1, (73, 73, 721): 1,
+                (768, 384, 240): 7, (384, 768, 240): 7, (384, 384, 240): 7}
+    total = 0.0
+    for (M, K, B, H, W) in shapes:
+        torch.manual_seed(M + K + H)
+        x = (torch.rand(B, K, H, W, device=dev) - 0.3).bfloat16()
+        g = (torch.randn(B, M, H, W, device=dev) * 0.5).bfloat16()
+        dW = ops.conv1x1_wgrad(g, x)
+        ref = torch.einsum("bmn,bkn->mk", g.view(B, M, -1).float(), x.view(B, K, -1).float())
+        err = ((dW - ref).norm() / ref.norm()).item()
+        ms = timeit(lambda: ops.conv1x1_wgrad(g, x), reps=20, warm=3)
+        nb = 2.0 * B * H * W * (M + K)
+        n = per_step.get((M, K, H), 0)
+        total += n * ms
+        print(f"wgrad M={M:3d} K={K:3d} B={B} {H}x{W}: {ms:7.3f} ms  {nb/ms/1e6:7.0f} GB/s  {2.0*B*M*K*H*W/ms/1e9:6.0f} TF  rel err {err:.1e}"
+              f"  {'x%d per step' % n if n else ''}")
+        del x, g
+    print(f"wgrad per step (29 launches): {total:.3f} ms  -> {16.72e3/total/1e3:.2f} TB/s algorithmic = {16.72e3/total/8e3:.3f} of 8 TB/s")
 
 
 def spectral():
