@@ -402,15 +402,45 @@ def run_worker(args):
             dom_family, dom_members = dominant_family(warm_prof)
     torch.cuda.synchronize()
 
+    # ---- hipGraph: the whole step (forward, backward, clip, AdamW: ~380 dependent launches) captured once, replayed
+    # per step.  Nothing in the step depends on host state (the optimizer's step counter lives in device memory,
+    # inputs are static tensors), so a replay IS the step.  One GPU only: with more ranks the collectives stay eager.
+    graph, graph_note = None, None
+    want_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    if want_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                     # one eager step on a side stream (torch's capture recipe)
+                train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_loss = train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+            torch.cuda.synchronize()
+            graph.replay()                                    # first replay outside the timed region
+            torch.cuda.synchronize()
+        except Exception as e:                                # capture is an optimisation: never lose the measurement to it
+            graph, graph_note = None, f"graph capture failed ({type(e).__name__}: {str(e)[:200]}); eager launches"
+            print(f"[bench] {graph_note}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+
     ops.PROFILER.reset()
-    ops.PROFILER.enabled = True
+    ops.PROFILER.enabled = graph is None
     ops.PROFILER.only = set(dom_members) if dom_members else None      # HIP events on the dominant kernel only (see above)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+    if graph is not None:
+        for _ in range(args.steps):
+            graph.replay()
+        loss = graph_loss
+    else:
+        for _ in range(args.steps):
+            loss = train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
     torch.cuda.synchronize()
     gc.enable()
     if world > 1:
@@ -418,6 +448,17 @@ def run_worker(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.PROFILER.enabled = False
+    event_steps = args.steps
+    if graph is not None:
+        # launch durations of the dominant kernel: HIP events cannot bracket a node inside a replayed graph, so the same
+        # launches are timed in eager steps right after the timed region (same process, same tensors, same shapes)
+        event_steps = 3
+        ops.PROFILER.reset()
+        ops.PROFILER.enabled = True
+        for _ in range(event_steps):
+            train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+        torch.cuda.synchronize()
+        ops.PROFILER.enabled = False
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -432,7 +473,7 @@ def run_worker(args):
         # rocprofv3 --stats table of the same command shows on top); its numbers come from the timed steps
         if not (dom_family and any(m in prof for m in dom_members)):
             dom_family, dom_members = dominant_family(prof)
-        kernels = kernel_table(warm_prof, prof, args.steps)
+        kernels = kernel_table(warm_prof, prof, event_steps)
         pmc = load_pmc_traffic() if (args.config == "sfno_sc3_layers8_edim384" and msize == 1) else {}
         roofline = roofline_of(dom_family, dom_members, prof, ops.GEMM_MODE, pmc.get(dom_family)) if dom_family else None
         # the runners-up, from the fully profiled warm-up step (one launch set, not an average over the timed steps)
@@ -463,7 +504,9 @@ def run_worker(args):
                        "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32",
                        "multistep_count": args.multistep_count,
                        "multistep_checkpoint": bool(args.multistep_checkpoint),
-                       "collectives": (dist.get_backend() if world > 1 else None)},
+                       "collectives": (dist.get_backend() if world > 1 else None),
+                       "launch": ("hipGraph replay of the captured step" if graph is not None else "eager"),
+                       "channel_gemm": os.environ.get("MAKANI_AMD_CONV", "hip")},
             "roofline": roofline,
             "roofline_runners_up": others,
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
@@ -471,6 +514,11 @@ def run_worker(args):
             "hip_kernel_ms_per_step": round(hip_ms, 2),
             "final_loss": final_loss,
         }
+        if graph_note:
+            out["note"] = graph_note
+        if graph is not None and roofline:
+            roofline["timing"] = (f"HIP events around the launches in {event_steps} eager steps run right after the timed region "
+                                  "(the timed steps are hipGraph replays, whose nodes cannot carry events)")
         if world == 1 and not args.no_sht_metric and args.config == "sfno_sc3_layers8_edim384":
             del model, net, opt
             torch.cuda.empty_cache()
@@ -500,7 +548,7 @@ def _free_port():
 def _worker_cmd(args, parallelism):
     cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--config", args.config, "--parallelism", parallelism, "--no-sht-metric",
-           "--no-cpu-baseline", "--multistep-count", str(args.multistep_count)]
+           "--no-cpu-baseline", "--multistep-count", str(args.multistep_count), "--graph", args.graph]
     if args.fp32:
         cmd.append("--fp32")
     if args.multistep_checkpoint:
@@ -596,6 +644,8 @@ def main():
                          "4: h4w1, 8: h4w2 — strong scaling), 'dp' (one sample per GPU, weak scaling) or 'hHwW': spatial "
                          "model parallelism over H x W GPUs per model instance, remaining ranks data parallel")
     ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the second (data-parallel) measurement")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture the train step in a hipGraph and replay it (auto: on one GPU)")
     ap.add_argument("--multistep-count", type=int, default=1,
                     help="autoregressive rollout length per sample (makani's --multistep_count, BASELINE configs[4]); "
                          "1 = the headline single-step metric")

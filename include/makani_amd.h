@@ -225,7 +225,12 @@ int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* part, int M
  * (config/sfnonet.yaml:50-54) after global-norm clipping (utils/training/training_helpers.py:123-165):
  * `grad_scale` (device pointer, may be NULL) is that clipping coefficient, applied to g on the fly. */
 int mk_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* grad_scale, float lr,
-                  float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+                  float beta1, float beta2, float eps, float weight_decay, int step, const float* step_state, void* stream);
+/* Device-side step counter: `state` = 3 floats {step, 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} (zero-initialised by
+ * the caller); one launch increments the step and refreshes the two bias corrections.  The update kernels read them when
+ * `step_state` is non-NULL (and ignore `step`): no launch argument depends on the step number, which is what makes a
+ * captured hipGraph of the whole train step replayable. */
+int mk_adamw_advance(float* state, float beta1, float beta2, void* stream);
 /* The same update over `count` tensors (host array of descriptors) in ceil(count / 48) launches: for the ~80 small
  * tensors of the model, where one launch each costs more in dispatch gaps than in HBM time. */
 typedef struct MkAdamTensor {
@@ -235,9 +240,12 @@ typedef struct MkAdamTensor {
     float* v;
     long long n;
     void* p_bf16;   /* optional (mk_adamw_multi only): receives bf16(updated p), the autocast operand of the next step */
+    void* p_bf16_t; /* optional: receives bf16(updated p) transposed (needs cols > 0): the data-gradient GEMM's operand */
+    int cols;       /* > 0: p is an (n / cols, cols) matrix; then p_bf16 has row pitch ld, p_bf16_t row pitch ld_t */
+    int ld, ld_t;
 } MkAdamTensor;
 int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_scale, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, void* stream);
+                   float eps, float weight_decay, int step, const float* step_state, void* stream);
 /* Global gradient norm and the clipping coefficient of makani/utils/training/training_helpers.py:123-165 over all
  * `tensors[i].g` (only g and n are read): out[0] = min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0), out[1] = norm.
  * `partial` needs mk_grad_norm_workspace() floats.  ceil(count / 48) + 1 launches, fixed summation order. */

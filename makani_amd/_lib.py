@@ -21,7 +21,7 @@ c_ll, c_int, c_f, c_vp = C.c_longlong, C.c_int, C.c_float, C.c_void_p
 class MkAdamTensor(C.Structure):
     """mirrors `struct MkAdamTensor` of include/makani_amd.h"""
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong),
-                ("p_bf16", C.c_void_p)]
+                ("p_bf16", C.c_void_p), ("p_bf16_t", C.c_void_p), ("cols", C.c_int), ("ld", C.c_int), ("ld_t", C.c_int)]
 
 
 class MkGemm(C.Structure):
@@ -64,9 +64,10 @@ _SIGS = {
     "mk_conv1x1_nn": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
     "mk_conv1x1_wgrad_workspace": ([c_int, c_int, c_int, c_ll], c_ll),
     "mk_conv1x1_wgrad": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
-    "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
+    "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp, c_vp], c_int),
+    "mk_adamw_advance": ([c_vp, c_f, c_f, c_vp], c_int),
     "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
-    "mk_adamw_multi": ([c_vp, c_int, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp], c_int),
+    "mk_adamw_multi": ([c_vp, c_int, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp, c_vp], c_int),
     "mk_instnorm_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_ll, c_int, c_ll, c_f, c_int, c_vp], c_int),
     "mk_grad_norm_workspace": ([c_vp, c_int], c_ll),
     "mk_grad_clip_coef": ([c_vp, c_int, c_f, c_vp, c_vp, c_vp], c_int),

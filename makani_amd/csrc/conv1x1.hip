@@ -79,6 +79,18 @@ __device__ __forceinline__ void dma4(unsigned lds0, v4i_t rs, unsigned soff, uns
         : "memory", "scc");
 }
 template <int STEP>
+__device__ __forceinline__ void dma2(unsigned lds0, v4i_t rs, unsigned soff, unsigned v0, unsigned v1) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_nop 4\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds0), "s"(rs), "s"(soff), "v"(v0), "v"(v1), "i"(STEP)
+        : "memory", "scc");
+}
+template <int STEP>
 __device__ __forceinline__ void dma3(unsigned lds0, v4i_t rs, unsigned soff, unsigned v0, unsigned v1, unsigned v2) {
     unsigned keep;
     asm volatile(
@@ -562,14 +574,14 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
                         }
                         if (p.act) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                            for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
                         }
                         if (p.G) {
                             const uint32_t gw[4] = {gq[u4].x, gq[u4].y, gq[u4].z, gq[u4].w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                v[2 * e] *= gelu_grad_f(__uint_as_float(gw[e] << 16));
-                                v[2 * e + 1] *= gelu_grad_f(__uint_as_float(gw[e] & 0xffff0000u));
+                                v[2 * e] *= gelu_grad_fast_f(__uint_as_float(gw[e] << 16));
+                                v[2 * e + 1] *= gelu_grad_fast_f(__uint_as_float(gw[e] & 0xffff0000u));
                             }
                         }
                         if (p.R) {
@@ -591,6 +603,252 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // the staging image is free for the next round
+        }
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward / data-gradient channel GEMM with the WEIGHTS STATIONARY IN REGISTERS (K = 384, the embedding width).
+// The ring kernel above re-ingests its weight tile for every pixel tile: 196 KB of weights + 196 KB of activations
+// per 128 KB of output, and the memory path of a CU (about 27 GB/s, loads + stores, L2 hits included) is what bounds
+// it.  Here a 256-thread workgroup (one wave per SIMD, the full 512-register file per lane) owns a slab of 384 output
+// channels for its whole life: wave w keeps W[96 w .. 96 w + 95][0 .. 383] as 72 MFMA operand fragments (288 VGPRs),
+// loaded once.  Only activations stream: pixel tiles of 64 pixels, cut into chunks of 64 input channels (8 KB) that
+// travel through a ring of 16 LDS slots by LDS-DMA, up to LOOK chunks (a whole pixel tile and more) ahead of the
+// multiplication and across tile boundaries.  Ingest per output element: 2 bytes (M = 384: every activation is read
+// once) instead of 6.  Output: D[pixel][channel] accumulators -> bf16 -> 16 KB staging image -> whole 128-byte rows.
+//   activations in LDS: rows of 128 B (64 pixels of one input channel), chunk index XOR ((k >> 1) & 1) << 2
+//   staging image:      rows of 128 B (64 pixels of one output channel), chunk index XOR (row >> 1) & 7
+// The stores of the epilogue are buffer stores that are always issued (lanes without a valid target carry an
+// out-of-range offset), so the number of memory instructions between a DMA piece and the wait for it is a constant
+// and the counted s_waitcnt vmcnt(N) stays exact across tile boundaries.
+template <bool PRE, bool EPI_LOADS>
+__global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, int slabs, long long tilesN, long long ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = 24;                              // k16-steps: K = 384
+    constexpr int TM = 3, TN = 2;                       // wave tile: 96 channels x 64 pixels
+    constexpr int BM = 4 * TM * 32, BN = 64;
+    constexpr int CH = 8192;                            // one chunk: 64 input channels x 64 pixels, bf16
+    constexpr int NSLOT = 16, LOOK = 8;                 // ring slots; chunks in flight ahead of the one being multiplied
+    constexpr int NCH = 6;                              // chunks per pixel tile
+    constexpr int NSTORE = 3 * 4 * (PRE ? 2 : 1);       // epilogue memory instructions per thread and tile (always issued)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * CH + 128 * 128];
+    unsigned char* const stg = smem + NSLOT * CH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int s15 = lane & 15, g1 = (lane >> 4) & 1;
+
+    // ---- work: blockIdx.y = batch entry; slab = id % slabs keeps the weights; pixel tiles id / slabs, + gridDim.x / slabs, ... ----
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int slab = vid % slabs;
+    const int pstride = gridDim.x / slabs;              // the launcher makes gridDim.x a multiple of slabs
+    const int pfirst = vid / slabs;
+    const int tilesN32 = (int)tilesN;
+    const int my_tiles = pfirst < tilesN32 ? (tilesN32 - pfirst + pstride - 1) / pstride : 0;
+    const int cb = blockIdx.y;
+    const int m_base = slab * BM + wave * (TM * 32);
+    const unsigned nbytes = (unsigned)(p.N * 2);        // one channel row; all in-plane byte offsets fit 32 bits (checked by the launcher)
+
+    // ---- the stationary operand: W[m_base + i*32 + l31][ks*16 + lh*8 .. +7] ----
+    bf16x8 af[TM][KS];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = min(m_base + i * 32 + l31, p.M - 1);
+        const u16* src = p.A + (long long)row * p.lda + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[i][ks] = __builtin_bit_cast(bf16x8, ld16(src + ks * 16));
+    }
+    float bvr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow = m_base + i * 32 + l31;
+        bvr[i] = (p.bias && mrow < p.M) ? p.bias[mrow] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {                      // wait for the weights here, before any DMA piece is in flight
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(af[i][ks]));
+        asm volatile("" : "+v"(bvr[i]));
+    }
+
+    // ---- DMA addressing: a chunk = 8 pieces of 1 KB (8 rows x 128 B); wave w issues pieces 2 w and 2 w + 1 ----
+    const unsigned rowbytes = nbytes;
+    const unsigned lds0 = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wave) * 2048;
+    unsigned vx[2];
+    int cxl[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 8 + (lane >> 3);                     // input channel within the chunk
+        cxl[q] = (lane & 7) ^ (((row >> 1) & 1) << 2);                        // logical 16-byte chunk this lane fetches
+        vx[q] = (unsigned)row * rowbytes + (unsigned)cxl[q] * 16u;
+    }
+    // the DMA stream: chunks in the order they are multiplied (tile after tile, 6 chunks each), kept as running scalar
+    // state so that issuing one costs a handful of scalar instructions
+    const v4i_t rsX = make_rsrc(p.X + (long long)cb * p.K * p.N);
+    const unsigned kstride = 64u * nbytes;              // 64 input channels further
+    int i_pt = pfirst, i_kc = 0, i_slot = 0;            // next chunk to issue: pixel tile, chunk within it, ring slot
+    auto issue_next = [&]() {
+        const unsigned n0b = (unsigned)i_pt * (BN * 2);                              // first pixel of the tile, in bytes
+        const int cmax = min(7, (int)((nbytes - n0b) / 16) - 1);                     // pixels past N: re-read the last valid chunk
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)i_kc * kstride + n0b));
+        const unsigned v0 = vx[0] - (unsigned)max(0, cxl[0] - cmax) * 16u, v1 = vx[1] - (unsigned)max(0, cxl[1] - cmax) * 16u;
+        dma2<1024>(lds0 + (unsigned)i_slot * CH, rsX, soff, v0, v1);
+        i_slot = (i_slot + 1) & (NSLOT - 1);
+        if (++i_kc == NCH) {
+            i_kc = 0;
+            i_pt += pstride;
+        }
+    };
+
+    // ---- fragment addressing inside a chunk: transpose read, rows ks4*16 + lh*8 + (s15 >> 2) [+4] ----
+    int xoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int kk = lh * 8 + (s15 >> 2);
+        const int chunk = (j * 4 + g1 * 2 + ((s15 & 3) >> 1)) ^ (((kk >> 1) & 1) << 2);
+        xoff[j] = kk * 128 + chunk * 16 + (s15 & 1) * 8;
+    }
+
+    const int nchunks = my_tiles * NCH;
+    for (int c = 0; c < LOOK && c < nchunks; ++c) issue_next();
+    int c_slot = 0;                                     // ring slot of the chunk being multiplied
+
+    f32x16 acc[TM][TN];
+    const long long plane0 = (long long)cb * p.M * p.N;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Y + plane0), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)((PRE ? p.Ypre : p.Y) + plane0), 0, 0x80000000u, 0x00020000);
+
+    for (int ts = 0; ts < my_tiles; ++ts) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const long long cn0 = (long long)(pfirst + ts * pstride) * BN;
+
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) {
+            const int c = ts * NCH + kc;
+            // Memory instructions this wave issued after the two pieces of chunk c (at step c - LOOK, or in the prologue):
+            // two pieces for each of the LOOK - 1 younger chunks, plus NSTORE for every epilogue that ran in between —
+            // none within the first tile, two when the LOOK = 8 steps reach back over two tile ends (kc < 2 from the third
+            // tile on), else one.  vmcnt retires in order (loads and stores alike), so "at most that many outstanding"
+            // means chunk c has landed.  Near the end of the stream fewer chunks are in flight: wait for everything.
+            // With operand loads in the epilogue (EPI_LOADS) hipcc's wait in front of their first use drains the whole
+            // counter three times per tile, and every chunk is issued at least one epilogue before its use: nothing to count.
+            if (c + LOOK > nchunks) wait_vmcnt<0>();
+            else if (EPI_LOADS) { if (kc == 0) wait_vmcnt<0>(); }
+            else if (ts == 0) wait_vmcnt<2 * (LOOK - 1)>();
+            else if (kc < 2 && ts >= 2) wait_vmcnt<2 * (LOOK - 1) + 2 * NSTORE>();
+            else wait_vmcnt<2 * (LOOK - 1) + NSTORE>();
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* sb = smem + c_slot * CH;
+            c_slot = (c_slot + 1) & (NSLOT - 1);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                bf16x8 xf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned char* q0 = sb + xoff[j] + k4 * 16 * 128;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 128));
+                    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    xf[j] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[j], af[i][kc * 4 + k4], acc[i][j], 0, 0, 0);
+            }
+            // chunk c + LOOK goes to slot (c + LOOK) % 16, last multiplied at step c - 8: every wave finished that step
+            // before it reached the barrier of step c - 7
+            if (c + LOOK < nchunks) issue_next();
+        }
+
+        // ---- epilogue: 3 rounds of 128 channel rows (32 per wave) x 64 pixels through the staging image ----
+        const long long plane = plane0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            unsigned voff[4];
+            uint4 gq[4], rq[4];
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int idx = tid + 256 * u4;
+                const int row = idx >> 3, ch = idx & 7;
+                const int m = slab * BM + (row >> 5) * (TM * 32) + i * 32 + (row & 31);
+                const long long n = cn0 + ch * 8;
+                const bool live = m < p.M && n < p.N;
+                const long long o = plane + (long long)m * p.N + n;
+                voff[u4] = live ? (unsigned)(((long long)m * p.N + n) * 2) : 0xC0000000u;      // out of range: the store is dropped
+                gq[u4] = rq[u4] = make_uint4(0, 0, 0, 0);
+                if (EPI_LOADS) {
+                    if (live && p.G) gq[u4] = ld16(p.G + o);
+                    if (live && p.R) rq[u4] = ld16(p.R + o);
+                }
+            }
+            const float bv = bvr[i];
+            const int lrow = wave * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int px = j * 32 + 8 * q + 4 * lh;
+                    uint2 u;
+                    u.x = (uint32_t)f32_to_bf16(acc[i][j][4 * q] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 1] + bv) << 16);
+                    u.y = (uint32_t)f32_to_bf16(acc[i][j][4 * q + 2] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 3] + bv) << 16);
+                    *reinterpret_cast<uint2*>(stg + lrow * 128 + (((px >> 3) ^ ((lrow >> 1) & 7)) * 16) + ((px >> 2) & 1) * 8) = u;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int idx = tid + 256 * u4;
+                const int row = idx >> 3, ch = idx & 7;
+                const uint4 raw = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ ((row >> 1) & 7)) * 16));
+                typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                if (PRE) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{raw.x, raw.y, raw.z, raw.w}, rsP, voff[u4], 0, 0);
+                uint4 out = raw;
+                if (p.act || EPI_LOADS) {
+                    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = __uint_as_float(w[e] << 16);
+                        v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+                    }
+                    if (p.act) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+                    }
+                    if (EPI_LOADS && p.G) {
+                        const uint32_t gw[4] = {gq[u4].x, gq[u4].y, gq[u4].z, gq[u4].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] *= gelu_grad_fast_f(__uint_as_float(gw[e] << 16));
+                            v[2 * e + 1] *= gelu_grad_fast_f(__uint_as_float(gw[e] & 0xffff0000u));
+                        }
+                    }
+                    if (EPI_LOADS && p.R) {
+                        const uint32_t rw[4] = {rq[u4].x, rq[u4].y, rq[u4].z, rq[u4].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(rw[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                        }
+                    }
+                    out.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    out.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    out.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                    out.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff[u4], 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     }
 #endif
@@ -943,6 +1201,21 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     MK_REQUIRE((((uintptr_t)A | (uintptr_t)X) & 15) == 0, "conv1x1_nn: operands must be 16-byte aligned");
     ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
     static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
+    static const bool no_astat = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 'r'; }();   // "ring": no weight-stationary kernel
+    if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64) {
+        // weights stationary in registers: 384-channel slabs, 64-pixel tiles, persistent grid of 256-thread workgroups
+        const int slabs = (M + 383) / 384;
+        const long long tn = (N + 63) / 64;
+        const long long streams = tn < 256 / slabs ? tn : 256 / slabs;
+        const dim3 grid((unsigned)(streams * slabs), (unsigned)B), blk(256);
+        const bool epi_loads = R || G;
+        const bool pre = act && Ypre;
+        hipStream_t s = (hipStream_t)stream;
+        if (epi_loads) hipLaunchKernelGGL((conv_nn_astat_kernel<false, true>), grid, blk, 0, s, p, slabs, tn, tn);
+        else if (pre) hipLaunchKernelGGL((conv_nn_astat_kernel<true, false>), grid, blk, 0, s, p, slabs, tn, tn);
+        else hipLaunchKernelGGL((conv_nn_astat_kernel<false, false>), grid, blk, 0, s, p, slabs, tn, tn);
+        return mk_check_launch("mk_conv1x1_nn");
+    }
     if (!force_tile && (K % 64) == 0 && M >= 192 && (long long)K * N * 2 < (1ll << 31) && (long long)M * lda * 2 < (1ll << 31) && N >= 256) {
         // ring kernel: persistent grid, one 512-thread workgroup per CU
         const bool big = (M % 256 == 0) || M > 576;

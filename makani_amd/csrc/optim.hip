@@ -11,7 +11,8 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
                                                    const float* __restrict__ grad_scale, float lr, float beta1,
                                                    float beta2, float eps, float weight_decay, float bc1_inv,
-                                                   float bc2_rsqrt) {
+                                                   float bc2_rsqrt, const float* __restrict__ bc) {
+    if (bc) bc1_inv = bc[1], bc2_rsqrt = bc[2];      // bias corrections of a device-side step counter (mk_adamw_advance)
     const float gs = grad_scale ? *grad_scale : 1.f;
     const float decay = 1.f - lr * weight_decay;
     const float step = lr * bc1_inv;
@@ -55,6 +56,10 @@ constexpr int MULTI_CHUNK = NT * 4 * 4;       // elements per block
 
 struct AdamMulti {
     u16* pb[MULTI_MAX];          // optional bf16 copy of the updated parameter (the autocast operand of the next step)
+    u16* pbt[MULTI_MAX];         // optional bf16 copy of its transpose (the data-gradient GEMM's operand)
+    int cols[MULTI_MAX];         // > 0: the parameter is a (n / cols, cols) matrix; pb has row pitch ld, pbt row pitch ldt
+    int ld[MULTI_MAX];
+    int ldt[MULTI_MAX];
     float* p[MULTI_MAX];
     const float* g[MULTI_MAX];
     float* m[MULTI_MAX];
@@ -66,11 +71,14 @@ struct AdamMulti {
 
 __global__ __launch_bounds__(NT) void adamw_multi_kernel(const AdamMulti a, const float* __restrict__ grad_scale, float lr,
                                                          float beta1, float beta2, float eps, float weight_decay,
-                                                         float bc1_inv, float bc2_rsqrt) {
+                                                         float bc1_inv, float bc2_rsqrt, const float* __restrict__ bc) {
+    if (bc) bc1_inv = bc[1], bc2_rsqrt = bc[2];
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.first[t + 1]) ++t;
     float* __restrict__ p = a.p[t];
     u16* __restrict__ pb = a.pb[t];
+    u16* __restrict__ pbt = a.pbt[t];
+    const int cols = a.cols[t], ld = a.ld[t], ldt = a.ldt[t];
     const float* __restrict__ g = a.g[t];
     float* __restrict__ m = a.m[t];
     float* __restrict__ v = a.v[t];
@@ -88,8 +96,27 @@ __global__ __launch_bounds__(NT) void adamw_multi_kernel(const AdamMulti a, cons
         v[i] = vi;
         const float pn = p[i] * decay - step * (mi / (sqrtf(vi) * bc2_rsqrt + eps));
         p[i] = pn;
-        if (pb) pb[i] = f32_to_bf16(pn);
+        if (pb || pbt) {
+            const u16 h = f32_to_bf16(pn);
+            if (cols > 0) {
+                const long long r = i / cols, c = i - r * cols;
+                if (pb) pb[r * ld + c] = h;
+                if (pbt) pbt[c * ldt + r] = h;
+            } else if (pb) {
+                pb[i] = h;
+            }
+        }
     }
+}
+
+// step counter and bias corrections in device memory: st = {step, 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)};
+// one thread advances it, every update kernel of the step reads it (nothing about the step number is baked into a
+// launch, so a captured hipGraph of the train step replays correctly)
+__global__ void adamw_advance_kernel(float* __restrict__ st, float beta1, float beta2) {
+    const double step = (double)st[0] + 1.0;
+    st[0] = (float)step;
+    st[1] = (float)(1.0 / (1.0 - pow((double)beta1, step)));
+    st[2] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
 }
 
 // ---- global gradient norm -> clipping coefficient, over all tensors in 2-3 launches ---------------
@@ -152,23 +179,31 @@ __global__ __launch_bounds__(NT) void clip_coef_kernel(const float* __restrict__
 }
 }  // namespace
 
+extern "C" int mk_adamw_advance(float* state, float beta1, float beta2, void* stream) {
+    MK_REQUIRE(state, "adamw_advance: null pointer");
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+    return mk_check_launch("mk_adamw_advance");
+}
+
 extern "C" int mk_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* grad_scale,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                             void* stream) {
-    MK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+                             const float* step_state, void* stream) {
+    MK_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_state), "adamw: bad args");
+    if (step < 1) step = 1;
     MK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw: pointers must be 16-byte aligned");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     long long blocks = (n / 4 + NT - 1) / NT;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, grad_scale,
-                       lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+                       lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), step_state);
     return mk_check_launch("mk_adamw_step");
 }
 
 extern "C" int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_scale, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, void* stream) {
-    MK_REQUIRE(tensors && count > 0 && step >= 1, "adamw_multi: bad args");
+                              float beta2, float eps, float weight_decay, int step, const float* step_state, void* stream) {
+    MK_REQUIRE(tensors && count > 0 && (step >= 1 || step_state), "adamw_multi: bad args");
+    if (step < 1) step = 1;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     for (int base = 0; base < count; base += MULTI_MAX) {
         AdamMulti a;
@@ -179,12 +214,15 @@ extern "C" int mk_adamw_multi(const MkAdamTensor* tensors, int count, const floa
             MK_REQUIRE(s.p && s.g && s.m && s.v && s.n > 0, "adamw_multi: tensor %d has a null pointer or no elements", base + t);
             MK_REQUIRE(s.n < (1ll << 40), "adamw_multi: tensor %d too large for the multi-tensor path", base + t);
             a.p[t] = s.p, a.g[t] = s.g, a.m[t] = s.m, a.v[t] = s.v, a.n[t] = s.n, a.pb[t] = (u16*)s.p_bf16;
+            a.pbt[t] = (u16*)s.p_bf16_t, a.cols[t] = s.cols, a.ld[t] = s.ld, a.ldt[t] = s.ld_t;
+            MK_REQUIRE(s.cols >= 0 && (s.cols == 0 || (s.n % s.cols == 0 && s.ld >= s.cols && s.ld_t >= s.n / s.cols)) && (s.cols > 0 || !s.p_bf16_t),
+                       "adamw_multi: tensor %d: bad matrix shape for the bf16 copies", base + t);
             a.first[t] = blocks;
             blocks += (int)((s.n + MULTI_CHUNK - 1) / MULTI_CHUNK);
         }
         a.first[a.count] = blocks;
         hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, a, grad_scale, lr,
-                           beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+                           beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), step_state);
     }
     return mk_check_launch("mk_adamw_multi");
 }

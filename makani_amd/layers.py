@@ -4,10 +4,10 @@ State-dict layout and initialisation follow
 ``makani/models/common/layers.py:537-661`` (EncoderDecoder) and ``:664-894`` (MLP):
 ``<name>.fwd.<idx>.weight`` of shape ``(Cout, Cin, 1, 1)``.
 
-Instance norm, bias+GELU and the norm+GELU fusion are HIP kernels.  The channel
-GEMMs (1x1 convolutions) are issued as plain library GEMMs (hipBLASLt through
-``torch.matmul`` / ``torch.baddbmm``) on the NCHW planes — see DESIGN.md §5 for
-why that is the round-1 choice and what replaces it.
+Everything here runs on HIP kernels under bf16 autocast: the channel GEMMs (1x1 convolutions on the NCHW
+planes, forward / data gradient / weight gradient) on the LDS-DMA ring kernels of ``csrc/conv1x1.hip`` with the
+bias, GELU, gelu' and skip-connection work in their epilogues, instance norm (+GELU) in ``csrc/pointwise.hip``.
+Without autocast (fp32 parity runs) the GEMMs are plain library GEMMs — DESIGN.md §5.
 """
 import math
 import os
@@ -18,13 +18,14 @@ import torch.nn as nn
 from . import ops
 
 
-_HIP_NN = os.environ.get("MAKANI_AMD_CONV", "lib") == "hip"
+_HIP_NN = os.environ.get("MAKANI_AMD_CONV", "hip") == "hip"
 _DEFER_BIAS = os.environ.get("MAKANI_AMD_DEFER_BIAS", "1") != "0"
 
 
 def hip_conv_eligible(x) -> bool:
-    """Opt-in (MAKANI_AMD_CONV=hip): route forward / data-gradient channel GEMMs to the HIP NN kernel with
-    fused bias/GELU/skip epilogues instead of the library GEMM.  bf16 compute, pixel count % 8 == 0."""
+    """bf16 compute (autocast or bf16 tensors), pixel count % 8 == 0: forward / data-gradient channel GEMMs run on the
+    HIP kernels of csrc/conv1x1.hip (LDS-DMA ring kernel, fused bias / GELU / gelu' / skip epilogues).
+    ``MAKANI_AMD_CONV=lib`` routes them to the library GEMM instead (A/B measurements); fp32 always goes there."""
     if not _HIP_NN or not x.is_cuda or x.dim() != 4 or (x.shape[-1] * x.shape[-2]) % 8 != 0:
         return False
     if torch.is_autocast_enabled("cuda"):
@@ -131,12 +132,14 @@ class MLP(nn.Module):
 
     def can_defer_output_bias(self, x) -> bool:
         """the output bias can ride in the instance norm that follows (no add pass, no reduction for its gradient)"""
-        return (self.fwd[3].bias is not None and not self.checkpointing and _DEFER_BIAS
-                and not (self.fwd[1].is_gelu and hip_conv_eligible(x)))
+        return self.fwd[3].bias is not None and not self.checkpointing and _DEFER_BIAS
 
     @torch.compiler.disable(recursive=True)
     def forward_deferred_bias(self, x):
         """(fc2(act(fc1(x))) WITHOUT the output bias, that bias): for a caller that folds it into its next op"""
+        if self.fwd[1].is_gelu and hip_conv_eligible(x):
+            c1, c2 = self.fwd[0], self.fwd[3]
+            return ops.ConvGeluConvFn.apply(x.to(torch.bfloat16), c1.weight, c1.bias, c2.weight, None), c2.bias
         h = _conv_act(self.fwd[0], self.fwd[1], x)
         return self.fwd[3].matmul(h), self.fwd[3].bias
 

@@ -663,7 +663,10 @@ def conv1x1_nn(A: torch.Tensor, K: int, x: torch.Tensor, bias=None, act=False, w
     bf = bias.float().contiguous() if bias is not None else None
     r = residual.contiguous() if residual is not None else None
     g = gelu_grad_of.contiguous() if gelu_grad_of is not None else None
-    with _timed(f"conv1x1_nn_m{M}_k{K}_n{N}", flops=2.0 * B * M * K * N, nbytes=2.0 * B * N * (M + K)):
+    # algorithmic bytes: read x, write y, plus every fused operand that is read (residual, gelu' argument) or written
+    # (pre-activation) in the same pass
+    extra = (ypre is not None) + (r is not None) + (g is not None)
+    with _timed(f"conv1x1_nn_m{M}_k{K}_n{N}", flops=2.0 * B * M * K * N, nbytes=2.0 * B * N * (M * (1 + extra) + K)):
         check(lib().mk_conv1x1_nn(ptr(A), ptr(x), ptr(y), ptr(ypre), ptr(bf), ptr(r), ptr(g), M, K, lda, B, N,
                                   1 if act else 0, stream()), "mk_conv1x1_nn")
     return y, ypre
@@ -693,21 +696,20 @@ class Conv1x1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
         M, K = weight.shape[0], weight.shape[1]
-        A = pad_weight_bf16(weight.view(M, K))
+        A, At = weight_operands(weight, need_t=ctx.needs_input_grad[0])
         y, _ = conv1x1_nn(A, K, x, bias=bias, residual=residual)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, At)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, At = ctx.saved_tensors
         M, K = weight.shape[0], weight.shape[1]
         gy = gy.contiguous()
         gx = gw = gb = gr = None
         if ctx.needs_input_grad[0]:
-            At = pad_weight_bf16(weight.view(M, K).t())
             gx, _ = conv1x1_nn(At, M, gy)
         if ctx.needs_input_grad[1]:
             gw = conv1x1_wgrad(gy, x).view_as(weight)
@@ -727,33 +729,40 @@ class ConvGeluConvFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2):
         H1, K = w1.shape[0], w1.shape[1]
         M = w2.shape[0]
-        h, a1 = conv1x1_nn(pad_weight_bf16(w1.view(H1, K)), K, x, bias=b1, act=True, want_pre=True)
-        y, _ = conv1x1_nn(pad_weight_bf16(w2.view(M, H1)), H1, h, bias=b2)
-        ctx.save_for_backward(x, w1, w2, a1, h)
+        A1, A1t = weight_operands(w1, need_t=ctx.needs_input_grad[0])
+        A2, A2t = weight_operands(w2, need_t=True)
+        h, a1 = conv1x1_nn(A1, K, x, bias=b1, act=True, want_pre=True)
+        y, _ = conv1x1_nn(A2, H1, h, bias=b2)
+        ctx.save_for_backward(x, w1, w2, a1, h, A1t, A2t)
         ctx.has_b = (b1 is not None, b2 is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w1, w2, a1, h = ctx.saved_tensors
+        x, w1, w2, a1, h, A1t, A2t = ctx.saved_tensors
         H1, K = w1.shape[0], w1.shape[1]
         M = w2.shape[0]
         gy = gy.contiguous()
         # ga1 = (W2^T gy) * gelu'(a1)
-        ga1, _ = conv1x1_nn(pad_weight_bf16(w2.view(M, H1).t()), M, gy, gelu_grad_of=a1)
+        ga1, _ = conv1x1_nn(A2t, M, gy, gelu_grad_of=a1)
         gw2 = conv1x1_wgrad(gy, h).view_as(w2) if ctx.needs_input_grad[3] else None
         gb2 = _sum_planes(gy) if (ctx.has_b[1] and ctx.needs_input_grad[4]) else None
         gw1 = conv1x1_wgrad(ga1, x).view_as(w1) if ctx.needs_input_grad[1] else None
         gb1 = _sum_planes(ga1) if (ctx.has_b[0] and ctx.needs_input_grad[2]) else None
         gx = None
         if ctx.needs_input_grad[0]:
-            gx, _ = conv1x1_nn(pad_weight_bf16(w1.view(H1, K).t()), H1, ga1)
+            gx, _ = conv1x1_nn(A1t, H1, ga1)
         return gx, gw1, gb1, gw2, gb2
 
 
 def want_bf16_shadow(param):
     """mark a fp32 parameter whose bf16 copy ``makani_amd.optim.FusedAdamW`` should emit with every update"""
     param._mk_want_bf16 = True
+
+
+def _shadow_valid(weight):
+    return (getattr(weight, "_mk_shadow", None) is not None and getattr(weight, "_mk_shadow_version", -1) == weight._version
+            and getattr(weight, "_mk_shadow_ptr", 0) == weight.data_ptr() and weight._mk_shadow.device == weight.device)
 
 
 def cast_weight(weight, dtype):
@@ -763,11 +772,23 @@ def cast_weight(weight, dtype):
     version counter and are not supported while shadows are in use; ``load_state_dict`` / ``copy_`` / optimizers are."""
     if dtype == weight.dtype:
         return weight
-    sh = getattr(weight, "_mk_shadow", None)
-    if (sh is not None and dtype == torch.bfloat16 and getattr(weight, "_mk_shadow_version", -1) == weight._version
-            and getattr(weight, "_mk_shadow_ptr", 0) == weight.data_ptr() and sh.device == weight.device):
-        return sh
+    if dtype == torch.bfloat16 and _shadow_valid(weight):
+        K = weight.numel() // weight.shape[0]
+        sh = weight._mk_shadow                      # (M, round8(K)): a strided (M, K) slice when K is not a multiple of 8
+        return sh.view(weight.shape) if sh.shape[1] == K else sh[:, :K]
     return weight.to(dtype)
+
+
+def weight_operands(weight, need_t=False):
+    """bf16 operands of the HIP channel GEMMs for a (M, K, 1, 1) weight: A = (M, round8(K)) zero padded and, if asked
+    for, its transpose At = (K, round8(M)).  FusedAdamW writes both with every update (valid for exactly that version
+    of the parameter); otherwise they are produced here."""
+    M = weight.shape[0]
+    K = weight.numel() // M
+    if _shadow_valid(weight):
+        return weight._mk_shadow, (weight._mk_shadow_t if need_t else None)
+    w2 = weight.detach().view(M, K)
+    return pad_weight_bf16(w2), (pad_weight_bf16(w2.t()) if need_t else None)
 
 
 class ConvMmFn(torch.autograd.Function):

@@ -27,7 +27,7 @@ class FusedAdamW(torch.optim.Optimizer):
         grads = [_real(p.grad) for g in self.param_groups for p in g["params"] if p.grad is not None]
         if any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
             raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 gradients")
-        arr = (MkAdamTensor * len(grads))(*[MkAdamTensor(None, g.data_ptr(), None, None, g.numel(), None) for g in grads])
+        arr = (MkAdamTensor * len(grads))(*[MkAdamTensor(None, g.data_ptr(), None, None, g.numel(), None, None, 0, 0, 0) for g in grads])
         nws = lib().mk_grad_norm_workspace(C.cast(arr, C.c_void_p), len(grads))
         ws = torch.empty((nws,), dtype=torch.float32, device=grads[0].device)
         out = torch.empty((2,), dtype=torch.float32, device=grads[0].device)
@@ -39,21 +39,36 @@ class FusedAdamW(torch.optim.Optimizer):
     def grad_norm(self):
         return self.clip_coef(None)[1]
 
+    def _step_state(self, group, device):
+        """device-side step counter + bias corrections of a parameter group (mk_adamw_advance)"""
+        st = group.get("_mk_step_state")
+        if st is None or st.device != device:
+            st = torch.zeros(3, dtype=torch.float32, device=device)
+            group["_mk_step_state"] = st
+        return st
+
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm=None, grad_scale=None):
         """``max_grad_norm``: clip by the global norm of the local gradients; ``grad_scale``: a precomputed
-        clipping coefficient (1-element device tensor) when the norm needs cross-rank reduction."""
+        clipping coefficient (1-element device tensor) when the norm needs cross-rank reduction.
+
+        The step number lives in device memory (one counter per parameter group, advanced by one tiny launch per
+        ``step()``); the per-parameter ``state["step"]`` entries are kept as the host-side mirror torch expects.  No
+        launch argument depends on the step number, so a captured graph of the train step can be replayed.  All
+        parameters of a group that receive gradients share the group's counter (a parameter that skips steps would
+        see a slightly different bias correction than torch's per-parameter count: not a case of this path)."""
         scale = grad_scale
         if scale is None and max_grad_norm is not None:
             scale = self.clip_coef(max_grad_norm)[:1]
         for group in self.param_groups:
             b1, b2 = group["betas"]
-            small = {}                       # step count -> [descriptors]: one launch per 48 small tensors
-            keep = []                        # python references that must outlive the launches
-            shadowed = []
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            sdev = self._step_state(group, live[0].device)
+            check(lib().mk_adamw_advance(ptr(sdev), b1, b2, stream()), "mk_adamw_advance")
+            descs, keep, shadowed = [], [], []
+            for p in live:
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
@@ -65,29 +80,34 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 parameters and gradients")
                 m, v = _real(st["exp_avg"]), _real(st["exp_avg_sq"])
                 if pr.numel() < SMALL:
-                    # parameters that asked for it (ops.want_bf16_shadow) get bf16(p) written by the same kernel: the
-                    # operand the bf16-autocast GEMMs of the next step would otherwise produce with one cast kernel each
-                    shadow = None
-                    if getattr(p, "_mk_want_bf16", False) and pr.dtype == torch.float32:
-                        shadow = getattr(p, "_mk_shadow", None)
-                        if shadow is None or shadow.shape != p.shape or shadow.device != p.device:
-                            shadow = torch.empty_like(p, dtype=torch.bfloat16)
-                            p._mk_shadow = shadow
-                    small.setdefault(int(st["step"]), []).append(
-                        MkAdamTensor(pr.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), pr.numel(),
-                                     shadow.data_ptr() if shadow is not None else None))
-                    keep.append((pr, gr, m, v, shadow))
-                    if shadow is not None:
+                    # parameters that asked for it (ops.want_bf16_shadow) get bf16(p) written by the same kernel — as the
+                    # (M, round8(K)) operand of the forward GEMM and, transposed, the (K, round8(M)) operand of the
+                    # data-gradient GEMM: what the bf16-autocast step would otherwise produce with cast / transpose
+                    # kernels per weight
+                    sh = sht = None
+                    cols = ld = ldt = 0
+                    if getattr(p, "_mk_want_bf16", False) and pr.dtype == torch.float32 and p.dim() >= 2:
+                        Mr, Kc = p.shape[0], p.numel() // p.shape[0]
+                        cols, ld, ldt = Kc, (Kc + 7) // 8 * 8, (Mr + 7) // 8 * 8
+                        sh, sht = getattr(p, "_mk_shadow", None), getattr(p, "_mk_shadow_t", None)
+                        if sh is None or sh.shape != (Mr, ld) or sh.device != p.device:
+                            sh = torch.zeros((Mr, ld), dtype=torch.bfloat16, device=p.device)      # pad columns stay zero
+                            sht = torch.zeros((Kc, ldt), dtype=torch.bfloat16, device=p.device)
+                            p._mk_shadow, p._mk_shadow_t = sh, sht
                         shadowed.append(p)
+                    descs.append(MkAdamTensor(pr.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), pr.numel(),
+                                              sh.data_ptr() if sh is not None else None,
+                                              sht.data_ptr() if sht is not None else None, cols, ld, ldt))
+                    keep.append((pr, gr, m, v, sh, sht))
                 else:
                     check(lib().mk_adamw_step(ptr(pr), ptr(gr), ptr(m), ptr(v), pr.numel(), ptr(scale), group["lr"], b1, b2,
-                                              group["eps"], group["weight_decay"], int(st["step"]), stream()), "mk_adamw_step")
+                                              group["eps"], group["weight_decay"], 0, ptr(sdev), stream()), "mk_adamw_step")
                 # the update goes through raw pointers: tell autograd the parameter changed in place
                 torch.autograd.graph.increment_version(p)
-            for step, descs in small.items():
+            if descs:
                 arr = (MkAdamTensor * len(descs))(*descs)
                 check(lib().mk_adamw_multi(C.cast(arr, C.c_void_p), len(descs), ptr(scale), group["lr"], b1, b2, group["eps"],
-                                           group["weight_decay"], step, stream()), "mk_adamw_multi")
+                                           group["weight_decay"], 0, ptr(sdev), stream()), "mk_adamw_multi")
             for p in shadowed:               # valid for exactly this version (and storage) of the parameter
                 p._mk_shadow_version = p._version
                 p._mk_shadow_ptr = p.data_ptr()

@@ -349,7 +349,10 @@ def test_fused_adamw_matches_torch():
 # bf16 channel GEMMs
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("B,M,K,H,W", [(1, 64, 32, 8, 32), (2, 73, 40, 12, 24), (1, 40, 73, 37, 72), (1, 384, 768, 16, 40),
-                                     (2, 130, 260, 10, 52)])
+                                     (2, 130, 260, 10, 52),
+                                     # K = 384: the weight-stationary kernel (one slab, two slabs + ragged pixel tail + batch,
+                                     # a slab with rows past M, more pixel tiles than the DMA look-ahead)
+                                     (1, 384, 384, 16, 40), (2, 768, 384, 10, 52), (1, 300, 384, 37, 72), (1, 768, 384, 91, 184)])
 def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
     from makani_amd import ops
     torch.manual_seed(M + K)
@@ -401,26 +404,60 @@ def test_conv_gelu_conv_autograd():
 
 
 def test_bf16_weight_shadow_is_exact_and_invalidated_by_inplace_updates():
-    """FusedAdamW writes bf16(p) for the channel-GEMM weights; the GEMM uses it only for that exact parameter version"""
+    """FusedAdamW writes bf16(p) — and its transpose — for the channel-GEMM weights (zero-padded to multiples of 8
+    columns); the GEMMs use them only for that exact parameter version"""
     import makani_amd as ma
     from makani_amd import ops
     from makani_amd.optim import FusedAdamW
     torch.manual_seed(4)
-    conv = ma.PointwiseConv(16, 24, bias=False).to(_dev())
-    opt = FusedAdamW(conv.parameters(), lr=1e-2, weight_decay=0.0)
-    x = torch.randn(1, 16, 8, 16, device=_dev())
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        conv(x).float().square().mean().backward()
-    assert getattr(conv.weight, "_mk_shadow", None) is None
-    opt.step()
-    sh = conv.weight._mk_shadow
-    assert sh.dtype == torch.bfloat16 and torch.equal(sh, conv.weight.detach().to(torch.bfloat16))
-    assert ops.cast_weight(conv.weight, torch.bfloat16) is sh
-    with torch.no_grad():
-        conv.weight.mul_(2.0)                                   # any in-place change through torch
-    w = ops.cast_weight(conv.weight, torch.bfloat16)
-    assert w is not sh and torch.equal(w, conv.weight.detach().to(torch.bfloat16))
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        y = conv(x)
-    ref = torch.einsum("oi,bihw->bohw", conv.weight.detach().view(24, 16).to(torch.bfloat16).float(), x.to(torch.bfloat16).float())
-    assert rel_l2(y, ref) < 1e-2
+    for cin, cout in ((16, 24), (73, 20), (12, 73)):
+        conv = ma.PointwiseConv(cin, cout, bias=False).to(_dev())
+        opt = FusedAdamW(conv.parameters(), lr=1e-2, weight_decay=0.0)
+        x = torch.randn(1, cin, 8, 16, device=_dev())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            conv(x).float().square().mean().backward()
+        assert getattr(conv.weight, "_mk_shadow", None) is None
+        opt.step()
+        wb = conv.weight.detach().view(cout, cin).to(torch.bfloat16)
+        sh, sht = conv.weight._mk_shadow, conv.weight._mk_shadow_t
+        assert sh.dtype == torch.bfloat16 and sh.shape == (cout, (cin + 7) // 8 * 8) and sht.shape == (cin, (cout + 7) // 8 * 8)
+        assert torch.equal(sh[:, :cin], wb) and torch.equal(sht[:, :cout], wb.t())
+        assert (sh[:, cin:] == 0).all() and (sht[:, cout:] == 0).all()
+        A, At = ops.weight_operands(conv.weight, need_t=True)
+        assert A.data_ptr() == sh.data_ptr() and At.data_ptr() == sht.data_ptr()
+        assert ops.cast_weight(conv.weight, torch.bfloat16).data_ptr() == sh.data_ptr()
+        with torch.no_grad():
+            conv.weight.mul_(2.0)                                   # any in-place change through torch
+        w = ops.cast_weight(conv.weight, torch.bfloat16)
+        assert w.data_ptr() != sh.data_ptr() and torch.equal(w, conv.weight.detach().to(torch.bfloat16))
+        A, At = ops.weight_operands(conv.weight, need_t=True)
+        assert A.data_ptr() != sh.data_ptr() and torch.equal(At[:, :cout], conv.weight.detach().view(cout, cin).to(torch.bfloat16).t())
+        xr = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(xr)
+        y.float().sum().backward()
+        wf = conv.weight.detach().view(cout, cin).to(torch.bfloat16).float()
+        ref = torch.einsum("oi,bihw->bohw", wf, x.to(torch.bfloat16).float())
+        assert rel_l2(y, ref) < 1e-2
+        assert rel_l2(xr.grad, wf.sum(0).view(1, -1, 1, 1).expand_as(x)) < 1e-2
+
+
+def test_fused_adamw_device_step_counter_matches_host_steps():
+    """the step number lives in device memory (mk_adamw_advance): five steps give torch.optim.AdamW's result, i.e. the
+    bias corrections follow the counter, not a launch argument"""
+    from makani_amd.optim import FusedAdamW
+    torch.manual_seed(1)
+    a = [torch.nn.Parameter(torch.randn(300, 40, device=_dev())), torch.nn.Parameter(torch.randn(1200, 1024, device=_dev()))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = FusedAdamW(a, lr=3e-3, betas=(0.9, 0.95), weight_decay=0.0)
+    ob = torch.optim.AdamW(b, lr=3e-3, betas=(0.9, 0.95), weight_decay=0.0)
+    for it in range(5):
+        for pa, pb in zip(a, b):
+            g = torch.randn_like(pa)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    st = oa.param_groups[0]["_mk_step_state"].cpu()
+    assert st[0].item() == 5.0 and abs(st[1].item() - 1.0 / (1 - 0.9 ** 5)) < 1e-5
+    for pa, pb in zip(a, b):
+        assert rel_l2(pa, pb) < 2e-6
