@@ -114,6 +114,23 @@ def stream():
     return c_vp(torch.cuda.current_stream().cuda_stream)
 
 
+def device_guard(fn):
+    """Module ``forward``s of the package run with the CURRENT device = the device of their first tensor argument: every
+    C-ABI launch goes to ``torch.cuda.current_stream()`` of the current device, so a model living on cuda:1 while the
+    process's current device is cuda:0 would otherwise enqueue its kernels on the wrong device's stream.  (Backward nodes
+    run on autograd's per-device worker threads, which set the device themselves.)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, x, *args, **kwargs):
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(self, x, *args, **kwargs)
+        return fn(self, x, *args, **kwargs)
+
+    return wrapped
+
+
 def ptr(t):
     if t is None:
         return c_vp(0)

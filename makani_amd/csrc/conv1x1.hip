@@ -78,6 +78,16 @@ __device__ __forceinline__ void dma4(unsigned lds0, v4i_t rs, unsigned soff, uns
         : "s"(lds0), "s"(rs), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "i"(STEP)
         : "memory", "scc");
 }
+__device__ __forceinline__ void dma1(unsigned lds0, v4i_t rs, unsigned soff, unsigned v0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_nop 4\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds0), "s"(rs), "s"(soff), "v"(v0)
+        : "memory");
+}
 template <int STEP>
 __device__ __forceinline__ void dma2(unsigned lds0, v4i_t rs, unsigned soff, unsigned v0, unsigned v1) {
     unsigned keep;
@@ -623,16 +633,30 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
 // The stores of the epilogue are buffer stores that are always issued (lanes without a valid target carry an
 // out-of-range offset), so the number of memory instructions between a DMA piece and the wait for it is a constant
 // and the counted s_waitcnt vmcnt(N) stays exact across tile boundaries.
-template <bool PRE, bool EPI_LOADS>
-__global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, int slabs, long long tilesN, long long ntiles) {
+template <int N_> __device__ __forceinline__ void wait_vmcnt_le() {      // N_ may exceed the 6-bit field only in dead branches
+    if constexpr (N_ <= 63) wait_vmcnt<N_>(); else wait_vmcnt<63>();
+}
+
+// TM: 32-row channel tiles per wave (slab = 4 waves x TM x 32 = 256 or 384 channels); KCH: input channels per ring
+// chunk and barrier (64 or 128)
+template <int TM, int KCH, bool PRE, bool EPI_LOADS>
+__global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, int slabs, long long tilesN) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = 24;                              // k16-steps: K = 384
-    constexpr int TM = 3, TN = 2;                       // wave tile: 96 channels x 64 pixels
-    constexpr int BM = 4 * TM * 32, BN = 64;
-    constexpr int CH = 8192;                            // one chunk: 64 input channels x 64 pixels, bf16
-    constexpr int NSLOT = 16, LOOK = 8;                 // ring slots; chunks in flight ahead of the one being multiplied
-    constexpr int NCH = 6;                              // chunks per pixel tile
-    constexpr int NSTORE = 3 * 4 * (PRE ? 2 : 1);       // epilogue memory instructions per thread and tile (always issued)
+    constexpr int TN = 2;                               // wave tile: TM * 32 channels x 64 pixels
+    constexpr int BM = 4 * TM * 32, BN = 64, NT_ = 256;
+    constexpr int CH = KCH * 128;                       // one chunk: KCH input channels x 64 pixels, bf16
+    constexpr int NCH = 384 / KCH;                      // chunks per pixel tile
+    constexpr int K4 = KCH / 16;                        // k16-steps per chunk
+    constexpr int NSLOT = (128 * 1024) / CH;            // ring slots (128 KB)
+    constexpr int NP = KCH / 32;                        // DMA pieces (8 rows x 128 B) per wave and chunk
+    constexpr int ROUNDS = TM;                          // staging rounds of 128 channel rows (32 per wave)
+    constexpr int NSTORE = ROUNDS * 4 * (PRE ? 2 : 1);  // epilogue memory instructions per thread and tile (always issued)
+    // chunks in flight ahead of the one being multiplied: as many as the ring and the 6-bit vmcnt field allow
+    constexpr int LOOK = KCH == 64 ? 8 : ((NP * 4 + 2 * NSTORE <= 63) ? 5 : 4);
+    constexpr int NEPI_MAX = (LOOK + NCH - 1) / NCH;    // tile ends the look-ahead window can span
+    static_assert(LOOK <= NSLOT - 1, "a slot is refilled only after every wave has left it");
+    static_assert(EPI_LOADS || NP * (LOOK - 1) + NEPI_MAX * NSTORE <= 63, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * CH + 128 * 128];
     unsigned char* const stg = smem + NSLOT * CH;
 
@@ -673,36 +697,34 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
         asm volatile("" : "+v"(bvr[i]));
     }
 
-    // ---- DMA addressing: a chunk = 8 pieces of 1 KB (8 rows x 128 B); wave w issues pieces 2 w and 2 w + 1 ----
-    const unsigned rowbytes = nbytes;
-    const unsigned lds0 = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wave) * 2048;
-    unsigned vx[2];
-    int cxl[2];
+    // ---- DMA addressing: a chunk = KCH / 8 pieces of 1 KB (8 rows x 128 B); wave w issues pieces NP w .. NP w + NP - 1 ----
+    const unsigned lds0 = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wave) * (NP * 1024);
+    unsigned vx[NP];
+    // logical 16-byte chunk this lane fetches: (lane & 7) ^ swizzle(row), swizzle = ((row >> 1) & 1) << 2 with
+    // row = 8 * piece + (lane >> 3): the same for every piece
+    const int cxl = (lane & 7) ^ ((((lane >> 3) >> 1) & 1) << 2);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = (wave * 2 + q) * 8 + (lane >> 3);                     // input channel within the chunk
-        cxl[q] = (lane & 7) ^ (((row >> 1) & 1) << 2);                        // logical 16-byte chunk this lane fetches
-        vx[q] = (unsigned)row * rowbytes + (unsigned)cxl[q] * 16u;
-    }
-    // the DMA stream: chunks in the order they are multiplied (tile after tile, 6 chunks each), kept as running scalar
+    for (int q = 0; q < NP; ++q) vx[q] = (unsigned)((wave * NP + q) * 8 + (lane >> 3)) * nbytes + (unsigned)cxl * 16u;
+    // the DMA stream: chunks in the order they are multiplied (tile after tile, NCH chunks each), kept as running scalar
     // state so that issuing one costs a handful of scalar instructions
     const v4i_t rsX = make_rsrc(p.X + (long long)cb * p.K * p.N);
-    const unsigned kstride = 64u * nbytes;              // 64 input channels further
+    const unsigned kstride = (unsigned)KCH * nbytes;    // KCH input channels further
     int i_pt = pfirst, i_kc = 0, i_slot = 0;            // next chunk to issue: pixel tile, chunk within it, ring slot
     auto issue_next = [&]() {
         const unsigned n0b = (unsigned)i_pt * (BN * 2);                              // first pixel of the tile, in bytes
         const int cmax = min(7, (int)((nbytes - n0b) / 16) - 1);                     // pixels past N: re-read the last valid chunk
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)i_kc * kstride + n0b));
-        const unsigned v0 = vx[0] - (unsigned)max(0, cxl[0] - cmax) * 16u, v1 = vx[1] - (unsigned)max(0, cxl[1] - cmax) * 16u;
-        dma2<1024>(lds0 + (unsigned)i_slot * CH, rsX, soff, v0, v1);
-        i_slot = (i_slot + 1) & (NSLOT - 1);
+        const unsigned back = (unsigned)max(0, cxl - cmax) * 16u;
+        if constexpr (NP == 2) dma2<1024>(lds0 + (unsigned)i_slot * CH, rsX, soff, vx[0] - back, vx[1] - back);
+        else dma4<1024>(lds0 + (unsigned)i_slot * CH, rsX, soff, vx[0] - back, vx[1] - back, vx[2] - back, vx[3] - back);
+        i_slot = i_slot + 1 == NSLOT ? 0 : i_slot + 1;
         if (++i_kc == NCH) {
             i_kc = 0;
             i_pt += pstride;
         }
     };
 
-    // ---- fragment addressing inside a chunk: transpose read, rows ks4*16 + lh*8 + (s15 >> 2) [+4] ----
+    // ---- fragment addressing inside a chunk: transpose read, rows k4*16 + lh*8 + (s15 >> 2) [+4] ----
     int xoff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -732,23 +754,31 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
 #pragma unroll
         for (int kc = 0; kc < NCH; ++kc) {
             const int c = ts * NCH + kc;
-            // Memory instructions this wave issued after the two pieces of chunk c (at step c - LOOK, or in the prologue):
-            // two pieces for each of the LOOK - 1 younger chunks, plus NSTORE for every epilogue that ran in between —
-            // none within the first tile, two when the LOOK = 8 steps reach back over two tile ends (kc < 2 from the third
-            // tile on), else one.  vmcnt retires in order (loads and stores alike), so "at most that many outstanding"
-            // means chunk c has landed.  Near the end of the stream fewer chunks are in flight: wait for everything.
-            // With operand loads in the epilogue (EPI_LOADS) hipcc's wait in front of their first use drains the whole
-            // counter three times per tile, and every chunk is issued at least one epilogue before its use: nothing to count.
-            if (c + LOOK > nchunks) wait_vmcnt<0>();
-            else if (EPI_LOADS) { if (kc == 0) wait_vmcnt<0>(); }
-            else if (ts == 0) wait_vmcnt<2 * (LOOK - 1)>();
-            else if (kc < 2 && ts >= 2) wait_vmcnt<2 * (LOOK - 1) + 2 * NSTORE>();
-            else wait_vmcnt<2 * (LOOK - 1) + NSTORE>();
+            // Memory instructions this wave issued after the NP pieces of chunk c (at step c - LOOK, or in the prologue):
+            // NP pieces for each of the LOOK - 1 younger chunks, plus NSTORE for every epilogue that ran in between: the
+            // tile ends among the steps c - LOOK .. c - 1, i.e. ceil((LOOK - kc) / NCH) of them once the stream is that old,
+            // fewer within the first tiles (never more than ts).  vmcnt retires in order (loads and stores alike), so "at
+            // most that many outstanding" means chunk c has landed.  Near the end of the stream fewer chunks are in flight:
+            // wait for everything.  With operand loads in the epilogue (EPI_LOADS) hipcc's wait in front of their first use
+            // drains the whole counter in every round, and every chunk is issued at least one epilogue before its use
+            // (LOOK >= NCH); one explicit drain at the start of a tile makes that independent of the compiler.
+            const int nfull = (LOOK - kc + NCH - 1) / NCH;      // a constant once the kc loop is unrolled
+            if (c + LOOK > nchunks) {
+                wait_vmcnt<0>();
+            } else if (EPI_LOADS) {
+                if (kc == 0) wait_vmcnt<0>();
+            } else {
+                const int nepi = min(nfull, ts);
+                if (nepi == 0) wait_vmcnt_le<NP * (LOOK - 1)>();
+                else if (nepi == 1) wait_vmcnt_le<NP * (LOOK - 1) + NSTORE>();
+                else if (nepi == 2) wait_vmcnt_le<NP * (LOOK - 1) + 2 * NSTORE>();
+                else wait_vmcnt_le<NP * (LOOK - 1) + 3 * NSTORE>();
+            }
             __builtin_amdgcn_s_barrier();
             const unsigned char* sb = smem + c_slot * CH;
-            c_slot = (c_slot + 1) & (NSLOT - 1);
+            c_slot = c_slot + 1 == NSLOT ? 0 : c_slot + 1;
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
+            for (int k4 = 0; k4 < K4; ++k4) {
                 bf16x8 xf[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -762,32 +792,31 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[j], af[i][kc * 4 + k4], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[j], af[i][kc * K4 + k4], acc[i][j], 0, 0, 0);
             }
-            // chunk c + LOOK goes to slot (c + LOOK) % 16, last multiplied at step c - 8: every wave finished that step
-            // before it reached the barrier of step c - 7
+            // chunk c + LOOK goes to slot (c + LOOK) % NSLOT, last multiplied at step c + LOOK - NSLOT <= c - 1: every wave
+            // finished that step before it reached the barrier of the step after it, which lies behind us
             if (c + LOOK < nchunks) issue_next();
         }
 
-        // ---- epilogue: 3 rounds of 128 channel rows (32 per wave) x 64 pixels through the staging image ----
-        const long long plane = plane0;
+        // ---- epilogue: TM rounds of 128 channel rows (32 per wave) x 64 pixels through the staging image ----
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             unsigned voff[4];
             uint4 gq[4], rq[4];
 #pragma unroll
             for (int u4 = 0; u4 < 4; ++u4) {
-                const int idx = tid + 256 * u4;
+                const int idx = tid + NT_ * u4;
                 const int row = idx >> 3, ch = idx & 7;
                 const int m = slab * BM + (row >> 5) * (TM * 32) + i * 32 + (row & 31);
                 const long long n = cn0 + ch * 8;
                 const bool live = m < p.M && n < p.N;
-                const long long o = plane + (long long)m * p.N + n;
-                voff[u4] = live ? (unsigned)(((long long)m * p.N + n) * 2) : 0xC0000000u;      // out of range: the store is dropped
+                const long long o = (long long)m * p.N + n;
+                voff[u4] = live ? (unsigned)(o * 2) : 0xC0000000u;          // out of range: the store is dropped
                 gq[u4] = rq[u4] = make_uint4(0, 0, 0, 0);
                 if (EPI_LOADS) {
-                    if (live && p.G) gq[u4] = ld16(p.G + o);
-                    if (live && p.R) rq[u4] = ld16(p.R + o);
+                    if (live && p.G) gq[u4] = ld16(p.G + plane0 + o);
+                    if (live && p.R) rq[u4] = ld16(p.R + plane0 + o);
                 }
             }
             const float bv = bvr[i];
@@ -806,7 +835,7 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
             __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int u4 = 0; u4 < 4; ++u4) {
-                const int idx = tid + 256 * u4;
+                const int idx = tid + NT_ * u4;
                 const int row = idx >> 3, ch = idx & 7;
                 const uint4 raw = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ ((row >> 1) & 7)) * 16));
                 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -1203,17 +1232,34 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
     static const bool no_astat = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 'r'; }();   // "ring": no weight-stationary kernel
     if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64) {
-        // weights stationary in registers: 384-channel slabs, 64-pixel tiles, persistent grid of 256-thread workgroups
-        const int slabs = (M + 383) / 384;
+        // weights stationary in registers: 256- or 384-channel slabs (4 waves x 2 or 3 row tiles), 64-pixel tiles,
+        // persistent grid of 256-thread workgroups.  MAKANI_AMD_ASTAT = "<tm><kch>" (e.g. 3128, 264) overrides the choice.
+        static const int forced_tm = [] { const char* e = getenv("MAKANI_AMD_ASTAT"); int a = 0, b = 0; return (e && sscanf(e, "%d,%d", &a, &b) == 2) ? a : 0; }();
+        static const int forced_kch = [] { const char* e = getenv("MAKANI_AMD_ASTAT"); int a = 0, b = 0; return (e && sscanf(e, "%d,%d", &a, &b) == 2) ? b : 0; }();
+        const bool epi_loads = R || G;
+        int tmv = 3;      // 384-row slabs measured faster than 256-row ones on every shape of the step (M = 384 and 768)
+        if (forced_tm == 2 || forced_tm == 3) tmv = forced_tm;
+        int kch = (forced_kch == 64 || forced_kch == 128) ? forced_kch : 128;
+        if (tmv == 3 && epi_loads) kch = 64;           // (the 128-channel chunk form of that variant runs out of registers)
+        const int bm = 128 * tmv;
+        const int slabs = (M + bm - 1) / bm;
         const long long tn = (N + 63) / 64;
         const long long streams = tn < 256 / slabs ? tn : 256 / slabs;
         const dim3 grid((unsigned)(streams * slabs), (unsigned)B), blk(256);
-        const bool epi_loads = R || G;
         const bool pre = act && Ypre;
         hipStream_t s = (hipStream_t)stream;
-        if (epi_loads) hipLaunchKernelGGL((conv_nn_astat_kernel<false, true>), grid, blk, 0, s, p, slabs, tn, tn);
-        else if (pre) hipLaunchKernelGGL((conv_nn_astat_kernel<true, false>), grid, blk, 0, s, p, slabs, tn, tn);
-        else hipLaunchKernelGGL((conv_nn_astat_kernel<false, false>), grid, blk, 0, s, p, slabs, tn, tn);
+#define MK_ASTAT(TM_, KCH_)                                                                                              \
+    do {                                                                                                                  \
+        if (epi_loads && pre) hipLaunchKernelGGL((conv_nn_astat_kernel<TM_, KCH_, true, true>), grid, blk, 0, s, p, slabs, tn);   \
+        else if (epi_loads) hipLaunchKernelGGL((conv_nn_astat_kernel<TM_, KCH_, false, true>), grid, blk, 0, s, p, slabs, tn);    \
+        else if (pre) hipLaunchKernelGGL((conv_nn_astat_kernel<TM_, KCH_, true, false>), grid, blk, 0, s, p, slabs, tn);          \
+        else hipLaunchKernelGGL((conv_nn_astat_kernel<TM_, KCH_, false, false>), grid, blk, 0, s, p, slabs, tn);                  \
+    } while (0)
+        if (tmv == 2 && kch == 128) MK_ASTAT(2, 128);
+        else if (tmv == 2) MK_ASTAT(2, 64);
+        else if (kch == 128) MK_ASTAT(3, 128);
+        else MK_ASTAT(3, 64);
+#undef MK_ASTAT
         return mk_check_launch("mk_conv1x1_nn");
     }
     if (!force_tile && (K % 64) == 0 && M >= 192 && (long long)K * N * 2 < (1ll << 31) && (long long)M * lda * 2 < (1ll << 31) && N >= 256) {

@@ -166,6 +166,30 @@ def _exchange(recv, send, group):
                 recv[peer].copy_(hr[peer])
 
 
+def _a2a(x, sdim, ssizes, cdim, csizes, group, me):
+    """split ``x`` along ``sdim`` into one chunk per peer (``ssizes``), exchange, join what arrives along ``cdim``
+    (``csizes[src]`` wide from peer ``src``).  One copy per exchange instead of the reference's two: when the chunks
+    that arrive are slabs of the OUTERMOST dimension they are received straight into slices of the result (no ``cat``),
+    and when the chunks that leave are slabs of the outermost dimension they are sent as views (no pack copy)."""
+    P = len(ssizes)
+    send = [c if c.is_contiguous() else c.contiguous() for c in torch.split(x, ssizes, dim=sdim)]
+    shape = list(x.shape)
+    shape[sdim] = ssizes[me]
+    shape[cdim] = sum(csizes)
+    if cdim == 0:                                   # arriving slabs are contiguous ranges of the result
+        y = torch.empty(shape, dtype=x.dtype, device=x.device)
+        recv = list(torch.split(y, csizes, dim=0))
+        _exchange(recv, send, group)
+        return y
+    recv = []
+    for src in range(P):
+        sh = list(shape)
+        sh[cdim] = csizes[src]
+        recv.append(torch.empty(sh, dtype=x.dtype, device=x.device))
+    _exchange(recv, send, group)
+    return torch.cat(recv, dim=cdim)
+
+
 class _TransposeFn(torch.autograd.Function):
     """Split ``x`` along ``sdim`` into one chunk per peer (sizes ``ssizes``), exchange, concatenate what
     arrives along ``cdim`` (``makani/mpu/mappings.py:38-67``).  ``svalid``/padded dims: a padded dim is
@@ -180,30 +204,15 @@ class _TransposeFn(torch.autograd.Function):
         svalid = sum(ssizes)
         xs = x.narrow(sdim, 0, svalid) if x.shape[sdim] != svalid else x
         xc = xs.narrow(cdim, 0, csizes[me]) if xs.shape[cdim] != csizes[me] else xs
-        send = [c.contiguous() for c in torch.split(xc, ssizes, dim=sdim)]
-        recv = []
-        for src in range(P):
-            shape = list(send[me].shape)
-            shape[cdim] = csizes[src]
-            recv.append(torch.empty(shape, dtype=x.dtype, device=x.device))
-        _exchange(recv, send, group)
-        y = torch.cat(recv, dim=cdim)
+        y = _a2a(xc, sdim, ssizes, cdim, csizes, group, me)
         ctx.meta = (sdim, ssizes, cdim, csizes, group, x.shape, me)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         sdim, ssizes, cdim, csizes, group, xshape, me = ctx.meta
-        P = len(ssizes)
         g = gy.narrow(cdim, 0, sum(csizes)) if gy.shape[cdim] != sum(csizes) else gy
-        send = [c.contiguous() for c in torch.split(g, csizes, dim=cdim)]
-        recv = []
-        for src in range(P):
-            shape = list(send[me].shape)
-            shape[sdim] = ssizes[src]
-            recv.append(torch.empty(shape, dtype=gy.dtype, device=gy.device))
-        _exchange(recv, send, group)
-        gx = torch.cat(recv, dim=sdim)
+        gx = _a2a(g, cdim, csizes, sdim, ssizes, group, me)
         # restore the (padded) input extents
         for d in (sdim, cdim):
             if gx.shape[d] != xshape[d]:

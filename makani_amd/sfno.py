@@ -18,6 +18,8 @@ from functools import partial
 
 import torch
 import torch.nn as nn
+
+from ._lib import device_guard
 from torch.utils.checkpoint import checkpoint
 
 from . import distributed as thd
@@ -265,6 +267,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         return x
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, x):
         if self.big_skip:
             if self.out_shape != self.inp_shape:

@@ -18,6 +18,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ._lib import device_guard
+
 from . import legendre as _leg
 from . import ops
 
@@ -82,6 +84,7 @@ class RealSHT(_SHTBase):
         return ops.AnalysisFn.apply(F, self.weights, self.weights_t)
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError(f"RealSHT (HIP) supports float32 / bfloat16 input, got {x.dtype}")
@@ -108,6 +111,7 @@ class InverseRealSHT(_SHTBase):
         return ops.IrfftFn.apply(F, B, C, self.nlon, out_dtype, self._w)
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, c: torch.Tensor) -> torch.Tensor:
         if c.dtype != torch.complex64:
             raise TypeError(f"InverseRealSHT (HIP) supports complex64 input, got {c.dtype}")

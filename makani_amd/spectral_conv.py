@@ -16,6 +16,8 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from ._lib import device_guard
+
 from . import ops
 from .sht import RealSHT, InverseRealSHT
 
@@ -112,6 +114,7 @@ class SpectralConv(nn.Module):
         return ops.DhconvFn.apply(S, w, B, self._tri_off)
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, x):
         if x.dim() != 4:
             raise ValueError(f"expected (B, C, H, W), got {tuple(x.shape)}")
