@@ -123,8 +123,10 @@ int mk_complex_to_slayout(const float* in_c64, float* S, int B, int C, int Cp, i
  * caller-provided (all-reduced) `sums` and `hw_total` = pixels of the whole plane over all spatial ranks —
  * the split DistributedInstanceNorm2d (makani/mpu/layer_norm.py:108-170) needs.                      */
 int mk_pointwise_chunks(long long hw, int dtype);
+/* `quad` (hw fp32 weights of this shard, may be NULL) with `quad_sum` = their sum: quadrature-weighted local moments
+ * with count = quad_sum — what DistributedGeometricInstanceNormS2 merges (makani/mpu/layer_norm.py:207-222). */
 int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long long planes, long long hw, float eps,
-                      void* stream);
+                      const float* quad, float quad_sum, void* stream);
 int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma, const float* beta,
                       long long planes, int channels, long long hw, int fuse_gelu, void* stream);
 /* stats + apply in two launches (the apply kernel finishes the statistics reduction itself and writes `stats` for the

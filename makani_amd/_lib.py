@@ -57,7 +57,7 @@ _SIGS = {
     "mk_spec_diag_apply": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_spec_diag_wgrad": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_pointwise_chunks": ([c_ll, c_int], c_int),
-    "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp], c_int),
+    "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp, c_f, c_vp], c_int),
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
     "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_int, c_ll, c_ll, c_int, c_int, c_vp], c_int),
     "mk_bias_gelu_fwd": ([c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
 
 template <typename T>
 __global__ void in_stats_final(const T* __restrict__ x, const float* __restrict__ ws, float* __restrict__ stats,
-                               long long planes, long long hw, int chunks, float eps) {
+                               long long planes, long long hw, int chunks, float eps, float qsum) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= planes) return;
     const double pivot = (double)VecIO<T>::load1(x + p * hw);
@@ -181,8 +181,11 @@ __global__ void in_stats_final(const T* __restrict__ x, const float* __restrict_
         s1 += (double)ws[2 * (p * chunks + c)];
         s2 += (double)ws[2 * (p * chunks + c) + 1];
     }
-    const double m = s1 / (double)hw;
-    double var = s2 / (double)hw - m * m;   // biased variance, as nn.InstanceNorm2d
+    // plain: count = hw; quadrature-weighted (qsum = sum of this shard's weights): count = qsum — the local moments the
+    // distributed geometric norm merges (makani/mpu/layer_norm.py:207-222)
+    const double cnt = qsum > 0.f ? (double)qsum : (double)hw;
+    const double m = s1 / cnt;
+    double var = s2 / cnt - m * m;   // biased variance, as nn.InstanceNorm2d
     if (var < 0.0) var = 0.0;
     stats[2 * p] = (float)(pivot + m);
     stats[2 * p + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -580,20 +583,22 @@ extern "C" int mk_pointwise_chunks(long long hw, int dtype) {
     } while (0)
 
 extern "C" int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long long planes, long long hw,
-                                 float eps, void* stream) {
+                                 float eps, const float* quad, float quad_sum, void* stream) {
     int rc = check_common(x, planes, hw, dtype, "instnorm_stats");
     if (rc) return rc;
     MK_REQUIRE(stats && ws, "instnorm_stats: null stats/ws");
+    MK_REQUIRE(quad == nullptr || quad_sum > 0.f, "instnorm_stats: quadrature weights need their (positive) sum");
     hipStream_t s = (hipStream_t)stream;
     const int fb = (int)((planes + 255) / 256);
+    const float qs = quad ? quad_sum : 0.f;
     if (dtype == MK_F32) {
         const int ch = chunks_for<float>(hw);
-        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch, nullptr, 1, nullptr);
-        hipLaunchKernelGGL(in_stats_final<float>, dim3(fb), dim3(256), 0, s, (const float*)x, ws, stats, planes, hw, ch, eps);
+        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch, nullptr, 1, quad);
+        hipLaunchKernelGGL(in_stats_final<float>, dim3(fb), dim3(256), 0, s, (const float*)x, ws, stats, planes, hw, ch, eps, qs);
     } else {
         const int ch = chunks_for<u16>(hw);
-        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch, nullptr, 1, nullptr);
-        hipLaunchKernelGGL(in_stats_final<u16>, dim3(fb), dim3(256), 0, s, (const u16*)x, ws, stats, planes, hw, ch, eps);
+        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch, nullptr, 1, quad);
+        hipLaunchKernelGGL(in_stats_final<u16>, dim3(fb), dim3(256), 0, s, (const u16*)x, ws, stats, planes, hw, ch, eps, qs);
     }
     return mk_check_launch("mk_instnorm_stats");
 }

@@ -409,6 +409,28 @@ class DistributedInstanceNorm2d(nn.Module):
         return ops.DistInstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, spatial_group())
 
 
+class DistributedGeometricInstanceNormS2(DistributedInstanceNorm2d):
+    """``makani/mpu/layer_norm.py:173-253``: instance norm with the (normalised) quadrature weights of the sphere grid over
+    planes sharded across the spatial group — local area-weighted moments with count = sum of the local weights, merged
+    over the group, then the usual normalise (+ affine, + fused GELU) in the HIP kernels."""
+
+    def __init__(self, img_shape, crop_shape, crop_offset, grid_type, num_features, eps=1e-05, affine=False):
+        super().__init__(num_features, eps, affine)
+        from .losses import GridQuadrature, grid_to_quadrature_rule
+        quad = GridQuadrature(grid_to_quadrature_rule(grid_type), img_shape=img_shape, crop_shape=crop_shape,
+                              crop_offset=crop_offset, normalize=True, distributed=True).quad_weight
+        self.register_buffer("quad_weight", quad.reshape(-1).contiguous().float(), persistent=False)
+        self._qsum = float(quad.double().sum())          # this shard's share of the total weight
+
+    @torch.compiler.disable(recursive=True)
+    def forward(self, x, fuse_gelu=False):
+        if x.dim() != 4 or x.shape[1] != self.num_features or x.shape[-2] * x.shape[-1] != self.quad_weight.numel():
+            raise ValueError(f"expected (B, {self.num_features}, H_loc, W_loc) with {self.quad_weight.numel()} local grid points, got {tuple(x.shape)}")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        return ops.DistInstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, spatial_group(), self.quad_weight, self._qsum)
+
+
 # --------------------------------------------------------------------------- #
 # gradient reduction (makani/mpu/mappings.py:321-525) and the sharded gradient norm
 # (makani/utils/training/training_helpers.py:123-165)

@@ -107,8 +107,16 @@ class MLP(nn.Module):
         super().__init__()
         if input_format != "nchw":
             raise NotImplementedError("the HIP MLP implements input_format='nchw'")
-        if drop_rate > 0.0:
-            raise NotImplementedError("dropout inside the MLP is not part of the accelerated path (drop_rate must be 0)")
+        if drop_rate > 0.0:                            # layers.py:798-806
+            if drop_type == "iid":
+                drop = nn.Dropout(drop_rate)
+            elif drop_type == "features":
+                drop = nn.Dropout2d(drop_rate)
+            else:
+                raise NotImplementedError(f"Error, drop_type {drop_type} not supported")
+        else:
+            drop = nn.Identity()
+        self.has_dropout = drop_rate > 0.0
         self.checkpointing = checkpointing
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
@@ -122,9 +130,12 @@ class MLP(nn.Module):
         nn.init.normal_(fc2.weight, mean=0.0, std=math.sqrt(gain / hidden_features))
         if fc2.bias is not None:
             nn.init.constant_(fc2.bias, 0.0)
-        self.fwd = nn.Sequential(fc1, _Act(act_layer), nn.Identity(), fc2, nn.Identity())
+        self.fwd = nn.Sequential(fc1, _Act(act_layer), drop, fc2, drop)
 
     def _run(self, x):
+        if self.has_dropout:        # dropout sits between the two GEMMs and after the second: no fused pair (stochastic
+            h = self.fwd[2](_conv_act(self.fwd[0], self.fwd[1], x))          # masks come from torch's generator)
+            return self.fwd[4](self.fwd[3](h))
         if self.fwd[1].is_gelu and hip_conv_eligible(x):
             return _conv_gelu_conv(self.fwd[0], self.fwd[3], x)
         h = _conv_act(self.fwd[0], self.fwd[1], x)
@@ -132,7 +143,7 @@ class MLP(nn.Module):
 
     def can_defer_output_bias(self, x) -> bool:
         """the output bias can ride in the instance norm that follows (no add pass, no reduction for its gradient)"""
-        return self.fwd[3].bias is not None and not self.checkpointing and _DEFER_BIAS
+        return self.fwd[3].bias is not None and not self.checkpointing and _DEFER_BIAS and not self.has_dropout
 
     @torch.compiler.disable(recursive=True)
     def forward_deferred_bias(self, x):
@@ -240,3 +251,40 @@ class GeometricInstanceNormS2(nn.Module):
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         return ops.InstanceNormFn.apply(x, self.weight, self.bias, self.eps, fuse_gelu, None, q.reshape(-1), self._qsum)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (``makani/models/common/layers.py:30-75``): in training the whole residual branch of a
+    random subset of the batch is zeroed and the survivors are scaled by 1 / (1 - p); identity in eval mode."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device)).floor_()
+        return x.div(keep) * mask
+
+
+class ChannelLayerNorm(nn.Module):
+    """``DistributedLayerNorm`` of ``makani/mpu/layer_norm.py:256-290`` (``normalization_layer="layer_norm"``): a layer
+    norm over the CHANNELS of an NCHW tensor, one statistic per grid point — the same on a lat/lon shard as on the full
+    grid, so the spatially parallel network uses this class unchanged.  State-dict keys ``norm.weight`` / ``norm.bias``
+    as the reference.  Runs on torch's layer-norm kernel over a channels-last view (this option is not on the
+    benchmarked path; the instance norms are the HIP kernels)."""
+
+    def __init__(self, normalized_shape, eps=1e-05, elementwise_affine=True, bias=True):
+        super().__init__()
+        self.norm = nn.LayerNorm(normalized_shape, eps=eps, elementwise_affine=elementwise_affine, bias=bias)
+        if elementwise_affine:
+            self.norm.weight.is_shared_mp = ["model"]
+            self.norm.weight.sharded_dims_mp = [None]
+            if bias:
+                self.norm.bias.is_shared_mp = ["model"]
+                self.norm.bias.sharded_dims_mp = [None]
+
+    def forward(self, x):
+        return torch.transpose(self.norm(torch.transpose(x, 1, 3)), 1, 3).contiguous()

@@ -899,10 +899,12 @@ class DistInstanceNormFn(torch.autograd.Function):
     """Instance norm over a plane that is sharded across the ``spatial`` process group
     (``DistributedInstanceNorm2d``, makani/mpu/layer_norm.py:108-170): local fp32 statistics (HIP) ->
     all-gather of (mean, var, count) -> merge -> normalise (+GELU) with the merged statistics (HIP).
-    Backward all-reduces the two per-plane sums between the HIP reduce and apply phases."""
+    Backward all-reduces the two per-plane sums between the HIP reduce and apply phases.
+    With ``quad`` (this shard's quadrature weights, ``quad_sum`` their sum) the moments are area-weighted and the counts are
+    the weight sums: ``DistributedGeometricInstanceNormS2`` (makani/mpu/layer_norm.py:173-253)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fuse_gelu, group):
+    def forward(ctx, x, gamma, beta, eps, fuse_gelu, group, quad=None, quad_sum=0.0):
         import torch.distributed as dist
         x = x.contiguous()
         B, Cc, H, W = x.shape
@@ -910,9 +912,9 @@ class DistInstanceNormFn(torch.autograd.Function):
         dt = dtype_code(x)
         stats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
-        check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, stream()), "instnorm_stats")
-        P = dist.get_world_size(group)
-        local = torch.stack([stats[:, 0], 1.0 / stats[:, 1] ** 2 - eps, torch.full_like(stats[:, 0], float(hw))], dim=0)
+        check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, ptr(quad), float(quad_sum), stream()), "instnorm_stats")
+        count = float(quad_sum) if quad is not None else float(hw)
+        local = torch.stack([stats[:, 0], 1.0 / stats[:, 1] ** 2 - eps, torch.full_like(stats[:, 0], count)], dim=0)
         allm = _all_gather_stack(local.contiguous(), group)      # (P, 3, planes)
         mean, var, n = merge_moments(allm[:, 0], allm[:, 1].clamp_min(0.0), allm[:, 2])
         mstats = torch.stack([mean, torch.rsqrt(var + eps)], dim=1).contiguous()
@@ -921,16 +923,14 @@ class DistInstanceNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(mstats), ptr(g), ptr(b), planes, Cc, hw,
                                       1 if fuse_gelu else 0, stream()), "instnorm_apply")
-        ctx.save_for_backward(x, mstats, g, b)
-        ctx.meta = (fuse_gelu, group, None)
-        ctx.hw_total = n
+        ctx.save_for_backward(x, mstats, g, b, quad, n)
+        ctx.meta = (fuse_gelu, group, dist.get_world_size(group) * hw if quad is None else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        import torch.distributed as dist
-        x, mstats, g, b = ctx.saved_tensors
-        fuse_gelu, group, _ = ctx.meta
+        x, mstats, g, b, quad, n = ctx.saved_tensors
+        fuse_gelu, group, hw_total = ctx.meta
         B, Cc, H, W = x.shape
         planes, hw = B * Cc, H * W
         gy = gy.contiguous()
@@ -940,13 +940,22 @@ class DistInstanceNormFn(torch.autograd.Function):
         sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
         fg = 1 if fuse_gelu else 0
-        hw_total = int(ctx.hw_total[0].item())
+        # unweighted: every shard of a plane has hw pixels except along ragged splits; the true total is the merged count
+        if quad is None:
+            hw_tot = int(round(float(n[0])))          # counts are exact small integers in fp32; one host read per backward
+        else:
+            hw_tot = hw
         check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
-                                    ptr(ws), planes, Cc, hw, hw_total, 1, fg, stream()), "instnorm_bwd(reduce)")
+                                    ptr(ws), planes, Cc, hw, hw_tot, 1, fg, stream()), "instnorm_bwd(reduce)")
         local = _batch_sum(sums, B, Cc).clone()                   # this rank's share of dgamma / dbeta
         _all_reduce_sum(sums, group)
-        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
-                                    ptr(ws), planes, Cc, hw, hw_total, 2, fg, stream()), "instnorm_bwd(apply)")
+        if quad is not None:
+            # normalised weights p_i = q_i / Q (Q = merged count): gx = k (ga - p_i (S1 + n_i S2)); the kernel multiplies the
+            # sums by q_i per element, so they are divided by Q here and the kernel's crop term is switched off (sum = 1)
+            sums = (sums / n.unsqueeze(0)).contiguous()
+        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(quad),
+                                    1.0 if quad is not None else 0.0, ptr(sums), ptr(ws), planes, Cc, hw, hw_tot, 2, fg, stream()),
+              "instnorm_bwd(apply)")
         dgamma = local[1] if g is not None else None
         dbeta = local[0] if b is not None else None
-        return gx, dgamma, dbeta, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None

@@ -10,8 +10,9 @@ It can be named in a makani yaml as ``nettype: "makani_amd/sfno.py:SphericalFour
 Scope: the serial (one GPU per model instance) configuration family of
 BASELINE.json — ``spectral_transform="sht"``, ``filter_type="linear"``,
 every ``operator_type`` / ``separable`` combination of ``SpectralConv``, ``normalization_layer in {"instance_norm",
-"instance_norm_s2", "none"}``, ``pos_embed in {"none", "direct", "frequency"}``, all drop rates 0.  Anything else
-raises ``NotImplementedError`` (``ValueError`` where the reference raises one).
+"instance_norm_s2", "layer_norm", "none"}``, ``pos_embed in {"none", "direct", "frequency"}``, dropout / stochastic depth
+(torch's generator; the fused MLP pair is only taken with drop rate 0).  Anything else raises ``NotImplementedError``
+(``ValueError`` where the reference raises one).
 """
 import math
 from functools import partial
@@ -23,7 +24,7 @@ from ._lib import device_guard
 from torch.utils.checkpoint import checkpoint
 
 from . import distributed as thd
-from .layers import MLP, EncoderDecoder, GeometricInstanceNormS2, InstanceNorm2d, PointwiseConv
+from .layers import MLP, ChannelLayerNorm, DropPath, EncoderDecoder, GeometricInstanceNormS2, InstanceNorm2d, PointwiseConv
 from .sht import InverseRealSHT, RealSHT
 from .spectral_conv import SpectralConv
 
@@ -54,8 +55,6 @@ class NeuralOperatorBlock(nn.Module):
                  outer_skip=None, use_mlp=False, comm_feature_name="matmul", complex_activation="real",
                  spectral_layers=1, bias=False, final_activation=False, checkpointing_level=0):
         super().__init__()
-        if path_drop_rate > 0.0 or mlp_drop_rate > 0.0:
-            raise NotImplementedError("drop rates must be 0 on the accelerated path")
         if hasattr(forward_transform, "lat_shapes"):
             self.input_shape_loc = (forward_transform.lat_shapes[forward_transform.comm_rank_polar],
                                     forward_transform.lon_shapes[forward_transform.comm_rank_azimuth])
@@ -89,13 +88,14 @@ class NeuralOperatorBlock(nn.Module):
         if use_mlp:
             self.mlp = MLP(in_features=embed_dim, hidden_features=int(embed_dim * mlp_ratio), act_layer=act_layer,
                            drop_rate=mlp_drop_rate, drop_type="features", checkpointing=(checkpointing_level >= 2), gain=gain)
+        self.drop_path = DropPath(path_drop_rate) if path_drop_rate > 0.0 else nn.Identity()      # sfnonet.py:361-362
         if final_activation:
             self.act_layer1 = act_layer()
 
     @torch.compiler.disable(recursive=True)
     def forward(self, x):
         x, residual = self.filter(x)
-        norms = (InstanceNorm2d, GeometricInstanceNormS2, thd.DistributedInstanceNorm2d)
+        norms = (InstanceNorm2d, GeometricInstanceNormS2, thd.DistributedInstanceNorm2d)        # (the distributed S2 norm derives from the last)
         if self.act_is_gelu and isinstance(self.norm0, norms):
             x = self.norm0(x, fuse_gelu=True)                 # norm + exact GELU in one pass over the plane
         else:
@@ -108,11 +108,12 @@ class NeuralOperatorBlock(nn.Module):
             if hasattr(self, "mlp"):
                 x = self.mlp(x)
             x = self.norm1(x)
+        x = self.drop_path(x)
 
         if hasattr(self, "outer_skip"):
             # the skip GEMM accumulates into x (beta = 1) when x is a tensor nobody saved for backward: the output of
             # a norm kernel or of the MLP's last GEMM (+ bias); an activation output (ReLU saves it) is not
-            fresh = hasattr(self, "mlp") or isinstance(self.norm1, norms)
+            fresh = (hasattr(self, "mlp") or isinstance(self.norm1, norms)) and isinstance(self.drop_path, nn.Identity)
             x = self.outer_skip(residual, add_to=x, add_to_is_fresh=fresh)
         if hasattr(self, "act_layer1"):
             x = self.act_layer1(x)
@@ -134,8 +135,6 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             raise NotImplementedError("only spectral_transform='sht' is implemented")
         if pos_embed not in ("none", "None", None, "direct", "frequency"):
             raise ValueError("Unknown position embedding type")
-        if pos_drop_rate > 0.0 or path_drop_rate > 0.0 or mlp_drop_rate > 0.0:
-            raise NotImplementedError("drop rates must be 0 on the accelerated path")
 
         self.inp_shape, self.out_shape = tuple(inp_shape), tuple(out_shape)
         self.inp_chans, self.out_chans, self.embed_dim = inp_chans, out_chans, embed_dim
@@ -152,19 +151,21 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
 
         self.encoder = EncoderDecoder(num_layers=encoder_layers, input_dim=inp_chans, output_dim=embed_dim,
                                       hidden_dim=int(encoder_ratio * embed_dim), act_layer=act, input_format="nchw")
-        self.pos_drop = nn.Identity()
+        self.pos_drop = nn.Dropout(p=pos_drop_rate) if pos_drop_rate > 0.0 else nn.Identity()      # sfnonet.py:605-606
+        dpr = [v.item() for v in torch.linspace(0, path_drop_rate, num_layers)]
 
-        if normalization_layer == "instance_norm":
+        if normalization_layer == "layer_norm":              # sfnonet.py:609-613
+            norm = partial(ChannelLayerNorm, normalized_shape=embed_dim, elementwise_affine=True, eps=1e-6)
+        elif normalization_layer == "instance_norm":
             if self.spatial_parallel:     # sfnonet.py:614-617
                 norm = partial(thd.DistributedInstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True)
             else:
                 norm = partial(InstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True, track_running_stats=False)
         elif normalization_layer == "instance_norm_s2":        # sfnonet.py:620-645
-            if self.spatial_parallel:
-                raise NotImplementedError("DistributedGeometricInstanceNormS2 is not implemented: use instance_norm with h x w parallelism")
-            norm = partial(GeometricInstanceNormS2, img_shape=(self.h, self.w), crop_shape=(self.h, self.w), crop_offset=(0, 0),
+            handle = thd.DistributedGeometricInstanceNormS2 if self.spatial_parallel else GeometricInstanceNormS2
+            norm = partial(handle, img_shape=(self.h, self.w), crop_shape=(self.h, self.w), crop_offset=(0, 0),
                            grid_type=model_grid_type, num_features=embed_dim, eps=1e-6, affine=True)
-            norm_out = partial(GeometricInstanceNormS2, img_shape=self.out_shape, crop_shape=self.out_shape, crop_offset=(0, 0),
+            norm_out = partial(handle, img_shape=self.out_shape, crop_shape=self.out_shape, crop_offset=(0, 0),
                                grid_type=model_grid_type, num_features=embed_dim, eps=1e-6, affine=True)
         elif normalization_layer == "none":
             norm = nn.Identity
@@ -180,7 +181,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 self.trans_down if first else self.trans,
                 self.itrans_up if last else self.itrans,
                 embed_dim, filter_type=filter_type, operator_type=operator_type, mlp_ratio=mlp_ratio,
-                mlp_drop_rate=mlp_drop_rate, path_drop_rate=0.0, act_layer=act,
+                mlp_drop_rate=mlp_drop_rate, path_drop_rate=dpr[i], act_layer=act,
                 norm_layer=(norm, norm) if (first or not last) else (norm_out, norm_out),       # sfnonet.py:668-673
                 inner_skip="none", outer_skip="linear", use_mlp=use_mlp, rank=rank, separable=separable,
                 complex_activation=complex_activation, spectral_layers=spectral_layers, bias=bias,

@@ -103,6 +103,17 @@ def sfno_fixtures():
         )
 
 
+def sfno_layernorm_fixture():
+    """normalization_layer="layer_norm" (sfnonet.py:609-613: DistributedLayerNorm over the channels, mpu/layer_norm.py:256-290)"""
+    SFNO = ref_shims.import_reference_sfno()
+    _run_model(
+        SFNO,
+        dict(inp_shape=(24, 48), out_shape=(24, 48), inp_chans=3, out_chans=3, num_layers=2, scale_factor=2, embed_dim=12,
+             mlp_ratio=2, normalization_layer="layer_norm"),
+        batch=2, seed=342, name="sfno_layernorm_24x48.npz",
+    )
+
+
 def spectral_conv_fixtures():
     sc = ref_shims.import_reference_module("makani.models.common.spectral_convolution")
     th = sys.modules["torch_harmonics"]
@@ -339,6 +350,8 @@ def main():
         spectral_conv_fixtures()
     if "sfno" in which:
         sfno_fixtures()
+    if "sfno" in which or "sfno_layernorm" in which:
+        sfno_layernorm_fixture()
     if "loss" in which:
         loss_fixtures()
     if "stepper" in which:

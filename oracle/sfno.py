@@ -168,6 +168,17 @@ def _instance_norm(embed_dim):
     return nn.InstanceNorm2d(embed_dim, eps=1e-6, affine=True, track_running_stats=False)
 
 
+class ChannelLayerNorm(nn.Module):
+    """``DistributedLayerNorm`` (``makani/mpu/layer_norm.py:256-290``): nn.LayerNorm over the channels of an NCHW tensor"""
+
+    def __init__(self, embed_dim, eps=1e-6):
+        super().__init__()
+        self.norm = nn.LayerNorm(embed_dim, eps=eps, elementwise_affine=True)
+
+    def forward(self, x):
+        return torch.transpose(self.norm(torch.transpose(x, 1, 3)), 1, 3).contiguous()
+
+
 class NeuralOperatorBlock(nn.Module):
     """``makani/models/networks/sfnonet.py:169-408`` with the SFNO settings
     ``inner_skip="none"``, ``outer_skip="linear"``, ``use_mlp=True``."""
@@ -231,6 +242,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         elif normalization_layer == "instance_norm_s2":
             n_inp = n_mid = lambda: GeometricInstanceNormS2((self.h, self.w), model_grid_type, embed_dim)
             n_out = lambda: GeometricInstanceNormS2(tuple(out_shape), model_grid_type, embed_dim)
+        elif normalization_layer == "layer_norm":
+            n_inp = n_mid = n_out = lambda: ChannelLayerNorm(embed_dim)
         elif normalization_layer == "none":
             n_inp = n_mid = n_out = nn.Identity
         else:

@@ -26,7 +26,7 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
-def _worker(rank, world, port, h, w):
+def _worker(rank, world, port, h, w, norm="instance_norm"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
@@ -36,7 +36,7 @@ def _worker(rank, world, port, h, w):
         import makani_amd.distributed as thd
         dev = torch.device("cuda:0")
         cfg = dict(inp_shape=(37, 72), out_shape=(37, 72), inp_chans=4, out_chans=4, scale_factor=3, embed_dim=16,
-                   num_layers=3, mlp_ratio=2)
+                   num_layers=3, mlp_ratio=2, normalization_layer=norm)
         B = 2
         torch.manual_seed(11)
         serial = ma.SphericalFourierNeuralOperatorNet(**cfg).to(dev)
@@ -101,6 +101,15 @@ def _worker(rank, world, port, h, w):
 def test_spatial_parallel_sfno_matches_serial(h, w):
     world = h * w
     mp.spawn(_worker, args=(world, _free_port(), h, w), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("h,w", [(2, 1), (2, 2)])
+def test_spatial_parallel_sfno_with_geometric_instance_norm_matches_serial(h, w):
+    """normalization_layer="instance_norm_s2" under h x w parallelism: DistributedGeometricInstanceNormS2
+    (makani/mpu/layer_norm.py:173-253: area-weighted local moments merged over the spatial group) against the serial
+    GeometricInstanceNormS2 network, forward, input gradient and every parameter gradient"""
+    world = h * w
+    mp.spawn(_worker, args=(world, _free_port(), h, w, "instance_norm_s2"), nprocs=world, join=True)
 
 
 class _OneRankTree:

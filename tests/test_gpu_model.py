@@ -11,7 +11,7 @@ import torch
 
 SFNO_GOLDEN = ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz",
                "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz", "sfno_options_a_24x48.npz",
-               "sfno_options_b_24x48.npz"]
+               "sfno_options_b_24x48.npz", "sfno_layernorm_24x48.npz"]
 
 from conftest import load_golden, rel_l2
 
@@ -205,7 +205,7 @@ def test_sfno_batch_split_equivalence():
         ys.append(yi)
     assert rel_l2(torch.cat(ys), y) < 5e-6
     for k, p in model.named_parameters():
-        if k.endswith("mlp.fwd.3.bias") and kwargs.get("normalization_layer", "instance_norm") != "none":
+        if k.endswith("mlp.fwd.3.bias") and kwargs.get("normalization_layer", "instance_norm") not in ("none", "layer_norm"):
             continue
         assert rel_l2(p.grad, full[k]) < 5e-5, k
 
@@ -384,3 +384,35 @@ def test_relu_without_norm_and_mlp_backward_matches_oracle():
     model.zero_grad()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         model(x.to(DEV)).float().square().mean().backward()
+
+
+def test_dropout_options_are_identity_in_eval_and_stochastic_in_train():
+    """pos_drop_rate / mlp_drop_rate / path_drop_rate (sfnonet.py:604-606,361-362, layers.py:798-806): same state dict as
+    the drop-free network, identical output in eval mode, and in training mode the masks act (different outputs run to
+    run, stochastic depth zeroes whole residual branches of a sample)"""
+    import makani_amd as ma
+    from makani_amd.layers import DropPath
+    cfg = dict(inp_shape=(24, 48), out_shape=(24, 48), inp_chans=3, out_chans=3, num_layers=3, scale_factor=2, embed_dim=12,
+               mlp_ratio=2)
+    torch.manual_seed(0)
+    plain = ma.SphericalFourierNeuralOperatorNet(**cfg).to(DEV)
+    drop = ma.SphericalFourierNeuralOperatorNet(pos_drop_rate=0.1, mlp_drop_rate=0.2, path_drop_rate=0.3, **cfg).to(DEV)
+    drop.load_state_dict(plain.state_dict(), strict=True)
+    assert [type(b.drop_path) is DropPath for b in drop.blocks] == [False, True, True]      # linspace(0, 0.3, 3): the first rate is 0
+    assert abs(drop.blocks[2].drop_path.drop_prob - 0.3) < 1e-6 and abs(drop.blocks[1].drop_path.drop_prob - 0.15) < 1e-6
+    x = torch.rand(4, 3, 24, 48, device=DEV)
+    assert torch.equal(drop.eval()(x), plain.eval()(x))
+    drop.train()
+    torch.manual_seed(1)
+    a = drop(x)
+    b = drop(x)
+    assert not torch.equal(a, b)
+    xg = x.clone().requires_grad_(True)
+    drop(xg).square().mean().backward()                    # autograd through the masked branches
+    assert torch.isfinite(xg.grad).all()
+    dp = DropPath(0.5).train()
+    t = torch.ones(64, 2, 3, 3, device=DEV)
+    out = dp(t)
+    kept = out[:, 0, 0, 0]
+    assert set(kept.unique().tolist()) <= {0.0, 2.0} and 8 < int((kept == 0).sum()) < 56
+    assert torch.equal(dp.eval()(t), t)

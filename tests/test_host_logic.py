@@ -13,7 +13,7 @@ import torch
 
 SFNO_GOLDEN = ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz",
                "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz", "sfno_options_a_24x48.npz",
-               "sfno_options_b_24x48.npz"]
+               "sfno_options_b_24x48.npz", "sfno_layernorm_24x48.npz"]
 
 from conftest import ROOT, load_golden
 
@@ -158,7 +158,9 @@ def test_sfno_state_dict_is_reference_compatible(name):
         tags = ("encoder", "decoder", "mlp", "norm", "residual_transform")
         if kwargs.get("normalization_layer") == "instance_norm_s2":          # models/common/layer_norm.py:30-160 sets none
             tags = tuple(t for t in tags if t != "norm")
-        if any(t in n for t in tags):
+        if kwargs.get("normalization_layer") == "layer_norm" and ".norm." in n:      # mpu/layer_norm.py:277-282: ["model"]
+            assert p.is_shared_mp == ["model"], n
+        elif any(t in n for t in tags):
             assert p.is_shared_mp == ["spatial"], n
 
 
@@ -171,7 +173,7 @@ def test_no_cpu_fallback():
     with pytest.raises(ValueError):
         ma.SphericalFourierNeuralOperatorNet(pos_embed="bogus", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2)
     with pytest.raises(NotImplementedError):
-        ma.SphericalFourierNeuralOperatorNet(normalization_layer="layer_norm", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2)
+        ma.SphericalFourierNeuralOperatorNet(normalization_layer="batch_norm", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2)
     pe = ma.SphericalFourierNeuralOperatorNet(pos_embed="frequency", inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2, embed_dim=8)
     assert [tuple(p.shape) for p in pe.pos_embed] == [(1, 8, 8, 9), (1, 8, 8, 8)] and pe.pos_embed.type == "frequency"
     assert pe.no_weight_decay() == {"pos_embed", "cls_token"}

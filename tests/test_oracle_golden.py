@@ -8,7 +8,7 @@ import torch
 
 SFNO_GOLDEN = ["sfno_tiny_64x128.npz", "sfno_small_37x72.npz", "sfno_s2norm_resample_33x64.npz",
                "sfno_posembed_direct_19x36.npz", "sfno_posembed_frequency_19x36.npz", "sfno_options_a_24x48.npz",
-               "sfno_options_b_24x48.npz"]
+               "sfno_options_b_24x48.npz", "sfno_layernorm_24x48.npz"]
 
 from conftest import load_golden, rel_l2
 from oracle import sfno as osf
@@ -55,7 +55,7 @@ def test_sfno_matches_reference(name):
     assert rel_l2(y, torch.from_numpy(g["y"])) < 1e-6
     assert rel_l2(x.grad, torch.from_numpy(g["gx"])) < 1e-5
     for k, p in model.named_parameters():
-        if k.endswith("mlp.fwd.3.bias") and kwargs.get("normalization_layer", "instance_norm") != "none":
+        if k.endswith("mlp.fwd.3.bias") and kwargs.get("normalization_layer", "instance_norm") not in ("none", "layer_norm"):
             # a per-channel constant in front of an instance norm has exactly zero gradient: both sides hold round-off
             wmax = float(np.abs(g["grad/" + k.replace("bias", "weight")]).max())
             assert p.grad.abs().max().item() < 1e-3 * max(wmax, 1e-3) and np.abs(g["grad/" + k]).max() < 1e-3 * max(wmax, 1e-3), k
