@@ -112,17 +112,21 @@ int mk_complex_to_slayout(const float* in_c64, float* S, int B, int C, int Cp, i
 
 /* ---- pointwise blocks -----------------------------------------------------------
  * All operate on NCHW planes: x[(b*channels + c)][hw], dtype f32 | bf16, fp32 arithmetic.
- * `ws` is a caller-provided scratch of >= planes * mk_pointwise_chunks(hw, dtype) * 2 floats.
+ * `ws` is a caller-provided scratch of >= planes * mk_pointwise_chunks(hw, dtype, planes) * 2 floats (a plane is cut
+ * into as many chunks as keep every workgroup of the launch resident at once).
  *
  * Instance norm = nn.InstanceNorm2d(C, eps, affine=True) at makani/models/networks/sfnonet.py:618-620
- * (statistics in fp32 as in makani/mpu/layer_norm.py:147-168); optional fused exact-erf GELU
- * (nn.GELU, sfnonet.py:392-393).  stats: (planes, 2) f32 = {mean, rstd}.
+ * (statistics in fp32 as in makani/mpu/layer_norm.py:147-168); optional fused GELU
+ * (nn.GELU, sfnonet.py:392-393; exact erff on fp32 tensors, the A&S 7.1.26 erf — |err| < 1.5e-7 — on bf16 tensors).  stats: (planes, 2) f32 = {mean, rstd}.
  * Backward: sums (2, planes) f32, planar: row 0 = sum ga (dbeta per plane), row 1 = sum ga * xhat (dgamma per plane),
  * gx = rstd*gamma*(ga - mean(ga) - xhat*mean(ga*xhat)), ga = gy * (gelu'(a) if fused).
  * phase 0 = reduce + apply (serial); 1 = reduce only (writes the local `sums`); 2 = apply only with the
  * caller-provided (all-reduced) `sums` and `hw_total` = pixels of the whole plane over all spatial ranks —
  * the split DistributedInstanceNorm2d (makani/mpu/layer_norm.py:108-170) needs.                      */
-int mk_pointwise_chunks(long long hw, int dtype);
+int mk_pointwise_chunks(long long hw, int dtype, long long planes);
+/* sums[p] = sum of plane p (fp32; `sums` holds 2 * planes floats, the second row is zero): the bias gradient of a 1x1
+ * convolution, `grad_output.sum((0, 2, 3))` in the autograd of nn.Conv2d (makani/models/common/layers.py:603-643). */
+int mk_plane_sums(const void* x, int dtype, float* sums, float* ws, long long planes, long long hw, void* stream);
 /* `quad` (hw fp32 weights of this shard, may be NULL) with `quad_sum` = their sum: quadrature-weighted local moments
  * with count = quad_sum — what DistributedGeometricInstanceNormS2 merges (makani/mpu/layer_norm.py:207-222). */
 int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long long planes, long long hw, float eps,

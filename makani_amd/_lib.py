@@ -56,7 +56,8 @@ _SIGS = {
     "mk_spec_sep_wgrad": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_spec_diag_apply": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_spec_diag_wgrad": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
-    "mk_pointwise_chunks": ([c_ll, c_int], c_int),
+    "mk_pointwise_chunks": ([c_ll, c_int, c_ll], c_int),
+    "mk_plane_sums": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_vp], c_int),
     "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp, c_f, c_vp], c_int),
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
     "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_int, c_ll, c_ll, c_int, c_int, c_vp], c_int),
@@ -145,3 +146,14 @@ def dtype_code(t):
     if t.dtype == torch.bfloat16:
         return MK_BF16
     raise TypeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def dense_view(t):
+    """``t`` as a contiguous view in MEMORY order (its dims permuted by decreasing stride), or None when ``t`` has gaps or
+    overlaps.  Element-wise kernels (optimizer, norms, all-reduce) run on this view of tensors that are dense but not
+    C-contiguous — the native-order dhconv weight, its gradient and its optimizer state."""
+    if t.is_contiguous():
+        return t
+    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), -t.size(d)))
+    v = t.permute(order)
+    return v if v.is_contiguous() else None

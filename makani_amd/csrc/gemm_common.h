@@ -44,16 +44,27 @@ __device__ __forceinline__ BlockCoord decode_block(const MkGemm& p, int tilesM, 
     return c;
 }
 
-static inline int validate(const MkGemm* g, bool cplx, bool* a_kc, bool* b_kc) {
+// Complex operands are planar (re / im planes `*_im` floats apart) except, where the engine says it can (ilv_ok):
+//   B interleaved  (b_im == 1): b_col / b_k count floats, the contiguous direction has stride 2 (re, im pairs);
+//   C interleaved  (c_im == 1, c_col == 2): (re, im) pairs are stored with one 8-byte write.
+// This is the memory order of a complex64 torch tensor: the dhconv weight and its gradient are used in place.
+static inline int validate(const MkGemm* g, bool cplx, bool* a_kc, bool* b_kc, bool ilv_ok = false, bool* b_ilv = nullptr) {
     MK_REQUIRE(g && g->A && g->B && g->C, "gemm: null pointer");
     MK_REQUIRE(g->M > 0 && g->N > 0 && g->K >= 0 && g->batch > 0, "gemm: bad extents M=%d N=%d K=%d batch=%d", g->M,
                g->N, g->K, g->batch);
-    MK_REQUIRE(g->c_col == 1, "gemm: c_col must be 1");
+    const bool bi = cplx && ilv_ok && g->b_im == 1;
+    const bool ci = cplx && ilv_ok && g->c_im == 1;
+    if (b_ilv) *b_ilv = bi;
+    const long long bu = bi ? 2 : 1;
+    MK_REQUIRE(ci ? (g->c_col == 2 && (g->c_row & 1) == 0 && (g->c_batch & 1) == 0 && (g->c_inner & 1) == 0 &&
+                     ((uintptr_t)g->C & 7) == 0)
+                  : g->c_col == 1,
+               "gemm: c_col must be 1 (planar C) or 2 with c_im == 1 (interleaved complex C, split engine only)");
     MK_REQUIRE(g->a_k == 1 || g->a_row == 1, "gemm: A needs a unit stride");
-    MK_REQUIRE(g->b_k == 1 || g->b_col == 1, "gemm: B needs a unit stride");
+    MK_REQUIRE(g->b_k == bu || g->b_col == bu, "gemm: B needs a unit stride (2 floats when interleaved)");
     MK_REQUIRE(g->inner >= 1 && g->batch % g->inner == 0, "gemm: inner must be >= 1 and divide batch");
     *a_kc = (g->a_k == 1);
-    *b_kc = (g->b_k == 1);
+    *b_kc = (g->b_k == bu);
     // vector loads along the unit-stride dim: 16-byte alignment of everything else
     auto al = [](long long s) { return (s & 3) == 0; };
     MK_REQUIRE(((uintptr_t)g->A & 15) == 0 && ((uintptr_t)g->B & 15) == 0, "gemm: A/B must be 16-byte aligned");
@@ -68,10 +79,10 @@ static inline int validate(const MkGemm* g, bool cplx, bool* a_kc, bool* b_kc) {
     if (*b_kc) {
         MK_REQUIRE(al(g->b_col), "gemm: b_col must be a multiple of 4");
     } else {
-        MK_REQUIRE(al(g->b_k) && g->b_k >= ((g->N + 3) & ~3),
+        MK_REQUIRE(al(g->b_k) && g->b_k >= bu * ((g->N + 3) & ~3),
                    "gemm: col-contiguous B needs b_k %% 4 == 0 and b_k >= N rounded up to 4 (16-byte row vectors)");
     }
-    if (cplx) MK_REQUIRE(al(g->a_im) && al(g->b_im), "gemm: plane offsets must be multiples of 4");
+    if (cplx) MK_REQUIRE(al(g->a_im) && (bi || al(g->b_im)), "gemm: plane offsets must be multiples of 4");
     return 0;
 }
 

@@ -52,27 +52,52 @@ struct VecIO<u16> {
     __device__ static __forceinline__ void store1(u16* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// one pass of a block: NT lanes x 16 B x UNROLL loads in flight per lane
 template <typename T>
-__host__ __device__ constexpr long long chunk_elems() {
+__host__ __device__ constexpr long long pass_elems() {
     return (long long)NT * VecIO<T>::N * UNROLL;
 }
 
-// Visit every element of this block's chunk.  f(value_index_in_plane, float* vals, n) is called
-// with up to VEC values; vector path needs 16-byte aligned plane bases (hw % VEC == 0).
+// A plane of hw elements is cut into `chunks` equal pieces (a multiple of the vector width each); the launch picks
+// `chunks` so that all planes * chunks blocks are resident at once (chunks_for): a block then streams its piece in
+// passes instead of paying launch + prologue latency per 16 KB.
+__host__ __device__ inline long long chunk_len(long long hw, int chunks, int vec) {
+    const long long per = (hw + chunks - 1) / chunks;
+    return (per + vec - 1) / vec * vec;
+}
+
+// Visit every element of this block's chunk.  f(value_index_in_plane, n, vec) is called for up to VEC values; the
+// vector path needs 16-byte aligned plane bases (hw % VEC == 0).
 template <typename T, typename F>
-__device__ __forceinline__ void for_chunk(long long hw, int chunk, F&& f) {
+__device__ __forceinline__ void for_chunk(long long hw, int chunks, int chunk, F&& f) {
     constexpr int VEC = VecIO<T>::N;
-    const long long c0 = (long long)chunk * chunk_elems<T>();
-    const long long c1 = min(hw, c0 + chunk_elems<T>());
+    const long long len = chunk_len(hw, chunks, VEC);
+    const long long c0 = (long long)chunk * len;
+    const long long c1 = min(hw, c0 + len);
     if ((hw % VEC) == 0) {
+        for (long long base = c0; base < c1; base += pass_elems<T>()) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const long long e = c0 + ((long long)u * NT + threadIdx.x) * VEC;
-            if (e < c1) f(e, VEC, true);
+            for (int u = 0; u < UNROLL; ++u) {
+                const long long e = base + ((long long)u * NT + threadIdx.x) * VEC;
+                if (e < c1) f(e, VEC, true);
+            }
         }
     } else {
         for (long long e = c0 + threadIdx.x; e < c1; e += NT) f(e, 1, false);
     }
+}
+
+// GELU of a bf16 tensor: the A&S 7.1.26 erf (|err| < 1.5e-7, far below the bf16 rounding of the result) keeps the
+// streaming kernels HBM-bound; fp32 tensors take the exact erff
+template <typename T>
+__device__ __forceinline__ float gelu_t(float a) {
+    if constexpr (sizeof(T) == 2) return gelu_fast_f(a);
+    else return gelu_f(a);
+}
+template <typename T>
+__device__ __forceinline__ float gelu_grad_t(float a) {
+    if constexpr (sizeof(T) == 2) return gelu_grad_fast_f(a);
+    else return gelu_grad_f(a);
 }
 
 __device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[2*NT/64]*/) {
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
     const float pb = pre_bias ? pre_bias[plane % channels] : 0.f;
     const float pivot = pre<T>(VecIO<T>::load1(xp), pb, pre_bias != nullptr);
     float s1 = 0.f, s2 = 0.f;
-    for_chunk<T>(hw, chunk, [&](long long e, int n, bool vec) {
+    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
         float v[VecIO<T>::N];
         if (vec)
             VecIO<T>::load(xp + e, v);
@@ -167,6 +192,37 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
     if (threadIdx.x == 0) {
         ws[2 * (long long)blockIdx.x] = s1;
         ws[2 * (long long)blockIdx.x + 1] = s2;
+    }
+}
+
+// ---- plane sums (bias gradients of the 1x1 convolutions: sum of the output gradient over batch-plane pixels) -------
+template <typename T>
+__global__ __launch_bounds__(NT) void plane_sum_partial(const T* __restrict__ x, float* __restrict__ ws, long long hw,
+                                                        int chunks) {
+    __shared__ float red[2 * NT / 64];
+    const long long plane = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const T* xp = x + plane * hw;
+    float s1 = 0.f, s2 = 0.f;
+    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
+        float v[VecIO<T>::N];
+        if (vec) {
+            VecIO<T>::load(xp + e, v);
+#pragma unroll
+            for (int i = 0; i < VecIO<T>::N; i += 2) {
+                s1 += v[i];
+                s2 += v[i + 1];
+            }
+        } else {
+            s1 += VecIO<T>::load1(xp + e);
+        }
+    });
+    s1 += s2;
+    s2 = 0.f;
+    block_reduce2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        ws[2 * (long long)blockIdx.x] = s1;
+        ws[2 * (long long)blockIdx.x + 1] = 0.f;
     }
 }
 
@@ -231,19 +287,19 @@ __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __res
     const float sc = rstd * g, sh = b - mean * rstd * g;
     const T* xp = x + plane * hw;
     T* yp = y + plane * hw;
-    for_chunk<T>(hw, chunk, [&](long long e, int n, bool vec) {
+    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
         float v[VecIO<T>::N];
         if (vec) {
             VecIO<T>::load(xp + e, v);
 #pragma unroll
             for (int i = 0; i < VecIO<T>::N; ++i) {
                 const float a = pre<T>(v[i], pb, pre_bias != nullptr) * sc + sh;
-                v[i] = GELU ? gelu_f(a) : a;
+                v[i] = GELU ? gelu_t<T>(a) : a;
             }
             VecIO<T>::store(yp + e, v);
         } else {
             const float a = pre<T>(VecIO<T>::load1(xp + e), pb, pre_bias != nullptr) * sc + sh;
-            VecIO<T>::store1(yp + e, GELU ? gelu_f(a) : a);
+            VecIO<T>::store1(yp + e, GELU ? gelu_t<T>(a) : a);
         }
     });
 }
@@ -267,7 +323,7 @@ __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, co
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;
     float s1 = 0.f, s2 = 0.f;
-    for_chunk<T>(hw, chunk, [&](long long e, int n_, bool vec) {
+    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n_, bool vec) {
         float v[VecIO<T>::N], d[VecIO<T>::N];
         const int cnt = vec ? VecIO<T>::N : 1;
         if (vec) {
@@ -280,7 +336,7 @@ __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, co
         for (int i = 0; i < cnt; ++i) {
             const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
             float ga = d[i];
-            if (GELU) ga *= gelu_grad_f(n * g + b);
+            if (GELU) ga *= gelu_grad_t<T>(n * g + b);
             s1 += ga;
             s2 += ga * n;
         }
@@ -338,7 +394,7 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;
     T* op = gx + plane * hw;
-    for_chunk<T>(hw, chunk, [&](long long e, int n_, bool vec) {
+    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n_, bool vec) {
         float v[VecIO<T>::N], d[VecIO<T>::N];
         const int cnt = vec ? VecIO<T>::N : 1;
         if (vec) {
@@ -351,7 +407,7 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
         for (int i = 0; i < cnt; ++i) {
             const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
             float ga = d[i];
-            if (GELU) ga *= gelu_grad_f(n * g + b);
+            if (GELU) ga *= gelu_grad_t<T>(n * g + b);
             const float w = q ? q[e + i] : 1.f;
             v[i] = k * (ga - w * (m1 + (n - cq) * m2));
         }
@@ -371,7 +427,7 @@ __global__ __launch_bounds__(NT) void bias_gelu_fwd(const T* __restrict__ x, con
     const float b = bias ? bias[plane % channels] : 0.f;
     const T* xp = x + plane * hw;
     T* yp = y + plane * hw;
-    for_chunk<T>(hw, chunk, [&](long long e, int n, bool vec) {
+    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
         float v[VecIO<T>::N];
         if (vec) {
             VecIO<T>::load(xp + e, v);
@@ -397,7 +453,7 @@ __global__ __launch_bounds__(NT) void bias_gelu_bwd(const T* __restrict__ x, con
     const T* gp = gy + plane * hw;
     T* op = gx + plane * hw;
     float s1 = 0.f, s2 = 0.f;
-    for_chunk<T>(hw, chunk, [&](long long e, int n, bool vec) {
+    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
         float v[VecIO<T>::N], d[VecIO<T>::N];
         const int cnt = vec ? VecIO<T>::N : 1;
         if (vec) {
@@ -554,9 +610,18 @@ __global__ __launch_bounds__(NT) void quad_lp_bwd(const TA* __restrict__ a, cons
     });
 }
 
+// chunks per plane: as many as keep every block resident (8 blocks of 256 lanes per CU, 256 CUs), never less than one
+// pass of work per block
 template <typename T>
-int chunks_for(long long hw) {
-    return (int)((hw + chunk_elems<T>() - 1) / chunk_elems<T>());
+int chunks_for(long long hw, long long planes) {
+    static const long long target = [] {
+        const char* e = getenv("MAKANI_AMD_PW_BLOCKS");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? v : 2048ll;
+    }();
+    const long long maxc = (hw + pass_elems<T>() - 1) / pass_elems<T>();
+    const long long want = std::max(1ll, (target + planes / 2) / planes);
+    return (int)std::min(maxc, want);
 }
 
 int check_common(const void* a, long long planes, long long hw, int dtype, const char* what) {
@@ -569,8 +634,9 @@ int check_common(const void* a, long long planes, long long hw, int dtype, const
 
 }  // namespace
 
-extern "C" int mk_pointwise_chunks(long long hw, int dtype) {
-    return dtype == MK_BF16 ? chunks_for<u16>(hw) : chunks_for<float>(hw);
+extern "C" int mk_pointwise_chunks(long long hw, int dtype, long long planes) {
+    if (hw <= 0 || planes <= 0) return 1;
+    return dtype == MK_BF16 ? chunks_for<u16>(hw, planes) : chunks_for<float>(hw, planes);
 }
 
 #define DISPATCH_DTYPE(dtype, CALL_F32, CALL_BF16) \
@@ -592,11 +658,11 @@ extern "C" int mk_instnorm_stats(const void* x, int dtype, float* stats, float* 
     const int fb = (int)((planes + 255) / 256);
     const float qs = quad ? quad_sum : 0.f;
     if (dtype == MK_F32) {
-        const int ch = chunks_for<float>(hw);
+        const int ch = chunks_for<float>(hw, planes);
         hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch, nullptr, 1, quad);
         hipLaunchKernelGGL(in_stats_final<float>, dim3(fb), dim3(256), 0, s, (const float*)x, ws, stats, planes, hw, ch, eps, qs);
     } else {
-        const int ch = chunks_for<u16>(hw);
+        const int ch = chunks_for<u16>(hw, planes);
         hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch, nullptr, 1, quad);
         hipLaunchKernelGGL(in_stats_final<u16>, dim3(fb), dim3(256), 0, s, (const u16*)x, ws, stats, planes, hw, ch, eps, qs);
     }
@@ -625,9 +691,9 @@ extern "C" int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, 
     MK_REQUIRE(y && stats && ws && channels > 0, "instnorm_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MK_F32)
-        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * chunks_for<float>(hw))), dim3(NT), 0, s, (const float*)x, ws, hw, chunks_for<float>(hw), pre_bias, channels, quad);
+        hipLaunchKernelGGL(in_stats_partial<float>, dim3((unsigned)(planes * chunks_for<float>(hw, planes))), dim3(NT), 0, s, (const float*)x, ws, hw, chunks_for<float>(hw, planes), pre_bias, channels, quad);
     else
-        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * chunks_for<u16>(hw))), dim3(NT), 0, s, (const u16*)x, ws, hw, chunks_for<u16>(hw), pre_bias, channels, quad);
+        hipLaunchKernelGGL(in_stats_partial<u16>, dim3((unsigned)(planes * chunks_for<u16>(hw, planes))), dim3(NT), 0, s, (const u16*)x, ws, hw, chunks_for<u16>(hw, planes), pre_bias, channels, quad);
     MK_REQUIRE(quad == nullptr || quad_sum > 0.f, "instnorm_fwd: quadrature weights need their (positive) sum");
     return instnorm_apply_impl(x, y, dtype, stats, gamma, beta, ws, eps, planes, channels, hw, fuse_gelu, pre_bias,
                                quad ? quad_sum : 0.f, s);
@@ -637,14 +703,14 @@ static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, 
                                const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
                                const float* pre_bias, float qsum, hipStream_t s) {
     if (dtype == MK_F32) {
-        const int ch = chunks_for<float>(hw);
+        const int ch = chunks_for<float>(hw, planes);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
             hipLaunchKernelGGL((in_apply<float, true>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias, qsum);
         else
             hipLaunchKernelGGL((in_apply<float, false>), g, dim3(NT), 0, s, (const float*)x, (float*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias, qsum);
     } else {
-        const int ch = chunks_for<u16>(hw);
+        const int ch = chunks_for<u16>(hw, planes);
         dim3 g((unsigned)(planes * ch));
         if (fuse_gelu)
             hipLaunchKernelGGL((in_apply<u16, true>), g, dim3(NT), 0, s, (const u16*)x, (u16*)y, stats, gamma, beta, ws, eps, channels, hw, ch, pre_bias, qsum);
@@ -667,7 +733,7 @@ extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtyp
     const float inv_total = 1.0f / (float)hw_total;
 #define IN_BWD(T, G)                                                                                                   \
     do {                                                                                                               \
-        const int ch = chunks_for<T>(hw);                                                                              \
+        const int ch = chunks_for<T>(hw, planes);                                                                              \
         dim3 g((unsigned)(planes * ch));                                                                               \
         if (phase != 2)                                                                                                \
             hipLaunchKernelGGL((in_bwd_partial<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, stats, gamma,    \
@@ -688,6 +754,24 @@ extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtyp
     return mk_check_launch("mk_instnorm_bwd");
 }
 
+extern "C" int mk_plane_sums(const void* x, int dtype, float* sums, float* ws, long long planes, long long hw, void* stream) {
+    int rc = check_common(x, planes, hw, dtype, "plane_sums");
+    if (rc) return rc;
+    MK_REQUIRE(sums && ws, "plane_sums: null sums/ws");
+    hipStream_t s = (hipStream_t)stream;
+    const int fb = (int)((planes + 255) / 256);
+    if (dtype == MK_F32) {
+        const int ch = chunks_for<float>(hw, planes);
+        hipLaunchKernelGGL(plane_sum_partial<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, ws, hw, ch);
+        hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);
+    } else {
+        const int ch = chunks_for<u16>(hw, planes);
+        hipLaunchKernelGGL(plane_sum_partial<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, ws, hw, ch);
+        hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);
+    }
+    return mk_check_launch("mk_plane_sums");
+}
+
 extern "C" int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int dtype, long long planes, int channels,
                                 long long hw, void* stream) {
     int rc = check_common(x, planes, hw, dtype, "bias_gelu_fwd");
@@ -695,10 +779,10 @@ extern "C" int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int d
     MK_REQUIRE(y && channels > 0, "bias_gelu_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MK_F32) {
-        const int ch = chunks_for<float>(hw);
+        const int ch = chunks_for<float>(hw, planes);
         hipLaunchKernelGGL(bias_gelu_fwd<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, bias, (float*)y, channels, hw, ch);
     } else {
-        const int ch = chunks_for<u16>(hw);
+        const int ch = chunks_for<u16>(hw, planes);
         hipLaunchKernelGGL(bias_gelu_fwd<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, bias, (u16*)y, channels, hw, ch);
     }
     return mk_check_launch("mk_bias_gelu_fwd");
@@ -713,11 +797,11 @@ extern "C" int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy
     hipStream_t s = (hipStream_t)stream;
     const int fb = (int)((planes + 255) / 256);
     if (dtype == MK_F32) {
-        const int ch = chunks_for<float>(hw);
+        const int ch = chunks_for<float>(hw, planes);
         hipLaunchKernelGGL(bias_gelu_bwd<float>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const float*)x, bias, (const float*)gy, (float*)gx, ws, channels, hw, ch);
         if (sums) hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);
     } else {
-        const int ch = chunks_for<u16>(hw);
+        const int ch = chunks_for<u16>(hw, planes);
         hipLaunchKernelGGL(bias_gelu_bwd<u16>, dim3((unsigned)(planes * ch)), dim3(NT), 0, s, (const u16*)x, bias, (const u16*)gy, (u16*)gx, ws, channels, hw, ch);
         if (sums) hipLaunchKernelGGL(sum_chunks_final, dim3(fb), dim3(256), 0, s, ws, sums, planes, ch);
     }

@@ -70,6 +70,73 @@ struct Stage {
         }
     }
 
+    // interleaved complex operand ((re, im) pairs, strides rs / ks in floats): this stage holds the addresses, its
+    // partner `im` receives the odd floats (load_ilv)
+    __device__ __forceinline__ void init_ilv(const float* __restrict__ base, long long rs, long long ks, int r0, int rmax,
+                                             int tid) {
+        ok = 0u;
+        kstride = KC ? 2 : ks;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + q * NT;
+            if constexpr (KC) {
+                const int row = f >> 2, kq = f & 3;
+                p0[q] = base + (long long)(r0 + row) * rs + kq * 8;
+                ok |= (r0 + row < rmax ? 1u : 0u) << q;
+            } else {
+                constexpr int RQ = ROWS / 4;
+                const int kk = f / RQ, rq = f % RQ;
+                p0[q] = base + (long long)kk * ks + (long long)(r0 + rq * 4) * 2;
+                ok |= (r0 + rq * 4 < rmax ? 1u : 0u) << q;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void load_pair(int q, long long koff, Stage& im) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p0[q] + koff);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p0[q] + koff + 4);
+        v[q] = f32x4{a[0], a[2], b[0], b[2]};
+        im.v[q] = f32x4{a[1], a[3], b[1], b[3]};
+    }
+
+    // load() of an interleaved operand into the (re = *this, im) pair of stages
+    __device__ __forceinline__ void load_ilv(Stage& im, int k0, int klo, int khi, int tid) {
+        const long long koff = (long long)k0 * kstride;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (k0 >= klo && k0 + BK <= khi) {
+            keep = im.keep = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                v[q] = zero;
+                im.v[q] = zero;
+                if ((ok >> q) & 1u) load_pair(q, koff, im);
+            }
+            return;
+        }
+        keep = 0u;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + q * NT;
+            v[q] = zero;
+            im.v[q] = zero;
+            if constexpr (KC) {
+                const int k = k0 + (f & 3) * 4;
+                if (((ok >> q) & 1u) && k < khi && k + 3 >= klo) {
+                    load_pair(q, koff, im);
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m |= in_range(k + e, klo, khi) ? (1u << e) : 0u;
+                    keep |= m << (4 * q);
+                }
+            } else {
+                constexpr int RQ = ROWS / 4;
+                const int k = k0 + f / RQ;
+                if (((ok >> q) & 1u) && in_range(k, klo, khi)) load_pair(q, koff, im);
+            }
+        }
+        im.keep = keep;
+    }
+
     // tile [k0, k0 + BK) of the operand, zero outside [klo, khi)
     __device__ __forceinline__ void load(int k0, int klo, int khi, int tid) {
         const long long koff = (long long)k0 * kstride;                 // uniform
@@ -261,7 +328,8 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(const MkGemm p, int tilesM
 // ---- complex kernel (planar): block tile 64 x 128, waves 2 x 2, wave tile 32 x 64 ------------
 // DEPTH = register prefetch distance in k-tiles (2: two staging register sets, the loads of tile kt+2 are issued
 // while tile kt is multiplied)
-template <bool A_KC, bool B_KC, int NP, int DEPTH>
+// B_ILV: B is an interleaved complex tensor (gemm_common.h); C interleaved is a run-time property of the epilogue
+template <bool A_KC, bool B_KC, int NP, int DEPTH, bool B_ILV = false>
 __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tilesM, int tilesN) {
     constexpr int BM = 64, BN = 128;
     constexpr int PLA = plane_elems<BM, A_KC>(), PLB = plane_elems<BN, B_KC>();
@@ -300,14 +368,22 @@ __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tiles
     for (int d = 0; d < DEPTH; ++d) {
         sar[d].init(Ab, p.a_row, p.a_k, c.i0, a_rmax, tid);
         sai[d].init(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, tid);
-        sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
-        sbi[d].init(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, tid);
+        if constexpr (B_ILV) {
+            sbr[d].init_ilv(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
+        } else {
+            sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
+            sbi[d].init(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, tid);
+        }
     }
     auto ld = [&](int d, int kt) {
         sar[d].load(kt * BK, c.klo, c.khi, tid);
         sai[d].load(kt * BK, c.klo, c.khi, tid);
-        sbr[d].load(kt * BK, c.klo, c.khi, tid);
-        sbi[d].load(kt * BK, c.klo, c.khi, tid);
+        if constexpr (B_ILV) {
+            sbr[d].load_ilv(sbi[d], kt * BK, c.klo, c.khi, tid);
+        } else {
+            sbr[d].load(kt * BK, c.klo, c.khi, tid);
+            sbi[d].load(kt * BK, c.klo, c.khi, tid);
+        }
     };
     auto step = [&](int d, int kt) {           // tile kt sits in register set d
         sar[d].template store<NP, PLA>(Are, tid, 1.f);
@@ -356,15 +432,19 @@ __global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tiles
         for (int r = 0; r < 16; ++r) {
             const int row = c.i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (row < c.Meff && col < p.N) {
-                float* dr = Cb + (long long)row * p.c_row + col;
+                float* dr = Cb + (long long)row * p.c_row + (long long)col * p.c_col;
                 float* di = dr + p.c_im;
                 float vr = cre[tb][r] - cng[tb][r], vi = cim[tb][r];
                 if (p.beta) {
                     vr += *dr;
                     vi += *di;
                 }
-                *dr = vr;
-                *di = vi;
+                if (p.c_col == 2) {          // interleaved complex C: one 8-byte store per entry
+                    *reinterpret_cast<float2*>(dr) = make_float2(vr, vi);
+                } else {
+                    *dr = vr;
+                    *di = vi;
+                }
             }
         }
     }
@@ -389,7 +469,7 @@ int launch_real(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
 }
 
 template <int NP>
-int launch_cplx(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
+int launch_cplx(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t s) {
     constexpr int BM = 64, BN = 128;
     const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
     const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
@@ -399,7 +479,13 @@ int launch_cplx(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
     // measured and rejected: prefetch distance 2 (dgrad -2 %, wgrad +2 %); a wave-specialised variant (4 producer
     // waves split + stage, 4 consumer waves run the MFMAs, one barrier per k-tile): 15-25 % slower (DESIGN.md par. 10)
 #define MK_XC_LAUNCH(AK, BK_) hipLaunchKernelGGL((xcgemm_kernel<AK, BK_, NP, 1>), grid, block, 0, s, *g, tm, tn)
-    if (a_kc && b_kc)
+    if (b_ilv) {             // the dhconv weight in place: forward (B row-contiguous) and data gradient (B k-contiguous)
+        MK_REQUIRE(a_kc, "xcgemm: an interleaved B operand needs a k-contiguous A");
+        if (b_kc)
+            hipLaunchKernelGGL((xcgemm_kernel<true, true, NP, 1, true>), grid, block, 0, s, *g, tm, tn);
+        else
+            hipLaunchKernelGGL((xcgemm_kernel<true, false, NP, 1, true>), grid, block, 0, s, *g, tm, tn);
+    } else if (a_kc && b_kc)
         MK_XC_LAUNCH(true, true);
     else if (a_kc && !b_kc)
         MK_XC_LAUNCH(true, false);
@@ -425,10 +511,10 @@ extern "C" int mk_sgemm_split_batched(const MkGemm* g, int limbs, void* stream) 
 }
 
 extern "C" int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream) {
-    bool a_kc, b_kc;
-    int rc = validate(g, true, &a_kc, &b_kc);
+    bool a_kc, b_kc, b_ilv;
+    int rc = validate(g, true, &a_kc, &b_kc, true, &b_ilv);
     if (rc) return rc;
     MK_REQUIRE(limbs == 2 || limbs == 3, "split gemm: limbs must be 2 or 3");
     hipStream_t s = (hipStream_t)stream;
-    return limbs == 3 ? launch_cplx<3>(g, a_kc, b_kc, s) : launch_cplx<2>(g, a_kc, b_kc, s);
+    return limbs == 3 ? launch_cplx<3>(g, a_kc, b_kc, b_ilv, s) : launch_cplx<2>(g, a_kc, b_kc, b_ilv, s);
 }

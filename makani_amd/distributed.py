@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import _lib
 from . import comm as _comm
 from . import legendre as _leg
 from . import ops
@@ -436,7 +437,11 @@ class DistributedGeometricInstanceNormS2(DistributedInstanceNorm2d):
 # (makani/utils/training/training_helpers.py:123-165)
 # --------------------------------------------------------------------------- #
 def _real(g):
-    return torch.view_as_real(g) if g.is_complex() else g
+    """real view of a gradient, in memory order when the tensor is dense but not C-contiguous (native-order dhconv
+    weight gradients): reductions and norms do not care about the order, collectives need contiguity"""
+    r = torch.view_as_real(g) if g.is_complex() else g
+    d = _lib.dense_view(r)
+    return r if d is None else d
 
 
 class GradReducer:
@@ -529,9 +534,13 @@ class GradReducer:
                     flat.mul_(st[2])
             off = 0
             for q in params:            # the reduced bucket becomes the gradients (views, no copy-back kernels)
-                n = _real(q.grad).numel()
+                r = _real(q.grad)
+                n = r.numel()
                 piece = flat[off:off + n]
-                q.grad = torch.view_as_complex(piece.view(*q.grad.shape, 2)) if q.grad.is_complex() else piece.view_as(q.grad)
+                if not q.grad.is_contiguous():          # dense in another order (native dhconv weight): keep its strides
+                    r.copy_(piece.view(r.shape))
+                else:
+                    q.grad = torch.view_as_complex(piece.view(*q.grad.shape, 2)) if q.grad.is_complex() else piece.view_as(q.grad)
                 off += n
         self.small = {}
         while self.pending:

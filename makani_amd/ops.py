@@ -205,6 +205,33 @@ def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int
 # --------------------------------------------------------------------------- #
 # dhconv (complex, batched over l)
 # --------------------------------------------------------------------------- #
+def native_w_empty(cin: int, cout: int, L: int, device=None) -> torch.Tensor:
+    """uninitialised complex64 (1, Cin, Cout, L) tensor whose MEMORY order is [l][i][o] (re, im interleaved): the order
+    the dhconv GEMMs read their weight in.  ``SpectralConv`` allocates its dhconv parameter like this, autograd hands
+    the weight gradient back in the same strides, and no layout kernel runs per step (round 1 re-laid 2.26 GB out
+    twice per step).  Shape, values, ``state_dict`` and ``load_state_dict`` are those of the reference parameter."""
+    return torch.empty((L, cin, cout), dtype=torch.complex64, device=device).permute(1, 2, 0).unsqueeze(0)
+
+
+def is_native_w(weight: torch.Tensor) -> bool:
+    if weight.dim() != 4 or weight.shape[0] != 1 or weight.dtype != torch.complex64:
+        return False
+    _, cin, cout, L = weight.shape
+    return (cin % 4 == 0 and cout % 4 == 0 and (cout == 1 or weight.stride(2) == 1) and (cin == 1 or weight.stride(1) == cout)
+            and (L == 1 or weight.stride(3) == cin * cout) and weight.data_ptr() % 16 == 0 and GEMM_MODE != "fp32")
+
+
+def _w_operand(W, transposed):
+    """B-operand fields of the dhconv GEMMs for W = planar (L, 2, Cip, Cop) fp32 or a native-order complex64 weight"""
+    if W.is_complex():
+        _, cip, cop, L = W.shape
+        d = dict(b_batch=2 * cip * cop, b_inner=0, b_im=1, b_col=2 * cop if transposed else 2, b_k=2 if transposed else 2 * cop)
+    else:
+        L, _, cip, cop = W.shape
+        d = dict(b_batch=2 * cip * cop, b_inner=0, b_im=cip * cop, b_col=cop if transposed else 1, b_k=1 if transposed else cop)
+    return L, cip, cop, d
+
+
 def weight_to_wlayout(weight: torch.Tensor) -> torch.Tensor:
     """complex64 (1, Cin, Cout, L) -> W (L, 2, Cip, Cop), zero padded."""
     G, cin, cout, L = weight.shape
@@ -229,14 +256,13 @@ def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int, tri_off: int 
     ``grp = (first input channel, first output channel, x_ld, y_ld)`` runs one channel group of a grouped operator:
     S and ``out`` then hold all groups (x_ld / y_ld channels per batch entry), W this group's matrices."""
     L, M, _, R = S.shape
-    Lw, _, cip, cop = W.shape
+    Lw, cip, cop, bdesc = _w_operand(W, False)
     a_off, c_off, xld, yld = grp if grp is not None else (0, 0, cip, cop)
     assert Lw == L and R == B * xld
     Ro = B * yld
     T = out if out is not None else torch.empty((L, M, 2, Ro), dtype=torch.float32, device=S.device)
     g = _gemm(A=S.data_ptr() + 4 * a_off, B=W.data_ptr(), C=T.data_ptr() + 4 * c_off,
-              a_batch=M * 2 * R, a_inner=xld, a_row=2 * R, a_k=1, a_im=R,
-              b_batch=2 * cip * cop, b_inner=0, b_col=1, b_k=cop, b_im=cip * cop,
+              a_batch=M * 2 * R, a_inner=xld, a_row=2 * R, a_k=1, a_im=R, **bdesc,
               c_batch=M * 2 * Ro, c_inner=yld, c_row=2 * Ro, c_im=Ro,
               M=M, N=cop, K=cin, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off)
     # dense-formulation work: 8 * B * Cin * Cout * L * M flops (complex MAC = 8 real flops)
@@ -249,14 +275,13 @@ def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int, tri_off: int 
 def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int, tri_off: int = 0, out=None, grp=None) -> torch.Tensor:
     """gS[l][m][b][i] = sum_o gT[l][m][b][o] * conj(W[l][i][o])."""
     L, M, _, Ro = gT.shape
-    _, _, cip, cop = W.shape
+    _, cip, cop, bdesc = _w_operand(W, True)
     a_off, c_off, xld, yld = grp if grp is not None else (0, 0, cip, cop)      # (input ch., output ch., x_ld, y_ld)
     assert Ro == B * yld
     R = B * xld
     gS = out if out is not None else torch.empty((L, M, 2, R), dtype=torch.float32, device=gT.device)
     g = _gemm(A=gT.data_ptr() + 4 * c_off, B=W.data_ptr(), C=gS.data_ptr() + 4 * a_off,
-              a_batch=M * 2 * Ro, a_inner=yld, a_row=2 * Ro, a_k=1, a_im=Ro,
-              b_batch=2 * cip * cop, b_inner=0, b_col=cop, b_k=1, b_im=cip * cop,
+              a_batch=M * 2 * Ro, a_inner=yld, a_row=2 * Ro, a_k=1, a_im=Ro, **bdesc,
               c_batch=M * 2 * R, c_inner=xld, c_row=2 * R, c_im=R,
               M=M, N=cin, K=cout, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off, conj_b=1)
     with _timed("dhconv_dgrad", flops=8.0 * B * cin * cout * L * M,
@@ -265,19 +290,25 @@ def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int,
     return gS
 
 
-def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0, grp=None) -> torch.Tensor:
+def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0, grp=None, native=False) -> torch.Tensor:
     """gW[l][i][o] = sum_{b, m <= l} conj(S[l][m][b][i]) * gT[l][m][b][o].
-    ``grp = (first input channel, first output channel, group inputs, group outputs)`` for one group of a grouped operator."""
+    ``grp = (first input channel, first output channel, group inputs, group outputs)`` for one group of a grouped operator.
+    ``native``: the result is the complex64 (1, Cin, Cout, L) gradient in the memory order of ``native_w_empty``
+    (written interleaved by the GEMM epilogue) instead of the planar (L, 2, Cip, Cop) W-layout."""
     L, M, _, R = S.shape
     Ro = gT.shape[-1]
     xld, yld = R // B, Ro // B
     a_off, c_off, cip, cop = grp if grp is not None else (0, 0, xld, yld)
-    gW = torch.empty((L, 2, cip, cop), dtype=torch.float32, device=S.device)
+    if native:
+        gW = native_w_empty(cip, cop, L, S.device)
+        cdesc = dict(c_batch=2 * cip * cop, c_row=2 * cop, c_col=2, c_im=1)
+    else:
+        gW = torch.empty((L, 2, cip, cop), dtype=torch.float32, device=S.device)
+        cdesc = dict(c_batch=2 * cip * cop, c_row=cop, c_im=cip * cop)
     for b in range(B):
         g = _gemm(A=S.data_ptr() + 4 * (b * xld + a_off), B=gT.data_ptr() + 4 * (b * yld + c_off), C=gW.data_ptr(),
                   a_batch=M * 2 * R, a_row=1, a_k=2 * R, a_im=R,
-                  b_batch=M * 2 * Ro, b_col=1, b_k=2 * Ro, b_im=Ro,
-                  c_batch=2 * cip * cop, c_row=cop, c_im=cip * cop,
+                  b_batch=M * 2 * Ro, b_col=1, b_k=2 * Ro, b_im=Ro, **cdesc,
                   M=cip, N=cop, K=M, batch=L, inner=1, tri_mode=_lib.TRI_K_LE, tri_off=tri_off, conj_a=1,
                   beta=1 if b > 0 else 0)
         with _timed("dhconv_wgrad", flops=8.0 * cip * cop * L * M,
@@ -364,20 +395,24 @@ class DhconvFn(torch.autograd.Function):
     def forward(ctx, S, weight, B, tri_off=0):
         """tri_off = (first l of this shard) - (first m of this shard); 0 when not sharded."""
         _, cin, cout, _ = weight.shape
-        W = weight_to_wlayout(weight)
+        native = is_native_w(weight)          # the parameter is already in the GEMM's order: used (and saved) in place
+        W = weight.detach() if native else weight_to_wlayout(weight)
         ctx.save_for_backward(S, W)
-        ctx.meta = (B, cin, cout, tri_off)
+        ctx.meta = (B, cin, cout, tri_off, native)
         return dhconv_fwd(S, W, B, cin, tri_off)
 
     @staticmethod
     def backward(ctx, gT):
         S, W = ctx.saved_tensors
-        B, cin, cout, tri_off = ctx.meta
+        B, cin, cout, tri_off, native = ctx.meta
         gT = gT.contiguous()
         gS = dhconv_dgrad(gT, W, B, cin, cout, tri_off) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            gw = wlayout_to_weight_grad(dhconv_wgrad(S, gT, B, tri_off), cin, cout)
+            if native and S.shape[-1] == B * cin and gT.shape[-1] == B * cout:
+                gw = dhconv_wgrad(S, gT, B, tri_off, native=True)
+            else:
+                gw = wlayout_to_weight_grad(dhconv_wgrad(S, gT, B, tri_off), cin, cout)
         return gS, gw, None, None
 
 
@@ -547,7 +582,7 @@ class ComplexToSFn(torch.autograd.Function):
 # pointwise
 # --------------------------------------------------------------------------- #
 def _ws(planes, hw, dtype, device):
-    ch = lib().mk_pointwise_chunks(hw, _lib.MK_BF16 if dtype == torch.bfloat16 else _lib.MK_F32)
+    ch = lib().mk_pointwise_chunks(hw, _lib.MK_BF16 if dtype == torch.bfloat16 else _lib.MK_F32, planes)
     return torch.empty((planes * ch * 2,), dtype=torch.float32, device=device)
 
 
@@ -687,7 +722,15 @@ def conv1x1_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 
 def _sum_planes(t: torch.Tensor) -> torch.Tensor:
-    return t.sum(dim=(0, 2, 3), dtype=torch.float32)
+    """(B, C, H, W) -> (C,) fp32 sums over batch and pixels (bias gradient of a 1x1 convolution)"""
+    if not (t.is_cuda and t.dim() == 4 and t.dtype in (torch.bfloat16, torch.float32)):
+        raise RuntimeError("makani_amd ops need 4-d bf16 / fp32 GPU tensors (the HIP path has no CPU fallback)")
+    t = t.contiguous()
+    B, Cc, H, W = t.shape
+    sums = torch.empty((2, B * Cc), dtype=torch.float32, device=t.device)
+    check(lib().mk_plane_sums(ptr(t), dtype_code(t), ptr(sums), ptr(_ws(B * Cc, H * W, t.dtype, t.device)), B * Cc, H * W,
+                              stream()), "mk_plane_sums")
+    return _batch_sum(sums, B, Cc)[0]
 
 
 class Conv1x1Fn(torch.autograd.Function):

@@ -4,13 +4,21 @@ import ctypes as C
 
 import torch
 
-from ._lib import MkAdamTensor, check, lib, ptr, stream
+from ._lib import MkAdamTensor, check, dense_view, lib, ptr, stream
 
 SMALL = 1 << 20          # tensors below this many floats share multi-tensor launches
 
 
 def _real(t):
     return torch.view_as_real(t) if t.is_complex() else t
+
+
+def _flat(t, like=None):
+    """fp32 view of ``t`` in memory order for the element-wise kernels; ``like``: a tensor it must share strides with"""
+    r = dense_view(_real(t))
+    if r is None or r.dtype != torch.float32 or (like is not None and t.stride() != like.stride()):
+        raise RuntimeError("FusedAdamW needs dense fp32 / complex64 parameters with gradients and state in the same strides")
+    return r
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -24,9 +32,7 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def clip_coef(self, max_grad_norm):
         """(2,) device tensor: [min(1, max_norm / (||g|| + 1e-6)), ||g||] over all local gradients, 3 launches."""
-        grads = [_real(p.grad) for g in self.param_groups for p in g["params"] if p.grad is not None]
-        if any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
-            raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 gradients")
+        grads = [_flat(p.grad) for g in self.param_groups for p in g["params"] if p.grad is not None]
         arr = (MkAdamTensor * len(grads))(*[MkAdamTensor(None, g.data_ptr(), None, None, g.numel(), None, None, 0, 0, 0) for g in grads])
         nws = lib().mk_grad_norm_workspace(C.cast(arr, C.c_void_p), len(grads))
         ws = torch.empty((nws,), dtype=torch.float32, device=grads[0].device)
@@ -75,10 +81,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                pr, gr = _real(p), _real(p.grad)
-                if not (pr.is_contiguous() and gr.is_contiguous()) or pr.dtype != torch.float32 or gr.dtype != torch.float32:
-                    raise RuntimeError("FusedAdamW needs contiguous fp32 / complex64 parameters and gradients")
-                m, v = _real(st["exp_avg"]), _real(st["exp_avg_sq"])
+                pr, gr = _flat(p), _flat(p.grad, p)
+                m, v = _flat(st["exp_avg"], p), _flat(st["exp_avg_sq"], p)
                 if pr.numel() < SMALL:
                     # parameters that asked for it (ops.want_bf16_shadow) get bf16(p) written by the same kernel — as the
                     # (M, round8(K)) operand of the forward GEMM and, transposed, the (K, round8(M)) operand of the

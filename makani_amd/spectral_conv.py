@@ -11,6 +11,7 @@ with the bf16<->fp32 casts of the reference (``:237-239,252-256``) fused into
 the FFT kernels' loads and stores.
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -85,7 +86,13 @@ class SpectralConv(nn.Module):
         # per-l scale against the LAST weight axis (which is m for the "diagonal" operator)
         scale = math.sqrt(gain / (in_channels // num_groups)) * torch.ones(self.modes_lat_local, dtype=torch.complex64)
         scale[0] *= math.sqrt(2.0)
-        self.weight = nn.Parameter(scale * torch.randn(*weight_shape, dtype=torch.complex64))
+        w0 = scale * torch.randn(*weight_shape, dtype=torch.complex64)
+        cgi, cgo = in_channels // num_groups, out_channels // num_groups
+        if (operator_type == "dhconv" and not separable and num_groups == 1 and cgi % 4 == 0 and cgo % 4 == 0
+                and os.environ.get("MAKANI_AMD_NATIVE_W", "1") != "0"):
+            # same shape and values, memory in the order the dhconv GEMMs read ([l][i][o]): no re-layout per step
+            w0 = ops.native_w_empty(cgi, cgo, self.modes_lat_local).copy_(w0)
+        self.weight = nn.Parameter(w0)
         if operator_type == "dhconv":
             self.weight.is_shared_mp = ["matmul", "w"]
             self.weight.sharded_dims_mp = [None for _ in weight_shape]

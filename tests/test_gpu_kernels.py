@@ -253,6 +253,62 @@ def test_weight_layout_roundtrip(cin, cout, L):
     assert torch.equal(back, w)
 
 
+@pytest.mark.parametrize("B,cin,cout,L,M", [(1, 8, 12, 9, 10), (2, 36, 140, 20, 21), (1, 128, 64, 40, 41), (1, 384, 384, 6, 241)])
+@pytest.mark.parametrize("engine", ["x6", "x3"])
+def test_dhconv_native_weight_order_matches_planar(B, cin, cout, L, M, engine, monkeypatch):
+    """the dhconv weight used IN PLACE (complex64 (1, Cin, Cout, L) whose memory order is [l][i][o], interleaved B operand
+    of the split engine; gradient written interleaved by the GEMM epilogue) against the planar W-layout path: the same
+    limbs meet in the same order, so forward, data gradient and weight gradient agree bit for bit"""
+    from makani_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", engine)
+    torch.manual_seed(L * 7 + cin)
+    w = torch.randn(1, cin, cout, L, dtype=torch.complex64, device=_dev())
+    wn = ops.native_w_empty(cin, cout, L, _dev()).copy_(w)
+    assert ops.is_native_w(wn) and not ops.is_native_w(w) and wn.shape == w.shape and torch.equal(wn, w)
+    tri = torch.tril(torch.ones(L, M, device=_dev()))
+    x = torch.randn(B, cin, L, M, dtype=torch.complex64, device=_dev()) * tri
+    gy = torch.randn(B, cout, L, M, dtype=torch.complex64, device=_dev()) * tri
+    res = []
+    for wt in (w, wn):
+        wt = wt.detach().requires_grad_(True)
+        xs = x.clone().requires_grad_(True)
+        T = ops.DhconvFn.apply(ops.ComplexToSFn.apply(xs), wt, B)
+        y = ops.SToComplexFn.apply(T, B, cout)
+        torch.view_as_real(y).mul(torch.view_as_real(gy)).sum().backward()
+        res.append((y.detach(), xs.grad, wt.grad))
+    (y0, gx0, gw0), (y1, gx1, gw1) = res
+    assert gw1.stride() == wn.stride() and ops.is_native_w(gw1)            # autograd keeps it without a copy
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1) and torch.equal(gw0, gw1)
+    ref = torch.einsum("bilm,iol->bolm", x.to(torch.complex128), w[0].to(torch.complex128))
+    assert rel_l2(y1, ref) < (1e-5 if engine == "x6" else 1e-4)
+
+
+def test_fused_adamw_on_native_order_weight():
+    """FusedAdamW on a dense, non-C-contiguous complex parameter (gradient and state in the same strides)"""
+    from makani_amd import ops
+    from makani_amd.optim import FusedAdamW
+    torch.manual_seed(4)
+    w = torch.randn(1, 8, 12, 5, dtype=torch.complex64, device=_dev())
+    a = torch.nn.Parameter(ops.native_w_empty(8, 12, 5, _dev()).copy_(w))
+    b = torch.nn.Parameter(w.clone())
+    big = torch.nn.Parameter(ops.native_w_empty(256, 256, 9, _dev()).copy_(torch.randn(1, 256, 256, 9, dtype=torch.complex64)))
+    bigr = torch.nn.Parameter(big.detach().contiguous().clone())
+    oa = FusedAdamW([a, big], lr=1e-2, weight_decay=0.01)
+    ob = torch.optim.AdamW([b, bigr], lr=1e-2, weight_decay=0.01)
+    for it in range(3):
+        torch.manual_seed(20 + it)
+        g, gb = torch.randn_like(w), torch.randn(1, 256, 256, 9, dtype=torch.complex64, device=_dev())
+        a.grad = ops.native_w_empty(8, 12, 5, _dev()).copy_(g)
+        b.grad = g.clone()
+        big.grad = ops.native_w_empty(256, 256, 9, _dev()).copy_(gb)
+        bigr.grad = gb.clone()
+        torch.nn.utils.clip_grad_norm_([b, bigr], 1.5)
+        ob.step()
+        oa.step(max_grad_norm=1.5)
+    assert a.stride() == ops.native_w_empty(8, 12, 5).stride() and oa.state[a]["exp_avg"].stride() == a.stride()
+    assert rel_l2(a, b) < 2e-6 and rel_l2(big, bigr) < 2e-6
+
+
 @pytest.mark.parametrize("B,C,L,M", [(1, 3, 5, 6), (2, 33, 40, 35), (2, 8, 12, 13)])
 def test_s_layout_roundtrip(B, C, L, M):
     from makani_amd import ops
@@ -297,6 +353,18 @@ def test_instance_norm(dtype, tol, fuse_gelu, B, C, H, W):
     assert rel_l2(xd.grad, xr.grad) < (tol * 5 if dtype == torch.float32 else 2e-2)
     assert rel_l2(gd.grad, gr.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
     assert rel_l2(bd.grad, br.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(2, 5, 12, 24), (1, 3, 37, 71), (1, 768, 240, 480), (3, 700, 9, 16)])
+def test_plane_sums_bias_gradient(dtype, B, C, H, W):
+    from makani_amd import ops
+    torch.manual_seed(B * C + H)
+    x = (torch.randn(B, C, H, W) + 0.25).to(dtype)
+    got = ops._sum_planes(x.to(_dev()))
+    ref = x.double().sum(dim=(0, 2, 3))
+    assert got.shape == (C,) and got.dtype == torch.float32
+    assert float((got.cpu().double() - ref).abs().max()) < 2e-6 * float(x.double().abs().sum(dim=(0, 2, 3)).max())
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)])

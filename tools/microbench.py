@@ -68,14 +68,60 @@ def pointwise():
         x = torch.randn(1, 384, H, W, device=dev).bfloat16().requires_grad_(True)
         g = torch.ones(384, device=dev); b = torch.zeros(384, device=dev)
         nb = x.numel() * 2
-        ms = timeit(lambda: ops.InstanceNormFn.apply(x, g, b, 1e-6, True))
-        print(f"instnorm+gelu fwd {H}x{W}: {ms:7.3f} ms  {3*nb/ms/1e6:7.1f} GB/s (2 reads + 1 write)")
-        y = ops.InstanceNormFn.apply(x, g, b, 1e-6, True)
-        gy = torch.randn_like(y)
-        ms = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True))
-        print(f"instnorm+gelu bwd {H}x{W}: {ms:7.3f} ms  {5*nb/ms/1e6:7.1f} GB/s (4 reads + 1 write)")
+        for gelu in (False, True):
+            tag = "instnorm+gelu" if gelu else "instnorm     "
+            ms = timeit(lambda: ops.InstanceNormFn.apply(x, g, b, 1e-6, gelu))
+            print(f"{tag} fwd {H}x{W}: {ms:7.3f} ms  {3*nb/ms/1e6:7.1f} GB/s (2 reads + 1 write)")
+            y = ops.InstanceNormFn.apply(x, g, b, 1e-6, gelu)
+            gy = torch.randn_like(y)
+            ms = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True))
+            print(f"{tag} bwd {H}x{W}: {ms:7.3f} ms  {5*nb/ms/1e6:7.1f} GB/s (4 reads + 1 write)")
         ms = timeit(lambda: ops.BiasGeluFn.apply(x, b))
         print(f"bias_gelu fwd     {H}x{W}: {ms:7.3f} ms  {2*nb/ms/1e6:7.1f} GB/s")
+
+
+def cold():
+    """streaming kernels on ROTATING buffers (12 x 88 MB inputs: nothing is left in the 256 MB memory-side cache or
+    the L2s from the previous call) — what the kernels see inside the train step"""
+    NB, C, H, W = 12, 384, 240, 480
+    xs = [torch.randn(1, C, H, W, device=dev).bfloat16() for _ in range(NB)]
+    ys = [torch.empty_like(x) for x in xs]
+    g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+    nb = xs[0].numel() * 2
+    it = [0]
+    def rot(fn):
+        def f():
+            i = it[0] = (it[0] + 1) % NB
+            fn(i)
+        return f
+    ms = timeit(rot(lambda i: torch.add(xs[i], xs[(i + 5) % NB], out=ys[i])), reps=24, warm=12)
+    print(f"cold torch add bf16       : {ms*1e3:7.1f} us  {3*nb/ms/1e6:7.1f} GB/s")
+    ms = timeit(rot(lambda i: ys[i].copy_(xs[i])), reps=24, warm=12)
+    print(f"cold torch copy bf16      : {ms*1e3:7.1f} us  {2*nb/ms/1e6:7.1f} GB/s")
+    ms = timeit(rot(lambda i: ops._sum_planes(xs[i])), reps=24, warm=12)
+    print(f"cold plane sums           : {ms*1e3:7.1f} us  {nb/ms/1e6:7.1f} GB/s")
+    ms = timeit(rot(lambda i: xs[i].sum(dim=(0, 2, 3), dtype=torch.float32)), reps=24, warm=12)
+    print(f"cold torch sum(0,2,3)     : {ms*1e3:7.1f} us  {nb/ms/1e6:7.1f} GB/s")
+    for gelu in (False, True):
+        ms = timeit(rot(lambda i: ops.InstanceNormFn.apply(xs[i], g, b, 1e-6, gelu)), reps=24, warm=12)
+        print(f"cold instnorm fwd gelu={int(gelu)}  : {ms*1e3:7.1f} us  {3*nb/ms/1e6:7.1f} GB/s (2 reads + 1 write)")
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    for gelu in (False, True):
+        outs = [ops.InstanceNormFn.apply(x, g, b, 1e-6, gelu) for x in xr]
+        ms = timeit(rot(lambda i: torch.autograd.grad(outs[i], xr[i], ys[i], retain_graph=True)), reps=24, warm=12)
+        print(f"cold instnorm bwd gelu={int(gelu)}  : {ms*1e3:7.1f} us  {5*nb/ms/1e6:7.1f} GB/s (4 reads + 1 write)")
+        del outs
+    c = 2 * math.pi / W
+    Fs = [ops.rfft_rows(xs[i], 241, C, (c, c, c)) for i in range(NB)]
+    nbf = C * H * (W * 2 + 241 * 8)
+    ms = timeit(rot(lambda i: ops.rfft_rows(xs[i], 241, C, (c, c, c))), reps=24, warm=12)
+    print(f"cold rfft 240x480 bf16    : {ms*1e3:7.1f} us  {nbf/ms/1e6:7.1f} GB/s")
+    ms = timeit(rot(lambda i: ops.irfft_rows(Fs[i], 1, C, W, torch.bfloat16, (1.0, 2.0, 1.0))), reps=24, warm=12)
+    print(f"cold irfft 240x480 bf16   : {ms*1e3:7.1f} us  {nbf/ms/1e6:7.1f} GB/s")
+    ms = timeit(lambda: ops.rfft_rows(xs[0], 241, C, (c, c, c)), reps=24, warm=4)
+    print(f"warm rfft 240x480 bf16    : {ms*1e3:7.1f} us  {nbf/ms/1e6:7.1f} GB/s")
+    ms = timeit(lambda: ops.irfft_rows(Fs[0], 1, C, W, torch.bfloat16, (1.0, 2.0, 1.0)), reps=24, warm=4)
+    print(f"warm irfft 240x480 bf16   : {ms*1e3:7.1f} us  {nbf/ms/1e6:7.1f} GB/s")
 
 
 def conv():
