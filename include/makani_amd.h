@@ -79,6 +79,18 @@ int mk_cgemm_batched(const MkGemm* g, void* stream);
  *  2: x = hi+mid, 3 MFMAs, ~4e-6), fp32 accumulation.  6/16 resp. 3/16 of the exact-fp32 MFMA time. */
 int mk_sgemm_split_batched(const MkGemm* g, int limbs, void* stream);
 int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream);
+/* Second-generation kernels of the same arithmetic for the hot shapes (csrc/xgemm2.hip: 512-thread workgroups whose two
+ * wave groups alternate between the matrix pipe and the limb split, double-buffered LDS images).
+ * mk_cgemm_split2_batched: any descriptor mk_cgemm_split_batched accepts (the dhconv forward / data-gradient /
+ *   weight-gradient GEMMs of _contract_lwise, makani/models/common/contractions.py:23-24).
+ * mk_sgemm_presplit_batched: real GEMM whose A operand is a CONSTANT matrix handed over already split into `limbs`
+ *   bf16 limb planes — the Legendre matrices of th.RealSHT / th.InverseRealSHT [un-vendored; precomputed in
+ *   makani_amd/legendre.py].  g->A is ignored; plane q of batch b holds A[b][k][row] at
+ *   a_planes + q*pl_stride + b*pl_batch + k*pl_k + row (bf16 elements; row contiguous, pl_k % 8 == 0, rows beyond M
+ *   inside pl_k are zero).  B must be [k][col] with the column index contiguous (b_col == 1), inner == 1. */
+int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream);
+int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, long long pl_stride, long long pl_batch,
+                              long long pl_k, int limbs, void* stream);
 
 /* ---- longitude FFTs ----------------------------------------------------------
  * mk_rfft_rows: x[row][lat][lon] (f32|bf16)  ->  F-layout, modes m < mmax:

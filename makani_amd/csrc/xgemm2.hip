@@ -1,0 +1,676 @@
+// Second-generation split-bf16 GEMM kernels for the spectral hot shapes (same arithmetic as xgemm.hip: fp32 operands
+// expanded into 3 (or 2) bf16 limbs, 6 (3) bf16 MFMAs per product, fp32 accumulation).
+//
+// What xgemm.hip's kernels lose (SQ counters, profiles/r02_pmc_sq_bench_raw.md): a workgroup alternates a "split the
+// next fp32 tile into limbs" segment (VALU + LDS stores) with an MFMA segment, two barriers per 16-deep k-step, and the
+// two workgroups that share a CU fall into lockstep, so that the matrix pipe and the VALU take turns instead of
+// overlapping (MFMA busy + VALU busy = the whole SIMD time).  Here the overlap is built into one 512-thread workgroup:
+//   * the LDS limb images are double buffered; tile kt+1 is split and stored while tile kt is multiplied;
+//   * the 8 waves form two groups of 4 (one wave of each group per SIMD).  A k-step has two phases separated by
+//     barriers: in phase g group g runs its MFMAs on the current LDS image while the other group splits and stores
+//     ITS share of the next tile and issues the global loads of the tile after that ("ping-pong").  On every SIMD one
+//     wave feeds the matrix pipe while its partner uses the VALU and the memory path;
+//   * work is spread over the SIMDs by COLUMN slices (wave = 32 or 64 output columns x every second live 32-row
+//     tile), so that the triangular structure of the spectral operators (rows l < m / m > l are skipped in 32-row
+//     steps) shortens every SIMD's segment by the same amount instead of idling whole SIMDs;
+//   * tiles are 128 x 128 (complex) and 256 x 256 (real) instead of 64 x 128 and 64 x 256: every fp32 element is
+//     split by fewer workgroups;
+//   * the real kernel takes its A operand (the constant Legendre matrices) ALREADY split into bf16 limb planes
+//     (prepared once per matrix by the host side), copies them global -> LDS as 16-byte vectors and only splits the
+//     data operand: 1.25 VALU instructions per MFMA instead of 5.
+#include <type_traits>
+
+#include "xsplit.h"
+
+namespace {
+
+using gemm::BlockCoord;
+using gemm::decode_block;
+using gemm::validate;
+using namespace xsplit;
+
+constexpr int NT2 = 512;
+// timing diagnostics (tools/ab.py variants; results are WRONG with any of them): 1 = no limb split / LDS stores in the
+// main loop, 2 = no MFMA segment, 3 = no global loads in the main loop
+#ifndef MK_X2_DIAG
+#define MK_X2_DIAG 0
+#endif
+// structure knobs (tools/ab.py variants)
+#ifndef MK_X2_MIDBAR          // 1: barrier between the two phases of a k-step (strict ping-pong); 0: one barrier per k-step,
+#define MK_X2_MIDBAR 0        //    group 0 = produce then compute, group 1 = compute then produce (soft ping-pong)
+#endif
+#ifndef MK_X2_PRIO            // s_setprio 1 around the MFMA segment: the matrix pipe's wave wins the issue arbitration
+#define MK_X2_PRIO 1          // against its partner's split / store instructions
+#endif
+#ifndef MK_X2_REV             // heaviest batches first for the "<=" triangles (dhconv: l descending)
+#define MK_X2_REV 1
+#endif
+#ifndef MK_X2_DEPTH           // k-steps a global load is issued ahead of its split (1 or 2 staging register sets);
+#define MK_X2_DEPTH 2         // complex kernel.  Measured: 2 = 1 within noise (the kernels are bound by the bytes a CU
+#endif                        // can ingest per clock, not by load latency); the real kernel stays at 1 (2 would spill)
+#ifndef MK_X2_DEPTH_R
+#define MK_X2_DEPTH_R 1
+#endif
+#ifndef MK_X2_ILV             // limb products issued round-robin over the independent accumulators
+#define MK_X2_ILV 1
+#endif
+
+__device__ __forceinline__ void prio_hi() {
+#if MK_X2_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+}
+__device__ __forceinline__ void prio_lo() {
+#if MK_X2_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+// decode_block with the batch order reversed for the triangles that grow with the batch index: the long-running
+// workgroups start first and the short ones fill the tail of the launch
+template <int BM, int BN>
+__device__ __forceinline__ BlockCoord decode_block2(const MkGemm& p, int tilesM, int tilesN) {
+    BlockCoord c;
+    const int xcd = blockIdx.x % MK_NUM_XCD, j = blockIdx.x / MK_NUM_XCD;
+    const int tpb = tilesM * tilesN;
+    c.b = (j / tpb) * MK_NUM_XCD + xcd;
+    const int t = j % tpb;
+    c.i0 = (t / tilesN) * BM;
+    c.j0 = (t % tilesN) * BN;
+    c.Meff = p.M;
+    c.klo = 0;
+    c.khi = p.K;
+    c.active = c.b < p.batch;
+    if (!c.active) return c;
+    if (MK_X2_REV && (p.tri_mode == MK_TRI_ROW_LE || p.tri_mode == MK_TRI_K_LE)) c.b = p.batch - 1 - c.b;
+    const int tt = c.b / p.inner + p.tri_off;
+    switch (p.tri_mode) {
+        case MK_TRI_ROW_GE:
+            if (c.i0 + BM <= tt) c.active = false;
+            break;
+        case MK_TRI_K_GE:
+            c.klo = max(0, min(tt, p.K));
+            break;
+        case MK_TRI_ROW_LE:
+            c.Meff = max(0, min(p.M, tt + 1));
+            if (c.i0 >= c.Meff) c.active = false;
+            break;
+        case MK_TRI_K_LE:
+            c.khi = max(0, min(p.K, tt + 1));
+            break;
+        default:
+            break;
+    }
+    return c;
+}
+
+// one 32 x 32 x 16 complex tile update, limb products round-robin over the three accumulators (a dependent MFMA on the
+// same accumulator then finds its predecessor retired): re += ar br, ng += ai bi, im += ar bi + ai br
+template <int NP>
+__device__ __forceinline__ void cmma_split(const bf16x8* ar, const bf16x8* ai, const bf16x8* br, const bf16x8* bi,
+                                           f32x16& cre, f32x16& cng, f32x16& cim) {
+#if MK_X2_ILV
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int IA[6] = {1, 0, 2, 0, 1, 0}, IB[6] = {1, 2, 0, 1, 0, 0};      // smallest terms first (as mma_split)
+    constexpr int O = NP == 3 ? 0 : 3;
+#pragma unroll
+    for (int q = 0; q < NPROD; ++q) {
+        const int a = IA[O + q], b = IB[O + q];
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[a], br[b], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[a], bi[b], cim, 0, 0, 0);
+        cng = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[a], bi[b], cng, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[a], br[b], cim, 0, 0, 0);
+    }
+#else
+    cre = mma_split<NP>(ar, br, cre);
+    cng = mma_split<NP>(ai, bi, cng);
+    cim = mma_split<NP>(ar, bi, cim);
+    cim = mma_split<NP>(ai, br, cim);
+#endif
+}
+
+// two real 32 x 32 x 16 tile updates sharing the A fragment
+template <int NP>
+__device__ __forceinline__ void rmma_split2(const bf16x8* a, const bf16x8* b0, const bf16x8* b1, f32x16& c0, f32x16& c1) {
+#if MK_X2_ILV
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int IA[6] = {1, 0, 2, 0, 1, 0}, IB[6] = {1, 2, 0, 1, 0, 0};
+    constexpr int O = NP == 3 ? 0 : 3;
+#pragma unroll
+    for (int q = 0; q < NPROD; ++q) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[IA[O + q]], b0[IB[O + q]], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[IA[O + q]], b1[IB[O + q]], c1, 0, 0, 0);
+    }
+#else
+    c0 = mma_split<NP>(a, b0, c0);
+    c1 = mma_split<NP>(a, b1, c1);
+#endif
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// explicit global address space on the staging loads: a pointer that may be either an operand address or the zero
+// block is otherwise treated as generic and loaded with flat_load (which also ties up the LDS counter)
+typedef __attribute__((address_space(1))) const f32x4 g_f32x4;
+typedef __attribute__((address_space(1))) const u32x4 g_u32x4;
+
+// 32 bytes of zeros: the address a lane loads from when its vector lies outside the operand.  Every global load of
+// these kernels is UNCONDITIONAL (out-of-range lanes read zeros from here): a load under a lane condition, or one
+// whose destination was zeroed first, makes hipcc wait for all loads in flight (vmcnt(0)) before it issues the next
+// one, which serialises the memory round trips of a tile (seen in xgemm.hip's edge path and its interleaved-B path).
+__device__ const f32x4 g_zero32[2] = {};
+
+// fp32 tile staging: the tile of the NEXT k-step rides in registers while the current one is multiplied
+template <int ROWS, bool KC>
+struct Stage2 {
+    static constexpr int NV = (ROWS * BK / 4) / NT2;
+    static_assert(NV >= 1, "tile too small");
+    f32x4 v[NV];
+    unsigned keep;              // KC: 4 bits per vector = elements inside [klo, khi), applied when the tile is stored
+    const float* p0[NV];        // address of every vector at k = 0
+    unsigned ok;                // bit q: the row(s) of vector q exist
+    long long kstride;          // floats per unit of k
+
+    // ilv: the operand is an interleaved complex tensor; this stage then loads 8 consecutive floats per vector
+    // (v = first four, v2 = last four) and store_ilv() separates real and imaginary parts
+    f32x4 v2[NV];
+
+    __device__ __forceinline__ void init(const float* __restrict__ base, long long rs, long long ks, int r0, int rmax,
+                                         int tid, bool ilv = false) {
+        ok = 0u;
+        const int u = ilv ? 2 : 1;
+        kstride = KC ? u : ks;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + q * NT2;
+            if constexpr (KC) {
+                const int row = f >> 2, kq = f & 3;
+                p0[q] = base + (long long)(r0 + row) * rs + kq * 4 * u;
+                ok |= (r0 + row < rmax ? 1u : 0u) << q;
+            } else {
+                constexpr int RQ = ROWS / 4;
+                const int kk = f / RQ, rq = f % RQ;
+                p0[q] = base + (long long)kk * ks + (long long)(r0 + rq * 4) * u;
+                ok |= (r0 + rq * 4 < rmax ? 1u : 0u) << q;
+            }
+        }
+    }
+
+    template <bool ILV>
+    __device__ __forceinline__ void load(int k0, int klo, int khi, int tid) {
+        const long long koff = (long long)k0 * kstride;
+        const bool interior = k0 >= klo && k0 + BK <= khi;      // uniform
+        keep = 0u;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int f = tid + q * NT2;
+            bool valid = (ok >> q) & 1u;
+            unsigned m = 0xfu;
+            if (!interior) {
+                if constexpr (KC) {
+                    const int k = k0 + (f & 3) * 4;
+                    valid = valid && k < khi && k + 3 >= klo;
+                    m = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m |= in_range(k + e, klo, khi) ? (1u << e) : 0u;
+                } else {
+                    constexpr int RQ = ROWS / 4;
+                    valid = valid && in_range(k0 + f / RQ, klo, khi);
+                }
+            }
+            keep |= (valid ? m : 0u) << (4 * q);
+            const g_f32x4* src = valid ? (const g_f32x4*)(p0[q] + koff) : (const g_f32x4*)g_zero32;
+            v[q] = src[0];
+            if constexpr (ILV) v2[q] = src[1];
+        }
+    }
+
+    __device__ static __forceinline__ int lds_off(int f) {
+        if constexpr (KC) {
+            return (f >> 2) * PK + (f & 3) * 4;
+        } else {
+            constexpr int RQ = ROWS / 4;
+            return (f / RQ) * (ROWS + 32) + (f % RQ) * 4;
+        }
+    }
+
+    template <int NP, int PLANE>
+    __device__ static __forceinline__ void split_store(u16* lds, int off, float r0, float r1, float r2, float r3) {
+        float r[4] = {r0, r1, r2, r3};
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            u16 h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 hb = (__bf16)r[e];
+                h[e] = __builtin_bit_cast(u16, hb);
+                r[e] -= (float)hb;
+            }
+            const uint2 pk = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *reinterpret_cast<uint2*>(lds + pl * PLANE + off) = pk;
+        }
+    }
+
+    // split into NP bf16 limbs and store; limb plane p lives at lds + p * PLANE (elements)
+    template <int NP, int PLANE>
+    __device__ __forceinline__ void store(u16* lds, int tid, float sign) const {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[e] = v[q][e] * sign;
+                if constexpr (KC) r[e] = ((keep >> (4 * q + e)) & 1u) ? r[e] : 0.f;
+            }
+            split_store<NP, PLANE>(lds, lds_off(tid + q * NT2), r[0], r[1], r[2], r[3]);
+        }
+    }
+
+    // interleaved operand: real parts -> lre, imaginary parts (times sign) -> lim
+    template <int NP, int PLANE>
+    __device__ __forceinline__ void store_ilv(u16* lre, u16* lim, int tid, float sign) const {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            float re[4] = {v[q][0], v[q][2], v2[q][0], v2[q][2]};
+            float im[4] = {v[q][1] * sign, v[q][3] * sign, v2[q][1] * sign, v2[q][3] * sign};
+            if constexpr (KC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool kp = (keep >> (4 * q + e)) & 1u;
+                    re[e] = kp ? re[e] : 0.f;
+                    im[e] = kp ? im[e] : 0.f;
+                }
+            }
+            const int off = lds_off(tid + q * NT2);
+            split_store<NP, PLANE>(lre, off, re[0], re[1], re[2], re[3]);
+            split_store<NP, PLANE>(lim, off, im[0], im[1], im[2], im[3]);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// complex kernel: tile 128 x 128, wave (g = wave >> 2, cs = wave & 3) owns columns [32 cs, 32 cs + 32) of row tiles g, g + 2
+// ---------------------------------------------------------------------------------------------------------------
+template <bool A_KC, bool B_KC, int NP, bool B_ILV>
+__global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM, int tilesN) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int PLA = plane_elems<BM, A_KC>(), PLB = plane_elems<BN, B_KC>();
+    constexpr int STG = 2 * NP * (PLA + PLB);             // elements per stage: (re, im) x limbs x (A, B)
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * STG];
+
+    const BlockCoord c = decode_block2<BM, BN>(p, tilesM, tilesN);
+    if (!c.active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, cs = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long long bo = c.b / p.inner, bi = c.b % p.inner;
+    const float* Ab = p.A + bo * p.a_batch + bi * p.a_inner;
+    const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
+    const float sgn_a = p.conj_a ? -1.f : 1.f;
+    const float sgn_b = p.conj_b ? -1.f : 1.f;
+    bool live[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) live[j] = c.i0 + 32 * (grp + 2 * j) < c.Meff;
+
+    f32x16 cre[2], cim[2], cng[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            cre[j][r] = 0.f;
+            cim[j][r] = 0.f;
+            cng[j][r] = 0.f;
+        }
+
+    const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
+    const int nk = kt1 - kt0;
+    const int a_rmax = A_KC ? c.Meff : p.M;
+    constexpr int D = MK_X2_DEPTH;                          // staging register sets: tile t rides in set t % D
+    Stage2<BM, A_KC> sar[D], sai[D];
+    Stage2<BN, B_KC> sbr[D], sbi[D];                        // B_ILV: sbr carries both parts, sbi is unused
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        sar[d].init(Ab, p.a_row, p.a_k, c.i0, a_rmax, tid);
+        sai[d].init(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, tid);
+        if constexpr (B_ILV) {
+            sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid, true);
+        } else {
+            sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
+            sbi[d].init(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, tid);
+        }
+    }
+    auto ld = [&](auto set, int kt) {
+        constexpr int d = decltype(set)::value;
+        sar[d].template load<false>(kt * BK, c.klo, c.khi, tid);
+        sai[d].template load<false>(kt * BK, c.klo, c.khi, tid);
+        if constexpr (B_ILV) {
+            sbr[d].template load<true>(kt * BK, c.klo, c.khi, tid);
+        } else {
+            sbr[d].template load<false>(kt * BK, c.klo, c.khi, tid);
+            sbi[d].template load<false>(kt * BK, c.klo, c.khi, tid);
+        }
+    };
+    auto st = [&](auto set, int buf) {
+        constexpr int d = decltype(set)::value;
+        u16* Are = smem + buf * STG;
+        u16* Aim = Are + NP * PLA;
+        u16* Bre = Aim + NP * PLA;
+        u16* Bim = Bre + NP * PLB;
+        sar[d].template store<NP, PLA>(Are, tid, 1.f);
+        sai[d].template store<NP, PLA>(Aim, tid, sgn_a);
+        if constexpr (B_ILV) {
+            sbr[d].template store_ilv<NP, PLB>(Bre, Bim, tid, sgn_b);
+        } else {
+            sbr[d].template store<NP, PLB>(Bre, tid, 1.f);
+            sbi[d].template store<NP, PLB>(Bim, tid, sgn_b);
+        }
+    };
+    auto compute = [&](int buf) {
+        const u16* Are = smem + buf * STG;
+        const u16* Aim = Are + NP * PLA;
+        const u16* Bre = Aim + NP * PLA;
+        const u16* Bim = Bre + NP * PLB;
+        if (!live[0]) return;                               // row tile g + 2 is dead whenever row tile g is
+        bf16x8 br[NP], bim[NP];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            br[pl] = frag<BN, B_KC>(Bre + pl * PLB, cs * 32, lane);
+            bim[pl] = frag<BN, B_KC>(Bim + pl * PLB, cs * 32, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!live[j]) continue;
+            bf16x8 ar[NP], ai[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                ar[pl] = frag<BM, A_KC>(Are + pl * PLA, (grp + 2 * j) * 32, lane);
+                ai[pl] = frag<BM, A_KC>(Aim + pl * PLA, (grp + 2 * j) * 32, lane);
+            }
+            // (ar + i ai)(br + i bi): re = ar br - ai bi (second part accumulated apart), im = ar bi + ai br
+            prio_hi();
+            cmma_split<NP>(ar, ai, br, bim, cre[j], cng[j], cim[j]);
+            prio_lo();
+        }
+    };
+    auto produce = [&](auto set, int i) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
+        if (MK_X2_DIAG != 1 && i + 1 < nk) st(set, (i + 1) & 1);
+        if (MK_X2_DIAG != 3 && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, D - 1>;          // set of the odd tiles (= S0 when D == 1)
+    if (nk > 0) {
+        ld(S0{}, kt0);
+        st(S0{}, 0);
+        if (nk > 1) ld(S1{}, kt0 + 1);
+        if (D == 2 && nk > 2) ld(S0{}, kt0 + 2);
+    }
+    __syncthreads();
+    auto step = [&](auto set, int i) {
+#if MK_X2_MIDBAR
+        if (grp == 0) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+        __syncthreads();
+        if (grp == 1) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+#else
+        // one barrier per k-step; the groups run the two segments in opposite order, so that on every SIMD one wave
+        // starts on the matrix pipe while its partner starts on the VALU / memory path
+        if (grp == 0) {
+            produce(set, i);
+            if (MK_X2_DIAG != 2) compute(i & 1);
+        } else {
+            if (MK_X2_DIAG != 2) compute(i & 1);
+            produce(set, i);
+        }
+#endif
+        __syncthreads();
+    };
+    for (int i = 0; i < nk; i += 2) {                       // step i splits tile i + 1, which rides in set (i + 1) % D
+        step(S1{}, i);
+        if (i + 1 < nk) step(S0{}, i + 1);
+    }
+
+    float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
+    const int col = c.j0 + cs * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!live[j]) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = c.i0 + (grp + 2 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < c.Meff && col < p.N) {
+                float* dr = Cb + (long long)row * p.c_row + (long long)col * p.c_col;
+                float* di = dr + p.c_im;
+                float vr = cre[j][r] - cng[j][r], vi = cim[j][r];
+                if (p.beta) {
+                    vr += *dr;
+                    vi += *di;
+                }
+                if (p.c_col == 2) {          // interleaved complex C: one 8-byte store per entry
+                    *reinterpret_cast<float2*>(dr) = make_float2(vr, vi);
+                } else {
+                    *dr = vr;
+                    *di = vi;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// real kernel, A pre-split: tile 256 x 256, wave (g, cs) owns columns [64 cs, 64 cs + 64) of the live row tiles
+// t0 + g, t0 + g + 2, t0 + g + 4, t0 + g + 6 (t0 = first live 32-row tile of this block)
+//   A: NP bf16 limb planes, [k][row] with the row index contiguous (pitch pl_k elements, a multiple of 8; rows past M
+//      inside the pitch hold zeros), plane q at Apl + q * pl_stride, batch b at + b * pl_batch
+//   B: fp32, [k][col] with the column index contiguous (the F / S layouts), split on the fly
+// ---------------------------------------------------------------------------------------------------------------
+struct PreA {
+    const u16* planes;
+    long long pl_stride, pl_batch, pl_k;
+    int rows_valid;            // rows readable per k-row (multiple of 8)
+};
+
+template <int NP>
+__global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA a, int tilesM, int tilesN) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int PR = BM + 32;                            // pitch of the [k][row] limb tiles (both operands)
+    constexpr int PL = BK * PR;                            // elements per limb plane
+    constexpr int STG = 2 * NP * PL;
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * STG];
+
+    const BlockCoord c = decode_block2<BM, BN>(p, tilesM, tilesN);
+    if (!c.active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, cs = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const long long bo = c.b / p.inner, bi = c.b % p.inner;
+    const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
+    const u16* Ab = a.planes + (long long)c.b * a.pl_batch;
+
+    // live 32-row tiles of this block: [t0, t1)
+    const int rows_end = min(c.Meff, p.M) - c.i0;          // rows of this block that exist
+    int t0 = 0;
+    if (p.tri_mode == MK_TRI_ROW_GE) t0 = max(0, (c.b / p.inner + p.tri_off - c.i0) / 32);
+    const int t1 = min(BM / 32, (rows_end + 31) / 32);
+    int tile[4];
+    bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        tile[j] = t0 + grp + 2 * j;
+        live[j] = tile[j] < t1;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+    const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
+    const int nk = kt1 - kt0;
+    constexpr int D = MK_X2_DEPTH_R;
+    Stage2<BN, false> sb[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) sb[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
+    // A limb vectors of this thread: k-row ak (0..15), rows [ar0, ar0 + 8) of the block
+    const int ak = tid >> 5, ar0 = (tid & 31) * 8;
+    const bool a_ok = c.i0 + ar0 < a.rows_valid && ar0 < 32 * t1 && ar0 + 8 > 32 * t0;
+    const u16* ap = Ab + (long long)ak * a.pl_k + c.i0 + ar0;
+    u32x4 av[D][NP];
+    auto ld = [&](auto set, int kt) {
+        constexpr int d = decltype(set)::value;
+        sb[d].template load<false>(kt * BK, c.klo, c.khi, tid);
+        const int k = kt * BK + ak;
+        const bool ok = a_ok && k < p.K;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const g_u32x4* src = ok ? (const g_u32x4*)(ap + (long long)kt * BK * a.pl_k + q * a.pl_stride) : (const g_u32x4*)g_zero32;
+            av[d][q] = src[0];
+        }
+    };
+    auto st = [&](auto set, int buf) {
+        constexpr int d = decltype(set)::value;
+        u16* As = smem + buf * STG;
+        u16* Bs = As + NP * PL;
+        sb[d].template store<NP, PL>(Bs, tid, 1.f);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(As + q * PL + ak * PR + ar0) = av[d][q];
+    };
+    auto compute = [&](int buf) {
+        const u16* As = smem + buf * STG;
+        const u16* Bs = As + NP * PL;
+        if (!live[0]) return;
+        bf16x8 bf[2][NP];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) bf[n][pl] = frag<BN, false>(Bs + pl * PL, cs * 64 + n * 32, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!live[j]) continue;
+            bf16x8 af[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) af[pl] = frag<BM, false>(As + pl * PL, tile[j] * 32, lane);
+            prio_hi();
+            rmma_split2<NP>(af, bf[0], bf[1], acc[j][0], acc[j][1]);
+            prio_lo();
+        }
+    };
+    auto produce = [&](auto set, int i) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
+        if (MK_X2_DIAG != 1 && i + 1 < nk) st(set, (i + 1) & 1);
+        if (MK_X2_DIAG != 3 && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, D - 1>;          // set of the odd tiles (= S0 when D == 1)
+    if (nk > 0) {
+        ld(S0{}, kt0);
+        st(S0{}, 0);
+        if (nk > 1) ld(S1{}, kt0 + 1);
+        if (D == 2 && nk > 2) ld(S0{}, kt0 + 2);
+    }
+    __syncthreads();
+    auto step = [&](auto set, int i) {
+#if MK_X2_MIDBAR
+        if (grp == 0) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+        __syncthreads();
+        if (grp == 1) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+#else
+        // one barrier per k-step; the groups run the two segments in opposite order, so that on every SIMD one wave
+        // starts on the matrix pipe while its partner starts on the VALU / memory path
+        if (grp == 0) {
+            produce(set, i);
+            if (MK_X2_DIAG != 2) compute(i & 1);
+        } else {
+            if (MK_X2_DIAG != 2) compute(i & 1);
+            produce(set, i);
+        }
+#endif
+        __syncthreads();
+    };
+    for (int i = 0; i < nk; i += 2) {                       // step i splits tile i + 1, which rides in set (i + 1) % D
+        step(S1{}, i);
+        if (i + 1 < nk) step(S0{}, i + 1);
+    }
+
+    float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!live[j]) continue;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = c.j0 + cs * 64 + n * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c.i0 + tile[j] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < c.Meff && col < p.N) {
+                    float* dst = Cb + (long long)row * p.c_row + col;
+                    float val = acc[j][n][r];
+                    if (p.beta) val += *dst;
+                    *dst = val;
+                }
+            }
+        }
+    }
+}
+
+template <int NP>
+int launch_cplx2(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t s) {
+    constexpr int BM = 128, BN = 128;
+    const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
+    const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
+    MK_REQUIRE(nb < (1ll << 31), "xcgemm2: grid too large");
+    dim3 grid((unsigned)nb), block(NT2);
+#define MK_XC2(AK, BK_, IL) hipLaunchKernelGGL((xcgemm2_kernel<AK, BK_, NP, IL>), grid, block, 0, s, *g, tm, tn)
+    if (b_ilv) {
+        MK_REQUIRE(a_kc, "xcgemm2: an interleaved B operand needs a k-contiguous A");
+        if (b_kc)
+            MK_XC2(true, true, true);
+        else
+            MK_XC2(true, false, true);
+    } else if (a_kc && b_kc)
+        MK_XC2(true, true, false);
+    else if (a_kc && !b_kc)
+        MK_XC2(true, false, false);
+    else if (!a_kc && b_kc)
+        MK_XC2(false, true, false);
+    else
+        MK_XC2(false, false, false);
+#undef MK_XC2
+    return mk_check_launch("mk_cgemm_split2_batched");
+}
+
+}  // namespace
+
+extern "C" int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream) {
+    bool a_kc, b_kc, b_ilv;
+    int rc = validate(g, true, &a_kc, &b_kc, true, &b_ilv);
+    if (rc) return rc;
+    MK_REQUIRE(limbs == 2 || limbs == 3, "split gemm: limbs must be 2 or 3");
+    hipStream_t s = (hipStream_t)stream;
+    return limbs == 3 ? launch_cplx2<3>(g, a_kc, b_kc, b_ilv, s) : launch_cplx2<2>(g, a_kc, b_kc, b_ilv, s);
+}
+
+extern "C" int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, long long pl_stride, long long pl_batch,
+                                         long long pl_k, int limbs, void* stream) {
+    MK_REQUIRE(g && a_planes && g->B && g->C, "presplit gemm: null pointer");
+    MK_REQUIRE(g->M > 0 && g->N > 0 && g->K >= 0 && g->batch > 0, "presplit gemm: bad extents");
+    MK_REQUIRE(limbs == 2 || limbs == 3, "presplit gemm: limbs must be 2 or 3");
+    MK_REQUIRE(g->inner == 1, "presplit gemm: inner must be 1");
+    MK_REQUIRE(g->b_col == 1 && (g->b_k & 3) == 0 && g->b_k >= ((g->N + 3) & ~3), "presplit gemm: B must be [k][col], col contiguous");
+    MK_REQUIRE((g->b_batch & 3) == 0 && ((uintptr_t)g->B & 15) == 0, "presplit gemm: B alignment");
+    MK_REQUIRE(g->c_col == 1, "presplit gemm: c_col must be 1");
+    MK_REQUIRE((pl_k & 7) == 0 && (pl_batch & 7) == 0 && (pl_stride & 7) == 0 && ((uintptr_t)a_planes & 15) == 0 && pl_k >= g->M,
+               "presplit gemm: A limb planes need 16-byte aligned k-rows of at least M elements");
+    constexpr int BM = 256, BN = 256;
+    const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
+    const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
+    MK_REQUIRE(nb < (1ll << 31), "presplit gemm: grid too large");
+    PreA a{(const u16*)a_planes, pl_stride, pl_batch, pl_k, (int)(pl_k & ~7ll)};
+    dim3 grid((unsigned)nb), block(NT2);
+    hipStream_t s = (hipStream_t)stream;
+    if (limbs == 3)
+        hipLaunchKernelGGL((xgemm2_kernel<3>), grid, block, 0, s, *g, a, tm, tn);
+    else
+        hipLaunchKernelGGL((xgemm2_kernel<2>), grid, block, 0, s, *g, a, tm, tn);
+    return mk_check_launch("mk_sgemm_presplit_batched");
+}

@@ -12,6 +12,7 @@ CPU implementation behind these functions.
 """
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -36,14 +37,55 @@ if GEMM_MODE not in ("x6", "x3", "fp32"):
     raise ValueError(f"MAKANI_AMD_GEMM={GEMM_MODE!r}: expected x6, x3 or fp32")
 
 
-def _run_gemm(g, cplx, what, mode=None):
+# Kernel generation of the split engine: "2" (default) = the ping-pong kernels of csrc/xgemm2.hip (512-thread workgroups,
+# double-buffered limb images, pre-split Legendre matrices) wherever they apply, "1" = csrc/xgemm.hip everywhere
+# (kept for same-box A/B runs and as the engine of the shapes generation 2 does not cover).
+GEMM_GEN = os.environ.get("MAKANI_AMD_GEMM_GEN", "2")
+if GEMM_GEN not in ("1", "2"):
+    raise ValueError(f"MAKANI_AMD_GEMM_GEN={GEMM_GEN!r}: expected 1 or 2")
+
+
+def _run_gemm(g, cplx, what, mode=None, a_limbs=None):
+    """``a_limbs``: the constant A operand of a real GEMM already split into bf16 limb planes (``limb_planes``)."""
     mode = mode or GEMM_MODE
     L = lib()
     if mode == "fp32":
         rc = (L.mk_cgemm_batched if cplx else L.mk_sgemm_batched)(C.byref(g), stream())
     else:
-        rc = (L.mk_cgemm_split_batched if cplx else L.mk_sgemm_split_batched)(C.byref(g), 3 if mode == "x6" else 2, stream())
+        limbs = 3 if mode == "x6" else 2
+        if GEMM_GEN == "2" and cplx:
+            rc = L.mk_cgemm_split2_batched(C.byref(g), limbs, stream())
+        elif GEMM_GEN == "2" and a_limbs is not None:
+            pl = a_limbs
+            rc = L.mk_sgemm_presplit_batched(C.byref(g), ptr(pl), pl.stride(0), pl.stride(1), pl.stride(2), limbs, stream())
+        else:
+            rc = (L.mk_cgemm_split_batched if cplx else L.mk_sgemm_split_batched)(C.byref(g), limbs, stream())
     check(rc, what)
+
+
+_LIMB_PLANES = {}      # id(matrix tensor) -> (weak reference to it, version, limb planes); entries die with the matrix
+
+
+def limb_planes(mat: torch.Tensor) -> torch.Tensor:
+    """The three bf16 limbs ``hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)`` (round to nearest even, the
+    split the GEMM kernels apply on the fly) of a constant (batch, K, rows) fp32 matrix as one (3, batch, K, rows8)
+    bf16 tensor, rows padded with zeros to a multiple of 8.  Computed once per matrix object (the Legendre matrices are
+    module buffers that never change; an in-place write bumps ``_version`` and triggers a re-split) and consumed by
+    ``mk_sgemm_presplit_batched``.  The planes die with the matrix tensor."""
+    hit = _LIMB_PLANES.get(id(mat))
+    if hit is not None and hit[0]() is mat and hit[1] == mat._version:
+        return hit[2]
+    nb, K, rows = mat.shape
+    r8 = (rows + 7) // 8 * 8
+    pl = torch.zeros((3, nb, K, r8), dtype=torch.bfloat16, device=mat.device)
+    r = mat.detach().to(torch.float32).clone()
+    for q in range(3):
+        h = r.to(torch.bfloat16)
+        pl[q, :, :, :rows] = h
+        r -= h.to(torch.float32)
+    key = id(mat)
+    _LIMB_PLANES[key] = (weakref.ref(mat, lambda _r, key=key: _LIMB_PLANES.pop(key, None)), mat._version, pl)
+    return pl
 
 
 # --------------------------------------------------------------------------- #
@@ -167,6 +209,10 @@ def _gemm(**kw) -> MkGemm:
     return g
 
 
+def _presplit_ok() -> bool:
+    return GEMM_GEN == "2" and GEMM_MODE != "fp32"
+
+
 def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 0) -> torch.Tensor:
     """S[l][m][ri][row] = sum_k matT[m][k][l] F[m][k][ri][row]      (rows l >= m only)."""
     M, nlat, _, R = F.shape
@@ -181,7 +227,7 @@ def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 
     # dense-formulation work: 2 * (2R) * nlat * L * M flops
     with _timed(f"legendre_analysis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
                 nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
-        _run_gemm(g, False, "legendre_analysis")
+        _run_gemm(g, False, "legendre_analysis", a_limbs=limb_planes(matT) if _presplit_ok() else None)
     return S
 
 
@@ -198,7 +244,7 @@ def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int
               M=nlat, N=2 * R, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
     with _timed(f"legendre_synthesis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
                 nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
-        _run_gemm(g, False, "legendre_synthesis")
+        _run_gemm(g, False, "legendre_synthesis", a_limbs=limb_planes(mat) if _presplit_ok() else None)
     return F
 
 

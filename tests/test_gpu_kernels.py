@@ -50,19 +50,27 @@ def _tri_mask(mode, batch, M, K, inner):
     return rows, ks
 
 
-def _launch_gemm(g, cplx, engine):
+def _launch_gemm(g, cplx, engine, a_planes=None):
     from makani_amd._lib import lib, check
     if engine == "fp32":
         rc = (lib().mk_cgemm_batched if cplx else lib().mk_sgemm_batched)(C.byref(g), C.c_void_p(0))
+    elif engine.endswith("v2"):       # second-generation kernels (csrc/xgemm2.hip)
+        limbs = 3 if engine == "x6v2" else 2
+        if cplx:
+            rc = lib().mk_cgemm_split2_batched(C.byref(g), limbs, C.c_void_p(0))
+        else:
+            pl = a_planes
+            rc = lib().mk_sgemm_presplit_batched(C.byref(g), C.c_void_p(pl.data_ptr()), pl.stride(0), pl.stride(1), pl.stride(2),
+                                                 limbs, C.c_void_p(0))
     else:
         rc = (lib().mk_cgemm_split_batched if cplx else lib().mk_sgemm_split_batched)(C.byref(g), 3 if engine == "x6" else 2, C.c_void_p(0))
     check(rc, "gemm")
 
 
-ENGINE_TOL = {"fp32": 2e-6, "x6": 2e-6, "x3": 2e-5}
+ENGINE_TOL = {"fp32": 2e-6, "x6": 2e-6, "x3": 2e-5, "x6v2": 2e-6, "x3v2": 2e-5}
 
 
-@pytest.mark.parametrize("engine", ["fp32", "x6", "x3"])
+@pytest.mark.parametrize("engine", ["fp32", "x6", "x3", "x6v2", "x3v2"])
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("tri", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K,batch", [(68, 132, 37, 11), (200, 72, 129, 5), (12, 300, 16, 9),
@@ -71,8 +79,10 @@ ENGINE_TOL = {"fp32": 2e-6, "x6": 2e-6, "x3": 2e-5}
 def test_sgemm_batched(engine, a_kc, b_kc, tri, M, N, K, batch):
     from makani_amd import _lib
     from makani_amd._lib import MkGemm, lib, check
-    if N >= 512 and engine != "x6":
-        pytest.skip("the wide shapes exist for the big-tile kernel of the default (three-limb) engine")
+    if N >= 512 and engine not in ("x6", "x6v2"):
+        pytest.skip("the wide shapes exist for the big-tile kernels of the default (three-limb) engine")
+    if engine.endswith("v2") and (a_kc or b_kc):
+        pytest.skip("the pre-split kernel takes row-contiguous operands only (the Legendre layouts)")
     torch.manual_seed(M * 1000 + N + tri)
     A = torch.randn(batch, M, K)
     B = torch.randn(batch, N, K)
@@ -90,7 +100,12 @@ def test_sgemm_batched(engine, a_kc, b_kc, tri, M, N, K, batch):
     g.b_batch, g.b_col, g.b_k = b_b, b_col, b_k
     g.c_batch, g.c_row, g.c_col = M * (N + 4), N + 4, 1
     g.M, g.N, g.K, g.batch, g.inner, g.tri_mode = M, N, K, batch, 1, tri
-    _launch_gemm(g, False, engine)
+    planes = None
+    if engine.endswith("v2"):
+        from makani_amd import ops
+        planes = ops.limb_planes(Ad)              # (3, batch, K, round8(M)) bf16
+        g.A = 0                                   # the fp32 A is not read
+    _launch_gemm(g, False, engine, planes)
     torch.cuda.synchronize()
     out = Cd.cpu()
     assert (out[:, :, N:] == -123.0).all(), "wrote outside the N extent"
@@ -107,13 +122,15 @@ def test_sgemm_batched(engine, a_kc, b_kc, tri, M, N, K, batch):
         assert (out[:, :, :N][~vm] == -123.0).all(), "rows beyond the triangular bound must not be written"
 
 
-@pytest.mark.parametrize("engine", ["fp32", "x6", "x3"])
+@pytest.mark.parametrize("engine", ["fp32", "x6", "x3", "x6v2", "x3v2"])
 @pytest.mark.parametrize("a_kc,b_kc", [(True, False), (True, True), (False, False), (False, True)])
 @pytest.mark.parametrize("tri,conj_a,conj_b,beta", [(3, 0, 0, 0), (3, 0, 1, 0), (4, 1, 0, 0), (4, 1, 0, 1), (0, 1, 1, 1)])
-@pytest.mark.parametrize("M,N,K,outer,inner", [(36, 140, 24, 7, 2), (100, 64, 52, 9, 1)])
+@pytest.mark.parametrize("M,N,K,outer,inner", [(36, 140, 24, 7, 2), (100, 64, 52, 9, 1), (200, 132, 40, 210, 1)])
 def test_cgemm_batched(engine, a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, inner):
     from makani_amd import _lib
     from makani_amd._lib import MkGemm, lib, check
+    if outer > 100 and engine not in ("x6", "x6v2"):
+        pytest.skip("the many-row-tile shape exists for the default (three-limb) engines")
     torch.manual_seed(17 + M + tri)
     batch = outer * inner
     A = torch.randn(batch, M, K, dtype=torch.complex128)

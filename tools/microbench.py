@@ -37,30 +37,60 @@ def fft():
             del x, F
 
 
+def _both_gens(fn):
+    """run fn() under both kernel generations of the split engine (same process, same box) and check they agree"""
+    outs = {}
+    for gen in ("1", "2"):
+        ops.GEMM_GEN = gen
+        outs[gen] = fn(gen)
+    ops.GEMM_GEN = "2"
+    return outs
+
+
 def legendre():
     C = 384
     for nlat, nlon, grid in ((721, 1440, "equiangular"), (240, 480, "legendre-gauss")):
         S = ma.RealSHT(nlat, nlon, lmax=240, mmax=241, grid=grid).to(dev)
         I = ma.InverseRealSHT(nlat, nlon, lmax=240, mmax=241, grid=grid).to(dev)
         F = torch.randn(241, nlat, 2, C, device=dev)
-        ms = timeit(lambda: ops.legendre_analysis(F, S.weights_t, 240))
-        fl = 4.0 * C * nlat * 240 * 241
-        print(f"analysis  K={nlat}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
         Sc = torch.randn(240, 241, 2, C, device=dev)
-        ms = timeit(lambda: ops.legendre_synthesis(Sc, I.pct, nlat))
-        print(f"synthesis K={nlat}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
+        fl = 4.0 * C * nlat * 240 * 241
+
+        def run(gen):
+            a = ops.legendre_analysis(F, S.weights_t, 240)
+            b = ops.legendre_synthesis(Sc, I.pct, nlat)
+            ms = timeit(lambda: ops.legendre_analysis(F, S.weights_t, 240))
+            print(f"gen{gen} analysis  K={nlat}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
+            ms = timeit(lambda: ops.legendre_synthesis(Sc, I.pct, nlat))
+            print(f"gen{gen} synthesis K={nlat}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
+            return a, b
+        o = _both_gens(run)
+        tri = (torch.arange(240, device=dev)[:, None] >= torch.arange(241, device=dev)[None, :])[:, :, None, None]
+        ea = ((o["1"][0] - o["2"][0]) * tri).norm() / (o["1"][0] * tri).norm()
+        eb = (o["1"][1] - o["2"][1]).norm() / o["1"][1].norm()
+        print(f"     gen2 vs gen1 rel-L2: analysis {ea:.2e}  synthesis {eb:.2e}")
 
 
 def dhconv():
     C, L, M = 384, 240, 241
     S = torch.randn(L, M, 2, C, device=dev)
-    w = torch.randn(1, C, C, L, dtype=torch.complex64, device=dev)
-    W = ops.weight_to_wlayout(w)
+    G = torch.randn(L, M, 2, C, device=dev)
+    w = ops.native_w_empty(C, C, L, dev)
+    w.copy_(torch.randn(1, C, C, L, dtype=torch.complex64, device=dev))
     fl = 8.0 * C * C * L * M
-    ms = timeit(lambda: ops.dhconv_fwd(S, W, 1, C)); print(f"dhconv fwd  : {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
-    ms = timeit(lambda: ops.dhconv_dgrad(S, W, 1, C, C)); print(f"dhconv dgrad: {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
-    ms = timeit(lambda: ops.dhconv_wgrad(S, S, 1)); print(f"dhconv wgrad: {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
-    ms = timeit(lambda: ops.weight_to_wlayout(w)); print(f"weight->W   : {ms:7.3f} ms {2*w.numel()*8/ms/1e6:7.1f} GB/s")
+    tri = (torch.arange(L, device=dev)[:, None] >= torch.arange(M, device=dev)[None, :])[:, :, None, None]
+
+    def run(gen):
+        y = ops.dhconv_fwd(S, w, 1, C)
+        gs = ops.dhconv_dgrad(G, w, 1, C, C)
+        gw = ops.dhconv_wgrad(S, G, 1, native=True)
+        ms = timeit(lambda: ops.dhconv_fwd(S, w, 1, C)); print(f"gen{gen} dhconv fwd  : {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
+        ms = timeit(lambda: ops.dhconv_dgrad(G, w, 1, C, C)); print(f"gen{gen} dhconv dgrad: {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
+        ms = timeit(lambda: ops.dhconv_wgrad(S, G, 1, native=True)); print(f"gen{gen} dhconv wgrad: {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
+        return y, gs, torch.view_as_real(gw)
+    o = _both_gens(run)
+    e = [(((o["1"][i] - o["2"][i]) * (tri if i < 2 else 1)).norm() / (o["1"][i] * (tri if i < 2 else 1)).norm()).item() for i in range(3)]
+    print(f"     gen2 vs gen1 rel-L2: fwd {e[0]:.2e} dgrad {e[1]:.2e} wgrad {e[2]:.2e}")
 
 
 def pointwise():
