@@ -7,7 +7,9 @@ from .layers import MLP, EncoderDecoder, InstanceNorm2d, PointwiseConv, Geometri
 from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, SpectralFilterLayer
 from .losses import GeometricLpLoss, GridQuadrature, SpectralLpLoss, SpectralH1Loss
 from .stepper import MultiStepWrapper, SingleStepWrapper
+from .disco import DiscreteContinuousConvS2, ResampleS2
 
 __all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
            "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer", "GeometricLpLoss",
-           "GridQuadrature", "SpectralLpLoss", "SpectralH1Loss", "GeometricInstanceNormS2", "MultiStepWrapper", "SingleStepWrapper"]
+           "GridQuadrature", "SpectralLpLoss", "SpectralH1Loss", "GeometricInstanceNormS2", "MultiStepWrapper", "SingleStepWrapper",
+           "DiscreteContinuousConvS2", "ResampleS2"]

@@ -77,6 +77,10 @@ _SIGS = {
     "mk_spec_lp_blocks": ([c_int, c_int], c_ll),
     "mk_spec_lp_fwd": ([c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_int, c_f, c_f, c_f, c_vp], c_int),
     "mk_spec_lp_bwd": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_int, c_f, c_f, c_f, c_vp], c_int),
+    "mk_disco_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_disco_bwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_resample_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_resample_bwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_quad_lp_chunks": ([c_ll], c_int),
     "mk_quad_lp_fwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),
     "mk_quad_lp_bwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_f, c_vp], c_int),

@@ -1,0 +1,357 @@
+"""Discrete-continuous (DISCO) convolution on the sphere and bilinear grid resampling: the local operators of
+FourCastNet3.
+
+Boundary: ``th.DiscreteContinuousConvS2`` / ``th.ResampleS2`` [torch-harmonics, un-vendored; pin
+887006c640f1d61c3f80590ecc2b207bbb647072] as constructed at ``makani/models/networks/fourcastnet3.py:189-205`` (encoder),
+``:356-381`` (decoder: resample + convolution on the output grid) and ``:518-534`` (local blocks): same constructor
+arguments, ``weight`` (out_channels, in_channels / groups, kernel_size) and ``bias`` (out_channels) parameters with the
+published initialisation, ``psi_idx`` / ``psi_vals`` buffers, ``forward((B, C, nlat_in, nlon_in)) -> (B, O, nlat_out,
+nlon_out)``.
+
+MI355X design.  The published operator is a sparse contraction ``y[b,c,k,t,p] = sum psi[k,t,(i,j)] x[b,c,i,(j + p s) mod
+nlon_in]`` (s = nlon_in / nlon_out) followed by a dense channel mix ``out[o] = sum_{c,k} w[o,c,k] y[c,k]``.  Its sparsity
+pattern is the same for every output longitude, so the convolution tensor is kept as per-(output latitude, basis
+function) lists of (input latitude, input longitude, value) — 9 short lists per latitude instead of a COO tensor over
+the whole grid:
+  * forward (``csrc/disco.hip``): one workgroup per output latitude and group of 4 planes stages the <= 2 cutoff / dlat + 1
+    input latitude rows it needs in LDS (read once from HBM, coalesced), every lane owns output longitudes and walks the
+    lists (wave-uniform scalar loads) against the LDS rows; the result is written as (B, C * K, nlat_out, nlon_out), i.e.
+    as the NCHW activation the channel GEMM kernels of ``csrc/conv1x1.hip`` consume in place — the channel mix IS a
+    1x1 convolution with C * K input channels and runs on those kernels (bf16, fused bias) with their weight-gradient
+    kernel in backward;
+  * backward: the adjoint contraction as a deterministic gather over the transposed lists (per input latitude), no atomics.
+The convolution tensor is computed in fp64 numpy at construction (vectorised over the input grid).  Filter basis: "morlet"
+(the one FourCastNet3's recipe selects, ``config/fourcastnet3.yaml:34``).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import legendre as _leg
+from . import ops
+from ._lib import check, dtype_code, lib, ptr, stream
+from .layers import hip_conv_eligible
+
+
+# --------------------------------------------------------------------------- #
+# convolution tensor
+# --------------------------------------------------------------------------- #
+def _morlet_vals(kernel_shape, r, phi):
+    """values of the kernel_shape[0] * kernel_shape[1] basis functions at unit-disk polar coordinates (r, phi): (K, n)"""
+    x, y = r * np.sin(phi), r * np.cos(phi)
+    window = np.cos(0.5 * math.pi * r) ** 2
+    out = np.empty((kernel_shape[0] * kernel_shape[1], r.shape[0]))
+    for k in range(out.shape[0]):
+        n, m = k % kernel_shape[1], k // kernel_shape[1]
+        hx = np.sin(math.ceil(n / 2) * math.pi * x) if n % 2 else np.cos(math.ceil(n / 2) * math.pi * x)
+        hy = np.sin(math.ceil(m / 2) * math.pi * y) if m % 2 else np.cos(math.ceil(m / 2) * math.pi * y)
+        out[k] = window * hx * hy
+    return out
+
+
+def convolution_tensor(in_shape, out_shape, kernel_shape, basis_type="morlet", grid_in="equiangular", grid_out="equiangular",
+                       theta_cutoff=0.01 * math.pi, theta_eps=1e-3, basis_norm_mode="mean", eps=1e-9):
+    """-> dict(k, t, i, j: int arrays of the non-zeros, v: float64 values with normalisation and quadrature merged)"""
+    if basis_type != "morlet":
+        raise NotImplementedError(f"filter basis {basis_type!r}: only 'morlet' is built (config/fourcastnet3.yaml:34)")
+    if basis_norm_mode not in ("none", "individual", "mean", "support"):
+        raise ValueError(f"Unknown basis normalization mode {basis_norm_mode}.")
+    nlat_in, nlon_in = in_shape
+    nlat_out, _ = out_shape
+    K = kernel_shape[0] * kernel_shape[1]
+    th_in, w_in = _leg.colatitudes(nlat_in, grid_in)
+    th_out, _ = _leg.colatitudes(nlat_out, grid_out)
+    lon = 2.0 * math.pi * np.arange(nlon_in) / nlon_in
+    q_lat = w_in / nlon_in / 2.0                            # quadrature weights that integrate to one over the sphere
+    cutoff = (1.0 + theta_eps) * theta_cutoff
+    cb, sb = np.cos(lon)[None, :], np.sin(lon)[None, :]
+    ks, ts, is_, js, vs = [], [], [], [], []
+    for t in range(nlat_out):
+        # only latitudes within the cutoff of the centre can fall inside the disk
+        rows = np.nonzero(np.abs(th_in - th_out[t]) <= cutoff)[0]
+        if rows.size == 0:
+            continue
+        cg, sg = np.cos(th_in[rows])[:, None], np.sin(th_in[rows])[:, None]
+        ca, sa = math.cos(-th_out[t]), math.sin(-th_out[t])
+        x = ca * cb * sg + cg * sa
+        y = sb * sg
+        z = -cb * sa * sg + ca * cg
+        nrm = np.sqrt(x * x + y * y + z * z)
+        x, y, z = x / nrm, y / nrm, z / nrm
+        theta = np.arccos(np.clip(z, -1.0, 1.0))
+        phi = np.arctan2(y, x)
+        phi = np.where(phi < 0.0, phi + 2.0 * math.pi, phi)
+        ri, jj = np.nonzero(theta <= cutoff)
+        if ri.size == 0:
+            continue
+        vals = _morlet_vals(kernel_shape, theta[ri, jj] / cutoff, phi[ri, jj])          # (K, n)
+        n = ri.size
+        ks.append(np.repeat(np.arange(K), n))
+        ts.append(np.full(K * n, t))
+        is_.append(np.tile(rows[ri], K))
+        js.append(np.tile(jj, K))
+        vs.append(vals.reshape(-1))
+    k, t, i, j, v = (np.concatenate(a) for a in (ks, ts, is_, js, vs))
+    q = q_lat[i]
+    flat = k * nlat_out + t
+    vnorm = np.bincount(flat, weights=np.abs(v) * q, minlength=K * nlat_out).reshape(K, nlat_out)
+    support = np.bincount(flat, weights=q, minlength=K * nlat_out).reshape(K, nlat_out)
+    if basis_norm_mode == "individual":
+        v = v / (vnorm[k, t] + eps)
+    elif basis_norm_mode == "mean":
+        v = v / (vnorm.mean(axis=1)[k] + eps)
+    elif basis_norm_mode == "support":
+        v = v / (support[k, t] + eps)
+    v = v * q
+    return dict(k=k.astype(np.int64), t=t.astype(np.int64), i=i.astype(np.int64), j=j.astype(np.int64), v=v, K=K)
+
+
+class _Lists:
+    """device-side list form of one convolution tensor (forward lists per (t, k), transposed lists per input latitude)"""
+
+    def __init__(self, psi, in_shape, out_shape, device):
+        nlat_in, nlon_in = in_shape
+        nlat_out, nlon_out = out_shape
+        K = psi["K"]
+        k, t, i, j, v = psi["k"], psi["t"], psi["i"], psi["j"], psi["v"]
+        # forward: sorted by (t, k); input rows relative to the first row the output latitude touches
+        order = np.lexsort((j, i, k, t))
+        kf, tf, if_, jf, vf = k[order], t[order], i[order], j[order], v[order]
+        lat_lo = np.full(nlat_out, 0, np.int64)
+        lat_n = np.zeros(nlat_out, np.int64)
+        for tt in range(nlat_out):
+            sel = if_[tf == tt]
+            if sel.size:
+                lat_lo[tt], lat_n[tt] = sel.min(), sel.max() - sel.min() + 1
+        off = np.zeros(nlat_out * K + 1, np.int64)
+        np.add.at(off, tf * K + kf + 1, 1)
+        off = np.cumsum(off)
+        to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device)
+        self.f_off, self.f_row, self.f_lon = to(off, np.int32), to(if_ - lat_lo[tf], np.int32), to(jf, np.int32)
+        self.f_val = to(vf, np.float32)
+        self.lat_lo, self.lat_n = to(lat_lo, np.int32), to(lat_n, np.int32)
+        self.max_rows = int(lat_n.max())
+        # transposed: sorted by input latitude
+        order = np.lexsort((j, k, t, i))
+        kb, tb, ib, jb, vb = k[order], t[order], i[order], j[order], v[order]
+        boff = np.zeros(nlat_in + 1, np.int64)
+        np.add.at(boff, ib + 1, 1)
+        boff = np.cumsum(boff)
+        self.b_off, self.b_k, self.b_t, self.b_lon = to(boff, np.int32), to(kb, np.int32), to(tb, np.int32), to(jb, np.int32)
+        self.b_val = to(vb, np.float32)
+        self.K, self.in_shape, self.out_shape = K, tuple(in_shape), tuple(out_shape)
+        self.nnz = int(v.size)
+
+
+def _contract_fwd(x, L: _Lists):
+    B, Cc, nlat_in, nlon_in = x.shape
+    nlat_out, nlon_out = L.out_shape
+    y = torch.empty((B, Cc * L.K, nlat_out, nlon_out), dtype=x.dtype, device=x.device)
+    with ops._timed("disco_fwd", flops=2.0 * B * Cc * nlon_out * L.nnz,
+                    nbytes=float(x.element_size()) * (x.numel() + y.numel())):
+        check(lib().mk_disco_fwd(ptr(x), ptr(y), dtype_code(x), ptr(L.f_off), ptr(L.f_row), ptr(L.f_lon), ptr(L.f_val),
+                                 ptr(L.lat_lo), ptr(L.lat_n), L.max_rows, B * Cc, L.K, nlat_in, nlon_in, nlat_out, nlon_out,
+                                 stream()), "mk_disco_fwd")
+    return y
+
+
+def _contract_bwd(gy, L: _Lists):
+    B, CK, nlat_out, nlon_out = gy.shape
+    nlat_in, nlon_in = L.in_shape
+    Cc = CK // L.K
+    gx = torch.empty((B, Cc, nlat_in, nlon_in), dtype=gy.dtype, device=gy.device)
+    with ops._timed("disco_bwd", flops=2.0 * B * Cc * nlon_out * L.nnz,
+                    nbytes=float(gy.element_size()) * (gx.numel() + gy.numel())):
+        check(lib().mk_disco_bwd(ptr(gy), ptr(gx), dtype_code(gy), ptr(L.b_off), ptr(L.b_k), ptr(L.b_t), ptr(L.b_lon),
+                                 ptr(L.b_val), B * Cc, L.K, nlat_in, nlon_in, nlat_out, nlon_out, stream()), "mk_disco_bwd")
+    return gx
+
+
+class DiscoContractFn(torch.autograd.Function):
+    """y = psi (*) x, (B, C, nlat_in, nlon_in) -> (B, C * K, nlat_out, nlon_out); linear with a constant tensor"""
+
+    @staticmethod
+    def forward(ctx, x, lists):
+        ctx.lists = lists
+        return _contract_fwd(x.contiguous(), lists)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _contract_bwd(gy.contiguous(), ctx.lists), None
+
+
+class DiscreteContinuousConvS2(nn.Module):
+    def __init__(self, in_channels, out_channels, in_shape, out_shape, kernel_shape, basis_type="morlet",
+                 basis_norm_mode="mean", groups=1, grid_in="equiangular", grid_out="equiangular", bias=True,
+                 theta_cutoff=None):
+        super().__init__()
+        self.nlat_in, self.nlon_in = in_shape
+        self.nlat_out, self.nlon_out = out_shape
+        if isinstance(kernel_shape, int):
+            kernel_shape = [kernel_shape, kernel_shape]
+        self.kernel_shape = list(kernel_shape)
+        self.kernel_size = self.kernel_shape[0] * self.kernel_shape[1]
+        if self.nlon_in % self.nlon_out != 0:
+            raise ValueError("nlon_in must be an integer multiple of nlon_out")
+        if theta_cutoff is None:
+            theta_cutoff = math.pi / float(self.nlat_out - 1)
+        if theta_cutoff <= 0.0:
+            raise ValueError("Error, theta_cutoff has to be positive.")
+        self.groups = groups
+        if in_channels % groups != 0 or out_channels % groups != 0:
+            raise ValueError("Error, the number of input and output channels have to be an integer multiple of the group size")
+        self.groupsize = in_channels // groups
+        scale = math.sqrt(1.0 / self.groupsize / self.kernel_size)
+        self.weight = nn.Parameter(scale * torch.randn(out_channels, self.groupsize, self.kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        psi = convolution_tensor(in_shape, out_shape, self.kernel_shape, basis_type=basis_type, grid_in=grid_in,
+                                 grid_out=grid_out, theta_cutoff=theta_cutoff, basis_norm_mode=basis_norm_mode)
+        self._psi = psi
+        idx = np.stack([psi["k"], psi["t"], psi["i"] * self.nlon_in + psi["j"]])
+        self.register_buffer("psi_idx", torch.from_numpy(idx), persistent=False)
+        self.register_buffer("psi_vals", torch.from_numpy(psi["v"]).float(), persistent=False)
+        self._lists = {}
+
+    def _device_lists(self, device):
+        key = str(device)
+        if key not in self._lists:
+            self._lists[key] = _Lists(self._psi, (self.nlat_in, self.nlon_in), (self.nlat_out, self.nlon_out), device)
+        return self._lists[key]
+
+    @torch.compiler.disable(recursive=True)
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+        bf16 = hip_conv_eligible(x)
+        with torch.autocast(device_type="cuda", enabled=False):
+            xc = x.to(torch.bfloat16) if bf16 else x.float()
+            y = DiscoContractFn.apply(xc, self._device_lists(x.device))           # (B, C * K, H, W)
+            O = self.weight.shape[0]
+            if self.groups == 1:
+                w4 = self.weight.reshape(O, -1, 1, 1)
+                if bf16:
+                    return ops.Conv1x1Fn.apply(y, w4, self.bias, None)
+                out = ops.ConvMmFn.apply(y, w4, None, False)
+            else:
+                B, _, H, W = y.shape
+                yg = y.reshape(B, self.groups, self.groupsize * self.kernel_size, H * W)
+                wg = self.weight.reshape(self.groups, O // self.groups, self.groupsize * self.kernel_size).to(y.dtype)
+                out = torch.einsum("gok,bgkn->bgon", wg, yg).reshape(B, O, H, W)
+            if self.bias is not None:
+                out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
+            return out
+
+
+# --------------------------------------------------------------------------- #
+# ResampleS2 (bilinear)
+# --------------------------------------------------------------------------- #
+class ResampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        ctx.mod = mod
+        ctx.in_shape = x.shape
+        return mod._launch(x.contiguous(), False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ctx.mod._launch(gy.contiguous(), True), None
+
+
+class ResampleS2(nn.Module):
+    """``th.ResampleS2(nlat_in, nlon_in, nlat_out, nlon_out, grid_in=, grid_out=, mode="bilinear")``: linear
+    interpolation in colatitude (the input is extended to the poles by the mean of its first / last row when the output
+    grid reaches beyond it), then periodic linear interpolation in longitude.  One HIP kernel for the forward map (gather
+    of four input points) and one for its adjoint (deterministic gather over the precomputed inverse stencils); float32
+    or bfloat16 tensors of any leading shape."""
+
+    def __init__(self, nlat_in, nlon_in, nlat_out, nlon_out, grid_in="equiangular", grid_out="equiangular", mode="bilinear"):
+        super().__init__()
+        if mode != "bilinear":
+            raise NotImplementedError(f"unknown interpolation mode {mode}")
+        self.nlat_in, self.nlon_in, self.nlat_out, self.nlon_out = nlat_in, nlon_in, nlat_out, nlon_out
+        self.mode = mode
+        self.skip_resampling = (nlat_in == nlat_out) and (nlon_in == nlon_out) and (grid_in == grid_out)
+        lats_in, _ = _leg.colatitudes(nlat_in, grid_in)
+        lats_out, _ = _leg.colatitudes(nlat_out, grid_out)
+        lons_in = np.linspace(0, 2 * math.pi, nlon_in, endpoint=False)
+        lons_out = np.linspace(0, 2 * math.pi, nlon_out, endpoint=False)
+        self.expand_poles = bool((lats_out > lats_in[-1]).any() or (lats_out < lats_in[0]).any())
+        if self.expand_poles:
+            lats_in = np.append(np.insert(lats_in, 0, 0.0), math.pi)
+        lat_idx = np.searchsorted(lats_in, lats_out, side="right") - 1
+        lat_idx = np.where(lats_out == lats_in[-1], lat_idx - 1, lat_idx)
+        lat_w = ((lats_out - lats_in[lat_idx]) / np.diff(lats_in)[lat_idx]).astype(np.float32)
+        left = np.searchsorted(lons_in, lons_out, side="right") - 1
+        right = np.where(lons_out >= lons_in[-1], np.zeros_like(left), left + 1)
+        diff = lons_in[right] - lons_in[left]
+        diff = np.where(diff < 0.0, diff + 2 * math.pi, diff)
+        lon_w = ((lons_out - lons_in[left]) / diff).astype(np.float32)
+        # the operator as two sparse 1-D maps.  Latitude: out row t = (1 - w) * R[a] + w * R[a + 1] over the (possibly pole
+        # extended) rows R; an extended row is the mean over longitude of input row 0 / nlat_in - 1, flagged by index -1 / -2.
+        off = 1 if self.expand_poles else 0
+
+        def src(r):                      # extended row index -> input row (or -1 north mean, -2 south mean)
+            if not self.expand_poles:
+                return r
+            return -1 if r == 0 else (-2 if r == nlat_in + 1 else r - off)
+        la = np.array([src(r) for r in lat_idx], np.int32)
+        lb = np.array([src(r + 1) for r in lat_idx], np.int32)
+        self.register_buffer("lat_a", torch.from_numpy(la), persistent=False)
+        self.register_buffer("lat_b", torch.from_numpy(lb), persistent=False)
+        self.register_buffer("lat_w", torch.from_numpy(lat_w), persistent=False)
+        self.register_buffer("lon_l", torch.from_numpy(left.astype(np.int32)), persistent=False)
+        self.register_buffer("lon_r", torch.from_numpy(right.astype(np.int32)), persistent=False)
+        self.register_buffer("lon_w", torch.from_numpy(lon_w), persistent=False)
+
+    def _inverse_stencils(self, device):
+        """adjoint operator as gather lists (CSR over input rows / input columns, plus the rows fed by a polar mean)"""
+        key = str(device)
+        if getattr(self, "_ikey", None) != key:
+            la, lb, lw = self.lat_a.cpu().numpy(), self.lat_b.cpu().numpy(), self.lat_w.cpu().numpy()
+            lat_lists = [[] for _ in range(self.nlat_in)]
+            pole_lists = [[], []]
+            for t in range(self.nlat_out):
+                for r, w in ((int(la[t]), 1.0 - float(lw[t])), (int(lb[t]), float(lw[t]))):
+                    (lat_lists[r] if r >= 0 else pole_lists[-r - 1]).append((t, w))
+            ll, lr, pw = self.lon_l.cpu().numpy(), self.lon_r.cpu().numpy(), self.lon_w.cpu().numpy()
+            lon_lists = [[] for _ in range(self.nlon_in)]
+            for p_ in range(self.nlon_out):
+                lon_lists[int(ll[p_])].append((p_, 1.0 - float(pw[p_])))
+                lon_lists[int(lr[p_])].append((p_, float(pw[p_])))
+
+            def csr(lists):
+                off = np.zeros(len(lists) + 1, np.int32)
+                off[1:] = np.cumsum([len(l) for l in lists])
+                idx = np.array([e[0] for l in lists for e in l] + [0], np.int32)
+                wts = np.array([e[1] for l in lists for e in l] + [0.0], np.float32)
+                return [torch.from_numpy(a_).to(device) for a_ in (off, idx, wts)]
+            self._inv = csr(lat_lists) + csr(lon_lists) + csr(pole_lists)
+            self._ikey = key
+        return self._inv
+
+    def _launch(self, x, adjoint):
+        lead = x.shape[:-2]
+        planes = int(np.prod(lead)) if len(lead) else 1
+        if not x.is_cuda:
+            raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+        if not adjoint:
+            y = torch.empty((*lead, self.nlat_out, self.nlon_out), dtype=x.dtype, device=x.device)
+            with ops._timed("resample_fwd", nbytes=float(x.element_size()) * (x.numel() + y.numel())):
+                check(lib().mk_resample_fwd(ptr(x), ptr(y), dtype_code(x), ptr(self.lat_a), ptr(self.lat_b), ptr(self.lat_w),
+                                            ptr(self.lon_l), ptr(self.lon_r), ptr(self.lon_w), planes, self.nlat_in,
+                                            self.nlon_in, self.nlat_out, self.nlon_out, stream()), "mk_resample_fwd")
+            return y
+        inv = self._inverse_stencils(x.device)
+        gx = torch.empty((*lead, self.nlat_in, self.nlon_in), dtype=x.dtype, device=x.device)
+        with ops._timed("resample_bwd", nbytes=float(x.element_size()) * (x.numel() + gx.numel())):
+            check(lib().mk_resample_bwd(ptr(x), ptr(gx), dtype_code(x), *[ptr(a_) for a_ in inv], planes, self.nlat_in,
+                                        self.nlon_in, self.nlat_out, self.nlon_out, stream()), "mk_resample_bwd")
+        return gx
+
+    def forward(self, x):
+        if self.skip_resampling:
+            return x
+        return ResampleFn.apply(x, self)

@@ -1,0 +1,265 @@
+"""CPU restatement of torch-harmonics' discrete-continuous (DISCO) convolution on the sphere and of ``ResampleS2``.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  torch-harmonics is an un-vendored dependency of the reference (pin:
+commit 887006c640f1d61c3f80590ecc2b207bbb647072, absent from this image), so this file restates the PUBLISHED algorithm
+(``torch_harmonics/convolution.py``, ``filter_basis.py``, ``resample.py`` as of the 0.7 / 0.8 releases) and is
+**parity unpinned** against the package itself: the reference tree holds no golden vectors for these operators.  What it
+is pinned against is mathematics (``tests/test_oracle_disco.py``): the rotation geometry against great-circle distances,
+the normalisation identities of every ``basis_norm_mode``, rotation equivariance in longitude, and the equivalence of
+the two contraction forms (dense roll / bmm, as torch-harmonics' CPU path does it, and the direct quadrature sum).
+
+Reference call sites (all of FourCastNet3's local operators):
+  * ``makani/models/networks/fourcastnet3.py:189-205``  encoder   ``th.DiscreteContinuousConvS2(inp, out, in_shape=,
+    out_shape=, kernel_shape=, basis_type=, basis_norm_mode=, grid_in=, grid_out=, groups=, bias=, theta_cutoff=)``
+  * ``fourcastnet3.py:356-381``  decoder: ``th.ResampleS2(*inp_shape, *out_shape, grid_in=, grid_out=, mode="bilinear")``
+    followed by a DISCO convolution on the output grid
+  * ``fourcastnet3.py:518-534``  the "local" blocks (theta_cutoff doubled)
+  * ``fourcastnet3.py:46-50``    the cutoff heuristic ``(kernel_shape[0] + 1) * 0.5 * pi / (nlat - 1)``
+
+Conventions of the restated algorithm:
+  * ``psi[k, t, i * nlon_in + j]`` = value of filter basis function k, centred on the output point (latitude t,
+    longitude 0), at input point (latitude i, longitude j); the centre is moved to longitude p by rolling the input by
+    ``p * (nlon_in // nlon_out)`` columns;
+  * the centre is taken to the north pole by the YZY Euler rotation (alpha = -theta_t passive, beta = input longitude,
+    gamma = input colatitude); theta = arccos z, phi = atan2(y, x) in [0, 2 pi);
+  * support: theta <= (1 + theta_eps) * theta_cutoff, theta_eps = 1e-3;
+  * quadrature weights q_i = w_i / (2 nlon_in) (they integrate to one over the sphere) are merged into psi after the
+    normalisation of ``basis_norm_mode`` ("none", "individual", "mean", "support");
+  * forward: y[b, c, k, t, p] = sum psi[k, t, (i, j)] x[b, c, i, (j + p * pscale) mod nlon_in], then
+    out[b, o, t, p] = sum_{c, k} weight[o, c, k] y[b, c, k, t, p] (+ bias), groups as in a grouped convolution.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .sht import precompute_latitudes
+
+
+# --------------------------------------------------------------------------- #
+# filter basis (torch_harmonics.filter_basis.MorletFilterBasis)
+# --------------------------------------------------------------------------- #
+class MorletFilterBasis:
+    """Hann-windowed sine / cosine products on the disk of radius ``r_cutoff``: basis function k = (m, n) with
+    n = k % kernel_shape[1], m = k // kernel_shape[1]; even index -> cos(ceil(n/2) pi x), odd -> sin(ceil(n/2) pi x)
+    on x = r sin(phi), y = r cos(phi), r scaled to the unit disk."""
+
+    def __init__(self, kernel_shape):
+        if isinstance(kernel_shape, int):
+            kernel_shape = [kernel_shape, kernel_shape]
+        if len(kernel_shape) != 2:
+            raise ValueError("expected kernel_shape to be a list or tuple of length 2")
+        self.kernel_shape = list(kernel_shape)
+
+    @property
+    def kernel_size(self):
+        return self.kernel_shape[0] * self.kernel_shape[1]
+
+    @staticmethod
+    def hann_window(r, width=1.0):
+        return torch.cos(0.5 * math.pi * r / width) ** 2
+
+    def compute_support_vals(self, r, phi, r_cutoff, width=1.0):
+        """r, phi: (nlat_in, nlon_in) -> (iidx (nnz, 3) = [k, i, j], vals (nnz,))"""
+        ikernel = torch.arange(self.kernel_size).reshape(-1, 1, 1)
+        nkernel = ikernel % self.kernel_shape[1]
+        mkernel = ikernel // self.kernel_shape[1]
+        iidx = torch.argwhere((r <= r_cutoff) & torch.full_like(ikernel, True, dtype=torch.bool))
+        rs = r[iidx[:, 1], iidx[:, 2]] / r_cutoff
+        ph = phi[iidx[:, 1], iidx[:, 2]]
+        x = rs * torch.sin(ph)
+        y = rs * torch.cos(ph)
+        n = nkernel[iidx[:, 0], 0, 0]
+        m = mkernel[iidx[:, 0], 0, 0]
+        harmonic = torch.where(n % 2 == 1, torch.sin(torch.ceil(n / 2) * math.pi * x / width),
+                               torch.cos(torch.ceil(n / 2) * math.pi * x / width))
+        harmonic = harmonic * torch.where(m % 2 == 1, torch.sin(torch.ceil(m / 2) * math.pi * y / width),
+                                          torch.cos(torch.ceil(m / 2) * math.pi * y / width))
+        vals = self.hann_window(rs, width=width) * harmonic
+        return iidx, vals
+
+
+def get_filter_basis(kernel_shape, basis_type):
+    if basis_type == "morlet":
+        return MorletFilterBasis(kernel_shape)
+    raise NotImplementedError(f"filter basis {basis_type!r} is not restated (FourCastNet3's recipe uses 'morlet', "
+                              "config/fourcastnet3.yaml:34)")
+
+
+# --------------------------------------------------------------------------- #
+# convolution tensor (torch_harmonics.convolution._precompute_convolution_tensor_s2 / _normalize_...)
+# --------------------------------------------------------------------------- #
+def rotated_coordinates(lat_out, lats_in, lons_in):
+    """(theta, phi) of every input point in the frame whose north pole is the output point (colatitude lat_out,
+    longitude 0)."""
+    alpha = -lat_out
+    beta = lons_in.reshape(1, -1)
+    gamma = lats_in.reshape(-1, 1)
+    x = torch.cos(alpha) * torch.cos(beta) * torch.sin(gamma) + torch.cos(gamma) * torch.sin(alpha)
+    y = torch.sin(beta) * torch.sin(gamma)
+    z = -torch.cos(beta) * torch.sin(alpha) * torch.sin(gamma) + torch.cos(alpha) * torch.cos(gamma)
+    norm = torch.sqrt(x * x + y * y + z * z)
+    x, y, z = x / norm, y / norm, z / norm
+    theta = torch.arccos(z)
+    phi = torch.arctan2(y, x)
+    phi = torch.where(phi < 0.0, phi + 2 * math.pi, phi)
+    return theta, phi
+
+
+def normalize_convolution_tensor(psi_idx, psi_vals, in_shape, out_shape, kernel_size, quad_weights,
+                                 basis_norm_mode="mean", merge_quadrature=True, eps=1e-9):
+    if basis_norm_mode == "none" and not merge_quadrature:
+        return psi_vals
+    ikernel, ilat_out = psi_idx[0], psi_idx[1]
+    ilat_in = psi_idx[2] // in_shape[1]
+    nlat_out = out_shape[0]
+    q = quad_weights[ilat_in].reshape(-1)
+    vnorm = torch.zeros(kernel_size, nlat_out, dtype=torch.float64)
+    support = torch.zeros(kernel_size, nlat_out, dtype=torch.float64)
+    flat = ikernel * nlat_out + ilat_out
+    vnorm.view(-1).index_add_(0, flat, psi_vals.abs() * q)
+    support.view(-1).index_add_(0, flat, q)
+    if basis_norm_mode == "individual":
+        val = vnorm[ikernel, ilat_out]
+    elif basis_norm_mode == "mean":
+        val = vnorm.mean(dim=1)[ikernel]
+    elif basis_norm_mode == "support":
+        val = support[ikernel, ilat_out]
+    elif basis_norm_mode == "none":
+        val = None
+    else:
+        raise ValueError(f"Unknown basis normalization mode {basis_norm_mode}.")
+    out = psi_vals if val is None else psi_vals / (val + eps)
+    if merge_quadrature:
+        out = out * q
+    return out
+
+
+def precompute_convolution_tensor(in_shape, out_shape, filter_basis, grid_in="equiangular", grid_out="equiangular",
+                                  theta_cutoff=0.01 * math.pi, theta_eps=1e-3, basis_norm_mode="mean",
+                                  merge_quadrature=True):
+    """-> (idx (3, nnz) int64 = [k, t, i * nlon_in + j], vals (nnz,) float64)"""
+    nlat_in, nlon_in = in_shape
+    nlat_out, nlon_out = out_shape
+    lats_in, win = precompute_latitudes(nlat_in, grid=grid_in)
+    lats_out, _ = precompute_latitudes(nlat_out, grid=grid_out)
+    lats_in, win, lats_out = torch.from_numpy(lats_in), torch.from_numpy(win), torch.from_numpy(lats_out)
+    lons_in = torch.linspace(0, 2 * math.pi, nlon_in + 1, dtype=torch.float64)[:-1]
+    quad_weights = win.reshape(-1, 1) / nlon_in / 2.0
+    cutoff = (1.0 + theta_eps) * theta_cutoff
+    out_idx, out_vals = [], []
+    for t in range(nlat_out):
+        theta, phi = rotated_coordinates(lats_out[t], lats_in, lons_in)
+        iidx, vals = filter_basis.compute_support_vals(theta, phi, r_cutoff=cutoff)
+        out_idx.append(torch.stack([iidx[:, 0], t * torch.ones_like(iidx[:, 0]), iidx[:, 1] * nlon_in + iidx[:, 2]], dim=0))
+        out_vals.append(vals)
+    out_idx = torch.cat(out_idx, dim=-1).contiguous()
+    out_vals = torch.cat(out_vals, dim=-1)
+    out_vals = normalize_convolution_tensor(out_idx, out_vals, in_shape, out_shape, filter_basis.kernel_size, quad_weights,
+                                            basis_norm_mode=basis_norm_mode, merge_quadrature=merge_quadrature)
+    return out_idx, out_vals.contiguous()
+
+
+def disco_contraction_dense(x, psi, nlon_out):
+    """torch-harmonics' CPU form (``_disco_s2_contraction_torch``): psi (K, nlat_out, nlat_in * nlon_in) dense or sparse,
+    one bmm per output longitude with the input rolled in between.  x (B, C, nlat_in, nlon_in) -> (B, C, K, nlat_out, nlon_out)"""
+    B, C, nlat_in, nlon_in = x.shape
+    K, nlat_out, _ = psi.shape
+    assert psi.shape[-1] == nlat_in * nlon_in and nlon_in % nlon_out == 0
+    pscale = nlon_in // nlon_out
+    xe = x.reshape(1, B * C, nlat_in, nlon_in).permute(0, 2, 3, 1).expand(K, -1, -1, -1)
+    y = torch.zeros(nlon_out, K, nlat_out, B * C, dtype=x.dtype)
+    for p in range(nlon_out):
+        y[p] = torch.bmm(psi, xe.reshape(K, nlat_in * nlon_in, -1))
+        xe = torch.roll(xe, -pscale, dims=2)
+    return y.permute(3, 1, 2, 0).reshape(B, C, K, nlat_out, nlon_out)
+
+
+class DiscreteContinuousConvS2(nn.Module):
+    """``th.DiscreteContinuousConvS2`` (constructor, parameters and forward as published)."""
+
+    def __init__(self, in_channels, out_channels, in_shape, out_shape, kernel_shape, basis_type="morlet",
+                 basis_norm_mode="mean", groups=1, grid_in="equiangular", grid_out="equiangular", bias=True,
+                 theta_cutoff=None):
+        super().__init__()
+        self.nlat_in, self.nlon_in = in_shape
+        self.nlat_out, self.nlon_out = out_shape
+        self.filter_basis = get_filter_basis(kernel_shape, basis_type)
+        self.kernel_size = self.filter_basis.kernel_size
+        if theta_cutoff is None:
+            theta_cutoff = math.pi / float(self.nlat_out - 1)
+        if theta_cutoff <= 0.0:
+            raise ValueError("Error, theta_cutoff has to be positive.")
+        self.groups = groups
+        if in_channels % groups != 0 or out_channels % groups != 0:
+            raise ValueError("Error, the number of input and output channels have to be an integer multiple of the group size")
+        self.groupsize = in_channels // groups
+        scale = math.sqrt(1.0 / self.groupsize / self.kernel_size)
+        self.weight = nn.Parameter(scale * torch.randn(out_channels, self.groupsize, self.kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        idx, vals = precompute_convolution_tensor(in_shape, out_shape, self.filter_basis, grid_in=grid_in, grid_out=grid_out,
+                                                  theta_cutoff=theta_cutoff, basis_norm_mode=basis_norm_mode,
+                                                  merge_quadrature=True)
+        self.register_buffer("psi_idx", idx, persistent=False)
+        self.register_buffer("psi_vals", vals.float(), persistent=False)
+
+    def get_psi(self, dtype=torch.float32):
+        """sparse COO (K, nlat_out, nlat_in * nlon_in), as torch-harmonics keeps it for its torch contraction path"""
+        return torch.sparse_coo_tensor(self.psi_idx, self.psi_vals.to(dtype),
+                                       size=(self.kernel_size, self.nlat_out, self.nlat_in * self.nlon_in)).coalesce()
+
+    def forward(self, x):
+        y = disco_contraction_dense(x, self.get_psi(x.dtype), self.nlon_out)
+        B, C, K, H, W = y.shape
+        y = y.reshape(B, self.groups, self.groupsize, K, H, W)
+        w = self.weight.reshape(self.groups, -1, self.weight.shape[1], self.weight.shape[2]).to(x.dtype)
+        out = torch.einsum("bgckxy,gock->bgoxy", y, w).reshape(B, -1, H, W)
+        if self.bias is not None:
+            out = out + self.bias.reshape(1, -1, 1, 1).to(x.dtype)
+        return out
+
+
+# --------------------------------------------------------------------------- #
+# ResampleS2 (torch_harmonics.resample.ResampleS2, mode = "bilinear")
+# --------------------------------------------------------------------------- #
+class ResampleS2(nn.Module):
+    def __init__(self, nlat_in, nlon_in, nlat_out, nlon_out, grid_in="equiangular", grid_out="equiangular", mode="bilinear"):
+        super().__init__()
+        if mode != "bilinear":
+            raise NotImplementedError(f"unknown interpolation mode {mode}")
+        self.nlat_in, self.nlon_in, self.nlat_out, self.nlon_out = nlat_in, nlon_in, nlat_out, nlon_out
+        self.skip_resampling = (nlat_in == nlat_out) and (nlon_in == nlon_out) and (grid_in == grid_out)
+        lats_in, _ = precompute_latitudes(nlat_in, grid=grid_in)
+        lats_out, _ = precompute_latitudes(nlat_out, grid=grid_out)
+        lons_in = np.linspace(0, 2 * math.pi, nlon_in, endpoint=False)
+        lons_out = np.linspace(0, 2 * math.pi, nlon_out, endpoint=False)
+        # points outside the latitude range of the input grid: extend the input to the poles (mean of the polar rows)
+        self.expand_poles = bool((lats_out > lats_in[-1]).any() or (lats_out < lats_in[0]).any())
+        if self.expand_poles:
+            lats_in = np.append(np.insert(lats_in, 0, 0.0), math.pi)
+        lat_idx = np.searchsorted(lats_in, lats_out, side="right") - 1
+        lat_idx = np.where(lats_out == lats_in[-1], lat_idx - 1, lat_idx)
+        lat_w = (lats_out - lats_in[lat_idx]) / np.diff(lats_in)[lat_idx]
+        self.register_buffer("lat_idx", torch.from_numpy(lat_idx).long(), persistent=False)
+        self.register_buffer("lat_weights", torch.from_numpy(lat_w).float().unsqueeze(-1), persistent=False)
+        left = np.searchsorted(lons_in, lons_out, side="right") - 1
+        right = np.where(lons_out >= lons_in[-1], np.zeros_like(left), left + 1)
+        diff = lons_in[right] - lons_in[left]
+        diff = np.where(diff < 0.0, diff + 2 * math.pi, diff)
+        lon_w = (lons_out - lons_in[left]) / diff
+        self.register_buffer("lon_idx_left", torch.from_numpy(left).long(), persistent=False)
+        self.register_buffer("lon_idx_right", torch.from_numpy(right).long(), persistent=False)
+        self.register_buffer("lon_weights", torch.from_numpy(lon_w).float(), persistent=False)
+
+    def forward(self, x):
+        if self.skip_resampling:
+            return x
+        if self.expand_poles:
+            north = x[..., 0:1, :].mean(dim=-1, keepdim=True).expand(*x.shape[:-2], 1, x.shape[-1])
+            south = x[..., -1:, :].mean(dim=-1, keepdim=True).expand(*x.shape[:-2], 1, x.shape[-1])
+            x = torch.cat([north, x, south], dim=-2)
+        w = self.lat_weights.to(x.dtype)
+        x = torch.lerp(x[..., self.lat_idx, :], x[..., self.lat_idx + 1, :], w)
+        x = torch.lerp(x[..., self.lon_idx_left], x[..., self.lon_idx_right], self.lon_weights.to(x.dtype))
+        return x

@@ -1,0 +1,138 @@
+"""CPU tests of the DISCO / ResampleS2 restatement (oracle/disco.py) and of the product's host-side precompute
+(makani_amd/disco.py: convolution tensor lists, interpolation tables).  torch-harmonics is absent from the image and the
+reference tree holds no vectors for these operators, so the oracle is pinned against mathematics (see its header)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import disco as od
+from oracle.sht import precompute_latitudes
+
+CASES = [((33, 64), (17, 32), "equiangular", "equiangular", 1.0),
+         ((24, 48), (24, 48), "legendre-gauss", "legendre-gauss", 2.0),
+         ((19, 36), (12, 36), "equiangular", "legendre-gauss", 1.0)]
+
+
+def _cutoff(nlat, factor):
+    return factor * (3 + 1) * 0.5 * math.pi / float(nlat - 1)      # fourcastnet3.py:46-50
+
+
+def test_rotation_gives_great_circle_distance_and_bearing():
+    lats, _ = precompute_latitudes(19, "equiangular")
+    lats = torch.from_numpy(lats)
+    lons = torch.linspace(0, 2 * math.pi, 37, dtype=torch.float64)[:-1]
+    for t in (0, 3, 9, 18):
+        theta, phi = od.rotated_coordinates(lats[t], lats, lons)
+        # great-circle distance between (colat_t, lon 0) and (colat_i, lon_j)
+        cosd = torch.cos(lats[t]) * torch.cos(lats)[:, None] + torch.sin(lats[t]) * torch.sin(lats)[:, None] * torch.cos(lons)[None, :]
+        assert torch.allclose(theta, torch.arccos(cosd.clamp(-1, 1)), atol=1e-7)
+        assert (phi >= 0).all() and (phi < 2 * math.pi + 1e-12).all()
+    # a point due south of the centre (same longitude, larger colatitude) has bearing phi = 0; due east phi = pi / 2
+    theta, phi = od.rotated_coordinates(lats[5], lats, lons)
+    assert abs(phi[8, 0].item()) < 1e-9 or abs(phi[8, 0].item() - 2 * math.pi) < 1e-9
+    assert 0.0 < phi[5, 1].item() < math.pi
+
+
+@pytest.mark.parametrize("mode", ["none", "individual", "mean", "support"])
+def test_normalisation_identities(mode):
+    in_shape, out_shape = (33, 64), (17, 32)
+    fb = od.MorletFilterBasis([3, 3])
+    idx, vals = od.precompute_convolution_tensor(in_shape, out_shape, fb, theta_cutoff=_cutoff(33, 1.0), basis_norm_mode=mode)
+    K, T = 9, 17
+    s = torch.zeros(K * T, dtype=torch.float64).index_add_(0, idx[0] * T + idx[1], vals.abs()).reshape(K, T)
+    if mode == "individual":                 # every (k, t) filter has unit 1-norm under the quadrature
+        assert torch.allclose(s, torch.ones_like(s), atol=1e-6)
+    if mode == "mean":                       # unit 1-norm on average over the output latitudes
+        assert torch.allclose(s.mean(dim=1), torch.ones(K, dtype=torch.float64), atol=1e-6)
+    if mode == "support":                    # the constant basis function (k = 0 is cos(0) cos(0) = window >= 0) integrates to <= 1
+        assert (s[0] <= 1.0 + 1e-9).all()
+    if mode == "none":                       # plain quadrature of the window: bounded by the area fraction of the disk
+        frac = 0.5 * (1.0 - math.cos(1.001 * _cutoff(33, 1.0)))
+        assert (s[0] <= frac * 1.2).all()
+
+
+@pytest.mark.parametrize("in_shape,out_shape,gi,go,fac", CASES)
+def test_dense_contraction_equals_direct_sum_and_is_equivariant(in_shape, out_shape, gi, go, fac):
+    torch.manual_seed(3)
+    m = od.DiscreteContinuousConvS2(2, 3, in_shape, out_shape, (3, 3), basis_type="morlet", grid_in=gi, grid_out=go, bias=True,
+                                    theta_cutoff=_cutoff(in_shape[0], fac)).double()
+    x = torch.randn(2, 2, *in_shape, dtype=torch.float64)
+    y = od.disco_contraction_dense(x, m.get_psi(torch.float64), out_shape[1])
+    # direct evaluation of the defining sum
+    pscale = in_shape[1] // out_shape[1]
+    k, t, ij = m.psi_idx
+    i, j = ij // in_shape[1], ij % in_shape[1]
+    ref = torch.zeros_like(y)
+    for p in range(out_shape[1]):
+        contrib = m.psi_vals.double() * x[:, :, i, (j + p * pscale) % in_shape[1]]
+        ref[:, :, :, :, p] = torch.zeros(2, 2, 9 * out_shape[0], dtype=torch.float64).index_add_(2, k * out_shape[0] + t, contrib).reshape(2, 2, 9, out_shape[0])
+    assert torch.allclose(y, ref, atol=1e-12)
+    out = m(x)
+    shifted = m(torch.roll(x, 2 * pscale, dims=-1))
+    assert torch.allclose(shifted, torch.roll(out, 2, dims=-1), atol=1e-12)
+
+
+@pytest.mark.parametrize("in_shape,out_shape,gi,go,fac", CASES)
+@pytest.mark.parametrize("mode", ["mean", "individual"])
+def test_product_convolution_tensor_matches_oracle(in_shape, out_shape, gi, go, fac, mode):
+    from makani_amd import disco as pd
+    cut = _cutoff(in_shape[0], fac)
+    idx, vals = od.precompute_convolution_tensor(in_shape, out_shape, od.MorletFilterBasis([3, 3]), grid_in=gi, grid_out=go,
+                                                 theta_cutoff=cut, basis_norm_mode=mode)
+    psi = pd.convolution_tensor(in_shape, out_shape, [3, 3], grid_in=gi, grid_out=go, theta_cutoff=cut, basis_norm_mode=mode)
+    size = (9, out_shape[0], in_shape[0] * in_shape[1])
+    A = torch.sparse_coo_tensor(idx, vals, size=size).to_dense()
+    pidx = torch.from_numpy(np.stack([psi["k"], psi["t"], psi["i"] * in_shape[1] + psi["j"]]))
+    B = torch.sparse_coo_tensor(pidx, torch.from_numpy(psi["v"]), size=size).to_dense()
+    # theta = arccos(z) near z = 1 carries sqrt(eps) conditioning: two fp64 evaluations agree to ~1e-8, not 1e-16
+    assert idx.shape == pidx.shape                      # same support
+    assert (A - B).abs().max() < 1e-6 * A.abs().max()
+    # list form: every forward list entry points inside the staged rows, the transposed lists hold the same entries
+    L = pd._Lists(psi, in_shape, out_shape, "cpu")
+    assert int(L.f_off[-1]) == psi["v"].size == int(L.b_off[-1])
+    assert (L.f_row >= 0).all() and (L.f_row < L.max_rows).all()
+    assert torch.allclose(L.f_val.double().sum(), L.b_val.double().sum(), rtol=1e-6)
+
+
+def test_morlet_only_and_argument_errors():
+    with pytest.raises(NotImplementedError):
+        od.get_filter_basis([3, 3], "zernike")
+    with pytest.raises(ValueError):
+        od.DiscreteContinuousConvS2(3, 4, (9, 16), (9, 16), (3, 3), groups=2)
+    from makani_amd import disco as pd
+    with pytest.raises(ValueError):
+        pd.DiscreteContinuousConvS2(3, 4, (9, 16), (9, 16), (3, 3), groups=2)
+    with pytest.raises(ValueError):
+        pd.DiscreteContinuousConvS2(4, 4, (9, 16), (9, 12), (3, 3))
+    with pytest.raises(NotImplementedError):
+        pd.DiscreteContinuousConvS2(4, 4, (9, 16), (9, 16), (3, 3), basis_type="harmonic")
+
+
+@pytest.mark.parametrize("nin,nout,gi,go", [((12, 24), (23, 48), "legendre-gauss", "equiangular"),
+                                            ((17, 32), (33, 64), "equiangular", "equiangular"),
+                                            ((24, 48), (12, 24), "equiangular", "legendre-gauss"),
+                                            ((9, 16), (9, 16), "equiangular", "equiangular")])
+def test_resample_properties_and_product_tables(nin, nout, gi, go):
+    from makani_amd import disco as pd
+    m = od.ResampleS2(*nin, *nout, grid_in=gi, grid_out=go)
+    lats_in, _ = precompute_latitudes(nin[0], gi)
+    lats_out, _ = precompute_latitudes(nout[0], go)
+    # constants are preserved; a function linear in colatitude is reproduced wherever no pole extension is involved
+    assert torch.allclose(m(torch.ones(1, 2, *nin)), torch.ones(1, 2, *nout), atol=1e-6)
+    f = torch.from_numpy(lats_in).float().view(1, 1, -1, 1).expand(1, 1, nin[0], nin[1]).contiguous()
+    g = m(f)
+    inside = (lats_out >= lats_in[0]) & (lats_out <= lats_in[-1])
+    assert torch.allclose(g[0, 0, inside, 0], torch.from_numpy(lats_out[inside]).float(), atol=1e-5)
+    if nin == nout and gi == go:
+        x = torch.randn(1, 1, *nin)
+        assert m(x) is x
+    p = pd.ResampleS2(*nin, *nout, grid_in=gi, grid_out=go)
+    assert p.expand_poles == m.expand_poles and p.skip_resampling == m.skip_resampling
+    assert torch.equal(p.lon_l.long(), m.lon_idx_left) and torch.equal(p.lon_r.long(), m.lon_idx_right)
+    assert torch.allclose(p.lon_w, m.lon_weights) and torch.allclose(p.lat_w, m.lat_weights.view(-1))
+    off = 1 if m.expand_poles else 0
+    a = p.lat_a.long()
+    exp_a = m.lat_idx - off
+    assert torch.equal(torch.where(a >= 0, a, exp_a), exp_a)      # non-polar sources agree with the (extended) row index
