@@ -8,8 +8,9 @@ from .sfno import SphericalFourierNeuralOperatorNet, NeuralOperatorBlock, Spectr
 from .losses import GeometricLpLoss, GridQuadrature, SpectralLpLoss, SpectralH1Loss
 from .stepper import MultiStepWrapper, SingleStepWrapper
 from .disco import DiscreteContinuousConvS2, ResampleS2
+from .fcn3 import AtmoSphericNeuralOperatorNet
 
 __all__ = ["RealSHT", "InverseRealSHT", "SpectralConv", "MLP", "EncoderDecoder", "InstanceNorm2d", "PointwiseConv",
            "SphericalFourierNeuralOperatorNet", "NeuralOperatorBlock", "SpectralFilterLayer", "GeometricLpLoss",
            "GridQuadrature", "SpectralLpLoss", "SpectralH1Loss", "GeometricInstanceNormS2", "MultiStepWrapper", "SingleStepWrapper",
-           "DiscreteContinuousConvS2", "ResampleS2"]
+           "DiscreteContinuousConvS2", "ResampleS2", "AtmoSphericNeuralOperatorNet"]

@@ -114,6 +114,47 @@ def sfno_layernorm_fixture():
     )
 
 
+def fcn3_fixtures():
+    """FourCastNet3 (makani/models/networks/fourcastnet3.py, the reference's own module) on top of the restated
+    torch-harmonics operators: SHT (oracle/sht.py) and DISCO convolution / ResampleS2 (oracle/disco.py).  The DISCO
+    restatement is parity-unpinned against the package itself (see its header), so these fixtures pin the NETWORK code
+    (channel grouping, encoders / decoders, global + local blocks, layer scale, big skip, water clamp), not psi."""
+    FCN3 = ref_shims.import_reference_module("makani.models.networks.fourcastnet3").AtmoSphericNeuralOperatorNet
+    chans = ["u500", "v500", "t500", "q500", "u850", "v850", "t850", "q850", "u10m", "v10m", "t2m", "tcwv"]
+    cases = [
+        # global + local blocks, aux channels, instance norm, big skip, water clamp, bilinear decoder
+        ("fcn3_small_33x64.npz", 2, 350,
+         dict(inp_shape=(33, 64), out_shape=(33, 64), scale_factor=2, filter_basis_type="morlet", channel_names=chans,
+              aux_channel_names=["xzen", "xoro"], atmo_embed_dim=4, surf_embed_dim=8, aux_embed_dim=4, num_layers=4,
+              normalization_layer="instance_norm", big_skip=True, clamp_water=True, sfno_block_frequency=2)),
+        # encoder MLPs, SHT upsampling in the decoder, channel layer norm, bias, no layer scale, no aux, 3 layers
+        # (normalization_layer="instance_norm_s2" cannot be built by the reference itself: fourcastnet3.py:98-108 passes
+        # pole_mask= to a GeometricInstanceNormS2 that has no such argument)
+        ("fcn3_options_24x48.npz", 1, 351,
+         dict(inp_shape=(24, 48), out_shape=(24, 48), scale_factor=2, filter_basis_type="morlet", channel_names=chans[:8] + ["t2m"],
+              aux_channel_names=[], atmo_embed_dim=6, surf_embed_dim=4, num_layers=3, encoder_mlp=True, upsample_sht=True,
+              normalization_layer="layer_norm", layer_scale=False, bias=True, activation_function="silu",
+              model_grid_type="equiangular", sht_grid_type="legendre-gauss", hard_thresholding_fraction=0.75)),
+    ]
+    for name, batch, seed, kwargs in cases:
+        torch.manual_seed(seed)
+        model = FCN3(**kwargs)
+        model.train()
+        nin = len(kwargs["channel_names"]) + len(kwargs["aux_channel_names"])
+        x = torch.rand(batch, nin, *kwargs["inp_shape"], requires_grad=True)
+        g = torch.randn(batch, len(kwargs["channel_names"]), *kwargs["out_shape"])
+        y = model(x)
+        (y * g).sum().backward()
+        rec = {"kwargs": np.array(json.dumps(kwargs)), "x": _np(x), "g": _np(g), "y": _np(y), "gx": _np(x.grad)}
+        for k, v in model.state_dict().items():
+            rec["param/" + k] = _np(v)
+        for k, p_ in model.named_parameters():
+            rec["grad/" + k] = _np(p_.grad)
+        path = os.path.join(OUT, name)
+        np.savez_compressed(path, **rec)
+        print(f"{name}: {os.path.getsize(path)/1e6:.2f} MB  |y|={y.abs().mean().item():.4f}")
+
+
 def spectral_conv_fixtures():
     sc = ref_shims.import_reference_module("makani.models.common.spectral_convolution")
     th = sys.modules["torch_harmonics"]
@@ -343,7 +384,7 @@ def main():
         raise SystemExit("reference tree not found; golden fixtures can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss", "stepper"]
+    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss", "stepper", "fcn3"]
     if "contractions" in which:
         contraction_fixtures()
     if "spectral_conv" in which:
@@ -356,6 +397,8 @@ def main():
         loss_fixtures()
     if "stepper" in which:
         stepper_fixtures()
+    if "fcn3" in which:
+        fcn3_fixtures()
 
 
 if __name__ == "__main__":

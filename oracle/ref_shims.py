@@ -6,7 +6,8 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Only ``oracle/make_golden.py`
 uses this, and only where ``/root/reference`` exists (never on the GPU box).
 The shims provide the two un-vendored dependencies:
 
-* ``torch_harmonics``  -> backed by the restatement in ``oracle/sht.py``
+* ``torch_harmonics``  -> backed by the restatements in ``oracle/sht.py`` (transforms) and ``oracle/disco.py``
+  (DISCO convolution, ResampleS2)
 * ``physicsnemo``      -> inert ``ModelMetaData`` / ``Module.from_torch``
   (no arithmetic lives there)
 
@@ -23,6 +24,7 @@ from dataclasses import dataclass
 import torch
 
 from . import sht as _sht
+from . import disco as _disco
 
 REFERENCE_ROOT = os.environ.get("MAKANI_REFERENCE_ROOT", "/root/reference")
 
@@ -115,8 +117,8 @@ def install():
         "torch_harmonics",
         RealSHT=_sht.RealSHT,
         InverseRealSHT=_sht.InverseRealSHT,
-        ResampleS2=type("ResampleS2", (_NoDist,), {}),
-        DiscreteContinuousConvS2=type("DiscreteContinuousConvS2", (_NoDist,), {}),
+        ResampleS2=_disco.ResampleS2,
+        DiscreteContinuousConvS2=_disco.DiscreteContinuousConvS2,
         DiscreteContinuousConvTransposeS2=type("DiscreteContinuousConvTransposeS2", (_NoDist,), {}),
         quadrature=quad,
         distributed=thd,

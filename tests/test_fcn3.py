@@ -1,0 +1,80 @@
+"""FourCastNet3 plug-in (makani_amd/fcn3.py) against fixtures generated from the reference's own
+``makani/models/networks/fourcastnet3.py`` (``python -m oracle.make_golden fcn3``): constructor / state-dict contract on
+the CPU, forward + every gradient on the GPU (fp32 end-to-end tolerance 1e-4)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+FCN3_GOLDEN = ["fcn3_small_33x64.npz", "fcn3_options_24x48.npz"]
+
+
+def _load(name):
+    import makani_amd as ma
+    g = load_golden(name)
+    kwargs = json.loads(str(g["kwargs"]))
+    model = ma.AtmoSphericNeuralOperatorNet(**kwargs, some_unknown_trainer_key=1)       # unknown kwargs are ignored
+    sd = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
+    model.load_state_dict(sd, strict=True)
+    return g, kwargs, model
+
+
+@pytest.mark.parametrize("name", FCN3_GOLDEN)
+def test_fcn3_state_dict_contract(name):
+    g, kwargs, model = _load(name)
+    ref_shapes = {k[len("param/"):]: g[k].shape for k in g.files if k.startswith("param/")}
+    own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert own == {k: tuple(v) for k, v in ref_shapes.items()}
+    assert set(dict(model.named_parameters())) == {k[len("grad/"):] for k in g.files if k.startswith("grad/")}
+    for k, p in model.named_parameters():
+        if ("coder.conv.weight" in k) or "local_conv" in k or "layer_scale" in k or k.startswith("residual_transform"):
+            assert getattr(p, "is_shared_mp", None) == ["spatial"], k
+    assert model.n_out_chans == len(kwargs["channel_names"])
+
+
+def test_fcn3_channel_grouping_and_errors():
+    from makani_amd import fcn3
+    atmo, surf, dyn, stat, levels = fcn3.get_channel_groups(["u500", "v500", "t2m", "u850", "v850", "d2", "tcwv"], ["xzen", "xoro"])
+    assert atmo == [0, 1, 3, 4] and surf == [2, 5, 6] and dyn == [7] and stat == [8] and levels == [500, 850]
+    assert fcn3.get_water_channels(["q500", "t500", "r850", "tcwv", "u10m"]) == [0, 2, 3]
+    with pytest.raises(ValueError):
+        fcn3.get_channel_groups(["u500", "v500", "u850"])
+    with pytest.raises(ValueError):
+        fcn3.AtmoSphericNeuralOperatorNet(inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2, filter_basis_type="morlet", n_history=1)
+    with pytest.raises(ValueError):
+        fcn3.AtmoSphericNeuralOperatorNet(inp_shape=(16, 32), out_shape=(16, 32), scale_factor=2, filter_basis_type="morlet",
+                                          activation_function="tanh")
+    x = torch.linspace(-1, 2, 13)
+    y = fcn3._soft_clamp(x)
+    assert (y[x <= 0] == 0).all() and torch.allclose(y[x >= 0.5], x[x >= 0.5] - 0.25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FCN3_GOLDEN)
+def test_fcn3_matches_reference_golden_fp32(name):
+    g, kwargs, model = _load(name)
+    model = model.to("cuda:0")
+    x = torch.from_numpy(g["x"]).to("cuda:0").requires_grad_(True)
+    y = model(x)
+    (y * torch.from_numpy(g["g"]).to("cuda:0")).sum().backward()
+    assert rel_l2(y, torch.from_numpy(g["y"])) < 1e-4
+    assert rel_l2(x.grad, torch.from_numpy(g["gx"])) < 1e-4
+    gmax = max(float(np.abs(g[k2]).max()) for k2 in g.files if k2.startswith("grad/"))
+    for k, p in model.named_parameters():
+        ref = torch.from_numpy(g["grad/" + k])
+        e = rel_l2(p.grad, ref)
+        a = (p.grad.detach().cpu() - ref).abs().max().item()
+        assert e < 2e-4 or a < 1e-4 * gmax, (k, e, a, gmax)        # zero-in-exact-arithmetic gradients: absolute scale
+
+
+@pytest.mark.gpu
+def test_fcn3_bf16_autocast_runs_close_to_fp32():
+    g, kwargs, model = _load("fcn3_small_33x64.npz")
+    model = model.to("cuda:0")
+    x = torch.from_numpy(g["x"]).to("cuda:0")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = model(x)
+    assert rel_l2(y.float(), torch.from_numpy(g["y"])) < 4e-2
