@@ -122,9 +122,14 @@ def roofline_of(family, members, prof, gemm_mode, traffic):
     peak, eng = {"fp32": (PEAK_F32_MFMA_TF, "exact-fp32 MFMA"),
                  "x6": (PEAK_BF16_MFMA_TF / 6, "bf16 MFMA, 6 limb products per fp32 product"),
                  "x3": (PEAK_BF16_MFMA_TF / 3, "bf16 MFMA, 3 limb products per fp32 product")}[gemm_mode]
+    mf = sum(d.get("mfma_flops", 0.0) for d in ds) / launches
     return dict(base, bound="mfma", achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
-                note=f"dense-formulation fp32-equivalent flops per launch / HIP-event launch time; engine: {eng}; "
-                     f"the kernel skips the structurally-zero l<m half (DESIGN.md §4)")
+                mfma_util_executed=round(mf / (ms_avg * 1e-3) / 1e12 / PEAK_BF16_MFMA_TF, 4) if mf else None,
+                executed_bf16_mfma_flops=int(mf),
+                note=f"achieved / frac: dense-formulation fp32-equivalent flops per launch / HIP-event launch time (comparable with "
+                     f"the reference's dense einsum); engine: {eng}; the kernel skips the structurally-zero l<m tiles, so "
+                     f"mfma_util_executed = bf16 MFMA flops actually issued (limb products and tile padding included) / time / "
+                     f"{PEAK_BF16_MFMA_TF:.0f} TF is the matrix-pipe utilisation (SURVEY.md §8d)")
 
 
 def load_pmc_traffic():

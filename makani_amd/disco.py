@@ -19,7 +19,9 @@ the whole grid:
     as the NCHW activation the channel GEMM kernels of ``csrc/conv1x1.hip`` consume in place — the channel mix IS a
     1x1 convolution with C * K input channels and runs on those kernels (bf16, fused bias) with their weight-gradient
     kernel in backward;
-  * backward: the adjoint contraction as a deterministic gather over the transposed lists (per input latitude), no atomics.
+  * backward: the adjoint contraction as a deterministic gather, no atomics: on equal longitude counts (the local blocks,
+    the decoder) it is the same LDS-staged correlation as the forward kernel over the lists transposed per (input
+    latitude, basis function); the strided case (encoder) gathers per input point.
 The convolution tensor is computed in fp64 numpy at construction (vectorised over the input grid).  Filter basis: "morlet"
 (the one FourCastNet3's recipe selects, ``config/fourcastnet3.yaml:34``).
 """
@@ -109,6 +111,15 @@ def convolution_tensor(in_shape, out_shape, kernel_shape, basis_type="morlet", g
     return dict(k=k.astype(np.int64), t=t.astype(np.int64), i=i.astype(np.int64), j=j.astype(np.int64), v=v, K=K)
 
 
+_PSI_CACHE = {}          # constructor arguments -> convolution tensor (FourCastNet3's eight local blocks share one)
+_LIST_CACHE = {}         # (constructor arguments, device) -> device lists
+
+
+def _psi_key(in_shape, out_shape, kernel_shape, basis_type, grid_in, grid_out, theta_cutoff, basis_norm_mode):
+    return (tuple(in_shape), tuple(out_shape), tuple(kernel_shape), basis_type, grid_in, grid_out, float(theta_cutoff),
+            basis_norm_mode)
+
+
 class _Lists:
     """device-side list form of one convolution tensor (forward lists per (t, k), transposed lists per input latitude)"""
 
@@ -144,6 +155,28 @@ class _Lists:
         self.b_val = to(vb, np.float32)
         self.K, self.in_shape, self.out_shape = K, tuple(in_shape), tuple(out_shape)
         self.nnz = int(v.size)
+        # same longitude count on both grids: the adjoint is the forward correlation over the lists transposed per
+        # (input latitude, basis function), longitudes negated, rows = output latitudes relative to the first one touched
+        self.same_lon = nlon_in == nlon_out
+        if self.same_lon:
+            order = np.lexsort((j, t, k, i))
+            ks, ts, is2, js, vs2 = k[order], t[order], i[order], j[order], v[order]
+            seg = is2 * K + ks
+            t_lo = np.zeros(nlat_in * K, np.int64)
+            t_n = np.zeros(nlat_in * K, np.int64)
+            lo = np.full(nlat_in * K, nlat_out, np.int64)
+            hi = np.full(nlat_in * K, -1, np.int64)
+            np.minimum.at(lo, seg, ts)
+            np.maximum.at(hi, seg, ts)
+            live = hi >= 0
+            t_lo[live], t_n[live] = lo[live], hi[live] - lo[live] + 1
+            soff = np.zeros(nlat_in * K + 1, np.int64)
+            np.add.at(soff, seg + 1, 1)
+            soff = np.cumsum(soff)
+            self.s_off, self.s_row = to(soff, np.int32), to(ts - t_lo[seg], np.int32)
+            self.s_lon, self.s_val = to((-js) % nlon_in, np.int32), to(vs2, np.float32)
+            self.t_lo, self.t_n = to(t_lo, np.int32), to(t_n, np.int32)
+            self.max_rows_b = int(t_n.max())
 
 
 def _contract_fwd(x, L: _Lists):
@@ -165,8 +198,13 @@ def _contract_bwd(gy, L: _Lists):
     gx = torch.empty((B, Cc, nlat_in, nlon_in), dtype=gy.dtype, device=gy.device)
     with ops._timed("disco_bwd", flops=2.0 * B * Cc * nlon_out * L.nnz,
                     nbytes=float(gy.element_size()) * (gx.numel() + gy.numel())):
-        check(lib().mk_disco_bwd(ptr(gy), ptr(gx), dtype_code(gy), ptr(L.b_off), ptr(L.b_k), ptr(L.b_t), ptr(L.b_lon),
-                                 ptr(L.b_val), B * Cc, L.K, nlat_in, nlon_in, nlat_out, nlon_out, stream()), "mk_disco_bwd")
+        if L.same_lon:
+            check(lib().mk_disco_bwd_same(ptr(gy), ptr(gx), dtype_code(gy), ptr(L.s_off), ptr(L.s_row), ptr(L.s_lon), ptr(L.s_val),
+                                          ptr(L.t_lo), ptr(L.t_n), L.max_rows_b, B * Cc, L.K, nlat_in, nlon_in, nlat_out,
+                                          stream()), "mk_disco_bwd_same")
+        else:
+            check(lib().mk_disco_bwd(ptr(gy), ptr(gx), dtype_code(gy), ptr(L.b_off), ptr(L.b_k), ptr(L.b_t), ptr(L.b_lon),
+                                     ptr(L.b_val), B * Cc, L.K, nlat_in, nlon_in, nlat_out, nlon_out, stream()), "mk_disco_bwd")
     return gx
 
 
@@ -207,19 +245,21 @@ class DiscreteContinuousConvS2(nn.Module):
         scale = math.sqrt(1.0 / self.groupsize / self.kernel_size)
         self.weight = nn.Parameter(scale * torch.randn(out_channels, self.groupsize, self.kernel_size))
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
-        psi = convolution_tensor(in_shape, out_shape, self.kernel_shape, basis_type=basis_type, grid_in=grid_in,
-                                 grid_out=grid_out, theta_cutoff=theta_cutoff, basis_norm_mode=basis_norm_mode)
-        self._psi = psi
+        self._key = _psi_key(in_shape, out_shape, self.kernel_shape, basis_type, grid_in, grid_out, theta_cutoff, basis_norm_mode)
+        if self._key not in _PSI_CACHE:
+            _PSI_CACHE[self._key] = convolution_tensor(in_shape, out_shape, self.kernel_shape, basis_type=basis_type,
+                                                       grid_in=grid_in, grid_out=grid_out, theta_cutoff=theta_cutoff,
+                                                       basis_norm_mode=basis_norm_mode)
+        psi = self._psi = _PSI_CACHE[self._key]
         idx = np.stack([psi["k"], psi["t"], psi["i"] * self.nlon_in + psi["j"]])
         self.register_buffer("psi_idx", torch.from_numpy(idx), persistent=False)
         self.register_buffer("psi_vals", torch.from_numpy(psi["v"]).float(), persistent=False)
-        self._lists = {}
 
     def _device_lists(self, device):
-        key = str(device)
-        if key not in self._lists:
-            self._lists[key] = _Lists(self._psi, (self.nlat_in, self.nlon_in), (self.nlat_out, self.nlon_out), device)
-        return self._lists[key]
+        key = (self._key, str(device))
+        if key not in _LIST_CACHE:
+            _LIST_CACHE[key] = _Lists(self._psi, (self.nlat_in, self.nlon_in), (self.nlat_out, self.nlon_out), device)
+        return _LIST_CACHE[key]
 
     @torch.compiler.disable(recursive=True)
     def forward(self, x):

@@ -98,7 +98,7 @@ class LaunchProfiler:
     def __init__(self):
         self.enabled = False
         self.only = None           # optional set of launch names to instrument (None = all)
-        self.records = []          # (name, start_event, end_event, flops, bytes)
+        self.records = []          # (name, start_event, end_event, flops, bytes, executed bf16-MFMA flops)
 
     def reset(self):
         self.records = []
@@ -106,12 +106,13 @@ class LaunchProfiler:
     def summary(self):
         """name -> dict(launches, ms_total, ms_avg, flops, bytes); call after a device synchronize."""
         out = {}
-        for name, e0, e1, fl, by in self.records:
-            d = out.setdefault(name, dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
+        for name, e0, e1, fl, by, mf in self.records:
+            d = out.setdefault(name, dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0, mfma_flops=0.0))
             d["launches"] += 1
             d["ms_total"] += e0.elapsed_time(e1)
             d["flops"] += fl
             d["bytes"] += by
+            d["mfma_flops"] += mf
         for d in out.values():
             d["ms_avg"] = d["ms_total"] / d["launches"]
         return out
@@ -121,8 +122,11 @@ PROFILER = LaunchProfiler()
 
 
 class _timed:
-    def __init__(self, name, flops=0.0, nbytes=0.0):
-        self.name, self.flops, self.nbytes = name, flops, nbytes
+    """``mfma_flops``: the bf16 matrix-core flops the launch actually EXECUTES (limb products and tile padding included,
+    structurally-zero tiles excluded) — what MFMA utilisation is measured with; ``flops`` is the dense formulation."""
+
+    def __init__(self, name, flops=0.0, nbytes=0.0, mfma_flops=0.0):
+        self.name, self.flops, self.nbytes, self.mfma_flops = name, flops, nbytes, mfma_flops
 
     def __enter__(self):
         self.on = PROFILER.enabled and (PROFILER.only is None or self.name in PROFILER.only)
@@ -135,7 +139,7 @@ class _timed:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record()
-            PROFILER.records.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+            PROFILER.records.append((self.name, self.e0, self.e1, self.flops, self.nbytes, self.mfma_flops))
         return False
 
 
@@ -209,6 +213,24 @@ def _gemm(**kw) -> MkGemm:
     return g
 
 
+def _limb_products() -> int:
+    return {"x6": 6, "x3": 3, "fp32": 16}[GEMM_MODE]       # fp32 MFMA = 1/16 of the bf16 rate: counted as 16 bf16-equivalents
+
+
+def _up(n, q):
+    return (n + q - 1) // q * q
+
+
+def _exec_rows_ge(nrows, nbatch, off=0, g=32):
+    """sum over batches b of the rows a kernel that skips dead row tiles of g rows executes (rows >= b + off are live)"""
+    return sum(max(0, _up(nrows, g) - min(_up(nrows, g), max(0, b + off) // g * g)) for b in range(nbatch))
+
+
+def _exec_le(n, nbatch, off=0, g=32):
+    """sum over batches b of min(n, b + off + 1) rounded up to the tile granularity g (rows / k <= b + off are live)"""
+    return sum(min(_up(n, g), _up(max(0, min(n, b + off + 1)), g)) for b in range(nbatch))
+
+
 def _presplit_ok() -> bool:
     return GEMM_GEN == "2" and GEMM_MODE != "fp32"
 
@@ -226,7 +248,8 @@ def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 
               M=L, N=2 * R, K=nlat, batch=M, tri_mode=_lib.TRI_ROW_GE, tri_off=m_off)
     # dense-formulation work: 2 * (2R) * nlat * L * M flops
     with _timed(f"legendre_analysis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
-                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
+                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat),
+                mfma_flops=2.0 * _limb_products() * _up(2 * R, 32) * _up(nlat, 16) * _exec_rows_ge(L, M, m_off)):
         _run_gemm(g, False, "legendre_analysis", a_limbs=limb_planes(matT) if _presplit_ok() else None)
     return S
 
@@ -243,7 +266,8 @@ def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int
               c_batch=nlat * 2 * R, c_row=2 * R,
               M=nlat, N=2 * R, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
     with _timed(f"legendre_synthesis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
-                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat)):
+                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat),
+                mfma_flops=2.0 * _limb_products() * _up(2 * R, 32) * _up(nlat, 32) * _exec_rows_ge(L, M, m_off, 16)):
         _run_gemm(g, False, "legendre_synthesis", a_limbs=limb_planes(mat) if _presplit_ok() else None)
     return F
 
@@ -313,7 +337,8 @@ def dhconv_fwd(S: torch.Tensor, W: torch.Tensor, B: int, cin: int, tri_off: int 
               M=M, N=cop, K=cin, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off)
     # dense-formulation work: 8 * B * Cin * Cout * L * M flops (complex MAC = 8 real flops)
     with _timed("dhconv_fwd", flops=8.0 * B * cin * cop * L * M,
-                nbytes=4.0 * (2 * B * cip * L * M + 2 * B * cop * L * M + 2 * cip * cop * L)):
+                nbytes=4.0 * (2 * B * cip * L * M + 2 * B * cop * L * M + 2 * cip * cop * L),
+                mfma_flops=8.0 * _limb_products() * B * _up(cin, 16) * _up(cop, 32) * _exec_le(M, L, tri_off)):
         _run_gemm(g, True, "dhconv_fwd")
     return T
 
@@ -331,7 +356,8 @@ def dhconv_dgrad(gT: torch.Tensor, W: torch.Tensor, B: int, cin: int, cout: int,
               c_batch=M * 2 * R, c_inner=xld, c_row=2 * R, c_im=R,
               M=M, N=cin, K=cout, batch=L * B, inner=B, tri_mode=_lib.TRI_ROW_LE, tri_off=tri_off, conj_b=1)
     with _timed("dhconv_dgrad", flops=8.0 * B * cin * cout * L * M,
-                nbytes=4.0 * (2 * B * cip * L * M + 2 * B * cop * L * M + 2 * cip * cop * L)):
+                nbytes=4.0 * (2 * B * cip * L * M + 2 * B * cop * L * M + 2 * cip * cop * L),
+                mfma_flops=8.0 * _limb_products() * B * _up(cout, 16) * _up(cin, 32) * _exec_le(M, L, tri_off)):
         _run_gemm(g, True, "dhconv_dgrad")
     return gS
 
@@ -358,7 +384,8 @@ def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0, gr
                   M=cip, N=cop, K=M, batch=L, inner=1, tri_mode=_lib.TRI_K_LE, tri_off=tri_off, conj_a=1,
                   beta=1 if b > 0 else 0)
         with _timed("dhconv_wgrad", flops=8.0 * cip * cop * L * M,
-                    nbytes=4.0 * (2 * cip * L * M + 2 * cop * L * M + 2 * cip * cop * L)):
+                    nbytes=4.0 * (2 * cip * L * M + 2 * cop * L * M + 2 * cip * cop * L),
+                    mfma_flops=8.0 * _limb_products() * _up(cip, 32) * _up(cop, 32) * _exec_le(M, L, tri_off, 16)):
             _run_gemm(g, True, "dhconv_wgrad")
     return gW
 
