@@ -11,9 +11,10 @@ import sys
 FAMILIES = [          # (family, regex on the kernel symbol, fetch correction)
     ("conv1x1_nn", r"^conv_nn_(astat|ring)?_?kernel", 2),
     ("conv1x1_wgrad", r"^conv_wgrad_(ring_)?kernel", 2),
-    ("dhconv_fwd", r"^xcgemm_kernel<true, false", 2),
-    ("dhconv_dgrad", r"^xcgemm_kernel<true, true", 2),
-    ("dhconv_wgrad", r"^xcgemm_kernel<false, false", 2),
+    ("dhconv_fwd", r"^xcgemm2?_kernel<true, false", 2),
+    ("dhconv_dgrad", r"^xcgemm2?_kernel<true, true", 2),
+    ("dhconv_wgrad", r"^xcgemm2?_kernel<false, false", 2),
+    ("legendre", r"^xgemm2?_kernel", 2),
     ("rfft_1440", r"^rfft_fast_kernel<720", 2),
     ("rfft_480", r"^rfft_fast_kernel<240", 2),
     ("irfft_1440", r"^irfft_fast_kernel<720", 1),
