@@ -217,6 +217,31 @@ def test_network_registers_with_the_reference_model_registry():
         mr._model_registry.pop(n, None)
 
 
+def test_fcn3_registers_with_the_reference_model_registry():
+    """FourCastNet3 through the reference's registry: by class and by the yaml "file.py:Class" string, constructed the way
+    get_model does (channel names arrive as yaml keys; inp_chans / out_chans and trainer keys are ignored)"""
+    from oracle import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip("reference tree not present")
+    mr = ref_shims.import_reference_module("makani.models.model_registry")
+    import makani_amd as ma
+    sys.path.insert(0, ROOT)
+    import makani_plugin
+    for n in ("FCN3_mi355x", "FCN3_mi355x_file"):
+        mr._model_registry.pop(n, None)
+    makani_plugin.register_fcn3("FCN3_mi355x")
+    assert mr._model_registry["FCN3_mi355x"] is ma.AtmoSphericNeuralOperatorNet
+    mr.register_model(os.path.join(ROOT, "makani_plugin.py") + ":AtmoSphericNeuralOperatorNet", "FCN3_mi355x_file")
+    cls = mr._model_registry["FCN3_mi355x_file"]
+    net = cls(inp_shape=(16, 32), out_shape=(16, 32), inp_chans=5, out_chans=4, scale_factor=2, filter_basis_type="morlet",
+              channel_names=["u500", "v500", "u850", "v850"], aux_channel_names=["xzen"], atmo_embed_dim=4, surf_embed_dim=4,
+              aux_embed_dim=2, num_layers=2, nettype="FCN3_mi355x_file", lr=1e-3, losses=[{"type": "l2"}])
+    assert type(net).__name__ == "AtmoSphericNeuralOperatorNet" and net.n_out_chans == 4 and net.n_aux_chans == 1
+    assert not hasattr(net, "surf_encoder")              # no surface variables in this channel list
+    for n in ("FCN3_mi355x", "FCN3_mi355x_file"):
+        mr._model_registry.pop(n, None)
+
+
 def test_reference_get_model_builds_and_drives_the_network():
     """the reference's own get_model (model_registry.py:123-262) constructs the registered MI355X network from a
     yaml-shaped parameter set (every yaml key arrives as a constructor kwarg), wraps it in its MultiStepWrapper +
