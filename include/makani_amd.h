@@ -87,10 +87,15 @@ int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream);
  *   bf16 limb planes — the Legendre matrices of th.RealSHT / th.InverseRealSHT [un-vendored; precomputed in
  *   makani_amd/legendre.py].  g->A is ignored; plane q of batch b holds A[b][k][row] at
  *   a_planes + q*pl_stride + b*pl_batch + k*pl_k + row (bf16 elements; row contiguous, pl_k % 8 == 0, rows beyond M
- *   inside pl_k are zero).  B must be [k][col] with the column index contiguous (b_col == 1), inner == 1. */
+ *   inside pl_k are zero).  B must be [k][col] with the column index contiguous (b_col == 1), inner == 1.
+ *   band_lo / band_hi (device int[batch], optional): outside [lo[b], hi[b]) every entry of A[b] is numerically zero by the
+ *   caller's threshold (the Legendre functions of order m vanish towards the poles like sin^m theta).  band_mode 1: a range
+ *   of k (analysis: the latitude sum is clipped); 2: a range of rows (synthesis: output latitudes outside the band are
+ *   written as exact zeros); 0: no band.  Neither A nor B is read outside the band. */
 int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream);
 int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, long long pl_stride, long long pl_batch,
-                              long long pl_k, int limbs, void* stream);
+                              long long pl_k, int limbs, const int* band_lo, const int* band_hi, int band_mode,
+                              void* stream);
 
 /* ---- longitude FFTs ----------------------------------------------------------
  * mk_rfft_rows: x[row][lat][lon] (f32|bf16)  ->  F-layout, modes m < mmax:

@@ -45,7 +45,7 @@ _SIGS = {
     "mk_sgemm_split_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
     "mk_cgemm_split_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
     "mk_cgemm_split2_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
-    "mk_sgemm_presplit_batched": ([C.POINTER(MkGemm), c_vp, c_ll, c_ll, c_ll, c_int, c_vp], c_int),
+    "mk_sgemm_presplit_batched": ([C.POINTER(MkGemm), c_vp, c_ll, c_ll, c_ll, c_int, c_vp, c_vp, c_int, c_vp], c_int),
     "mk_rfft_rows": ([c_vp, c_int, c_vp, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_f, c_f, c_f, c_vp], c_int),
     "mk_irfft_rows": ([c_vp, c_vp, c_int, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -465,6 +465,14 @@ struct PreA {
     const u16* planes;
     long long pl_stride, pl_batch, pl_k;
     int rows_valid;            // rows readable per k-row (multiple of 8)
+    // optional numerical band of the constant matrix per batch (device arrays of `batch` ints, or null): outside
+    // [lo[b], hi[b]) every entry of A[b] is below the caller's threshold (the Legendre functions of order m vanish
+    // towards the poles like sin^m).  mode 1: the band is a range of k (analysis: contraction over latitude) ->
+    // the k-loop is clipped; mode 2: a range of rows (synthesis: output latitudes) -> rows outside are written as
+    // exact zeros without being computed.  Skips A AND B traffic of the dead part.
+    const int* band_lo;
+    const int* band_hi;
+    int band_mode;
 };
 
 template <int NP>
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     constexpr int STG = 2 * NP * PL;
     __shared__ __attribute__((aligned(16))) u16 smem[2 * STG];
 
-    const BlockCoord c = decode_block2<BM, BN>(p, tilesM, tilesN);
+    BlockCoord c = decode_block2<BM, BN>(p, tilesM, tilesN);
     if (!c.active) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2, cs = wave & 3;
@@ -484,11 +492,21 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
     const u16* Ab = a.planes + (long long)c.b * a.pl_batch;
 
-    // live 32-row tiles of this block: [t0, t1)
+    // rows of this block that are stored: 32-row tiles [s0, s1); rows that are computed: tiles [t0, t1) inside them
     const int rows_end = min(c.Meff, p.M) - c.i0;          // rows of this block that exist
-    int t0 = 0;
-    if (p.tri_mode == MK_TRI_ROW_GE) t0 = max(0, (c.b / p.inner + p.tri_off - c.i0) / 32);
-    const int t1 = min(BM / 32, (rows_end + 31) / 32);
+    int s0 = 0;
+    if (p.tri_mode == MK_TRI_ROW_GE) s0 = max(0, (c.b / p.inner + p.tri_off - c.i0) / 32);
+    const int s1 = min(BM / 32, (rows_end + 31) / 32);
+    int t0 = s0, t1 = s1;
+    if (a.band_mode == 1) {
+        c.klo = max(c.klo, a.band_lo[c.b]);
+        c.khi = min(c.khi, a.band_hi[c.b]);
+        if (c.khi < c.klo) c.khi = c.klo;
+    } else if (a.band_mode == 2) {
+        t0 = max(s0, (a.band_lo[c.b] - c.i0) >> 5);                    // floor (arithmetic shift of a possibly negative value)
+        t1 = min(s1, (a.band_hi[c.b] - c.i0 + 31) >> 5);
+        if (t1 < t0) t1 = t0;
+    }
     int tile[4];
     bool live[4];
 #pragma unroll
@@ -593,6 +611,20 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     }
 
     float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
+    if (a.band_mode == 2 && !p.beta) {                     // stored rows outside the band: exact zeros
+        for (int t = s0 + grp; t < s1; t += 2) {
+            if (t >= t0 && t < t1) continue;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = c.j0 + cs * 64 + n * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = c.i0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < c.Meff && col < p.N) Cb[(long long)row * p.c_row + col] = 0.f;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (!live[j]) continue;
@@ -651,7 +683,8 @@ extern "C" int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream)
 }
 
 extern "C" int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, long long pl_stride, long long pl_batch,
-                                         long long pl_k, int limbs, void* stream) {
+                                         long long pl_k, int limbs, const int* band_lo, const int* band_hi, int band_mode,
+                                         void* stream) {
     MK_REQUIRE(g && a_planes && g->B && g->C, "presplit gemm: null pointer");
     MK_REQUIRE(g->M > 0 && g->N > 0 && g->K >= 0 && g->batch > 0, "presplit gemm: bad extents");
     MK_REQUIRE(limbs == 2 || limbs == 3, "presplit gemm: limbs must be 2 or 3");
@@ -665,7 +698,9 @@ extern "C" int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, 
     const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
     const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
     MK_REQUIRE(nb < (1ll << 31), "presplit gemm: grid too large");
-    PreA a{(const u16*)a_planes, pl_stride, pl_batch, pl_k, (int)(pl_k & ~7ll)};
+    MK_REQUIRE(band_mode == 0 || ((band_mode == 1 || band_mode == 2) && band_lo && band_hi),
+               "presplit gemm: band_mode must be 0, or 1 / 2 with both band arrays");
+    PreA a{(const u16*)a_planes, pl_stride, pl_batch, pl_k, (int)(pl_k & ~7ll), band_lo, band_hi, band_mode};
     dim3 grid((unsigned)nb), block(NT2);
     hipStream_t s = (hipStream_t)stream;
     if (limbs == 3)

@@ -61,7 +61,7 @@ def _launch_gemm(g, cplx, engine, a_planes=None):
         else:
             pl = a_planes
             rc = lib().mk_sgemm_presplit_batched(C.byref(g), C.c_void_p(pl.data_ptr()), pl.stride(0), pl.stride(1), pl.stride(2),
-                                                 limbs, C.c_void_p(0))
+                                                 limbs, None, None, 0, C.c_void_p(0))
     else:
         rc = (lib().mk_cgemm_split_batched if cplx else lib().mk_sgemm_split_batched)(C.byref(g), 3 if engine == "x6" else 2, C.c_void_p(0))
     check(rc, "gemm")
