@@ -1,0 +1,197 @@
+// Ensemble CRPS on the sphere: pointwise score over the ensemble dimension + quadrature over the plane, fused (gfx950).
+//
+// Replaces the kernels of makani/utils/losses/crps_loss.py ("skillspread" :124-162 — the default of CRPSLoss :277-452 —,
+// "probability weighted moment" :164-203, "naive skillspread" :205-243, "gauss" :245-275) together with the quadrature sum
+// `torch.sum(crps * quad_weight * spatial_weights, dim=-1)` (:435-438) and their autograd.
+//
+//   forecasts f[b][e][c][p]  (B, E, C, HW) f32 | bf16      observations o[b][c][p] (f32 | bf16)
+//   out[b * C + c] = sum_p q[p] * w[b][c][p] * crps(o, f[:, p])                      (w optional)
+//   gf[b][e][c][p] = gout[b * C + c] * q[p] * w * d crps / d f_e
+//
+// One thread owns one point: the E <= 32 members live in registers, ranks come from E^2 comparisons (ordinal ranks with the
+// stable tie order of torch.argsort, as rankdata() of the reference), everything else is a handful of flops: the kernel reads
+// (E + 1) values and, in backward, writes E — HBM-bound.  A NaN observation scores 0 and yields zero gradients, as the
+// reference's masking does.
+#include "common.h"
+
+namespace {
+
+constexpr int CNT = 256;
+constexpr int MAXE = 32;
+
+template <typename T>
+__device__ __forceinline__ float ldv(const T* p);
+template <>
+__device__ __forceinline__ float ldv<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ldv<u16>(const u16* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stv(u16* p, float v) { *p = f32_to_bf16(v); }
+
+enum { CRPS_SKILLSPREAD = 0, CRPS_PWM = 1, CRPS_NAIVE = 2, CRPS_GAUSS = 3 };
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// score of one point and (GRAD) its derivative with respect to every member, written back into f[]
+template <int E, bool GRAD>
+__device__ __forceinline__ float crps_point(float (&f)[E], float obs, int type, float alpha, float eps) {
+    const bool masked = type != CRPS_GAUSS && obs != obs;      // NaN observation (the gauss kernel of the reference does not mask)
+    const float o = masked ? 0.f : obs;
+    const float inv_e = 1.f / (float)E;
+    float skill = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) skill += fabsf(o - f[e]);
+    skill *= inv_e;
+    float score;
+    float g[E];
+    if (type == CRPS_GAUSS) {
+        float mu = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) mu += f[e];
+        mu *= inv_e;
+        float var = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) var += (f[e] - mu) * (f[e] - mu);
+        var *= inv_e;
+        const float sraw = sqrtf(var);
+        const float sigma = fmaxf(sraw, eps);
+        const float z = (obs - mu) / sigma;
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+        const float cdf2m1 = erff(z * 0.7071067811865476f);
+        score = sigma * (z * cdf2m1 + 2.f * pdf - 0.5641895835477563f);
+        if (GRAD) {
+            const float dmu = -cdf2m1, dsig = 2.f * pdf - 0.5641895835477563f;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                g[e] = dmu * inv_e + ((sraw > eps) ? dsig * (f[e] - mu) * inv_e / sigma : 0.f);
+        }
+    } else {
+        // ordinal ranks 1..E: members smaller than f_e, plus equal members that come before e
+        float acc = 0.f;               // sum_e (2 r_e - E - 1) f_e   (skillspread / naive)   or   sum_e (r_e - 1) f_e   (pwm)
+        float mean = 0.f;
+        float coef[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int r = 1;
+            float ssum = 0.f;          // sum_j sign(f_e - f_j)   (naive form: zero contribution from ties)
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                r += (f[j] < f[e] || (f[j] == f[e] && j < e)) ? 1 : 0;
+                ssum += sgn(f[e] - f[j]);
+            }
+            coef[e] = (type == CRPS_PWM) ? (float)(r - 1) : ((type == CRPS_NAIVE) ? ssum : (float)(2 * r - E - 1));
+            acc += coef[e] * f[e];
+            mean += f[e];
+        }
+        mean *= inv_e;
+        if (type == CRPS_PWM) {
+            const float c1 = 1.f / (float)(E * (E - 1));
+            score = skill + mean - 2.f * acc * c1;
+            if (GRAD) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) g[e] = sgn(f[e] - o) * inv_e + inv_e - 2.f * coef[e] * c1;
+            }
+        } else {
+            // espread = 2 mean((2r - E - 1) f) (E - 1 + alpha) / (E (E - 1));  naive: sum_ij |f_i - f_j| (E - 1 + alpha) / (E^2 (E - 1))
+            const float c = ((float)E - 1.f + alpha) / (float)(E * (E - 1));
+            score = skill - acc * inv_e * c;
+            if (GRAD) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) g[e] = sgn(f[e] - o) * inv_e - coef[e] * inv_e * c;
+            }
+        }
+    }
+    if (GRAD) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) f[e] = masked ? 0.f : g[e];
+    }
+    return masked ? 0.f : score;
+}
+
+// grid: (chunks, planes = B * C).  Forward: partial[plane][chunk]; backward: gf written in place of the loop.
+template <typename TF, typename TO, int E, bool GRAD>
+__global__ __launch_bounds__(CNT) void crps_kernel(const TF* __restrict__ f, const TO* __restrict__ obs, const float* __restrict__ q,
+                                                   const float* __restrict__ w, const float* __restrict__ gout, float* __restrict__ partial,
+                                                   TF* __restrict__ gf, int C, long long hw, int type, float alpha, float eps) {
+    __shared__ float red[CNT / 64];
+    const int plane = blockIdx.y, b = plane / C, c = plane % C;
+    const long long estride = (long long)C * hw;
+    const TF* fp = f + ((long long)b * E * C + c) * hw;
+    const TO* op = obs + (long long)plane * hw;
+    const float* wp = w ? w + (long long)plane * hw : nullptr;
+    const float go = GRAD ? gout[plane] : 0.f;
+    float sum = 0.f;
+    for (long long p = (long long)blockIdx.x * CNT + threadIdx.x; p < hw; p += (long long)gridDim.x * CNT) {
+        float v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = ldv(fp + e * estride + p);
+        const float s = crps_point<E, GRAD>(v, ldv(op + p), type, alpha, eps);
+        const float wt = q[p] * (wp ? wp[p] : 1.f);
+        if (GRAD) {
+            TF* gp = gf + ((long long)b * E * C + c) * hw;
+#pragma unroll
+            for (int e = 0; e < E; ++e) stv(gp + e * estride + p, go * wt * v[e]);
+        } else {
+            sum += wt * s;
+        }
+    }
+    if (!GRAD) {
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < CNT / 64; ++i) t += red[i];
+            partial[(long long)plane * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
+template <typename TF, typename TO, bool GRAD>
+int launch_e(int E, dim3 grid, hipStream_t s, const TF* f, const TO* obs, const float* q, const float* w, const float* gout,
+             float* partial, TF* gf, int C, long long hw, int type, float alpha, float eps) {
+#define MK_CRPS_E(N)                                                                                                           \
+    case N:                                                                                                                    \
+        hipLaunchKernelGGL((crps_kernel<TF, TO, N, GRAD>), grid, dim3(CNT), 0, s, f, obs, q, w, gout, partial, gf, C, hw, type, \
+                           alpha, eps);                                                                                        \
+        break
+    switch (E) {
+        MK_CRPS_E(2); MK_CRPS_E(3); MK_CRPS_E(4); MK_CRPS_E(5); MK_CRPS_E(6); MK_CRPS_E(7); MK_CRPS_E(8); MK_CRPS_E(10); MK_CRPS_E(12);
+        MK_CRPS_E(16); MK_CRPS_E(20); MK_CRPS_E(24); MK_CRPS_E(32);
+        default:
+            mk_set_error("crps: ensemble size %d is not instantiated (2-8, 10, 12, 16, 20, 24, 32)", E);
+            return MK_EUNSUP;
+    }
+#undef MK_CRPS_E
+    return mk_check_launch("mk_crps");
+}
+
+}  // namespace
+
+extern "C" int mk_crps_chunks(long long hw) {
+    long long c = (hw + 4 * CNT - 1) / (4 * CNT);
+    return (int)(c < 1 ? 1 : (c > 64 ? 64 : c));
+}
+
+// grad == 0: partial (planes * mk_crps_chunks(hw)) f32 receives the chunk sums (the caller adds them up);
+// grad == 1: gf (same shape and dtype as f) receives gout[plane] * q * w * dcrps/df
+extern "C" int mk_crps(const void* f, int f_dtype, const void* obs, int o_dtype, const float* q, const float* w, const float* gout,
+                       float* partial, void* gf, int B, int E, int C, long long hw, int type, float alpha, float eps, int grad,
+                       void* stream) {
+    MK_REQUIRE(f && obs && q && B > 0 && E >= 2 && E <= MAXE && C > 0 && hw > 0, "crps: bad arguments (2 <= E <= 32)");
+    MK_REQUIRE(type >= 0 && type <= 3, "crps: unknown score type %d", type);
+    MK_REQUIRE(grad ? (gout && gf) : (partial != nullptr), "crps: missing output");
+    MK_REQUIRE((long long)B * C <= 65535, "crps: too many planes");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)mk_crps_chunks(hw), (unsigned)(B * C));
+#define MK_CRPS_GO(TF, TO)                                                                                                          \
+    return grad ? launch_e<TF, TO, true>(E, grid, s, (const TF*)f, (const TO*)obs, q, w, gout, partial, (TF*)gf, C, hw, type, alpha, eps) \
+                : launch_e<TF, TO, false>(E, grid, s, (const TF*)f, (const TO*)obs, q, w, gout, partial, (TF*)gf, C, hw, type, alpha, eps)
+    if (f_dtype == MK_F32 && o_dtype == MK_F32) MK_CRPS_GO(float, float);
+    if (f_dtype == MK_BF16 && o_dtype == MK_F32) MK_CRPS_GO(u16, float);
+    if (f_dtype == MK_BF16 && o_dtype == MK_BF16) MK_CRPS_GO(u16, u16);
+    if (f_dtype == MK_F32 && o_dtype == MK_BF16) MK_CRPS_GO(float, u16);
+#undef MK_CRPS_GO
+    mk_set_error("crps: unsupported dtype combination");
+    return MK_EINVAL;
+}

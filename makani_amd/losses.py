@@ -337,3 +337,92 @@ class GeometricLpLoss(nn.Module):
     @torch.compiler.disable(recursive=True)
     def forward(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None, **kwargs):
         return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)
+
+
+# --------------------------------------------------------------------------- #
+# ensemble CRPS (makani/utils/losses/crps_loss.py:277-452)
+# --------------------------------------------------------------------------- #
+_CRPS_TYPES = {"skillspread": 0, "probability weighted moment": 1, "naive skillspread": 2, "gauss": 3}
+
+
+class CrpsFn(torch.autograd.Function):
+    """out[b, c] = sum_p q[p] * w[b, c, p] * crps(obs[b, c, p], forecasts[b, :, c, p]); gradient w.r.t. the forecasts"""
+
+    @staticmethod
+    def forward(ctx, forecasts, obs, q, wgt, ctype, alpha, eps):
+        B, E, Cc, H, W = forecasts.shape
+        hw = H * W
+        f, o = _prep(forecasts), _prep(obs)
+        w = wgt.float().contiguous() if wgt is not None else None
+        ch = lib().mk_crps_chunks(hw)
+        partial = torch.empty((B * Cc, ch), dtype=torch.float32, device=f.device)
+        check(lib().mk_crps(ptr(f), dtype_code(f), ptr(o), dtype_code(o), ptr(q), ptr(w), None, ptr(partial), None, B, E, Cc, hw,
+                            ctype, float(alpha), float(eps), 0, stream()), "mk_crps")
+        ctx.save_for_backward(f, o, q, w if w is not None else torch.empty(0, device=f.device))
+        ctx.meta = (ctype, alpha, eps, w is not None, forecasts.dtype)
+        return partial.sum(dim=1).reshape(B, Cc)
+
+    @staticmethod
+    def backward(ctx, g):
+        f, o, q, w = ctx.saved_tensors
+        ctype, alpha, eps, has_w, dt = ctx.meta
+        B, E, Cc, H, W = f.shape
+        gf = torch.empty_like(f)
+        go = g.float().contiguous()
+        check(lib().mk_crps(ptr(f), dtype_code(f), ptr(o), dtype_code(o), ptr(q), ptr(w) if has_w else None, ptr(go), None,
+                            ptr(gf), B, E, Cc, H * W, ctype, float(alpha), float(eps), 1, stream()), "mk_crps")
+        return gf.to(dt), None, None, None, None, None, None
+
+
+class CRPSLoss(nn.Module):
+    """``CRPSLoss`` of ``makani/utils/losses/crps_loss.py:277-452``: ``forward(forecasts (B, E, C, H, W), observations
+    (B, C, H, W), spatial_weights=None) -> (B, C)``, the quadrature-weighted ensemble CRPS.  Score and quadrature are one HIP
+    kernel (``csrc/crps.hip``), the gradient with respect to the forecasts one more.  Built: ``crps_type`` "skillspread"
+    (default, with the almost-fair factor ``alpha``), "naive skillspread", "probability weighted moment", "gauss";
+    constant ensemble weights; the "cdf" form, weighted ensembles and the ensemble-parallel transpose are not."""
+
+    def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
+                 channel_names: List[str], grid_type: str, crps_type: str = "skillspread",
+                 spatial_distributed: Optional[bool] = False, ensemble_distributed: Optional[bool] = False,
+                 ensemble_weights: Optional[torch.Tensor] = None, alpha: Optional[float] = 1.0, eps: Optional[float] = 1.0e-6,
+                 **kwargs):
+        super().__init__()
+        self.img_shape, self.crop_shape, self.crop_offset = img_shape, crop_shape, crop_offset
+        self.channel_names = channel_names
+        self.quadrature = GridQuadrature(grid_to_quadrature_rule(grid_type), img_shape=img_shape, crop_shape=crop_shape,
+                                         crop_offset=crop_offset, normalize=True, distributed=spatial_distributed)
+        self.spatial_distributed = self.quadrature.distributed
+        if ensemble_distributed:
+            raise NotImplementedError("the ensemble-parallel CRPS (transpose over the 'ensemble' group) is not built")
+        if ensemble_weights is not None:
+            raise NotImplementedError("currently only constant ensemble weights are supported")
+        if crps_type == "cdf":
+            raise NotImplementedError("crps_type='cdf' is not built (skillspread, naive skillspread, probability weighted "
+                                      "moment and gauss are)")
+        if crps_type not in _CRPS_TYPES:
+            raise ValueError(f"Unknown CRPS crps_type {crps_type}")
+        if crps_type not in ("skillspread", "naive skillspread") and alpha < 1.0:
+            raise NotImplementedError("The alpha parameter (almost fair CRPS factor) is only supported for the skillspread kernels.")
+        self.crps_type, self.alpha, self.eps = crps_type, alpha, eps
+        self.register_buffer("quad_weight_split", self.quadrature.quad_weight.reshape(1, 1, -1).contiguous(), persistent=False)
+
+    @property
+    def n_channels(self):
+        return len(self.channel_names)
+
+    @torch.compiler.disable(recursive=True)
+    def forward(self, forecasts: torch.Tensor, observations: torch.Tensor, spatial_weights: Optional[torch.Tensor] = None,
+                **kwargs) -> torch.Tensor:
+        if forecasts.dim() != 5:
+            raise ValueError(f"Error, forecasts tensor expected to have 5 dimensions but found {forecasts.dim()}.")
+        if spatial_weights is not None and spatial_weights.dim() != observations.dim():
+            raise ValueError(f"the weights have to have the same number of dimensions (found {spatial_weights.dim()}) as "
+                             f"observations (found {observations.dim()}).")
+        B, E, Cc, H, W = forecasts.shape
+        if E == 1:            # |obs - forecast| under the quadrature (crps_loss.py:375-377)
+            crps = self.quadrature.lp(forecasts.squeeze(1), observations, spatial_weights, 1.0).reshape(B, Cc)
+            return crps
+        w = spatial_weights.expand(B, Cc, H, W) if spatial_weights is not None else None
+        crps = CrpsFn.apply(forecasts, observations, self.quad_weight_split.reshape(-1), w,
+                            _CRPS_TYPES[self.crps_type], self.alpha, self.eps)
+        return self.quadrature._reduce(crps)

@@ -114,6 +114,47 @@ def sfno_layernorm_fixture():
     )
 
 
+def crps_fixtures():
+    """CRPSLoss (makani/utils/losses/crps_loss.py:277-452, the reference's own module): every built crps_type, with and
+    without spatial weights, a NaN observation, ties between members, E = 1: values and forecast gradients."""
+    CRPSLoss = ref_shims.import_reference_module("makani.utils.losses.crps_loss").CRPSLoss
+    cases = [
+        dict(img=(19, 36), grid="equiangular", E=4, crps_type="skillspread", alpha=1.0, wgt=False, nan=False, ties=False),
+        dict(img=(19, 36), grid="equiangular", E=5, crps_type="skillspread", alpha=0.95, wgt=True, nan=True, ties=True),
+        dict(img=(12, 24), grid="legendre-gauss", E=8, crps_type="naive skillspread", alpha=1.0, wgt=False, nan=False, ties=False),
+        dict(img=(12, 24), grid="legendre-gauss", E=3, crps_type="probability weighted moment", alpha=1.0, wgt=True, nan=True, ties=False),
+        dict(img=(17, 32), grid="equiangular", E=16, crps_type="gauss", alpha=1.0, wgt=False, nan=False, ties=False),
+        # E = 1 (the reference's own E = 1 branch fails with spatial weights: crps_loss.py:375-437 leaves
+        # spatial_weights_split unbound)
+        dict(img=(17, 32), grid="equiangular", E=1, crps_type="skillspread", alpha=1.0, wgt=False, nan=False, ties=False),
+    ]
+    rec = {"cases": json.dumps(cases)}
+    for i, c in enumerate(cases):
+        torch.manual_seed(500 + i)
+        B, C = 2, 3
+        mod = CRPSLoss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0), channel_names=[str(k) for k in range(C)],
+                       grid_type=c["grid"], crps_type=c["crps_type"], alpha=c["alpha"])
+        f = torch.randn(B, c["E"], C, *c["img"])
+        if c["ties"]:
+            f[:, 1] = f[:, 0]                      # two equal members everywhere: ordinal ranks break the tie by position
+            f[:, 3, :, ::2] = f[:, 2, :, ::2]
+        f.requires_grad_(True)
+        o = torch.randn(B, C, *c["img"])
+        if c["nan"]:
+            o[0, 1, 3, 5] = float("nan")
+            o[1, 2, :2] = float("nan")
+        wgt = torch.rand(B, C, *c["img"]) + 0.5 if c["wgt"] else None
+        out = mod(f, o, wgt)
+        g = torch.randn_like(out)
+        (out * g).sum().backward()
+        rec[f"{i}_f"], rec[f"{i}_o"], rec[f"{i}_g"], rec[f"{i}_out"], rec[f"{i}_df"] = _np(f), _np(o), _np(g), _np(out), _np(f.grad)
+        if wgt is not None:
+            rec[f"{i}_wgt"] = _np(wgt)
+    path = os.path.join(OUT, "crps_loss.npz")
+    np.savez_compressed(path, **rec)
+    print(f"crps_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
+
 def fcn3_fixtures():
     """FourCastNet3 (makani/models/networks/fourcastnet3.py, the reference's own module) on top of the restated
     torch-harmonics operators: SHT (oracle/sht.py) and DISCO convolution / ResampleS2 (oracle/disco.py).  The DISCO
@@ -384,7 +425,7 @@ def main():
         raise SystemExit("reference tree not found; golden fixtures can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss", "stepper", "fcn3"]
+    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss", "stepper", "fcn3", "crps"]
     if "contractions" in which:
         contraction_fixtures()
     if "spectral_conv" in which:
@@ -399,6 +440,8 @@ def main():
         stepper_fixtures()
     if "fcn3" in which:
         fcn3_fixtures()
+    if "crps" in which:
+        crps_fixtures()
 
 
 if __name__ == "__main__":
