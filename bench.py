@@ -369,7 +369,9 @@ def run_worker(args):
     B = 1
     model = build_model(args.config, device, seed=333)            # same seed on every rank -> same init
     opt = make_optimizer(model)
-    net = thd.init_gradient_reduction_hooks(model, device)         # mappings.py:321-525 (the model itself when world == 1)
+    # mappings.py:321-525 (the model itself when world == 1); --zero: ZeRO-1 over the data group (reduce-scattered
+    # gradients, sharded AdamW state, in-place parameter all-gather: makani_amd/optim.py)
+    net = thd.init_gradient_reduction_hooks(model, device, zero=args.zero and dsize > 1)
     if args.multistep_count > 1:                                   # makani/models/stepper.py:176-345
         from makani_amd.stepper import MultiStepWrapper
         net = MultiStepWrapper(net, n_future=args.multistep_count - 1, multistep_checkpoint=args.multistep_checkpoint).train()
@@ -559,6 +561,8 @@ def _worker_cmd(args, parallelism):
            "--no-cpu-baseline", "--multistep-count", str(args.multistep_count), "--graph", args.graph]
     if args.fp32:
         cmd.append("--fp32")
+    if args.zero:
+        cmd.append("--zero")
     if args.multistep_checkpoint:
         cmd.append("--multistep-checkpoint")
     return cmd
@@ -652,6 +656,10 @@ def main():
                          "4: h4w1, 8: h4w2 — strong scaling), 'dp' (one sample per GPU, weak scaling) or 'hHwW': spatial "
                          "model parallelism over H x W GPUs per model instance, remaining ranks data parallel")
     ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the second (data-parallel) measurement")
+    ap.add_argument("--zero", action="store_true",
+                    help="data parallelism with ZeRO-1: reduce-scatter the large gradients, shard the AdamW state over the data "
+                         "group, all-gather the parameters (gloo-tested; off by default because RCCL with N > 1 ranks cannot "
+                         "be exercised in the development environment)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="capture the train step in a hipGraph and replay it (auto: on one GPU)")
     ap.add_argument("--multistep-count", type=int, default=1,

@@ -459,9 +459,14 @@ class GradReducer:
     the gradients (views), so nothing is copied back.  ``finish()`` runs automatically at the end of ``backward()``
     (autograd engine callback, the mechanism DDP uses) and is idempotent, so calling it explicitly is harmless."""
 
-    def __init__(self, model, comm=None, big_bytes=8 << 20):
+    def __init__(self, model, comm=None, big_bytes=8 << 20, zero=False):
+        """``zero``: ZeRO-1 over the data group — the data-parallel stage of every gradient of at least ``big_bytes``
+        whose size divides evenly is a REDUCE-SCATTER: rank r of the data group ends up with the mean of slice r of the
+        flattened gradient in ``param._mk_zero[0]`` (``p.grad`` keeps the local, unreduced values), which
+        ``makani_amd.optim.FusedAdamW`` consumes (sharded optimizer state, in-place all-gather of the parameter)."""
         self.comm = comm or _comm
         self.big_bytes = big_bytes
+        self.zero = bool(zero)
         self.pending = []          # (work, real-view gradient, remaining stages)
         self.small = {}            # signature -> (stages, [params])
         self._armed = False
@@ -515,11 +520,38 @@ class GradReducer:
             from torch.autograd import Variable
             Variable._execution_engine.queue_callback(self.finish)
 
+    def _scatter_ok(self, g, stages):
+        n = dist.get_world_size(stages[-1][0])
+        return (self.zero and stages[-1][0] is self.comm.get_group("data") and n > 1 and g.numel() % (4 * n) == 0
+                and g.dtype == torch.float32)
+
+    def _issue_stage(self, p, g, stages):
+        """the next stage of a big gradient: an all-reduce, or (ZeRO, last stage = data) a reduce-scatter into the shard"""
+        if len(stages) == 1 and self._scatter_ok(g, stages):
+            grp, kind, _ = stages[0]
+            n = dist.get_world_size(grp)
+            flat = g.reshape(-1)
+            z = getattr(p, "_mk_zero", None)
+            shard = z[0] if z is not None and z[0] is not None and z[0].numel() == flat.numel() // n else None
+            if shard is None:
+                old = getattr(p, "_mk_zero_buf", None)
+                shard = old if old is not None and old.numel() == flat.numel() // n else torch.empty(flat.numel() // n, dtype=g.dtype, device=g.device)
+                p._mk_zero_buf = shard
+            p._mk_zero = (shard, grp, n, dist.get_rank(grp))
+            op = dist.ReduceOp.AVG if kind == "avg" else dist.ReduceOp.SUM
+            if dist.get_backend(grp) == "gloo":              # (CPU tests) gloo has no reduce_scatter_tensor
+                tmp = flat.clone()
+                work = dist.all_reduce(tmp, op=op, group=grp, async_op=True)
+                return _ScatterAfter(work, tmp, shard, dist.get_rank(grp))
+            return dist.reduce_scatter_tensor(shard, flat, op=op, group=grp, async_op=True)
+        return self._issue(g, stages[0])
+
     def _hook(self, p, stages):
         self._arm()
         g = _real(p.grad)
-        if g.numel() * g.element_size() >= self.big_bytes and g.is_contiguous():
-            self.pending.append([self._issue(g, stages[0]), g, list(stages)])
+        dense = g if g.is_contiguous() else _dense(g)
+        if dense is not None and dense.numel() * dense.element_size() >= self.big_bytes:
+            self.pending.append([self._issue_stage(p, dense, list(stages)), dense, list(stages), p])
         else:
             self.small.setdefault(tuple((id(s[0]), s[1]) for s in stages), (stages, []))[1].append(p)
 
@@ -545,13 +577,31 @@ class GradReducer:
         self.small = {}
         while self.pending:
             nxt = []
-            for work, g, stages in self.pending:
+            for work, g, stages, p in self.pending:
                 work.wait()
+                scattered = len(stages) == 1 and self._scatter_ok(g, stages)
                 if stages[0][2] != 1.0:
-                    g.mul_(stages[0][2])
+                    (p._mk_zero[0] if scattered else g).mul_(stages[0][2])
                 if len(stages) > 1:
-                    nxt.append([self._issue(g, stages[1]), g, stages[1:]])
+                    nxt.append([self._issue_stage(p, g, stages[1:]), g, stages[1:], p])
             self.pending = nxt
+
+
+class _ScatterAfter:
+    """gloo stand-in for an asynchronous reduce-scatter (CPU tests): all-reduce a copy, keep this rank's slice"""
+
+    def __init__(self, work, tmp, shard, rank):
+        self.work, self.tmp, self.shard, self.rank = work, tmp, shard, rank
+
+    def wait(self):
+        self.work.wait()
+        n = self.shard.numel()
+        self.shard.copy_(self.tmp[self.rank * n:(self.rank + 1) * n])
+
+
+def _dense(t):
+    from ._lib import dense_view
+    return dense_view(t)
 
 
 class GradReduceWrapper(nn.Module):
@@ -569,7 +619,7 @@ class GradReduceWrapper(nn.Module):
 
 def init_gradient_reduction_hooks(model, device=None, reduction_buffer_count=1, broadcast_buffers=True,
                                   find_unused_parameters=False, gradient_as_bucket_view=True, static_graph=False,
-                                  verbose=None, comm=None):
+                                  verbose=None, comm=None, zero=False):
     """Signature and semantics of ``makani/mpu/mappings.py:321-525``: returns the model unchanged when
     ``torch.distributed`` is not initialised, otherwise a wrapper (``.module`` = the model) whose backward pass performs
     the data-parallel mean and the per-group sums of the ``is_shared_mp`` annotations.  The DDP-specific knobs are
@@ -579,7 +629,7 @@ def init_gradient_reduction_hooks(model, device=None, reduction_buffer_count=1, 
     c = comm or _comm
     if not c.is_initialized():
         c.autodetect()
-    red = GradReducer(model, c)
+    red = GradReducer(model, c, zero=zero)
     if verbose:
         for n, st in red.plan.items():
             print(f"[grad reduction] {n}: {[(k, dist.get_world_size(g)) for g, k, _ in st]}")
@@ -593,6 +643,11 @@ def total_grad_norm(model, comm=None):
     c = comm or _comm
     groups = {}
     for p in model.parameters():
+        z = getattr(p, "_mk_zero", None)
+        if z is not None and z[0] is not None:          # ZeRO: this rank holds the reduced slice; the slices add up over "data"
+            key = tuple(g for g in getattr(p, "sharded_dims_mp", []) if g is not None and c.get_size(g) > 1) + ("data",)
+            groups.setdefault(key, []).append(z[0])
+            continue
         if p.grad is None:
             continue
         key = tuple(g for g in getattr(p, "sharded_dims_mp", []) if g is not None and c.get_size(g) > 1)

@@ -303,3 +303,85 @@ def test_parse_parallelism():
     assert [bench.default_parallelism(n) for n in (1, 2, 4, 8)] == ["dp", "h2w1", "h4w1", "h4w2"]
     with pytest.raises(SystemExit):
         bench.parse_parallelism("tp8")
+
+
+# --------------------------------------------------------------------------- #
+# ZeRO-1: reduce-scattered gradients + sharded optimizer state + in-place parameter all-gather
+# --------------------------------------------------------------------------- #
+def _worker_zero(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd.comm as mcomm
+        import makani_amd.distributed as thd
+        import makani_amd.optim as mo
+        mcomm.init(1, 1)
+
+        # torch stand-ins for the three HIP operations of the big-tensor path (the product has no CPU path)
+        def advance(sdev, b1, b2):
+            sdev[0] += 1
+            sdev[1] = 1.0 / (1.0 - b1 ** float(sdev[0]))
+            sdev[2] = 1.0 / math.sqrt(1.0 - b2 ** float(sdev[0]))
+
+        def adamw(pr, gr, m, v, scale, lr, b1, b2, eps, wd, sdev):
+            g = gr * (scale if scale is not None else 1.0)
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            pr.mul_(1 - lr * wd).sub_(lr * float(sdev[1]) * m / (v.sqrt() * float(sdev[2]) + eps))
+
+        def sumsq_clip(grads, max_norm):
+            n = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float().reshape(1)
+            coef = torch.clamp(max_norm / (n + 1e-6), max=1.0) if max_norm else torch.ones(1)
+            return torch.cat([coef, n])
+        mo._k_advance, mo._k_adamw, mo._k_sumsq_clip = advance, adamw, sumsq_clip
+        mo.SMALL = 0                                           # every tensor takes the big-tensor path in this test
+
+        torch.manual_seed(0)
+        model = torch.nn.Module()
+        model.w = torch.nn.Parameter(torch.randn(64, 48))                        # 3072 floats: sharded (divisible by 4 * world)
+        model.c = torch.nn.Parameter(torch.randn(16, 8, dtype=torch.complex64))   # complex: 256 reals, sharded through its real view
+        model.b = torch.nn.Parameter(torch.randn(37))                             # not divisible: stays replicated
+        ref = {k: v.detach().clone().requires_grad_(True) for k, v in model.named_parameters()}
+        ropt = torch.optim.AdamW(list(ref.values()), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+        net = thd.init_gradient_reduction_hooks(model, torch.device("cpu"), zero=True)
+        net.reducer.big_bytes = 512                            # bytes: w and c are "big", b is bucketed
+        opt = mo.FusedAdamW(model.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+        for it in range(3):
+            gens = [torch.Generator().manual_seed(100 * it + r) for r in range(world)]
+            tg = {k: [torch.randn(v.shape, generator=gens[r], dtype=v.dtype if not v.is_complex() else torch.float32).to(v.dtype)
+                      if not v.is_complex() else torch.complex(torch.randn(v.shape, generator=gens[r]), torch.randn(v.shape, generator=gens[r]))
+                      for r in range(world)] for k, v in model.named_parameters()}
+            for p in model.parameters():
+                p.grad = None
+            loss = sum((torch.view_as_real(p * tg[k][rank].conj()).select(-1, 0) if p.is_complex() else p * tg[k][rank]).sum()
+                       for k, p in model.named_parameters())
+            loss.backward()                                    # d loss / d p = tg[k][rank] (conj-linear form for the complex one)
+            assert mo.FusedAdamW.zero_shard(model.w) is not None and mo.FusedAdamW.zero_shard(model.c) is not None
+            assert mo.FusedAdamW.zero_shard(model.b) is None
+            assert mo.FusedAdamW.zero_shard(model.w)[0].numel() == 3072 // world
+            # reference: one process, averaged gradients, same clipping
+            for k, v in ref.items():
+                v.grad = sum(tg[k]) / world
+            gn_ref = torch.sqrt(sum((torch.view_as_real(v.grad) if v.is_complex() else v.grad).double().pow(2).sum() for v in ref.values()))
+            coef_ref = min(1.0, 0.5 / (float(gn_ref) + 1e-6))
+            for v in ref.values():
+                v.grad.mul_(coef_ref)
+            ropt.step()
+            cc = opt.clip_coef(0.5)
+            assert abs(float(cc[1]) - float(gn_ref)) < 1e-4 * float(gn_ref), (float(cc[1]), float(gn_ref))
+            assert abs(float(thd.total_grad_norm(model)) - float(gn_ref)) < 1e-4 * float(gn_ref)
+            opt.step(grad_scale=cc[:1])
+            for k, p in model.named_parameters():
+                a = torch.view_as_real(p.detach()) if p.is_complex() else p.detach()
+                b = torch.view_as_real(ref[k].detach()) if p.is_complex() else ref[k].detach()
+                assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), (it, k, (a - b).abs().max())
+        # sharded state: 1 / world of the elements
+        assert opt.state[model.w]["exp_avg"].numel() == 3072 // world and opt.state[model.b]["exp_avg"].numel() == 37
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_zero1_sharded_adamw_matches_single_process_adamw(world):
+    mp.spawn(_worker_zero, args=(world, _free_port()), nprocs=world, join=True)
