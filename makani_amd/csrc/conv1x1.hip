@@ -648,7 +648,12 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
     constexpr int CH = KCH * 128;                       // one chunk: KCH input channels x 64 pixels, bf16
     constexpr int NCH = 384 / KCH;                      // chunks per pixel tile
     constexpr int K4 = KCH / 16;                        // k16-steps per chunk
-    constexpr int NSLOT = (128 * 1024) / CH;            // ring slots (128 KB)
+    constexpr int ROUNDS_ = TM;
+    // EPI_LOADS: the epilogue operand (gelu'(G) factor or skip tensor R) of every staging round arrives by LDS-DMA in its
+    // own 16 KB image, requested at the START of the pixel tile, so that it lands behind the tile's multiplications;
+    // the ring gives up one slot's worth of space per round for that (128 -> 96 KB with three rounds)
+    constexpr int EBYTES = EPI_LOADS ? ROUNDS_ * 128 * 128 : 0;
+    constexpr int NSLOT = (EPI_LOADS ? (144 * 1024 - EBYTES) : 128 * 1024) / CH;   // ring slots
     constexpr int NP = KCH / 32;                        // DMA pieces (8 rows x 128 B) per wave and chunk
     constexpr int ROUNDS = TM;                          // staging rounds of 128 channel rows (32 per wave)
     constexpr int NSTORE = ROUNDS * 4 * (PRE ? 2 : 1);  // epilogue memory instructions per thread and tile (always issued)
@@ -657,8 +662,9 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
     constexpr int NEPI_MAX = (LOOK + NCH - 1) / NCH;    // tile ends the look-ahead window can span
     static_assert(LOOK <= NSLOT - 1, "a slot is refilled only after every wave has left it");
     static_assert(EPI_LOADS || NP * (LOOK - 1) + NEPI_MAX * NSTORE <= 63, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * CH + 128 * 128];
-    unsigned char* const stg = smem + NSLOT * CH;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * CH + EBYTES + 128 * 128];
+    unsigned char* const ebuf = smem + NSLOT * CH;      // [ROUNDS][128 rows][128 B], linear (as the DMA writes it)
+    unsigned char* const stg = ebuf + EBYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -724,6 +730,26 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
         }
     };
 
+    // ---- epilogue operand by DMA (EPI_LOADS): G if present, else R; round i, wave w: channel rows m_base + 32 i .. + 31 as
+    // four pieces of 8 rows x 128 B into ebuf + i * 16 KB + w * 4 KB.  Rows past M re-read row M - 1 (their results are
+    // never stored), pixel chunks past N the last valid chunk (as the activation stream does)
+    const u16* const eop = p.G ? p.G : p.R;
+    const v4i_t rsE = make_rsrc(EPI_LOADS ? (const void*)(eop + (long long)cb * p.M * p.N) : (const void*)p.X);
+    const unsigned ldsE = lds_addr(ebuf) + __builtin_amdgcn_readfirstlane(wave) * 4096;
+    auto issue_epi = [&](long long cn0) {               // (offsets recomputed per tile: the kernel has no registers to spare)
+        const unsigned n0b = (unsigned)(cn0 * 2);
+        const int cmax = min(7, (int)((nbytes - n0b) / 16) - 1);
+        const unsigned col = (unsigned)min(lane & 7, cmax) * 16u;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)n0b);
+#pragma unroll
+        for (int i = 0; i < (EPI_LOADS ? ROUNDS_ : 0); ++i) {
+            unsigned v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (unsigned)min(m_base + i * 32 + q * 8 + (lane >> 3), p.M - 1) * nbytes + col;
+            dma4<1024>(ldsE + (unsigned)i * 16384u, rsE, soff, v[0], v[1], v[2], v[3]);
+        }
+    };
+
     // ---- fragment addressing inside a chunk: transpose read, rows k4*16 + lh*8 + (s15 >> 2) [+4] ----
     int xoff[TN];
 #pragma unroll
@@ -775,6 +801,7 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
                 else wait_vmcnt_le<NP * (LOOK - 1) + 3 * NSTORE>();
             }
             __builtin_amdgcn_s_barrier();
+            if (EPI_LOADS && kc == 0) issue_epi(cn0);      // the previous tile's last round left the operand images behind this barrier
             const unsigned char* sb = smem + c_slot * CH;
             c_slot = c_slot + 1 == NSLOT ? 0 : c_slot + 1;
 #pragma unroll
@@ -800,10 +827,14 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
         }
 
         // ---- epilogue: TM rounds of 128 channel rows (32 per wave) x 64 pixels through the staging image ----
+        if constexpr (EPI_LOADS) {
+            // the operand images were requested before this tile's NCH chunk requests (NP pieces each): in-order retirement
+            // makes "at most NP * NCH outstanding" mean they have landed; at the end of the stream fewer chunks follow them
+            if ((ts + 1) * NCH - 1 + LOOK < nchunks) wait_vmcnt_le<NP * NCH>(); else wait_vmcnt<0>();
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             unsigned voff[4];
-            uint4 gq[4], rq[4];
 #pragma unroll
             for (int u4 = 0; u4 < 4; ++u4) {
                 const int idx = tid + NT_ * u4;
@@ -813,11 +844,6 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
                 const bool live = m < p.M && n < p.N;
                 const long long o = (long long)m * p.N + n;
                 voff[u4] = live ? (unsigned)(o * 2) : 0xC0000000u;          // out of range: the store is dropped
-                gq[u4] = rq[u4] = make_uint4(0, 0, 0, 0);
-                if (EPI_LOADS) {
-                    if (live && p.G) gq[u4] = ld16(p.G + plane0 + o);
-                    if (live && p.R) rq[u4] = ld16(p.R + plane0 + o);
-                }
             }
             const float bv = bvr[i];
             const int lrow = wave * 32 + l31;
@@ -840,6 +866,8 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
                 const uint4 raw = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ ((row >> 1) & 7)) * 16));
                 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
                 if (PRE) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{raw.x, raw.y, raw.z, raw.w}, rsP, voff[u4], 0, 0);
+                uint4 ev = make_uint4(0, 0, 0, 0);          // EPI_LOADS: the DMA image of this round (rows of 128 B, linear)
+                if constexpr (EPI_LOADS) ev = *reinterpret_cast<const uint4*>(ebuf + i * 16384 + row * 128 + ch * 16);
                 uint4 out = raw;
                 if (p.act || EPI_LOADS) {
                     const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -854,15 +882,15 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
                         for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
                     }
                     if (EPI_LOADS && p.G) {
-                        const uint32_t gw[4] = {gq[u4].x, gq[u4].y, gq[u4].z, gq[u4].w};
+                        const uint32_t gw[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             v[2 * e] *= gelu_grad_fast_f(__uint_as_float(gw[e] << 16));
                             v[2 * e + 1] *= gelu_grad_fast_f(__uint_as_float(gw[e] & 0xffff0000u));
                         }
                     }
-                    if (EPI_LOADS && p.R) {
-                        const uint32_t rw[4] = {rq[u4].x, rq[u4].y, rq[u4].z, rq[u4].w};
+                    if (EPI_LOADS && !p.G) {
+                        const uint32_t rw[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             v[2 * e] += __uint_as_float(rw[e] << 16);
@@ -1231,7 +1259,7 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
     static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
     static const bool no_astat = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 'r'; }();   // "ring": no weight-stationary kernel
-    if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64) {
+    if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
         // weights stationary in registers: 256- or 384-channel slabs (4 waves x 2 or 3 row tiles), 64-pixel tiles,
         // persistent grid of 256-thread workgroups.  MAKANI_AMD_ASTAT = "<tm><kch>" (e.g. 3128, 264) overrides the choice.
         static const int forced_tm = [] { const char* e = getenv("MAKANI_AMD_ASTAT"); int a = 0, b = 0; return (e && sscanf(e, "%d,%d", &a, &b) == 2) ? a : 0; }();
