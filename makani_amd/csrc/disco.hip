@@ -34,7 +34,7 @@ constexpr int DNT = 256;
 constexpr int DCH = 512;          // list entries staged in LDS per chunk
 
 struct __attribute__((aligned(16))) DEntry {
-    int base, lon;              // row * nlon_in * PB and lon * PB: offsets into the plane-interleaved row image
+    int base, lon;              // row * nlon_in * PB * 4 and lon * PB * 4: BYTE offsets into the plane-interleaved row image
     float val;
     int pad;
 };
@@ -50,33 +50,34 @@ struct PlaneVec<4> { typedef f32x4 type; };
 
 // acc[r][b] += sum over the staged list chunk of val * xs[row][(lon + shift[r]) mod nlon_in][b]
 // The row image keeps the PB planes interleaved, so one LDS read (4 / 8 / 16 bytes) fetches the operands of all planes;
-// every lane reads the same list entry (LDS broadcast).  All offsets are premultiplied by PB: 4 integer instructions and
-// one LDS read per PB multiply-adds.  Unrolled by 4: the list reads and the x reads of four entries are in flight together
+// every lane reads the same list entry (LDS broadcast).  All offsets are byte offsets (premultiplied by 4 PB): 4 integer
+// instructions (two adds, a subtract, an unsigned min for the longitude wrap) and one LDS read per PB multiply-adds.  Unrolled by 4: the list reads and the x reads of four entries are in flight together
 // (the loop is bound by LDS latency at the 1-2 workgroups per CU that the row images allow).
 template <int PB, int RR>
 __device__ __forceinline__ void disco_accumulate(float (&acc)[RR][PB], const DEntry* __restrict__ lst, int cnt,
                                                  const float* __restrict__ xs, const int (&shift)[RR], int wrap) {
     typedef typename PlaneVec<PB>::type vec;
-    typedef __attribute__((address_space(3))) const float lds_f;          // 32-bit LDS addressing (no 64-bit pointer math)
+    typedef __attribute__((address_space(3))) const unsigned char lds_b;    // 32-bit LDS addressing, byte offsets
     typedef __attribute__((address_space(3))) const vec lds_vec;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) const i32x4 lds_entry;      // a DEntry read as one 16-byte vector
-    lds_f* xl = (lds_f*)xs;
+    typedef __attribute__((address_space(3))) const i32x4 lds_entry;        // a DEntry read as one 16-byte vector
+    lds_b* xl = (lds_b*)xs;
     lds_entry* ll = (lds_entry*)lst;
 #pragma unroll 4
     for (int n = 0; n < cnt; ++n) {
         const i32x4 ev = ll[n];
-        struct { int base, lon; float val; } e = {ev[0], ev[1], __int_as_float(ev[2])};
+        const float val = __int_as_float(ev[2]);
 #pragma unroll
         for (int q = 0; q < RR; ++q) {
-            int c = e.lon + shift[q];
-            c -= (c >= wrap) ? wrap : 0;
-            const vec v = *(lds_vec*)(xl + (e.base + c));
+            // (lon + shift) mod wrap without a compare / select: the smaller of c and c - wrap as UNSIGNED numbers
+            const unsigned c1 = (unsigned)(ev[1] + shift[q]);
+            const unsigned c = min(c1, c1 - (unsigned)wrap);
+            const vec v = *(lds_vec*)(xl + (unsigned)ev[0] + c);
 #pragma unroll
             for (int b = 0; b < PB; ++b) {
                 float xv;
                 if constexpr (PB == 1) xv = v; else xv = v[b];
-                acc[q][b] = fmaf(e.val, xv, acc[q][b]);
+                acc[q][b] = fmaf(val, xv, acc[q][b]);
             }
         }
     }
@@ -87,8 +88,8 @@ __device__ __forceinline__ void stage_list(DEntry* lst, const int* __restrict__ 
                                            const float* __restrict__ nval, int n0, int cnt, int tid, int row_elems) {
     for (int e = tid; e < cnt; e += DNT) {
         DEntry d;
-        d.base = nrow[n0 + e] * row_elems * PB;
-        d.lon = nlon[n0 + e] * PB;
+        d.base = nrow[n0 + e] * row_elems * PB * 4;          // byte offsets into the fp32 image
+        d.lon = nlon[n0 + e] * PB * 4;
         d.val = nval[n0 + e];
         d.pad = 0;
         lst[e] = d;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(DNT) void disco_fwd_kernel(const T* __restrict__ x,
     stage_rows<T, PB>(xs, x + (long long)lo * nlon_in, plane_in, p0, planes, nr * nlon_in, tid);
     int shift[RR];
 #pragma unroll
-    for (int q = 0; q < RR; ++q) shift[q] = ((min(tid + q * DNT, nlon_out - 1) * s) % nlon_in) * PB;
+    for (int q = 0; q < RR; ++q) shift[q] = ((min(tid + q * DNT, nlon_out - 1) * s) % nlon_in) * PB * 4;
     for (int k = 0; k < K; ++k) {
         float acc[RR][PB];
 #pragma unroll
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(DNT) void disco_fwd_kernel(const T* __restrict__ x,
             __syncthreads();                                     // previous chunk consumed (and, first time, x staged)
             stage_list<PB>(lst, nrow, nlon, nval, c0, cnt, tid, nlon_in);
             __syncthreads();
-            disco_accumulate<PB, RR>(acc, lst, cnt, xs, shift, nlon_in * PB);
+            disco_accumulate<PB, RR>(acc, lst, cnt, xs, shift, nlon_in * PB * 4);
         }
 #pragma unroll
         for (int q = 0; q < RR; ++q) {
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(DNT) void disco_bwd_same_kernel(const T* __restrict
     const long long plane_out = (long long)nlat_out * nlon;
     int shift[RR];
 #pragma unroll
-    for (int q = 0; q < RR; ++q) shift[q] = min(tid + q * DNT, nlon - 1) * PB;
+    for (int q = 0; q < RR; ++q) shift[q] = min(tid + q * DNT, nlon - 1) * PB * 4;
     float acc[RR][PB];
 #pragma unroll
     for (int q = 0; q < RR; ++q)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(DNT) void disco_bwd_same_kernel(const T* __restrict
             if (c0 != n0) __syncthreads();
             stage_list<PB>(lst, nrow, nlst, nval, c0, cnt, tid, nlon);
             __syncthreads();
-            disco_accumulate<PB, RR>(acc, lst, cnt, xs, shift, nlon * PB);
+            disco_accumulate<PB, RR>(acc, lst, cnt, xs, shift, nlon * PB * 4);
         }
     }
 #pragma unroll
