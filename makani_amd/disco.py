@@ -121,13 +121,22 @@ def _psi_key(in_shape, out_shape, kernel_shape, basis_type, grid_in, grid_out, t
 
 
 class _Lists:
-    """device-side list form of one convolution tensor (forward lists per (t, k), transposed lists per input latitude)"""
+    """device-side list form of one convolution tensor (forward lists per (t, k), transposed lists per input latitude).
+    ``window = (in_first, in_count, out_first, out_count)``: the operator of a rank that owns those OUTPUT latitudes and has
+    gathered the input latitudes ``in_first .. in_first + in_count`` they touch (own rows + halo), re-indexed to the window."""
 
-    def __init__(self, psi, in_shape, out_shape, device):
+    def __init__(self, psi, in_shape, out_shape, device, window=None):
         nlat_in, nlon_in = in_shape
         nlat_out, nlon_out = out_shape
         K = psi["K"]
         k, t, i, j, v = psi["k"], psi["t"], psi["i"], psi["j"], psi["v"]
+        if window is not None:
+            i0, ni, t0, nt = window
+            sel = (t >= t0) & (t < t0 + nt)
+            k, t, i, j, v = k[sel], t[sel] - t0, i[sel] - i0, j[sel], v[sel]
+            assert i.size == 0 or (i.min() >= 0 and i.max() < ni), "window does not cover the stencil"
+            nlat_in, nlat_out = ni, nt
+            in_shape, out_shape = (ni, nlon_in), (nt, nlon_out)
         # forward: sorted by (t, k); input rows relative to the first row the output latitude touches
         order = np.lexsort((j, i, k, t))
         kf, tf, if_, jf, vf = k[order], t[order], i[order], j[order], v[order]
@@ -144,7 +153,7 @@ class _Lists:
         self.f_off, self.f_row, self.f_lon = to(off, np.int32), to(if_ - lat_lo[tf], np.int32), to(jf, np.int32)
         self.f_val = to(vf, np.float32)
         self.lat_lo, self.lat_n = to(lat_lo, np.int32), to(lat_n, np.int32)
-        self.max_rows = int(lat_n.max())
+        self.max_rows = max(1, int(lat_n.max()))
         # transposed: sorted by input latitude
         order = np.lexsort((j, k, t, i))
         kb, tb, ib, jb, vb = k[order], t[order], i[order], j[order], v[order]
@@ -176,13 +185,15 @@ class _Lists:
             self.s_off, self.s_row = to(soff, np.int32), to(ts - t_lo[seg], np.int32)
             self.s_lon, self.s_val = to((-js) % nlon_in, np.int32), to(vs2, np.float32)
             self.t_lo, self.t_n = to(t_lo, np.int32), to(t_n, np.int32)
-            self.max_rows_b = int(t_n.max())
+            self.max_rows_b = max(1, int(t_n.max()))
 
 
 def _contract_fwd(x, L: _Lists):
     B, Cc, nlat_in, nlon_in = x.shape
     nlat_out, nlon_out = L.out_shape
     y = torch.empty((B, Cc * L.K, nlat_out, nlon_out), dtype=x.dtype, device=x.device)
+    if B * Cc == 0:            # a rank of the azimuth group that got no channel (fewer channels than ranks)
+        return y
     with ops._timed("disco_fwd", flops=2.0 * B * Cc * nlon_out * L.nnz,
                     nbytes=float(x.element_size()) * (x.numel() + y.numel())):
         check(lib().mk_disco_fwd(ptr(x), ptr(y), dtype_code(x), ptr(L.f_off), ptr(L.f_row), ptr(L.f_lon), ptr(L.f_val),
@@ -196,6 +207,8 @@ def _contract_bwd(gy, L: _Lists):
     nlat_in, nlon_in = L.in_shape
     Cc = CK // L.K
     gx = torch.empty((B, Cc, nlat_in, nlon_in), dtype=gy.dtype, device=gy.device)
+    if B * Cc == 0:
+        return gx
     with ops._timed("disco_bwd", flops=2.0 * B * Cc * nlon_out * L.nnz,
                     nbytes=float(gy.element_size()) * (gx.numel() + gy.numel())):
         if L.same_lon:
@@ -269,20 +282,188 @@ class DiscreteContinuousConvS2(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             xc = x.to(torch.bfloat16) if bf16 else x.float()
             y = DiscoContractFn.apply(xc, self._device_lists(x.device))           # (B, C * K, H, W)
-            O = self.weight.shape[0]
-            if self.groups == 1:
-                w4 = self.weight.reshape(O, -1, 1, 1)
-                if bf16:
-                    return ops.Conv1x1Fn.apply(y, w4, self.bias, None)
-                out = ops.ConvMmFn.apply(y, w4, None, False)
+            return self._channel_mix(y, bf16)
+
+    def _channel_mix(self, y, bf16):
+        """out[o] = sum_{c, k} weight[o, c, k] y[c * K + k] (+ bias): a 1x1 convolution over the C * K channels"""
+        O = self.weight.shape[0]
+        if self.groups == 1:
+            w4 = self.weight.reshape(O, -1, 1, 1)
+            if bf16 and (y.shape[-1] * y.shape[-2]) % 8 == 0:
+                return ops.Conv1x1Fn.apply(y, w4, self.bias, None)
+            out = ops.ConvMmFn.apply(y.float() if not bf16 else y, w4, None, False)
+        else:
+            B, _, H, W = y.shape
+            yg = y.reshape(B, self.groups, self.groupsize * self.kernel_size, H * W)
+            wg = self.weight.reshape(self.groups, O // self.groups, self.groupsize * self.kernel_size).to(y.dtype)
+            out = torch.einsum("gok,bgkn->bgon", wg, yg).reshape(B, O, H, W)
+        if self.bias is not None:
+            out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
+        return out
+
+
+# --------------------------------------------------------------------------- #
+# h x w spatial model parallelism (thd.DistributedDiscreteContinuousConvS2 / thd.DistributedResampleS2)
+# --------------------------------------------------------------------------- #
+def _p2p(send, recv, group):
+    """one batched point-to-point round: ``send`` / ``recv`` map a group rank to a contiguous tensor.  RCCL runs the batch as
+    one grouped launch (neighbour traffic rides single xGMI links); gloo (tests) moves host memory, so GPU tensors are staged."""
+    import torch.distributed as dist
+    host = dist.get_backend(group) == "gloo" and any(t_.is_cuda for t_ in list(send.values()) + list(recv.values()))
+    hs = {p_: (t_.cpu() if host else t_) for p_, t_ in send.items()}
+    hr = {p_: (torch.empty(t_.shape, dtype=t_.dtype) if host else t_) for p_, t_ in recv.items()}
+    ops_ = []
+    for peer in sorted(set(hs) | set(hr)):
+        gp = dist.get_global_rank(group, peer)
+        if peer in hs:
+            ops_.append(dist.P2POp(dist.isend, hs[peer], gp, group=group))
+        if peer in hr:
+            ops_.append(dist.P2POp(dist.irecv, hr[peer], gp, group=group))
+    if ops_:
+        for req in dist.batch_isend_irecv(ops_):
+            req.wait()
+    if host:
+        for p_, t_ in recv.items():
+            t_.copy_(hr[p_])
+
+
+class _HaloPlan:
+    """which input latitudes every polar rank needs for ITS output latitudes, from the support of the convolution tensor:
+    ``win[r] = (first, count)`` and, for the pair (r, p), the rows of p's shard inside r's window."""
+
+    def __init__(self, psi, lat_in_shapes, lat_out_shapes):
+        P = len(lat_in_shapes)
+        self.in_off = np.concatenate([[0], np.cumsum(lat_in_shapes)]).astype(int)
+        self.out_off = np.concatenate([[0], np.cumsum(lat_out_shapes)]).astype(int)
+        self.win = []
+        for r in range(P):
+            sel = (psi["t"] >= self.out_off[r]) & (psi["t"] < self.out_off[r + 1])
+            if sel.any():
+                lo, hi = int(psi["i"][sel].min()), int(psi["i"][sel].max()) + 1
             else:
-                B, _, H, W = y.shape
-                yg = y.reshape(B, self.groups, self.groupsize * self.kernel_size, H * W)
-                wg = self.weight.reshape(self.groups, O // self.groups, self.groupsize * self.kernel_size).to(y.dtype)
-                out = torch.einsum("gok,bgkn->bgon", wg, yg).reshape(B, O, H, W)
-            if self.bias is not None:
-                out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
-            return out
+                lo, hi = int(self.in_off[r]), int(self.in_off[r]) + 1
+            self.win.append((lo, hi - lo))
+
+    def rows(self, r, p):
+        """global input rows [a, b) of rank p's shard that lie in rank r's window (empty: a >= b)"""
+        lo, n = self.win[r]
+        return max(lo, int(self.in_off[p])), min(lo + n, int(self.in_off[p + 1]))
+
+
+class _HaloGatherFn(torch.autograd.Function):
+    """local latitude rows -> this rank's input window (own rows + the halo rows the neighbours hold); the adjoint sends the
+    halo parts of the window gradient back to their owners, which add them in rank order (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, plan, group, me):
+        P = len(plan.win)
+        send, recv, parts = {}, {}, []
+        for p_ in range(P):
+            a, b = plan.rows(p_, me)                       # what peer p_ needs from my shard
+            if p_ != me and a < b:
+                send[p_] = x[..., a - plan.in_off[me]:b - plan.in_off[me], :].contiguous()
+            a, b = plan.rows(me, p_)                       # what I need from peer p_
+            if a < b:
+                if p_ == me:
+                    parts.append(x[..., a - plan.in_off[me]:b - plan.in_off[me], :])
+                else:
+                    recv[p_] = x.new_empty((*x.shape[:-2], b - a, x.shape[-1]))
+                    parts.append(recv[p_])
+        _p2p(send, recv, group)
+        ctx.meta = (plan, group, me, x.shape)
+        return torch.cat(parts, dim=-2) if len(parts) > 1 else parts[0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, group, me, shape = ctx.meta
+        P = len(plan.win)
+        lo = plan.win[me][0]
+        gx = g.new_zeros(shape)
+        send, recv = {}, {}
+        for p_ in range(P):
+            a, b = plan.rows(me, p_)                       # window rows owned by p_: their gradient goes home
+            if a < b:
+                if p_ == me:
+                    gx[..., a - plan.in_off[me]:b - plan.in_off[me], :] = g[..., a - lo:b - lo, :]
+                else:
+                    send[p_] = g[..., a - lo:b - lo, :].contiguous()
+            a, b = plan.rows(p_, me)
+            if p_ != me and a < b:
+                recv[p_] = g.new_empty((*shape[:-2], b - a, shape[-1]))
+        _p2p(send, recv, group)
+        for p_ in sorted(recv):
+            a, b = plan.rows(p_, me)
+            gx[..., a - plan.in_off[me]:b - plan.in_off[me], :] += recv[p_]
+        return gx, None, None, None
+
+
+class DistributedDiscreteContinuousConvS2(DiscreteContinuousConvS2):
+    """``thd.DistributedDiscreteContinuousConvS2`` (constructed at ``fourcastnet3.py:189-205,356-381,518-534`` when
+    ``comm.get_size("spatial") > 1``): local ``(B, C, nlat_in_loc, nlon_in_loc) -> (B, O, nlat_out_loc, nlon_out_loc)``, same
+    results as the serial operator on the gathered field.  The schedule differs from the published one on purpose.  The
+    reference lets every rank contract its input latitudes into partial sums for ALL output latitudes and reduce-scatters that
+    (B, C K, nlat_out, nlon_out) tensor over the polar group — K = 9 times the activation through a ring collective.  The
+    convolution tensor has compact support (``theta_cutoff``: a few latitude rows), so here each rank computes ITS output
+    latitudes only and first fetches the few input rows beyond its shard from the neighbours that hold them: one batched
+    point-to-point exchange of (B, C, halo, nlon) — point-to-point neighbour traffic is what xGMI links are, and it is ~K x
+    nlat_loc / halo times fewer bytes.  Steps: (1) all-to-all over the azimuth group trades the longitude split for a channel
+    split (whole latitude circles: the contraction is a correlation in longitude); (2) halo gather over the polar group; (3) local
+    contraction (HIP kernels of the serial operator with the window's lists); (4) the second all-to-all restores the longitude
+    split; (5) the channel mix is local.  The weight is replicated (``is_shared_mp = ["spatial"]`` is set by the caller)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from . import distributed as thd
+        if not thd.is_initialized():
+            raise RuntimeError("makani_amd.distributed.init(polar_group, azimuth_group) has not been called")
+        self.comm_size_polar, self.comm_rank_polar = thd.polar_group_size(), thd.polar_group_rank()
+        self.comm_size_azimuth, self.comm_rank_azimuth = thd.azimuth_group_size(), thd.azimuth_group_rank()
+        self.lat_in_shapes = thd.compute_split_shapes(self.nlat_in, self.comm_size_polar)
+        self.lon_in_shapes = thd.compute_split_shapes(self.nlon_in, self.comm_size_azimuth)
+        self.lat_out_shapes = thd.compute_split_shapes(self.nlat_out, self.comm_size_polar)
+        self.lon_out_shapes = thd.compute_split_shapes(self.nlon_out, self.comm_size_azimuth)
+        self.nlat_in_local = self.lat_in_shapes[self.comm_rank_polar]
+        self.nlat_out_local = self.lat_out_shapes[self.comm_rank_polar]
+        self._plan = _HaloPlan(self._psi, self.lat_in_shapes, self.lat_out_shapes)
+
+    def window(self):
+        """(first input row, input rows, first output row, output rows) of this rank's local operator"""
+        r = self.comm_rank_polar
+        return (*self._plan.win[r], int(self._plan.out_off[r]), self.nlat_out_local)
+
+    def _device_lists(self, device):
+        if self.comm_size_polar == 1:
+            return super()._device_lists(device)
+        key = (self._key, str(device), self.window())
+        if key not in _LIST_CACHE:
+            _LIST_CACHE[key] = _Lists(self._psi, (self.nlat_in, self.nlon_in), (self.nlat_out, self.nlon_out), device,
+                                      window=self.window())
+        return _LIST_CACHE[key]
+
+    def _spatial_contract(self, xc, contract):
+        """steps (1)-(4): ``contract`` is the local contraction (B, C_loc, window rows, nlon_in) -> (B, C_loc * K, nlat_out_loc,
+        nlon_out) (the HIP kernels; the CPU schedule test passes a torch stand-in)"""
+        from . import distributed as thd
+        chan_shapes = thd.compute_split_shapes(xc.shape[1], self.comm_size_azimuth)
+        if self.comm_size_azimuth > 1:          # channels <-> longitude
+            xc = thd.transpose(xc, 1, chan_shapes, 3, self.lon_in_shapes, thd.azimuth_group())
+        if self.comm_size_polar > 1:
+            xc = _HaloGatherFn.apply(xc, self._plan, thd.polar_group(), self.comm_rank_polar)
+        y = contract(xc)
+        if self.comm_size_azimuth > 1:
+            y = thd.transpose(y, 3, self.lon_out_shapes, 1, [c * self.kernel_size for c in chan_shapes], thd.azimuth_group())
+        return y.contiguous()
+
+    @torch.compiler.disable(recursive=True)
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+        bf16 = hip_conv_eligible(x)
+        with torch.autocast(device_type="cuda", enabled=False):
+            xc = x.to(torch.bfloat16) if bf16 else x.float()
+            lists = self._device_lists(x.device)
+            y = self._spatial_contract(xc, lambda t: DiscoContractFn.apply(t, lists))
+            return self._channel_mix(y, bf16)
 
 
 # --------------------------------------------------------------------------- #
@@ -395,3 +576,40 @@ class ResampleS2(nn.Module):
         if self.skip_resampling:
             return x
         return ResampleFn.apply(x, self)
+
+
+class DistributedResampleS2(ResampleS2):
+    """``thd.DistributedResampleS2``: local ``(B, C, nlat_in_loc, nlon_in_loc) -> (B, C, nlat_out_loc, nlon_out_loc)``.  Two
+    all-to-alls (azimuth, then polar) trade the spatial split for a channel split, the serial HIP kernel interpolates
+    whole planes of this rank's channels, two all-to-alls restore the spatial split on the output grid."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from . import distributed as thd
+        if not thd.is_initialized():
+            raise RuntimeError("makani_amd.distributed.init(polar_group, azimuth_group) has not been called")
+        self.comm_size_polar, self.comm_size_azimuth = thd.polar_group_size(), thd.azimuth_group_size()
+        self.lat_in_shapes = thd.compute_split_shapes(self.nlat_in, self.comm_size_polar)
+        self.lon_in_shapes = thd.compute_split_shapes(self.nlon_in, self.comm_size_azimuth)
+        self.lat_out_shapes = thd.compute_split_shapes(self.nlat_out, self.comm_size_polar)
+        self.lon_out_shapes = thd.compute_split_shapes(self.nlon_out, self.comm_size_azimuth)
+
+    def forward(self, x):
+        from . import distributed as thd
+        if self.skip_resampling:
+            return x
+        lead = x.shape[:-3]
+        x4 = x.reshape(-1, *x.shape[-3:]) if x.dim() != 4 else x
+        Cc = x4.shape[1]
+        ca = thd.compute_split_shapes(Cc, self.comm_size_azimuth)
+        if self.comm_size_azimuth > 1:
+            x4 = thd.transpose(x4, 1, ca, 3, self.lon_in_shapes, thd.azimuth_group())
+        cp = thd.compute_split_shapes(x4.shape[1], self.comm_size_polar)
+        if self.comm_size_polar > 1:
+            x4 = thd.transpose(x4, 1, cp, 2, self.lat_in_shapes, thd.polar_group())
+        y = ResampleFn.apply(x4.contiguous(), self)
+        if self.comm_size_polar > 1:
+            y = thd.transpose(y, 2, self.lat_out_shapes, 1, cp, thd.polar_group())
+        if self.comm_size_azimuth > 1:
+            y = thd.transpose(y, 3, self.lon_out_shapes, 1, ca, thd.azimuth_group())
+        return y.reshape(*lead, *y.shape[-3:]) if x.dim() != 4 else y

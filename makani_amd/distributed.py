@@ -322,8 +322,9 @@ class DistributedRealSHT(RealSHT, _DistBase):
     def analysis(self, x4: torch.Tensor) -> torch.Tensor:
         """(B, C, nlat_loc, nlon_loc) -> S-layout (l_loc, m_loc, 2, round4(B*C)), planes = b*C + c."""
         B, C = x4.shape[:2]
-        if B > 1 and C % 4:
-            raise NotImplementedError("distributed SHT needs C % 4 == 0 when B > 1")
+        if B > 1 and C % 4:            # the S layout pads every sample's channels to a multiple of 4: zero planes
+            x4 = torch.nn.functional.pad(x4, (0, 0, 0, 0, 0, (-C) % 4))
+            C = x4.shape[1]
         hl, wl = self.lat_shapes[self.comm_rank_polar], self.lon_shapes[self.comm_rank_azimuth]
         if x4.shape[-2] != hl or x4.shape[-1] != wl:
             raise ValueError(f"expected local shape (..., {hl}, {wl}), got {tuple(x4.shape)}")
@@ -362,9 +363,10 @@ class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
         self.pct_t = self.pct_t[m0:m1].contiguous()
 
     def synthesis(self, S: torch.Tensor, B: int, C: int, out_dtype=torch.float32) -> torch.Tensor:
+        Cc = C
+        if B > 1 and C % 4:            # S holds round4(C) planes per sample: transform the zero planes too, drop them at the end
+            C = C + (-C) % 4
         P = B * C
-        if B > 1 and C % 4:
-            raise NotImplementedError("distributed SHT needs C % 4 == 0 when B > 1")
         pw, ph = self._plane_shapes(P)
         hl, wl = self.lat_shapes[self.comm_rank_polar], self.lon_shapes[self.comm_rank_azimuth]
         # (h) planes <-> l
@@ -377,13 +379,13 @@ class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
         x = _BACKEND.irfft(F.contiguous(), pw[self.comm_rank_azimuth], self.nlon, out_dtype, self._w)
         # (w) lon <-> planes
         x = transpose(x, 3, self.lon_shapes, 1, pw, azimuth_group())                  # (1, P, hl, wl)
-        return x.reshape(B, C, hl, wl)
+        return x.reshape(B, C, hl, wl)[:, :Cc]
 
     @torch.compiler.disable(recursive=True)
     def forward(self, c: torch.Tensor) -> torch.Tensor:
         from .sht import _as4d
         c4, lead = _as4d(c, 2)
-        S = ops.ComplexToSFn.apply(c4)
+        S = ops.ComplexToSFn.apply(c4, self.l_off, self.m_off)
         x = self.synthesis(S, c4.shape[0], c4.shape[1])
         return x.reshape(*lead, x.shape[-2], x.shape[-1])
 

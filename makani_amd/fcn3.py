@@ -9,8 +9,9 @@ What runs where:
     (``csrc/disco.hip`` + the channel GEMM kernels);
   * "global" blocks: ``makani_amd.SpectralConv`` (HIP FFT + split-bf16 Legendre / dhconv GEMMs);
   * norms, MLPs, skip convolutions: the pointwise HIP kernels of the SFNO path.
-Serial in space: the h x w split of FourCastNet3 needs a halo-exchanging DISCO convolution, which is not built
-(``comm.get_size("spatial") > 1`` raises).
+Spatial (h x w) model parallelism as in the reference: when ``comm.get_size("spatial") > 1`` the network builds the
+distributed DISCO convolution / resampling (``makani_amd.disco``), the distributed transforms and the distributed instance
+norms (``makani_amd.distributed``); every rank then works on its latitude / longitude shard.
 """
 import math
 import re
@@ -22,7 +23,8 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from . import comm
-from .disco import DiscreteContinuousConvS2, ResampleS2
+from . import distributed as thd
+from .disco import (DiscreteContinuousConvS2, DistributedDiscreteContinuousConvS2, DistributedResampleS2, ResampleS2)
 from .layers import MLP, ChannelLayerNorm, DropPath, EncoderDecoder, GeometricInstanceNormS2, InstanceNorm2d, PointwiseConv
 from .sht import InverseRealSHT, RealSHT
 from .spectral_conv import SpectralConv
@@ -78,17 +80,26 @@ class LayerScale(nn.Module):
         return x * self.weight.view(1, -1, 1, 1).to(x.dtype)
 
 
-def _spatial_size():
-    return comm.get_size("spatial") if comm.is_initialized() else 1
+def _spatial_parallel():
+    """as the reference decides it (``comm.get_size("spatial") > 1``; the transform layer is initialised from the tree's
+    h / w groups on first use, ``fourcastnet3.py:340-343,922-927``)"""
+    return thd.ensure_initialized()
+
+
+def _conv_handle():
+    return DistributedDiscreteContinuousConvS2 if _spatial_parallel() else DiscreteContinuousConvS2
 
 
 def _norm_handle(h, w, embed_dim, normalization_layer="none", sht_grid_type="legendre-gauss"):
     if normalization_layer == "layer_norm":
         return partial(ChannelLayerNorm, normalized_shape=embed_dim, elementwise_affine=True, eps=1e-6)
     if normalization_layer == "instance_norm":
+        if _spatial_parallel():
+            return partial(thd.DistributedInstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True)
         return partial(InstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True, track_running_stats=False)
     if normalization_layer == "instance_norm_s2":
-        return partial(GeometricInstanceNormS2, img_shape=(h, w), crop_shape=(h, w), crop_offset=(0, 0),
+        handle = thd.DistributedGeometricInstanceNormS2 if _spatial_parallel() else GeometricInstanceNormS2
+        return partial(handle, img_shape=(h, w), crop_shape=(h, w), crop_offset=(0, 0),
                        grid_type=sht_grid_type, num_features=embed_dim, eps=1e-6, affine=True)
     if normalization_layer == "none":
         return nn.Identity
@@ -112,9 +123,9 @@ class DiscreteContinuousEncoder(nn.Module):
                  activation_function=nn.GELU, groups=1, bias=False):
         super().__init__()
         cutoff = _compute_cutoff_radius(nlat=inp_shape[0], kernel_shape=kernel_shape, basis_type=basis_type)
-        self.conv = DiscreteContinuousConvS2(inp_chans, out_chans, in_shape=inp_shape, out_shape=out_shape,
-                                             kernel_shape=kernel_shape, basis_type=basis_type, basis_norm_mode=basis_norm_mode,
-                                             grid_in=grid_in, grid_out=grid_out, groups=groups, bias=bias, theta_cutoff=cutoff)
+        self.conv = _conv_handle()(inp_chans, out_chans, in_shape=inp_shape, out_shape=out_shape,
+                                   kernel_shape=kernel_shape, basis_type=basis_type, basis_norm_mode=basis_norm_mode,
+                                   grid_in=grid_in, grid_out=grid_out, groups=groups, bias=bias, theta_cutoff=cutoff)
         _annotate_spatial(self.conv)
         if use_mlp:
             with torch.no_grad():
@@ -142,16 +153,19 @@ class DiscreteContinuousDecoder(nn.Module):
                                       hidden_dim=int(mlp_ratio * inp_chans), act_layer=activation_function, input_format="nchw",
                                       gain=2.0)
             self.act = activation_function()
+        par = _spatial_parallel()
         if upsample_sht:
-            self.sht = RealSHT(*inp_shape, grid=grid_in).float()
-            self.isht = InverseRealSHT(*out_shape, lmax=self.sht.lmax, mmax=self.sht.mmax, grid=grid_out).float()
+            sht, isht = (thd.DistributedRealSHT, thd.DistributedInverseRealSHT) if par else (RealSHT, InverseRealSHT)
+            self.sht = sht(*inp_shape, grid=grid_in).float()
+            self.isht = isht(*out_shape, lmax=self.sht.lmax, mmax=self.sht.mmax, grid=grid_out).float()
             self.upsample = nn.Sequential(self.sht, self.isht)
         else:
-            self.upsample = ResampleS2(*inp_shape, *out_shape, grid_in=grid_in, grid_out=grid_out, mode="bilinear")
+            self.upsample = (DistributedResampleS2 if par else ResampleS2)(*inp_shape, *out_shape, grid_in=grid_in,
+                                                                            grid_out=grid_out, mode="bilinear")
         cutoff = _compute_cutoff_radius(nlat=out_shape[0], kernel_shape=kernel_shape, basis_type=basis_type)
-        self.conv = DiscreteContinuousConvS2(inp_chans, out_chans, in_shape=out_shape, out_shape=out_shape,
-                                             kernel_shape=kernel_shape, basis_type=basis_type, basis_norm_mode=basis_norm_mode,
-                                             grid_in=grid_out, grid_out=grid_out, groups=groups, bias=False, theta_cutoff=cutoff)
+        self.conv = _conv_handle()(inp_chans, out_chans, in_shape=out_shape, out_shape=out_shape,
+                                   kernel_shape=kernel_shape, basis_type=basis_type, basis_norm_mode=basis_norm_mode,
+                                   grid_in=grid_out, grid_out=grid_out, groups=groups, bias=False, theta_cutoff=cutoff)
         _annotate_spatial(self.conv)
 
     def forward(self, x):
@@ -181,11 +195,10 @@ class NeuralOperatorBlock(nn.Module):
         gain_factor = 1.0
         if conv_type == "local":
             cutoff = 2 * _compute_cutoff_radius(nlat=self.inp_shape[0], kernel_shape=kernel_shape, basis_type=basis_type)
-            self.local_conv = DiscreteContinuousConvS2(inp_chans, inp_chans, in_shape=self.inp_shape, out_shape=self.out_shape,
-                                                       kernel_shape=kernel_shape, basis_type=basis_type,
-                                                       basis_norm_mode=basis_norm_mode, groups=num_groups,
-                                                       grid_in=forward_transform.grid, grid_out=inverse_transform.grid, bias=False,
-                                                       theta_cutoff=cutoff)
+            self.local_conv = _conv_handle()(inp_chans, inp_chans, in_shape=self.inp_shape, out_shape=self.out_shape,
+                                             kernel_shape=kernel_shape, basis_type=basis_type, basis_norm_mode=basis_norm_mode,
+                                             groups=num_groups, grid_in=forward_transform.grid,
+                                             grid_out=inverse_transform.grid, bias=False, theta_cutoff=cutoff)
             _annotate_spatial(self.local_conv)
             with torch.no_grad():
                 self.local_conv.weight *= gain_factor
@@ -247,9 +260,6 @@ class AtmoSphericNeuralOperatorNet(nn.Module):
                  big_skip=False, clamp_water=False, bias=False, checkpointing_level=0, freeze_encoder=False,
                  freeze_processor=False, **kwargs):
         super().__init__()
-        if _spatial_size() > 1:
-            raise NotImplementedError("FourCastNet3 under h x w model parallelism needs the distributed DISCO convolution "
-                                      "(thd.DistributedDiscreteContinuousConvS2), which is not built")
         self.inp_shape, self.out_shape = tuple(inp_shape), tuple(out_shape)
         self.atmo_embed_dim, self.surf_embed_dim, self.aux_embed_dim = atmo_embed_dim, surf_embed_dim, aux_embed_dim
         self.big_skip = big_skip
@@ -333,8 +343,9 @@ class AtmoSphericNeuralOperatorNet(nn.Module):
         else:
             modes_lat = int(self.h * hard_thresholding_fraction)
             modes_lon = int((self.w // 2 + 1) * hard_thresholding_fraction)
-        self.sht = RealSHT(self.h, self.w, lmax=modes_lat, mmax=modes_lon, grid=sht_grid_type).float()
-        self.isht = InverseRealSHT(self.h, self.w, lmax=modes_lat, mmax=modes_lon, grid=sht_grid_type).float()
+        sht, isht = (thd.DistributedRealSHT, thd.DistributedInverseRealSHT) if _spatial_parallel() else (RealSHT, InverseRealSHT)
+        self.sht = sht(self.h, self.w, lmax=modes_lat, mmax=modes_lon, grid=sht_grid_type).float()
+        self.isht = isht(self.h, self.w, lmax=modes_lat, mmax=modes_lon, grid=sht_grid_type).float()
 
     def _precompute_channel_groups(self, channel_names, aux_channel_names):
         atmo, surf, dyn, stat, levels = get_channel_groups(channel_names, aux_channel_names)

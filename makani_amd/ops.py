@@ -698,14 +698,15 @@ class SToComplexFn(torch.autograd.Function):
 
 class ComplexToSFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, c):
-        ctx.meta = c.shape[:2]
+    def forward(ctx, c, l_off=0, m_off=0):
+        """l_off / m_off: first degree / order of this rank's shard (the gradient of the l < m entries is an exact zero)"""
+        ctx.meta = (*c.shape[:2], l_off, m_off)
         return complex_to_s(c)
 
     @staticmethod
     def backward(ctx, gS):
-        B, Cc = ctx.meta
-        return s_to_complex(gS.contiguous(), B, Cc)
+        B, Cc, l_off, m_off = ctx.meta
+        return s_to_complex(gS.contiguous(), B, Cc, l_off, m_off), None, None
 
 
 # --------------------------------------------------------------------------- #

@@ -64,15 +64,22 @@ class OracleBackend:
         return torch.einsum("lmir,mlk->mkir", S, mat[:, :, :nlat].to(S.dtype))
 
 
+def _s_planes(B, C):
+    """S layout: plane b * Cp + c with Cp = round4(C) when B > 1 (every sample's channels padded), round4(C) planes for B == 1"""
+    return B * (C + (-C) % 4) if B > 1 else C + (-C) % 4
+
+
 def _s_to_complex(S, B, C):
     L, M, _, R = S.shape
-    return torch.complex(S[:, :, 0, : B * C], S[:, :, 1, : B * C]).permute(2, 0, 1).reshape(B, C, L, M)
+    Cp = R // B
+    S = S.reshape(L, M, 2, B, Cp)[..., :C]
+    return torch.complex(S[:, :, 0], S[:, :, 1]).permute(2, 3, 0, 1)
 
 
 def _complex_to_s(c):
     B, C, L, M = c.shape
-    S = torch.stack([c.real, c.imag], dim=0).reshape(2, B * C, L, M).permute(2, 3, 0, 1)
-    return torch.nn.functional.pad(S, (0, (-(B * C)) % 4)).contiguous()
+    S = torch.stack([c.real, c.imag], dim=0).permute(3, 4, 0, 1, 2)                  # (L, M, 2, B, C)
+    return torch.nn.functional.pad(S, (0, (-C) % 4)).reshape(L, M, 2, -1).contiguous()
 
 
 def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C):
@@ -107,7 +114,7 @@ def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C):
         # ---- forward + its gradient ----
         xl = x[..., lat0:lat0 + hl, lon0:lon0 + wl].clone().requires_grad_(True)
         S = fwd.analysis(xl)
-        assert S.shape == (ll, ml, 2, (B * C + 3) // 4 * 4)
+        assert S.shape == (ll, ml, 2, _s_planes(B, C))
         c = _s_to_complex(S, B, C)
         So = osht.RealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
         xs = x.clone().requires_grad_(True)
@@ -140,7 +147,8 @@ def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C):
 
 
 @pytest.mark.parametrize("h,w", [(2, 1), (1, 2), (2, 2)])
-@pytest.mark.parametrize("nlat,nlon,lmax,mmax,grid,B,C", [(33, 64, 16, 17, "equiangular", 1, 6), (12, 24, 12, 13, "legendre-gauss", 2, 8)])
+@pytest.mark.parametrize("nlat,nlon,lmax,mmax,grid,B,C", [(33, 64, 16, 17, "equiangular", 1, 6), (12, 24, 12, 13, "legendre-gauss", 2, 8),
+                                                    (12, 24, 12, 13, "legendre-gauss", 2, 3)])
 def test_distributed_sht_schedule_matches_serial(h, w, nlat, nlon, lmax, mmax, grid, B, C):
     world = h * w
     mp.spawn(_worker_sht, args=(world, _free_port(), h, w, nlat, nlon, lmax, mmax, grid, B, C), nprocs=world, join=True)
@@ -385,3 +393,82 @@ def _worker_zero(rank, world, port):
 @pytest.mark.parametrize("world", [2, 4])
 def test_zero1_sharded_adamw_matches_single_process_adamw(world):
     mp.spawn(_worker_zero, args=(world, _free_port()), nprocs=world, join=True)
+
+
+# --------------------------------------------------------------------------- #
+# distributed DISCO contraction / resampling schedule (makani_amd/disco.py)
+# --------------------------------------------------------------------------- #
+def _psi_contract(x, psi, nlat_out, nlon_out, window=None):
+    """torch stand-in for the HIP contraction: y[b, c*K + k, t, p] = sum_e v_e x[b, c, i_e, (j_e + p s) % nlon_in] over the
+    entries of the convolution tensor (``window = (i0, ni, t0, nt)``: only the output latitudes t0 .. t0 + nt, the input given
+    as rows i0 .. i0 + ni)"""
+    k, t, i, j, v = (torch.from_numpy(psi[n]) for n in ("k", "t", "i", "j", "v"))
+    K = psi["K"]
+    if window is not None:
+        i0, ni, t0, nt = window
+        sel = (t >= t0) & (t < t0 + nt)
+        k, t, i, j, v = k[sel], t[sel] - t0, i[sel] - i0, j[sel], v[sel]
+        assert x.shape[2] == ni
+        nlat_out = nt
+    B, C, _, nlon_in = x.shape
+    s = nlon_in // nlon_out
+    cols = (j[:, None] + s * torch.arange(nlon_out)[None, :]) % nlon_in                 # (nnz, nlon_out)
+    g = x[:, :, i, :].gather(3, cols.expand(B, C, -1, -1)) * v.to(x.dtype)[:, None]       # (B, C, nnz, nlon_out)
+    y = torch.zeros(B, C, K * nlat_out, nlon_out, dtype=x.dtype).index_add(2, k * nlat_out + t, g)
+    return y.reshape(B, C * K, nlat_out, nlon_out)
+
+
+def _worker_disco(rank, world, port, h, w):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd.distributed as thd
+        from makani_amd import disco
+        ih, iw = rank // w, rank % w
+        hg = wg = None
+        for j in range(w):
+            g = dist.new_group([i * w + j for i in range(h)])
+            if j == iw:
+                hg = g
+        for i in range(h):
+            g = dist.new_group([i * w + j for j in range(w)])
+            if i == ih:
+                wg = g
+        thd.init(hg if h > 1 else None, wg if w > 1 else None)
+        for in_shape, out_shape, C in (((19, 36), (10, 18), 5), ((13, 24), (13, 24), 4), ((13, 24), (7, 12), 1)):
+            d = disco.DistributedDiscreteContinuousConvS2(C, 3, in_shape, out_shape, (3, 3), basis_type="morlet", bias=False,
+                                                          theta_cutoff=4.0 * math.pi / (in_shape[0] - 1))
+            torch.manual_seed(3)
+            x = torch.randn(2, C, *in_shape, dtype=torch.float64, requires_grad=True)
+            G = torch.randn(2, C * d.kernel_size, *out_shape, dtype=torch.float64)
+            ys = _psi_contract(x, d._psi, *out_shape)
+            (ys * G).sum().backward()
+            a0, b0 = sum(d.lat_in_shapes[:ih]), sum(d.lon_in_shapes[:iw])
+            a1, b1 = sum(d.lat_out_shapes[:ih]), sum(d.lon_out_shapes[:iw])
+            xl = x.detach()[..., a0:a0 + d.lat_in_shapes[ih], b0:b0 + d.lon_in_shapes[iw]].clone().requires_grad_(True)
+            win = d.window() if h > 1 else None
+            yl = d._spatial_contract(xl, lambda t_: _psi_contract(t_, d._psi, *out_shape, window=win))
+            sl = (Ellipsis, slice(a1, a1 + d.lat_out_shapes[ih]), slice(b1, b1 + d.lon_out_shapes[iw]))
+            assert yl.shape == ys[sl].shape
+            (yl * G[sl]).sum().backward()
+            assert torch.allclose(yl, ys[sl], atol=1e-12), (rank, (yl - ys[sl]).abs().max())
+            gref = x.grad[..., a0:a0 + d.lat_in_shapes[ih], b0:b0 + d.lon_in_shapes[iw]]
+            assert torch.allclose(xl.grad, gref, atol=1e-12), (rank, (xl.grad - gref).abs().max())
+            # the device lists of the ranks partition the convolution tensor by output latitude; the halo is a few rows
+            L = disco._Lists(d._psi, in_shape, out_shape, "cpu", window=win)
+            assert L.out_shape[0] == d.lat_out_shapes[ih]
+            if h > 1:
+                assert L.in_shape[0] == win[1] <= d.lat_in_shapes[ih] + 2 * 6
+            cnt = torch.tensor([L.nnz])
+            if hg is not None and h > 1:
+                dist.all_reduce(cnt, group=hg)
+            assert int(cnt) == d._psi["v"].size
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w", [(2, 1), (1, 2), (2, 2), (3, 1)])
+def test_distributed_disco_schedule_matches_serial(h, w):
+    mp.spawn(_worker_disco, args=(h * w, _free_port(), h, w), nprocs=h * w, join=True)
