@@ -310,6 +310,24 @@ int mk_disco_bwd(const void* gy, void* gx, int dtype, const int* off, const int*
 int mk_disco_bwd_same(const void* gy, void* gx, int dtype, const int* off, const int* nrow, const int* nlon_l,
                       const float* nval, const int* t_lo, const int* t_n, int max_rows, int planes, int K, int nlat_in,
                       int nlon, int nlat_out, void* stream);
+/* Run form of the same contraction for nlon_in == nlon_out (FourCastNet3's local blocks and decoder convolutions,
+ * fourcastnet3.py:356-381,518-534; forward and adjoint): csrc/disco_runs.hip, sliding-window correlations in registers.
+ *   mk_disco_runs_shape: 1 when the run-form kernels take (nlon, max_rows image rows, planes, dtype, img_bf16), with the
+ *     longitudes per lane R (4 | 8) and the planes per workgroup PB (4 | 2; *PB_out preset to 2 or 4 asks for exactly
+ *     that value); 0 -> use the list kernels above.
+ *   lists (makani_amd/disco.py: _build_runs): seg_off[s] .. seg_off[s + 1] index runs (n, 4) = {image row, first longitude,
+ *     offset into vals, groups of R values}; vals zero-padded to whole groups plus R trailing zeros.
+ *   mk_disco_fwd_runs: segments s = t * K + k, image rows relative to lat_lo[t] (lat_n[t] rows, max_rows their maximum).
+ *   mk_disco_bwd_runs: segments s = i * K + k with negated longitudes, image rows = output latitudes relative to
+ *     t_lo[(i / lat_group) * K + k] (t_n rows: lat_group = 2 | 4 consecutive latitudes share one staged image).
+ *   img_bf16: keep bf16 tensors as bf16 in the LDS row image (half the LDS per workgroup, one conversion per read). */
+int mk_disco_runs_shape(int nlon, int max_rows, int planes, int dtype, int img_bf16, int* R_out, int* PB_out);
+int mk_disco_fwd_runs(const void* x, void* y, int dtype, const int* seg_off, const int* runs, const float* vals,
+                      const int* lat_lo, const int* lat_n, int max_rows, int planes, int K, int nlat_in, int nlon, int nlat_out,
+                      int R, int PB, int img_bf16, void* stream);
+int mk_disco_bwd_runs(const void* gy, void* gx, int dtype, const int* seg_off, const int* runs, const float* vals,
+                      const int* t_lo, const int* t_n, int max_rows, int planes, int K, int nlat_in, int nlon, int nlat_out,
+                      int R, int PB, int img_bf16, int lat_group, void* stream);
 int mk_resample_fwd(const void* x, void* y, int dtype, const int* lat_a, const int* lat_b, const float* lat_w,
                     const int* lon_l, const int* lon_r, const float* lon_w, int planes, int nlat_in, int nlon_in,
                     int nlat_out, int nlon_out, void* stream);

@@ -82,6 +82,9 @@ _SIGS = {
     "mk_disco_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_disco_bwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_disco_bwd_same": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_disco_runs_shape": ([c_int, c_int, c_int, c_int, c_int, c_vp, c_vp], c_int),
+    "mk_disco_fwd_runs": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_disco_bwd_runs": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_resample_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_resample_bwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_quad_lp_chunks": ([c_ll], c_int),

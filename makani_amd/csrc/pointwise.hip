@@ -5,6 +5,7 @@
 // (plane, chunk) work items: one block streams CHUNK contiguous elements of one (batch, channel)
 // plane, so per-plane scalars (mean, rstd, gamma, beta, bias) are block-uniform.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -13,14 +14,17 @@ constexpr int UNROLL = 4;
 
 template <typename T>
 struct VecIO;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <>
 struct VecIO<float> {
     static constexpr int N = 4;
-    __device__ static __forceinline__ void load(const float* p, float* v) {
-        const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+    typedef f32x4 Raw;
+    __device__ static __forceinline__ Raw load_raw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    __device__ static __forceinline__ void unpack(const Raw& r, float* v) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = r[i];
     }
+    __device__ static __forceinline__ void load(const float* p, float* v) { unpack(load_raw(p), v); }
     __device__ static __forceinline__ void store(float* p, const float* v) {
         f32x4 r;
 #pragma unroll
@@ -33,15 +37,16 @@ struct VecIO<float> {
 template <>
 struct VecIO<u16> {
     static constexpr int N = 8;
-    __device__ static __forceinline__ void load(const u16* p, float* v) {
-        const uint4 r = *reinterpret_cast<const uint4*>(p);
-        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    typedef u32x4 Raw;
+    __device__ static __forceinline__ Raw load_raw(const u16* p) { return *reinterpret_cast<const u32x4*>(p); }
+    __device__ static __forceinline__ void unpack(const Raw& r, float* v) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(w[i] << 16);
-            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            v[2 * i] = __uint_as_float(r[i] << 16);
+            v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
         }
     }
+    __device__ static __forceinline__ void load(const u16* p, float* v) { unpack(load_raw(p), v); }
     __device__ static __forceinline__ void store(u16* p, const float* v) {
         uint32_t w[4];
 #pragma unroll
@@ -66,25 +71,59 @@ __host__ __device__ inline long long chunk_len(long long hw, int chunks, int vec
     return (per + vec - 1) / vec * vec;
 }
 
-// Visit every element of this block's chunk.  f(value_index_in_plane, n, vec) is called for up to VEC values; the
-// vector path needs 16-byte aligned plane bases (hw % VEC == 0).
-template <typename T, typename F>
-__device__ __forceinline__ void for_chunk(long long hw, int chunks, int chunk, F&& f) {
+// Visit every element of this block's chunk of NIN (1 or 2) same-shaped input planes p[0], p[1].
+// f(index_in_plane, cnt, a, b): cnt (an integral_constant) values of each input, already converted to fp32; the vector
+// path (cnt = VEC) needs 16-byte aligned plane bases (hw % VEC == 0).  All UNROLL x NIN 16-byte loads of a pass are issued
+// before the first value is used: lanes beyond the end of the chunk read the chunk's first vector instead (a load under a
+// lane condition makes hipcc wait for it on the spot, which left ONE load in flight per lane), and only the arithmetic and
+// the stores of `f` sit under the lane condition.
+template <int C>
+using cnt_t = std::integral_constant<int, C>;
+
+template <typename T, int NIN, typename F>
+__device__ __forceinline__ void for_chunk(long long hw, int chunks, int chunk, const T* p0, const T* p1, F&& f) {
     constexpr int VEC = VecIO<T>::N;
+    typedef typename VecIO<T>::Raw Raw;
     const long long len = chunk_len(hw, chunks, VEC);
     const long long c0 = (long long)chunk * len;
     const long long c1 = min(hw, c0 + len);
     if ((hw % VEC) == 0) {
-        for (long long base = c0; base < c1; base += pass_elems<T>()) {
+        constexpr int U = UNROLL / NIN;          // the same number of loads in flight per lane for one and two inputs
+        for (long long base = c0; base < c1; base += (long long)NT * VEC * U) {
+            Raw ra[U], rb[U];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const long long e = base + ((long long)u * NT + threadIdx.x) * VEC;
-                if (e < c1) f(e, VEC, true);
+                const long long a = e < c1 ? e : c0;
+                ra[u] = VecIO<T>::load_raw(p0 + a);
+                if (NIN > 1) rb[u] = VecIO<T>::load_raw(p1 + a);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long e = base + ((long long)u * NT + threadIdx.x) * VEC;
+                if (e < c1) {
+                    float va[VEC], vb[VEC];
+                    VecIO<T>::unpack(ra[u], va);
+                    if (NIN > 1) VecIO<T>::unpack(rb[u], vb);
+                    f(e, cnt_t<VEC>{}, va, vb);
+                }
             }
         }
     } else {
-        for (long long e = c0 + threadIdx.x; e < c1; e += NT) f(e, 1, false);
+        for (long long e = c0 + threadIdx.x; e < c1; e += NT) {
+            float va[1], vb[1] = {0.f};
+            va[0] = VecIO<T>::load1(p0 + e);
+            if (NIN > 1) vb[0] = VecIO<T>::load1(p1 + e);
+            f(e, cnt_t<1>{}, va, vb);
+        }
     }
+}
+
+// store cnt (VEC or 1) values
+template <typename T, int C>
+__device__ __forceinline__ void store_n(T* p, const float* v, cnt_t<C>) {
+    if constexpr (C == 1) VecIO<T>::store1(p, v[0]);
+    else VecIO<T>::store(p, v);
 }
 
 // GELU of a bf16 tensor: the A&S 7.1.26 erf (|err| < 1.5e-7, far below the bf16 rounding of the result) keeps the
@@ -175,13 +214,9 @@ __global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ x, 
     const float pb = pre_bias ? pre_bias[plane % channels] : 0.f;
     const float pivot = pre<T>(VecIO<T>::load1(xp), pb, pre_bias != nullptr);
     float s1 = 0.f, s2 = 0.f;
-    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
-        float v[VecIO<T>::N];
-        if (vec)
-            VecIO<T>::load(xp + e, v);
-        else
-            v[0] = VecIO<T>::load1(xp + e);
-        for (int i = 0; i < (vec ? VecIO<T>::N : 1); ++i) {
+    for_chunk<T, 1>(hw, chunks, chunk, xp, xp, [&](long long e, auto cnt, const float* v, const float*) {
+#pragma unroll
+        for (int i = 0; i < cnt(); ++i) {
             const float d = pre<T>(v[i], pb, pre_bias != nullptr) - pivot;
             const float w = q ? q[e + i] : 1.f;           // quadrature weights (sum 1): geometric norm on the sphere
             s1 += w * d;
@@ -204,17 +239,15 @@ __global__ __launch_bounds__(NT) void plane_sum_partial(const T* __restrict__ x,
     const int chunk = blockIdx.x % chunks;
     const T* xp = x + plane * hw;
     float s1 = 0.f, s2 = 0.f;
-    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
-        float v[VecIO<T>::N];
-        if (vec) {
-            VecIO<T>::load(xp + e, v);
+    for_chunk<T, 1>(hw, chunks, chunk, xp, xp, [&](long long e, auto cnt, const float* v, const float*) {
+        if constexpr (cnt() > 1) {
 #pragma unroll
-            for (int i = 0; i < VecIO<T>::N; i += 2) {
+            for (int i = 0; i < cnt(); i += 2) {
                 s1 += v[i];
                 s2 += v[i + 1];
             }
         } else {
-            s1 += VecIO<T>::load1(xp + e);
+            s1 += v[0];
         }
     });
     s1 += s2;
@@ -287,20 +320,14 @@ __global__ __launch_bounds__(NT) void in_apply(const T* __restrict__ x, T* __res
     const float sc = rstd * g, sh = b - mean * rstd * g;
     const T* xp = x + plane * hw;
     T* yp = y + plane * hw;
-    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
-        float v[VecIO<T>::N];
-        if (vec) {
-            VecIO<T>::load(xp + e, v);
+    for_chunk<T, 1>(hw, chunks, chunk, xp, xp, [&](long long e, auto cnt, const float* v, const float*) {
+        float o[cnt()];
 #pragma unroll
-            for (int i = 0; i < VecIO<T>::N; ++i) {
-                const float a = pre<T>(v[i], pb, pre_bias != nullptr) * sc + sh;
-                v[i] = GELU ? gelu_t<T>(a) : a;
-            }
-            VecIO<T>::store(yp + e, v);
-        } else {
-            const float a = pre<T>(VecIO<T>::load1(xp + e), pb, pre_bias != nullptr) * sc + sh;
-            VecIO<T>::store1(yp + e, GELU ? gelu_t<T>(a) : a);
+        for (int i = 0; i < cnt(); ++i) {
+            const float a = pre<T>(v[i], pb, pre_bias != nullptr) * sc + sh;
+            o[i] = GELU ? gelu_t<T>(a) : a;
         }
+        store_n(yp + e, o, cnt);
     });
 }
 
@@ -323,17 +350,9 @@ __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, co
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;
     float s1 = 0.f, s2 = 0.f;
-    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n_, bool vec) {
-        float v[VecIO<T>::N], d[VecIO<T>::N];
-        const int cnt = vec ? VecIO<T>::N : 1;
-        if (vec) {
-            VecIO<T>::load(xp + e, v);
-            VecIO<T>::load(gp + e, d);
-        } else {
-            v[0] = VecIO<T>::load1(xp + e);
-            d[0] = VecIO<T>::load1(gp + e);
-        }
-        for (int i = 0; i < cnt; ++i) {
+    for_chunk<T, 2>(hw, chunks, chunk, xp, gp, [&](long long e, auto cnt, const float* v, const float* d) {
+#pragma unroll
+        for (int i = 0; i < cnt(); ++i) {
             const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
             float ga = d[i];
             if (GELU) ga *= gelu_grad_t<T>(n * g + b);
@@ -394,27 +413,17 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;
     T* op = gx + plane * hw;
-    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n_, bool vec) {
-        float v[VecIO<T>::N], d[VecIO<T>::N];
-        const int cnt = vec ? VecIO<T>::N : 1;
-        if (vec) {
-            VecIO<T>::load(xp + e, v);
-            VecIO<T>::load(gp + e, d);
-        } else {
-            v[0] = VecIO<T>::load1(xp + e);
-            d[0] = VecIO<T>::load1(gp + e);
-        }
-        for (int i = 0; i < cnt; ++i) {
+    for_chunk<T, 2>(hw, chunks, chunk, xp, gp, [&](long long e, auto cnt, const float* v, const float* d) {
+        float o[cnt()];
+#pragma unroll
+        for (int i = 0; i < cnt(); ++i) {
             const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
             float ga = d[i];
             if (GELU) ga *= gelu_grad_t<T>(n * g + b);
             const float w = q ? q[e + i] : 1.f;
-            v[i] = k * (ga - w * (m1 + (n - cq) * m2));
+            o[i] = k * (ga - w * (m1 + (n - cq) * m2));
         }
-        if (vec)
-            VecIO<T>::store(op + e, v);
-        else
-            VecIO<T>::store1(op + e, v[0]);
+        store_n(op + e, o, cnt);
     });
 }
 
@@ -427,16 +436,11 @@ __global__ __launch_bounds__(NT) void bias_gelu_fwd(const T* __restrict__ x, con
     const float b = bias ? bias[plane % channels] : 0.f;
     const T* xp = x + plane * hw;
     T* yp = y + plane * hw;
-    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
-        float v[VecIO<T>::N];
-        if (vec) {
-            VecIO<T>::load(xp + e, v);
+    for_chunk<T, 1>(hw, chunks, chunk, xp, xp, [&](long long e, auto cnt, const float* v, const float*) {
+        float o[cnt()];
 #pragma unroll
-            for (int i = 0; i < VecIO<T>::N; ++i) v[i] = gelu_f(v[i] + b);
-            VecIO<T>::store(yp + e, v);
-        } else {
-            VecIO<T>::store1(yp + e, gelu_f(VecIO<T>::load1(xp + e) + b));
-        }
+        for (int i = 0; i < cnt(); ++i) o[i] = gelu_f(v[i] + b);
+        store_n(yp + e, o, cnt);
     });
 }
 
@@ -453,24 +457,14 @@ __global__ __launch_bounds__(NT) void bias_gelu_bwd(const T* __restrict__ x, con
     const T* gp = gy + plane * hw;
     T* op = gx + plane * hw;
     float s1 = 0.f, s2 = 0.f;
-    for_chunk<T>(hw, chunks, chunk, [&](long long e, int n, bool vec) {
-        float v[VecIO<T>::N], d[VecIO<T>::N];
-        const int cnt = vec ? VecIO<T>::N : 1;
-        if (vec) {
-            VecIO<T>::load(xp + e, v);
-            VecIO<T>::load(gp + e, d);
-        } else {
-            v[0] = VecIO<T>::load1(xp + e);
-            d[0] = VecIO<T>::load1(gp + e);
+    for_chunk<T, 2>(hw, chunks, chunk, xp, gp, [&](long long e, auto cnt, const float* v, const float* d) {
+        float o[cnt()];
+#pragma unroll
+        for (int i = 0; i < cnt(); ++i) {
+            o[i] = d[i] * gelu_grad_f(v[i] + b);
+            s1 += o[i];
         }
-        for (int i = 0; i < cnt; ++i) {
-            v[i] = d[i] * gelu_grad_f(v[i] + b);
-            s1 += v[i];
-        }
-        if (vec)
-            VecIO<T>::store(op + e, v);
-        else
-            VecIO<T>::store1(op + e, v[0]);
+        store_n(op + e, o, cnt);
     });
     if (ws) {
         block_reduce2(s1, s2, red);

@@ -27,11 +27,13 @@ The convolution tensor is computed in fp64 numpy at construction (vectorised ove
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import legendre as _leg
 from . import ops
 from ._lib import check, dtype_code, lib, ptr, stream
@@ -186,6 +188,156 @@ class _Lists:
             self.s_lon, self.s_val = to((-js) % nlon_in, np.int32), to(vs2, np.float32)
             self.t_lo, self.t_n = to(t_lo, np.int32), to(t_n, np.int32)
             self.max_rows_b = max(1, int(t_n.max()))
+        # the run form of the same tensor (sliding-window kernels) where it applies
+        self.runs = None
+        if self.same_lon and runs_radix(nlon_in) is not None and v.size:
+            self.runs = _RunLists(dict(k=k, t=t, i=i, j=j, v=v, K=K), ((nlat_in, nlon_in), (nlat_out, nlon_out)), device)
+
+
+def runs_radix(nlon):
+    """longitudes a lane owns in the run-form kernels (csrc/disco_runs.hip: N / R lanes in at most three waves), or None"""
+    if nlon % 4 == 0 and 2 <= nlon // 4 <= 192:
+        return 4
+    if nlon % 8 == 0 and 128 < nlon // 8 <= 192:
+        return 8
+    return None
+
+
+def _build_runs(seg, row, lon, val, nseg, nlon, R):
+    """entries (segment, image row, longitude, value) -> the run form of csrc/disco_runs.hip: for every (segment, row) the
+    longitudes are split into circular runs of consecutive longitudes (one run when the filter support is a disc); a run is
+    {row, first longitude, offset of its values, groups of R values}, values zero-padded to whole groups.
+    Returns seg_off (nseg + 1), runs (n, 4) int32, vals float32 (R trailing zeros: the kernels prefetch one group ahead)."""
+    order = np.lexsort((lon, row, seg))
+    seg, row, lon, val = seg[order], row[order], lon[order], val[order]
+    n = seg.size
+    key = seg * (int(row.max()) + 1 if n else 1) + row
+    first = np.flatnonzero(np.r_[True, key[1:] != key[:-1]]) if n else np.zeros(0, np.int64)
+    last = np.r_[first[1:], n]
+    out_runs, out_vals, counts = [], [], np.zeros(nseg, np.int64)
+    voff = 0
+    for a, b in zip(first, last):
+        l, v = lon[a:b], val[a:b]
+        if b - a == nlon:
+            pieces = [(0, v)]
+        else:
+            cuts = np.flatnonzero(np.diff(l) != 1) + 1
+            idx = np.split(np.arange(b - a), cuts)
+            pieces = [(int(l[i[0]]), v[i]) for i in idx]
+            if len(pieces) > 1 and l[0] == 0 and l[-1] == nlon - 1:             # the run that crosses longitude 0
+                pieces = [(pieces[-1][0], np.concatenate([pieces[-1][1], pieces[0][1]]))] + pieces[1:-1]
+        for js, pv in pieces:
+            ng = (pv.size + R - 1) // R
+            out_runs.append((int(row[a]), js, voff, ng))
+            pad = np.zeros(ng * R, np.float32)
+            pad[:pv.size] = pv
+            out_vals.append(pad)
+            voff += ng * R
+        counts[seg[a]] += len(pieces)
+    seg_off = np.zeros(nseg + 1, np.int64)
+    seg_off[1:] = np.cumsum(counts)
+    runs = np.array(out_runs, np.int32).reshape(-1, 4)
+    vals = np.concatenate(out_vals + [np.zeros(R, np.float32)])
+    return seg_off.astype(np.int32), runs, vals
+
+
+class _RunLists:
+    """run-form lists of one convolution tensor with nlon_in == nlon_out (forward: segments (t, k), image rows = input
+    latitudes relative to the first one latitude t touches; adjoint: segments (i, k), image rows = output latitudes relative to
+    the first one the latitude group (i // LG) touches for basis function k, longitudes negated; built per LG on demand)"""
+
+    def __init__(self, psi, shape, device):
+        (nlat_in, nlon), (nlat_out, _) = shape
+        K = psi["K"]
+        k, t, i, j, v = psi["k"], psi["t"], psi["i"], psi["j"], psi["v"]
+        self.R = R = runs_radix(nlon)
+        self._dev = device
+        self._e = (k, t, i, j, v.astype(np.float32))
+        to = self._to
+        lat_lo = np.zeros(nlat_out, np.int64)
+        lat_hi = np.full(nlat_out, -1, np.int64)
+        lo = np.full(nlat_out, nlat_in, np.int64)
+        np.minimum.at(lo, t, i)
+        np.maximum.at(lat_hi, t, i)
+        live = lat_hi >= 0
+        lat_lo[live] = lo[live]
+        lat_n = np.where(live, lat_hi - lat_lo + 1, 0)
+        so, rn, vl = _build_runs(t * K + k, i - lat_lo[t], j, self._e[4], nlat_out * K, nlon, R)
+        self.f_seg, self.f_runs, self.f_vals = to(so), to(rn), to(vl)
+        self.lat_lo, self.lat_n = to(lat_lo.astype(np.int32)), to(lat_n.astype(np.int32))
+        self.max_rows = max(1, int(lat_n.max()))
+        self.K, self.in_shape, self.out_shape, self.nnz = K, (nlat_in, nlon), (nlat_out, nlon), int(v.size)
+        self._groups, self._bwd = {}, {}
+        for LG in (4, 2):                      # the image rows of a latitude group: cheap, decides which LG fits the LDS
+            gseg = (i // LG) * K + k
+            ngrp = (nlat_in + LG - 1) // LG
+            t_lo = np.full(ngrp * K, nlat_out, np.int64)
+            t_hi = np.full(ngrp * K, -1, np.int64)
+            np.minimum.at(t_lo, gseg, t)
+            np.maximum.at(t_hi, gseg, t)
+            liveg = t_hi >= 0
+            t_n = np.where(liveg, t_hi - t_lo + 1, 0)
+            self._groups[LG] = (np.where(liveg, t_lo, 0), t_n, max(1, int(t_n.max())))
+
+    def _to(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self._dev)
+
+    def max_rows_b(self, LG):
+        return self._groups[LG][2]
+
+    def bwd(self, LG):
+        """(seg_off, runs, vals, t_lo, t_n, max_rows) of the adjoint for latitude groups of LG"""
+        if LG not in self._bwd:
+            k, t, i, j, v = self._e
+            K, (nlat_in, nlon) = self.K, self.in_shape
+            t_lo, t_n, mr = self._groups[LG]
+            so, rn, vl = _build_runs(i * K + k, t - t_lo[(i // LG) * K + k], (-j) % nlon, v, nlat_in * K, nlon, self.R)
+            self._bwd[LG] = (self._to(so), self._to(rn), self._to(vl), self._to(t_lo.astype(np.int32)), self._to(t_n.astype(np.int32)), mr)
+        return self._bwd[LG]
+
+
+def _runs_enabled(L):
+    return getattr(L, "runs", None) is not None and os.environ.get("MAKANI_AMD_DISCO", "runs") == "runs"
+
+
+def _runs_shape(L, planes, dtype, max_rows, img_bf16, pb=0):
+    R, PB = C.c_int(0), C.c_int(pb)
+    code = _lib.MK_BF16 if dtype == torch.bfloat16 else _lib.MK_F32
+    ok = lib().mk_disco_runs_shape(L.in_shape[1], max_rows, planes, code, img_bf16, C.byref(R), C.byref(PB))
+    return (R.value, PB.value) if ok and R.value == L.runs.R else None
+
+
+def _runs_plan_fwd(L, planes, dtype):
+    """(R, PB, img_bf16) when the run-form forward kernel takes this launch, else None.  bf16 tensors are widened to fp32 in
+    the LDS image when four planes of it fit (one conversion when staged instead of one per read: the kernel is bound by
+    VALU issue), MAKANI_AMD_DISCO_IMG=b forces the bf16 image."""
+    if not _runs_enabled(L):
+        return None
+    force_b = os.environ.get("MAKANI_AMD_DISCO_IMG", "") == "b"
+    for img, pb in ((0, 4), (1, 4), (0, 2), (1, 2)):
+        if (img and dtype != torch.bfloat16) or (force_b and not img and dtype == torch.bfloat16):
+            continue
+        got = _runs_shape(L, planes, dtype, L.runs.max_rows, img, pb)
+        if got is not None:
+            return got[0], got[1], img
+    return None
+
+
+def _runs_plan_bwd(L, planes, dtype):
+    """(R, PB, img_bf16, LG) for the run-form adjoint: four latitudes per workgroup (12 waves: the four SIMDs evenly loaded)
+    with an fp32 image of four planes when that fits the LDS, then two latitudes, then the bf16 image, then two planes"""
+    if not _runs_enabled(L):
+        return None
+    force_b = os.environ.get("MAKANI_AMD_DISCO_IMG", "") == "b"
+    pref = os.environ.get("MAKANI_AMD_DISCO_BWD", "")             # "LG,img,PB" (experiments)
+    order = [tuple(int(c) for c in pref.split(","))] if pref else [(4, 0, 4), (2, 0, 4), (4, 1, 4), (2, 1, 4), (4, 0, 2), (4, 1, 2)]
+    for LG, img, pb in order:
+        if (img and dtype != torch.bfloat16) or (force_b and not img and dtype == torch.bfloat16):
+            continue
+        got = _runs_shape(L, planes, dtype, L.runs.max_rows_b(LG), img, pb)
+        if got is not None:
+            return got[0], got[1], img, LG
+    return None
 
 
 def _contract_fwd(x, L: _Lists):
@@ -194,7 +346,16 @@ def _contract_fwd(x, L: _Lists):
     y = torch.empty((B, Cc * L.K, nlat_out, nlon_out), dtype=x.dtype, device=x.device)
     if B * Cc == 0:            # a rank of the azimuth group that got no channel (fewer channels than ranks)
         return y
-    with ops._timed("disco_fwd", flops=2.0 * B * Cc * nlon_out * L.nnz,
+    plan = _runs_plan_fwd(L, B * Cc, x.dtype)
+    if plan is not None:
+        RL = L.runs
+        with ops._timed(f"disco_fwd_{nlat_in}x{nlon_in}_p{B * Cc}", flops=2.0 * B * Cc * nlon_out * L.nnz,
+                        nbytes=float(x.element_size()) * (x.numel() + y.numel())):
+            check(lib().mk_disco_fwd_runs(ptr(x), ptr(y), dtype_code(x), ptr(RL.f_seg), ptr(RL.f_runs), ptr(RL.f_vals), ptr(RL.lat_lo),
+                                          ptr(RL.lat_n), RL.max_rows, B * Cc, L.K, nlat_in, nlon_in, nlat_out, plan[0], plan[1],
+                                          plan[2], stream()), "mk_disco_fwd_runs")
+        return y
+    with ops._timed(f"disco_fwd_{nlat_in}x{nlon_in}_p{B * Cc}", flops=2.0 * B * Cc * nlon_out * L.nnz,
                     nbytes=float(x.element_size()) * (x.numel() + y.numel())):
         check(lib().mk_disco_fwd(ptr(x), ptr(y), dtype_code(x), ptr(L.f_off), ptr(L.f_row), ptr(L.f_lon), ptr(L.f_val),
                                  ptr(L.lat_lo), ptr(L.lat_n), L.max_rows, B * Cc, L.K, nlat_in, nlon_in, nlat_out, nlon_out,
@@ -209,7 +370,16 @@ def _contract_bwd(gy, L: _Lists):
     gx = torch.empty((B, Cc, nlat_in, nlon_in), dtype=gy.dtype, device=gy.device)
     if B * Cc == 0:
         return gx
-    with ops._timed("disco_bwd", flops=2.0 * B * Cc * nlon_out * L.nnz,
+    plan = _runs_plan_bwd(L, B * Cc, gy.dtype)
+    if plan is not None:
+        b_seg, b_runs, b_vals, t_lo, t_n, mrb = L.runs.bwd(plan[3])
+        with ops._timed(f"disco_bwd_{nlat_in}x{nlon_in}_p{B * Cc}", flops=2.0 * B * Cc * nlon_out * L.nnz,
+                        nbytes=float(gy.element_size()) * (gx.numel() + gy.numel())):
+            check(lib().mk_disco_bwd_runs(ptr(gy), ptr(gx), dtype_code(gy), ptr(b_seg), ptr(b_runs), ptr(b_vals), ptr(t_lo), ptr(t_n), mrb,
+                                          B * Cc, L.K, nlat_in, nlon_in, nlat_out, plan[0], plan[1], plan[2], plan[3], stream()),
+                  "mk_disco_bwd_runs")
+        return gx
+    with ops._timed(f"disco_bwd_{nlat_in}x{nlon_in}_p{B * Cc}", flops=2.0 * B * Cc * nlon_out * L.nnz,
                     nbytes=float(gy.element_size()) * (gx.numel() + gy.numel())):
         if L.same_lon:
             check(lib().mk_disco_bwd_same(ptr(gy), ptr(gx), dtype_code(gy), ptr(L.s_off), ptr(L.s_row), ptr(L.s_lon), ptr(L.s_val),

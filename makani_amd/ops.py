@@ -741,8 +741,9 @@ class InstanceNormFn(torch.autograd.Function):
         b = beta.float().contiguous() if beta is not None else None
         pb = pre_bias.float().contiguous() if pre_bias is not None else None
         y = torch.empty_like(x)
-        check(lib().mk_instnorm_fwd(ptr(x), ptr(y), dt, ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(pb), ptr(quad), float(quad_sum), planes,
-                                    Cc, hw, eps, 1 if fuse_gelu else 0, stream()), "instnorm_fwd")
+        with _timed(f"instnorm_fwd{'_gelu' if fuse_gelu else ''}_n{hw}", nbytes=3.0 * x.numel() * x.element_size()):
+            check(lib().mk_instnorm_fwd(ptr(x), ptr(y), dt, ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(pb), ptr(quad), float(quad_sum),
+                                        planes, Cc, hw, eps, 1 if fuse_gelu else 0, stream()), "instnorm_fwd")
         ctx.save_for_backward(x, stats, g, b, pb, quad)
         ctx.quad_sum = float(quad_sum)
         ctx.fuse_gelu = fuse_gelu
@@ -759,9 +760,10 @@ class InstanceNormFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
-        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(quad),
-                                    ctx.quad_sum, ptr(sums), ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0, stream()),
-              "instnorm_bwd")
+        with _timed(f"instnorm_bwd{'_gelu' if ctx.fuse_gelu else ''}_n{hw}", nbytes=5.0 * x.numel() * x.element_size()):
+            check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(quad),
+                                        ctx.quad_sum, ptr(sums), ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0,
+                                        stream()), "instnorm_bwd")
         s = _batch_sum(sums, B, Cc)
         gpb = torch.zeros_like(pb) if (pb is not None and ctx.needs_input_grad[5]) else None
         return gx, (s[1] if g is not None else None), (s[0] if b is not None else None), None, None, gpb, None, None

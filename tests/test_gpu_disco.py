@@ -97,6 +97,38 @@ def test_disco_contraction_properties_at_fcn3_grids(in_shape, out_shape, fac):
     assert abs(lhs - rhs) / abs(lhs) < 1e-5
 
 
+@pytest.mark.parametrize("shape,grid,fac,planes", [((360, 720), "legendre-gauss", 2.0, 7), ((721, 1440), "equiangular", 1.0, 5),
+                                                   ((90, 180), "legendre-gauss", 2.0, 9), ((24, 48), "equiangular", 2.0, 2)])
+@pytest.mark.parametrize("dtype,img,bwd", [(torch.float32, "", ""), (torch.bfloat16, "", ""), (torch.bfloat16, "b", ""),
+                                           (torch.bfloat16, "", "2,0,4"), (torch.bfloat16, "", "4,1,4"), (torch.float32, "", "4,0,2")])
+def test_disco_run_form_kernels_match_list_kernels(shape, grid, fac, planes, dtype, img, bwd, monkeypatch):
+    """the sliding-window (run-form) kernels of csrc/disco_runs.hip against the list kernels of csrc/disco.hip on the same
+    convolution tensor: FourCastNet3's local-block grid (R = 4, three waves, PB = 4 with a ragged last plane group), its
+    decoder grid (R = 8), a two-wave grid and a PB = 2 case; forward and adjoint, fp32 and bf16 tensors, fp32 and bf16 LDS images,
+    latitude groups of 2 and 4 in the adjoint"""
+    import makani_amd.disco as pd
+    torch.manual_seed(3)
+    mod = pd.DiscreteContinuousConvS2(planes, 2, shape, shape, (3, 3), grid_in=grid, grid_out=grid, bias=False,
+                                      theta_cutoff=_cutoff(shape[0], fac)).to("cuda:0")
+    L = mod._device_lists(torch.device("cuda:0"))
+    assert L.runs is not None and L.runs.R == (8 if shape[1] > 768 else 4)
+    x = torch.randn(1, planes, *shape, device="cuda:0").to(dtype)
+    g = torch.randn(1, planes * 9, *shape, device="cuda:0").to(dtype)
+    monkeypatch.setenv("MAKANI_AMD_DISCO", "lists")
+    y0, gx0 = pd._contract_fwd(x, L), pd._contract_bwd(g, L)
+    monkeypatch.setenv("MAKANI_AMD_DISCO", "runs")
+    monkeypatch.setenv("MAKANI_AMD_DISCO_IMG", img)
+    monkeypatch.setenv("MAKANI_AMD_DISCO_BWD", bwd)
+    assert pd._runs_plan_fwd(L, planes, dtype) is not None
+    if pd._runs_plan_bwd(L, planes, dtype) is None:          # a forced adjoint variant that does not fit the LDS at this grid
+        assert bwd
+        pytest.skip("variant does not fit")
+    y1, gx1 = pd._contract_fwd(x, L), pd._contract_bwd(g, L)
+    tol = 1e-6 if dtype == torch.float32 else 4e-3          # bf16 outputs: both round the same fp32 sums (different order)
+    assert rel_l2(y1, y0) < tol and rel_l2(gx1, gx0) < tol
+    assert torch.isfinite(y1.float()).all() and torch.isfinite(gx1.float()).all()
+
+
 @pytest.mark.parametrize("nin,nout,gi,go", [((12, 24), (23, 48), "legendre-gauss", "equiangular"),
                                             ((17, 32), (33, 64), "equiangular", "equiangular"),
                                             ((24, 48), (12, 24), "equiangular", "legendre-gauss")])

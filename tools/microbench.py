@@ -135,7 +135,14 @@ def cold():
     for gelu in (False, True):
         ms = timeit(rot(lambda i: ops.InstanceNormFn.apply(xs[i], g, b, 1e-6, gelu)), reps=24, warm=12)
         print(f"cold instnorm fwd gelu={int(gelu)}  : {ms*1e3:7.1f} us  {3*nb/ms/1e6:7.1f} GB/s (2 reads + 1 write)")
+    pbias = torch.randn(C, device=dev) * 0.1
+    ms = timeit(rot(lambda i: ops.InstanceNormFn.apply(xs[i], g, b, 1e-6, False, pbias)), reps=24, warm=12)
+    print(f"cold instnorm fwd pre_bias: {ms*1e3:7.1f} us  {3*nb/ms/1e6:7.1f} GB/s (2 reads + 1 write)")
     xr = [x.clone().requires_grad_(True) for x in xs]
+    outs = [ops.InstanceNormFn.apply(x, g, b, 1e-6, False, pbias) for x in xr]
+    ms = timeit(rot(lambda i: torch.autograd.grad(outs[i], xr[i], ys[i], retain_graph=True)), reps=24, warm=12)
+    print(f"cold instnorm bwd pre_bias: {ms*1e3:7.1f} us  {5*nb/ms/1e6:7.1f} GB/s (4 reads + 1 write)")
+    del outs
     for gelu in (False, True):
         outs = [ops.InstanceNormFn.apply(x, g, b, 1e-6, gelu) for x in xr]
         ms = timeit(rot(lambda i: torch.autograd.grad(outs[i], xr[i], ys[i], retain_graph=True)), reps=24, warm=12)
