@@ -320,8 +320,16 @@ int mk_disco_bwd_same(const void* gy, void* gx, int dtype, const int* off, const
  *   mk_disco_fwd_runs: segments s = t * K + k, image rows relative to lat_lo[t] (lat_n[t] rows, max_rows their maximum).
  *   mk_disco_bwd_runs: segments s = i * K + k with negated longitudes, image rows = output latitudes relative to
  *     t_lo[(i / lat_group) * K + k] (t_n rows: lat_group = 2 | 4 consecutive latitudes share one staged image).
- *   img_bf16: keep bf16 tensors as bf16 in the LDS row image (half the LDS per workgroup, one conversion per read). */
+ *   img_bf16: keep bf16 tensors as bf16 in the LDS row image (half the LDS per workgroup, one conversion per read).
+ *   mk_disco_fwd_fused (K = 9): one stream per (output latitude, image row) shared by all basis functions (their filters
+ *     live on the same longitude interval): seg_off (nlat_out + 1), runs (n, 4) = {image row relative to lat_lo[t / LG], first
+ *     slot = first longitude / 4 (runs aligned to 4 longitudes), value offset, groups}, vals per group K x 4 ([k][tau]);
+ *     lat_lo / lat_n per group of LG output latitudes, LG as named by mk_disco_fused_shape for the longitude count. */
 int mk_disco_runs_shape(int nlon, int max_rows, int planes, int dtype, int img_bf16, int* R_out, int* PB_out);
+int mk_disco_fused_shape(int nlon, int K, int max_rows, int planes, int* LG_out, int* PB_out);
+int mk_disco_fwd_fused(const void* x, void* y, int dtype, const int* seg_off, const int* runs, const float* vals,
+                       const int* lat_lo, const int* lat_n, int max_rows, int planes, int K, int nlat_in, int nlon, int nlat_out,
+                       void* stream);
 int mk_disco_fwd_runs(const void* x, void* y, int dtype, const int* seg_off, const int* runs, const float* vals,
                       const int* lat_lo, const int* lat_n, int max_rows, int planes, int K, int nlat_in, int nlon, int nlat_out,
                       int R, int PB, int img_bf16, void* stream);

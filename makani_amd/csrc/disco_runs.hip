@@ -300,6 +300,104 @@ __global__ __launch_bounds__(64 * NW * LG) void disco_runs_bwd_kernel(const T* _
     }
 }
 
+
+// ---- forward, all K basis functions at once ---------------------------------------------------------------------------
+// For a fixed (output latitude, input row) the K filters live on the same longitude interval (the support is the disc, the
+// basis functions differ in their values), so the window of row elements is shared: one stream per (t, row) whose groups
+// carry K x R filter values.  R = 4 row elements fetched per group now feed K * R * R * PB multiply-adds (K = 9, PB = 2: 144
+// packed FMAs per four 8-byte LDS reads) and the per-run costs (header, window fill) are paid once instead of K times.
+// Runs are aligned to multiples of R by the host (zero taps in front), so every block is "the R classes of one slot" and the
+// kernel needs neither the class switch nor the duplicate slot.  Workgroup = (LG consecutive output latitudes, PB planes):
+// wave group lg of NW waves walks latitude tg * LG + lg; the row image is the union of what the LG latitudes touch.
+template <typename T, int PB, int K, int NW, int LG>
+__global__ __launch_bounds__(64 * NW * LG) void disco_fused_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                       const int* __restrict__ seg_off, const i32x4* __restrict__ runs,
+                                                                       const float* __restrict__ vals, const int* __restrict__ lat_lo,
+                                                                       const int* __restrict__ lat_n, int planes, int nlat_in, int nlon,
+                                                                       int nlat_out) {
+    typedef typename FV<PB>::type fv;
+    constexpr int R = 4;
+    constexpr int SLOT = PB * 4, SEGB = (64 * NW + 1) * SLOT, ROWB = R * SEGB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    const int tg = blockIdx.x, p0 = blockIdx.y * PB, tid = threadIdx.x;
+    const int n4 = nlon / R;
+    const int lo = lat_lo[tg], nr = lat_n[tg];
+    stage_image<T, float, PB, R, SEGB, ROWB>(smem_r, x + (long long)lo * nlon, (long long)nlat_in * nlon, p0, planes, nr, nlon, n4,
+                                             tid, 64 * NW * LG);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lg = wave / NW, wl = wave - lg * NW;
+    const int t = tg * LG + lg;
+    if (t >= nlat_out) return;
+    const int slot = wl * 64 + lane;
+    const unsigned laneB = (unsigned)min(slot, n4 - 1) * SLOT, n4B = (unsigned)n4 * SLOT;
+    lds_cb* img = (lds_cb*)smem_r;
+    fv acc[K][R];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[k][r] = fv(0.f);
+    const int r0 = seg_off[t], r1 = seg_off[t + 1];
+    for (int rr = r0; rr < r1; ++rr) {
+        const i32x4 h = runs[rr];                                  // {row, first slot (js / R), value offset, groups}
+        lds_cb* rowp = img + h[0] * ROWB;
+        const float* vp = vals + h[2];
+        const int ng = h[3];
+        unsigned s = laneB + (unsigned)h[1] * SLOT;
+        unsigned tB = min(s, s - n4B);
+        fv cur[R], nxt[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) cur[j] = load_slot<float, PB>(rowp + tB + j * SEGB);
+        s = tB + SLOT;
+        tB = min(s, s - n4B);
+#pragma unroll
+        for (int j = 0; j < R; ++j) nxt[j] = load_slot<float, PB>(rowp + tB + j * SEGB);
+        for (int g = 0; g < ng; ++g) {
+            fv fut[R];
+            s = tB + SLOT;
+            tB = min(s, s - n4B);
+#pragma unroll
+            for (int j = 0; j < R; ++j) fut[j] = load_slot<float, PB>(rowp + tB + j * SEGB);     // block g + 2
+            const float* v = vp + g * (K * R);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int tau = 0; tau < R; ++tau) {
+                    const float val = v[k * R + tau];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const fv xe = (tau + r < R) ? cur[tau + r] : nxt[tau + r - R];
+                        acc[k][r] = __builtin_elementwise_fma(fv(val), xe, acc[k][r]);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                cur[j] = nxt[j];
+                nxt[j] = fut[j];
+            }
+        }
+    }
+    if (slot < n4) {
+        const long long plane_out = (long long)nlat_out * nlon;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int b = 0; b < PB; ++b)
+                if (p0 + b < planes)
+                    store_outputs<T, PB, R>(y + ((long long)(p0 + b) * K + k) * plane_out + (long long)t * nlon + slot * R, acc[k], b);
+    }
+}
+
+// (NW, LG) of the fused forward kernel for a longitude count; false when it is not instantiated
+inline bool fused_shape(int nlon, int& NW, int& LG) {
+    if (nlon % 4) return false;
+    const int lanes = nlon / 4;
+    NW = (lanes + 63) / 64;
+    if (lanes < 2 || !(NW <= 3 || NW == 6)) return false;
+    LG = NW == 6 ? 2 : 4;
+    return true;
+}
+
 constexpr size_t RUNS_LDS_CAP = 160 * 1024;       // the whole LDS of a CU: such a workgroup runs alone on it
 
 template <typename KERN, typename... Args>
@@ -360,6 +458,51 @@ extern "C" int mk_disco_runs_shape(int nlon, int max_rows, int planes, int dtype
         if (PB == 2 && R == 8 && NW == 3) return runs_launch(KERNEL<T, IMG, 2, 8, 3, GROUPS8>, grid, threads, lds, s, what, __VA_ARGS__); \
         MK_REQUIRE(false, "%s: no kernel for PB=%d R=%d NW=%d", what, PB, R, NW);                                            \
     } while (0)
+
+
+// 1 when the fused forward kernel (all K basis functions per stream) takes this shape; *LG_out = output latitudes per workgroup
+// (the lists are built for it), *PB_out = planes per workgroup
+extern "C" int mk_disco_fused_shape(int nlon, int K, int max_rows, int planes, int* LG_out, int* PB_out) {
+    int NW, LG;
+    if (K != 9 || planes < 2 || !fused_shape(nlon, NW, LG)) return 0;
+    if ((size_t)max_rows * 4 * (64 * NW + 1) * 2 * 4 > RUNS_LDS_CAP) return 0;
+    if (LG_out) *LG_out = LG;
+    if (PB_out) *PB_out = 2;
+    return 1;
+}
+
+// forward, all K = 9 basis functions per stream: seg_off (nlat_out + 1) indexes runs (n, 4) = {image row relative to
+// lat_lo[t / LG], first slot = first longitude / 4, value offset, groups}; vals: per group K x 4 values ([k][tau]), runs
+// aligned to multiples of 4 longitudes; lat_lo / lat_n per latitude GROUP (max_rows = their maximum row count)
+extern "C" int mk_disco_fwd_fused(const void* x, void* y, int dtype, const int* seg_off, const int* runs, const float* vals,
+                                  const int* lat_lo, const int* lat_n, int max_rows, int planes, int K, int nlat_in, int nlon,
+                                  int nlat_out, void* stream) {
+    MK_REQUIRE(x && y && seg_off && runs && vals && lat_lo && lat_n, "disco_fwd_fused: null pointer");
+    int NW, LG;
+    MK_REQUIRE(K == 9 && fused_shape(nlon, NW, LG), "disco_fwd_fused: K = 9 and a covered longitude count (got K = %d, %d)", K, nlon);
+    constexpr int PB = 2;
+    MK_REQUIRE(planes >= PB && (planes + PB - 1) / PB <= 65535, "disco_fwd_fused: bad plane count");
+    const size_t lds = (size_t)max_rows * 4 * (64 * NW + 1) * PB * 4;
+    MK_REQUIRE(lds <= RUNS_LDS_CAP, "disco_fwd_fused: %d rows do not fit the LDS", max_rows);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((nlat_out + LG - 1) / LG, (planes + PB - 1) / PB);
+    const i32x4* rn = (const i32x4*)runs;
+    const int threads = 64 * NW * LG;
+#define MK_FUSED_GO(T, NW_, LG_)                                                                                              \
+    return runs_launch(disco_fused_fwd_kernel<T, PB, 9, NW_, LG_>, grid, threads, lds, s, "mk_disco_fwd_fused", (const T*)x, (T*)y, \
+                       seg_off, rn, vals, lat_lo, lat_n, planes, nlat_in, nlon, nlat_out)
+    if (dtype == MK_F32) {
+        if (NW == 1) MK_FUSED_GO(float, 1, 4);
+        if (NW == 2) MK_FUSED_GO(float, 2, 4);
+        if (NW == 3) MK_FUSED_GO(float, 3, 4);
+        MK_FUSED_GO(float, 6, 2);
+    }
+    if (NW == 1) MK_FUSED_GO(u16, 1, 4);
+    if (NW == 2) MK_FUSED_GO(u16, 2, 4);
+    if (NW == 3) MK_FUSED_GO(u16, 3, 4);
+    MK_FUSED_GO(u16, 6, 2);
+#undef MK_FUSED_GO
+}
 
 // forward, run form.  seg_off (nlat_out * K + 1), runs (n, 4) = {row, first lon, value offset, groups}, vals: see the header.
 // PB / R as returned by mk_disco_runs_shape (the lists are built for that R); img_bf16: keep bf16 tensors as bf16 in LDS.

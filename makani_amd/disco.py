@@ -241,6 +241,50 @@ def _build_runs(seg, row, lon, val, nseg, nlon, R):
     return seg_off.astype(np.int32), runs, vals
 
 
+def _build_fused(t, k, row, lon, val, nlat_out, K, nlon):
+    """entries (output latitude, basis function, image row, longitude, value) -> the streams of the fused forward kernel
+    (csrc/disco_runs.hip: disco_fused_fwd_kernel): per (t, row) the UNION over k of the longitudes is cut into circular runs,
+    each aligned down to a multiple of 4 longitudes; a run is {row, first slot = first longitude / 4, value offset, groups}
+    and carries groups x K x 4 values ([group][k][tau], zeros where a basis function has no tap)."""
+    R = 4
+    order = np.lexsort((lon, row, t))
+    t, k, row, lon, val = t[order], k[order], row[order], lon[order], val[order]
+    n = t.size
+    key = t * (int(row.max()) + 1 if n else 1) + row
+    first = np.flatnonzero(np.r_[True, key[1:] != key[:-1]]) if n else np.zeros(0, np.int64)
+    last = np.r_[first[1:], n]
+    out_runs, out_vals, counts = [], [], np.zeros(nlat_out, np.int64)
+    voff = 0
+    for a, b in zip(first, last):
+        l, kk, v = lon[a:b], k[a:b], val[a:b]
+        ul = np.unique(l)
+        if ul.size == nlon:
+            pieces = [(0, nlon)]
+        else:
+            cuts = np.flatnonzero(np.diff(ul) != 1) + 1
+            segs = np.split(ul, cuts)
+            pieces = [(int(sg[0]), sg.size) for sg in segs]
+            if len(pieces) > 1 and ul[0] == 0 and ul[-1] == nlon - 1:             # the run that crosses longitude 0
+                pieces = [(pieces[-1][0], pieces[-1][1] + pieces[0][1])] + pieces[1:-1]
+        for js, cnt in pieces:
+            ja = js - js % R
+            ng = (js - ja + cnt + R - 1) // R
+            blk = np.zeros((ng, K, R), np.float32)
+            off = (l - ja) % nlon
+            sel = off < (js - ja) + cnt                                          # the entries of this run
+            sel &= off >= (js - ja)
+            blk[off[sel] // R, kk[sel], off[sel] % R] = v[sel]
+            out_runs.append((int(row[a]), ja // R, voff, ng))
+            out_vals.append(blk.reshape(-1))
+            voff += blk.size
+        counts[t[a]] += len(pieces)
+    seg_off = np.zeros(nlat_out + 1, np.int64)
+    seg_off[1:] = np.cumsum(counts)
+    runs = np.array(out_runs, np.int32).reshape(-1, 4)
+    vals = np.concatenate(out_vals + [np.zeros(K * R, np.float32)])
+    return seg_off.astype(np.int32), runs, vals
+
+
 class _RunLists:
     """run-form lists of one convolution tensor with nlon_in == nlon_out (forward: segments (t, k), image rows = input
     latitudes relative to the first one latitude t touches; adjoint: segments (i, k), image rows = output latitudes relative to
@@ -267,7 +311,7 @@ class _RunLists:
         self.lat_lo, self.lat_n = to(lat_lo.astype(np.int32)), to(lat_n.astype(np.int32))
         self.max_rows = max(1, int(lat_n.max()))
         self.K, self.in_shape, self.out_shape, self.nnz = K, (nlat_in, nlon), (nlat_out, nlon), int(v.size)
-        self._groups, self._bwd = {}, {}
+        self._groups, self._bwd, self._fused, self._frows = {}, {}, {}, {}
         for LG in (4, 2):                      # the image rows of a latitude group: cheap, decides which LG fits the LDS
             gseg = (i // LG) * K + k
             ngrp = (nlat_in + LG - 1) // LG
@@ -281,6 +325,36 @@ class _RunLists:
 
     def _to(self, a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self._dev)
+
+    def fused(self, LG):
+        """(seg_off, runs, vals, lat_lo, lat_n, max_rows) of the fused forward kernel for groups of LG output latitudes"""
+        if LG not in self._fused:
+            k, t, i, j, v = self._e
+            nlat_out, nlon = self.out_shape
+            ngrp = (nlat_out + LG - 1) // LG
+            g_lo = np.full(ngrp, self.in_shape[0], np.int64)
+            g_hi = np.full(ngrp, -1, np.int64)
+            np.minimum.at(g_lo, t // LG, i)
+            np.maximum.at(g_hi, t // LG, i)
+            live = g_hi >= 0
+            g_lo = np.where(live, g_lo, 0)
+            g_n = np.where(live, g_hi - g_lo + 1, 0)
+            so, rn, vl = _build_fused(t, k, i - g_lo[t // LG], j, v, nlat_out, self.K, nlon)
+            self._fused[LG] = (self._to(so), self._to(rn), self._to(vl), self._to(g_lo.astype(np.int32)), self._to(g_n.astype(np.int32)),
+                               max(1, int(g_n.max())))
+        return self._fused[LG]
+
+    def fused_rows(self, LG):
+        """image rows of the fused forward kernel (without building its lists)"""
+        if LG not in self._frows:
+            _, t, i, _, _ = self._e
+            ngrp = (self.out_shape[0] + LG - 1) // LG
+            g_lo = np.full(ngrp, self.in_shape[0], np.int64)
+            g_hi = np.full(ngrp, -1, np.int64)
+            np.minimum.at(g_lo, t // LG, i)
+            np.maximum.at(g_hi, t // LG, i)
+            self._frows[LG] = max(1, int((g_hi - g_lo + 1).max()))
+        return self._frows[LG]
 
     def max_rows_b(self, LG):
         return self._groups[LG][2]
@@ -305,6 +379,17 @@ def _runs_shape(L, planes, dtype, max_rows, img_bf16, pb=0):
     code = _lib.MK_BF16 if dtype == torch.bfloat16 else _lib.MK_F32
     ok = lib().mk_disco_runs_shape(L.in_shape[1], max_rows, planes, code, img_bf16, C.byref(R), C.byref(PB))
     return (R.value, PB.value) if ok and R.value == L.runs.R else None
+
+
+def _fused_plan(L, planes):
+    """LG (output latitudes per workgroup) when the fused forward kernel (all K basis functions per stream) takes the launch"""
+    if not _runs_enabled(L) or os.environ.get("MAKANI_AMD_DISCO_FUSED", "1") != "1":
+        return None
+    LG, PB = C.c_int(0), C.c_int(0)
+    for lg in (4, 2):            # the library names the LG of this longitude count; the row count belongs to that LG
+        if lib().mk_disco_fused_shape(L.in_shape[1], L.K, L.runs.fused_rows(lg), planes, C.byref(LG), C.byref(PB)) and LG.value == lg:
+            return lg
+    return None
 
 
 def _runs_plan_fwd(L, planes, dtype):
@@ -345,6 +430,14 @@ def _contract_fwd(x, L: _Lists):
     nlat_out, nlon_out = L.out_shape
     y = torch.empty((B, Cc * L.K, nlat_out, nlon_out), dtype=x.dtype, device=x.device)
     if B * Cc == 0:            # a rank of the azimuth group that got no channel (fewer channels than ranks)
+        return y
+    fplan = _fused_plan(L, B * Cc)
+    if fplan is not None:
+        f_seg, f_runs, f_vals, g_lo, g_n, mr = L.runs.fused(fplan)
+        with ops._timed(f"disco_fwd_{nlat_in}x{nlon_in}_p{B * Cc}", flops=2.0 * B * Cc * nlon_out * L.nnz,
+                        nbytes=float(x.element_size()) * (x.numel() + y.numel())):
+            check(lib().mk_disco_fwd_fused(ptr(x), ptr(y), dtype_code(x), ptr(f_seg), ptr(f_runs), ptr(f_vals), ptr(g_lo), ptr(g_n), mr,
+                                           B * Cc, L.K, nlat_in, nlon_in, nlat_out, stream()), "mk_disco_fwd_fused")
         return y
     plan = _runs_plan_fwd(L, B * Cc, x.dtype)
     if plan is not None:

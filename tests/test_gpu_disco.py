@@ -119,13 +119,17 @@ def test_disco_run_form_kernels_match_list_kernels(shape, grid, fac, planes, dty
     monkeypatch.setenv("MAKANI_AMD_DISCO", "runs")
     monkeypatch.setenv("MAKANI_AMD_DISCO_IMG", img)
     monkeypatch.setenv("MAKANI_AMD_DISCO_BWD", bwd)
-    assert pd._runs_plan_fwd(L, planes, dtype) is not None
+    assert pd._runs_plan_fwd(L, planes, dtype) is not None and pd._fused_plan(L, planes) is not None
+    monkeypatch.setenv("MAKANI_AMD_DISCO_FUSED", "0")          # the per-basis-function forward kernel
+    assert pd._fused_plan(L, planes) is None
+    y2 = pd._contract_fwd(x, L)
+    monkeypatch.setenv("MAKANI_AMD_DISCO_FUSED", "1")          # one stream per (latitude, row) for all nine basis functions
     if pd._runs_plan_bwd(L, planes, dtype) is None:          # a forced adjoint variant that does not fit the LDS at this grid
         assert bwd
         pytest.skip("variant does not fit")
     y1, gx1 = pd._contract_fwd(x, L), pd._contract_bwd(g, L)
     tol = 1e-6 if dtype == torch.float32 else 4e-3          # bf16 outputs: both round the same fp32 sums (different order)
-    assert rel_l2(y1, y0) < tol and rel_l2(gx1, gx0) < tol
+    assert rel_l2(y1, y0) < tol and rel_l2(gx1, gx0) < tol and rel_l2(y2, y0) < tol
     assert torch.isfinite(y1.float()).all() and torch.isfinite(gx1.float()).all()
 
 
