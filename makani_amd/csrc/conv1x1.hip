@@ -62,6 +62,11 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* ptr) {      // raw buffer
     r[3] = 0x00020000;
     return r;
 }
+__device__ __forceinline__ v4i_t make_rsrc_n(const void* ptr, unsigned bytes) {      // raw buffer of `bytes`: offsets beyond it read zeros
+    v4i_t r = make_rsrc(ptr);
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    return r;
+}
 __device__ __forceinline__ unsigned lds_addr(const void* ptr) { return (unsigned)(unsigned long long)(lds_void_t*)ptr; }
 
 template <int STEP>
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int nk = p.K / BK;
+    const int nk = (p.K + BK - 1) / BK;                 // the last k-tile may be ragged: its missing activation rows read zeros
     const unsigned rowbytes = (unsigned)(p.N * 2);
 
     // ---- DMA addressing ----
@@ -396,7 +401,9 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
     unsigned voffx[NIX];
 #pragma unroll
     for (int j = 0; j < NIX; ++j) voffx[j] = (unsigned)(2 * (wave + 8 * j) + (lane >> 5)) * rowbytes + (unsigned)cx_log * 16u;
-    const v4i_t rsA = make_rsrc(p.A);
+    // weights: the buffer ends with the matrix (a ragged last k-tile reads columns k >= lda: the next row's first values,
+    // finite, against activation rows that read zero; behind the last row: zeros)
+    const v4i_t rsA = make_rsrc_n(p.A, (unsigned)((long long)p.M * p.lda * 2));
     const unsigned lds_w = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;    // this wave's 1 KB slot of a row-group stripe
 
     // ---- fragment addressing ----
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
     const long long first = xcd_remap(blockIdx.x, gridDim.x);
     unsigned voffa[NIA];
     unsigned voffx_t[NIX];
-    v4i_t rsX = rsA;
+    const u16* xb = p.X;                                // activations of the batch entry being multiplied
     int m0 = 0, bcur = -1;
     long long n0 = 0;
 
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
         n0 = (tnb % tilesN) * BN;
         if (b != bcur) {
             bcur = b;
-            rsX = make_rsrc(p.X + (long long)b * p.K * p.N);
+            xb = p.X + (long long)b * p.K * p.N;
         }
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
@@ -440,7 +447,10 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
     auto issue = [&](int kt, int stage) {
         const unsigned dst = lds_w + stage * STAGE;
         const unsigned soffa = (unsigned)(kt * BK * 2);
-        const unsigned soffx = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(((long long)kt * BK * p.N + n0) * 2));
+        // activations: a buffer per k-tile that ends with the tile's last existing input channel (rows k >= K read zeros);
+        // offsets inside it stay below 64 rows (any K x N fits)
+        const v4i_t rsX = make_rsrc_n(xb + (long long)kt * BK * p.N, (unsigned)min(BK, p.K - kt * BK) * rowbytes);
+        const unsigned soffx = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(n0 * 2));
         if constexpr (NIA == 4) dma4<8192>(dst, rsA, soffa, voffa[0], voffa[1], voffa[2], voffa[3]);
         else dma3<8192>(dst, rsA, soffa, voffa[0], voffa[1], voffa[2]);
         dma4<8192>(dst + ASZ, rsX, soffx, voffx_t[0], voffx_t[1], voffx_t[2], voffx_t[3]);
@@ -1080,10 +1090,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const ConvWg p, int t
 // with (row >> 1) & 7 — applied to the per-lane SOURCE address, the DMA destination is lane-linear — which makes the
 // ds_read_b128 fragment reads conflict-free.
 struct ConvWgR {
-    const u16* P;    // (B, RP, N)   slab operand
-    const u16* Q;    // (B, RQ, N)   operand held in full (RQ <= TQ)
+    const u16* P;    // (B, RP, N)   slab operand (slabs of TP rows)
+    const u16* Q;    // (B, RQ, N)   the other operand: slabs of TQ = 384 rows (one slab when RQ <= 384: held in full)
     float* part;     // (S, M, K) fp32 partials in OUTPUT orientation
-    int RP, RQ, B, S, slabs;
+    int RP, RQ, B, S, slabs, qslabs;
     int ldo;         // row length of the output (= K)
     long long N;
     long long chunk;   // pixels per split (multiple of 64)
@@ -1107,7 +1117,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);   // the slabs of one pixel split are neighbours on one XCD (share Q in L2)
     const int slab = bid % p.slabs;
-    const int sp = bid / p.slabs;
+    const int qs = (bid / p.slabs) % p.qslabs;
+    const int q0 = qs * TQ;                             // first Q row of this tile
+    const int sp = bid / (p.slabs * p.qslabs);
     const int splits_per_b = p.S / p.B;
     const int b = sp / splits_per_b;
     const long long nbeg = (long long)(sp % splits_per_b) * p.chunk;
@@ -1126,14 +1138,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int rg = wave + 8 * i;
-        int row;
-        if (i < NIP) row = min(slab * TP + rg * 8 + (lane >> 3), p.RP - 1);           // rows past the operand: any valid row
-        else row = min((rg - TP / 8) * 8 + (lane >> 3), p.RQ - 1);                    // (their products are never stored)
+        int row;                                                                      // relative to the tile's first row
+        if (i < NIP) row = min(rg * 8 + (lane >> 3), p.RP - 1 - slab * TP);           // rows past the operand: any valid row
+        else row = min((rg - TP / 8) * 8 + (lane >> 3), p.RQ - 1 - q0);               // (their products are never stored)
         voff[i] = (unsigned)row * rowbytes + (unsigned)c_log * 16u;
     }
-    // raw buffers (stride 0, 2^31 records): a lane whose voffset is >= 2^31 reads zeros — used for the ragged last pixel tile
-    const v4i_t rsP = make_rsrc(p.P + (long long)b * p.RP * p.N);
-    const v4i_t rsQ = make_rsrc(p.Q + (long long)b * p.RQ * p.N);
+    // raw buffers (stride 0, 2^31 records) that start at the tile's first row: offsets stay below 384 rows whatever the
+    // channel count; a lane whose voffset is >= 2^31 reads zeros — used for the ragged last pixel tile
+    const v4i_t rsP = make_rsrc(p.P + ((long long)b * p.RP + slab * TP) * p.N);
+    const v4i_t rsQ = make_rsrc(p.Q + ((long long)b * p.RQ + q0) * p.N);
     const unsigned lds_w = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;
 
     auto issue = [&](int kt, int stage) {
@@ -1205,7 +1218,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
     for (int i = 0; i < WTP; ++i)
 #pragma unroll
         for (int j = 0; j < WTQ; ++j) {
-            const int prow0 = slab * TP + (wp * WTP + i) * 32, qrow0 = (wq * WTQ + j) * 32;
+            const int prow0 = slab * TP + (wp * WTP + i) * 32, qrow0 = q0 + (wq * WTQ + j) * 32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1290,7 +1303,9 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
 #undef MK_ASTAT
         return mk_check_launch("mk_conv1x1_nn");
     }
-    if (!force_tile && (K % 64) == 0 && M >= 192 && (long long)K * N * 2 < (1ll << 31) && (long long)M * lda * 2 < (1ll << 31) && N >= 256) {
+    static const bool ring_any_k = [] { const char* e = getenv("MAKANI_AMD_CONV_RINGK"); return !(e && e[0] == '0'); }();
+    if (!force_tile && ((K % 64) == 0 || (ring_any_k && K >= 64)) && M >= 192 && N * 2 * 64 < (1ll << 31) &&
+        (long long)M * lda * 2 < (1ll << 31) && N >= 256) {
         // ring kernel: persistent grid, one 512-thread workgroup per CU
         const bool big = (M % 256 == 0) || M > 576;
         const int bm = big ? 256 : 192;
@@ -1332,6 +1347,7 @@ struct WgPlan {
     bool swap;          // ring: P = X, Q = G
     int tp;             // ring: slab height (256 / 192)
     int slabs;
+    int qslabs;         // ring: 384-row slabs of Q
     long long S;        // pixel splits (all batch entries)
     long long chunk;    // pixels per split
 };
@@ -1350,18 +1366,22 @@ WgPlan wgrad_plan(int M, int K, int B, long long N) {
     const int big = M > K ? M : K, small = M > K ? K : M;
     // ring kernel: the smaller channel count fits one 384-row tile, the other one is cut into slabs; 32-bit byte
     // offsets inside one batch entry; at least a few pixel tiles per split
-    const bool ok = wgrad_kernel_choice() == 0 && big <= 384 * 4 && big >= 96 && (long long)big * N * 2 < (1ll << 31) && N >= 2048;
-    if (ok && (small <= 384)) {
+    static const bool ring2d = [] { const char* e = getenv("MAKANI_AMD_WGRAD_2D"); return !(e && e[0] == '0'); }();
+    const bool ok = wgrad_kernel_choice() == 0 && big >= 96 && N * 2 * 384 < (1ll << 31) && N >= 2048;
+    if (ok && (small <= 384 || ring2d)) {
         pl.ring = true;
-        int q, pr;                                   // rows of Q (held in full) and of P (slabs)
-        if (big <= 384) { q = big; pr = small; } else { q = small; pr = big; }
+        int q, pr;                                   // rows of Q (384-row slabs; one slab = held in full) and of P (slabs of tp)
+        if (big <= 384) { q = big; pr = small; }
+        else if (small <= 384) { q = small; pr = big; }
+        else { q = big; pr = small; }                // both large (FourCastNet3): the longer operand in 384-row slabs
         // Q = X (k) unless that puts the larger operand in P's place the wrong way round
         const bool q_is_x = (K == q) && !(M == q && M > K);
         pl.swap = !q_is_x;
         pl.tp = (pr > 192 && pr % 256 != 192 && (pr % 192 != 0 || pr % 256 == 0)) ? 256 : 192;
         if (pr <= 192) pl.tp = 192;
         pl.slabs = (pr + pl.tp - 1) / pl.tp;
-        long long per_b = 256 / ((long long)pl.slabs * B);
+        pl.qslabs = (q + 383) / 384;
+        long long per_b = 256 / ((long long)pl.slabs * pl.qslabs * B);
         if (per_b < 1) per_b = 1;
         const long long maxs = (N + 1023) / 1024;    // at least 16 pixel tiles per split
         if (per_b > maxs) per_b = maxs;
@@ -1401,8 +1421,8 @@ extern "C" int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* 
         p.Q = (const u16*)(pl.swap ? G : X);
         p.RP = pl.swap ? K : M;
         p.RQ = pl.swap ? M : K;
-        p.part = part, p.B = B, p.S = (int)pl.S, p.slabs = pl.slabs, p.ldo = K, p.N = N, p.chunk = pl.chunk;
-        const dim3 grid((unsigned)(pl.slabs * pl.S)), blk(512);
+        p.part = part, p.B = B, p.S = (int)pl.S, p.slabs = pl.slabs, p.qslabs = pl.qslabs, p.ldo = K, p.N = N, p.chunk = pl.chunk;
+        const dim3 grid((unsigned)(pl.slabs * pl.qslabs * pl.S)), blk(512);
         if (pl.tp == 256) {
             if (pl.swap) hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 4, 4, 3, true>), grid, blk, 0, s, p);
             else hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 4, 4, 3, false>), grid, blk, 0, s, p);

@@ -441,7 +441,13 @@ def test_fused_adamw_matches_torch():
                                      (2, 130, 260, 10, 52),
                                      # K = 384: the weight-stationary kernel (one slab, two slabs + ragged pixel tail + batch,
                                      # a slab with rows past M, more pixel tiles than the DMA look-ahead)
-                                     (1, 384, 384, 16, 40), (2, 768, 384, 10, 52), (1, 300, 384, 37, 72), (1, 768, 384, 91, 184)])
+                                     (1, 384, 384, 16, 40), (2, 768, 384, 10, 52), (1, 300, 384, 37, 72), (1, 768, 384, 91, 184),
+                                     # FourCastNet3's channel counts: ring kernel with a ragged last k-tile (input channels past K
+                                     # read zeros), ragged channel slabs, one k-tile plus a remainder
+                                     (1, 677, 1354, 16, 40), (1, 641, 677, 20, 36), (2, 200, 100, 10, 52), (1, 1354, 641, 8, 40),
+                                     # ... and enough pixels for the weight-gradient ring kernel with both channel counts above 384
+                                     # (two-dimensional tiling: slabs of P x 384-row slabs of Q, either operand as Q, batch)
+                                     (1, 677, 1354, 48, 48), (1, 1354, 641, 48, 48), (2, 450, 400, 32, 72)])
 def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
     from makani_amd import ops
     torch.manual_seed(M + K)
