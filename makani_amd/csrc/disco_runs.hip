@@ -410,15 +410,29 @@ int runs_launch(KERN kern, dim3 grid, int threads, size_t lds, hipStream_t s, co
 
 // (R, NW) for a longitude count: N / R lanes in NW waves; 0 when the run form does not apply
 inline bool runs_shape(int nlon, int& R, int& NW) {
-    for (int r : {4, 8}) {
-        if (nlon % r) continue;
-        const int lanes = nlon / r;
-        if (lanes < 2 || lanes > 192 || (r == 8 && lanes <= 128)) continue;      // R = 8 is instantiated for three waves only
-        R = r;
-        NW = (lanes + 63) / 64;
-        return true;
+    if (nlon % 4 == 0) {                          // R = 4: up to three waves per latitude circle, or six (1284 .. 1536 longitudes)
+        const int lanes = nlon / 4;
+        const int nw = (lanes + 63) / 64;
+        if (lanes >= 2 && (nw <= 3 || nw == 6)) {
+            R = 4;
+            NW = nw;
+            return true;
+        }
+    }
+    if (nlon % 8 == 0) {                          // R = 8 with three waves covers 1032 .. 1536 longitudes
+        const int lanes = nlon / 8;
+        if (lanes > 128 && lanes <= 192) {
+            R = 8;
+            NW = 3;
+            return true;
+        }
     }
     return false;
+}
+
+inline int mk_runs_radix(int nlon) {
+    int R, NW;
+    return runs_shape(nlon, R, NW) ? R : 0;
 }
 
 template <int PB, int R, int NW>
@@ -451,6 +465,8 @@ extern "C" int mk_disco_runs_shape(int nlon, int max_rows, int planes, int dtype
         if (PB == 4 && R == 4 && NW == 1) return runs_launch(KERNEL<T, IMG, 4, 4, 1, GROUPS>, grid, threads, lds, s, what, __VA_ARGS__); \
         if (PB == 4 && R == 4 && NW == 2) return runs_launch(KERNEL<T, IMG, 4, 4, 2, GROUPS>, grid, threads, lds, s, what, __VA_ARGS__); \
         if (PB == 4 && R == 4 && NW == 3) return runs_launch(KERNEL<T, IMG, 4, 4, 3, GROUPS>, grid, threads, lds, s, what, __VA_ARGS__); \
+        if (PB == 4 && R == 4 && NW == 6) return runs_launch(KERNEL<T, IMG, 4, 4, 6, GROUPS>, grid, threads, lds, s, what, __VA_ARGS__); \
+        if (PB == 2 && R == 4 && NW == 6) return runs_launch(KERNEL<T, IMG, 2, 4, 6, GROUPS>, grid, threads, lds, s, what, __VA_ARGS__); \
         if (PB == 4 && R == 8 && NW == 3) return runs_launch(KERNEL<T, IMG, 4, 8, 3, GROUPS8>, grid, threads, lds, s, what, __VA_ARGS__); \
         if (PB == 2 && R == 4 && NW == 1) return runs_launch(KERNEL<T, IMG, 2, 4, 1, GROUPS>, grid, threads, lds, s, what, __VA_ARGS__); \
         if (PB == 2 && R == 4 && NW == 2) return runs_launch(KERNEL<T, IMG, 2, 4, 2, GROUPS>, grid, threads, lds, s, what, __VA_ARGS__); \
@@ -512,7 +528,7 @@ extern "C" int mk_disco_fwd_runs(const void* x, void* y, int dtype, const int* s
     MK_REQUIRE(x && y && seg_off && runs && vals && lat_lo && lat_n, "disco_fwd_runs: null pointer");
     int R2, NW;
     MK_REQUIRE(runs_shape(nlon, R2, NW) && R2 == R, "disco_fwd_runs: %d longitudes are not covered by R = %d", nlon, R);
-    MK_REQUIRE((R == 8 ? NW == 3 : true), "disco_fwd_runs: R = 8 is built for 1025..1536 longitudes");
+    MK_REQUIRE(mk_runs_radix(nlon) == R, "disco_fwd_runs: lists built for R = %d", R);
     MK_REQUIRE(planes >= PB && (PB == 2 || PB == 4) && K > 0 && (planes + PB - 1) / PB <= 65535, "disco_fwd_runs: bad plane count");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nlat_out, (planes + PB - 1) / PB);
@@ -538,10 +554,11 @@ extern "C" int mk_disco_bwd_runs(const void* gy, void* gx, int dtype, const int*
     MK_REQUIRE(gy && gx && seg_off && runs && vals && t_lo && t_n, "disco_bwd_runs: null pointer");
     int R2, NW;
     MK_REQUIRE(runs_shape(nlon, R2, NW) && R2 == R, "disco_bwd_runs: %d longitudes are not covered by R = %d", nlon, R);
-    MK_REQUIRE((R == 8 ? NW == 3 : true), "disco_bwd_runs: R = 8 is built for 1025..1536 longitudes");
+    MK_REQUIRE(mk_runs_radix(nlon) == R, "disco_bwd_runs: lists built for R = %d", R);
     MK_REQUIRE(planes >= PB && (PB == 2 || PB == 4) && K > 0 && (planes + PB - 1) / PB <= 65535, "disco_bwd_runs: bad plane count");
     hipStream_t s = (hipStream_t)stream;
     MK_REQUIRE(lat_group == 2 || lat_group == 4, "disco_bwd_runs: latitude groups of 2 or 4");
+    MK_REQUIRE(NW * lat_group <= 12, "disco_bwd_runs: %d waves per latitude x %d latitudes exceed a workgroup", NW, lat_group);
     const bool fixed_waves = false;
     const dim3 grid((nlat_in + lat_group - 1) / lat_group, (planes + PB - 1) / PB);
     const i32x4* rn = (const i32x4*)runs;

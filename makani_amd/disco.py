@@ -190,13 +190,31 @@ class _Lists:
             self.max_rows_b = max(1, int(t_n.max()))
         # the run form of the same tensor (sliding-window kernels) where it applies
         self.runs = None
+        self._transposed = None
         if self.same_lon and runs_radix(nlon_in) is not None and v.size:
             self.runs = _RunLists(dict(k=k, t=t, i=i, j=j, v=v, K=K), ((nlat_in, nlon_in), (nlat_out, nlon_out)), device)
+            self._tsrc = (dict(k=k, t=i, i=t, j=(-j) % nlon_in, v=v, K=K), ((nlat_out, nlon_out), (nlat_in, nlon_in)), device)
+
+    def transposed(self):
+        """run lists of the TRANSPOSED tensor (roles of input and output latitude exchanged, longitudes negated): with them the
+        adjoint-shaped kernel computes sum_k psi_k (*) z_k (K planes in, one out) and the forward-shaped one its adjoint"""
+        if self._transposed is None and self.runs is not None:
+            psi_t, shape, device = self._tsrc
+            self._transposed = _TLists(_RunLists(psi_t, shape, device), self.K, shape[0], shape[1], self.nnz)
+        return self._transposed
+
+
+class _TLists:
+    """what ``_contract_fwd`` / ``_contract_bwd`` read from a list object, for the transposed tensor (run form only)"""
+
+    def __init__(self, runs, K, in_shape, out_shape, nnz):
+        self.runs, self.K, self.in_shape, self.out_shape, self.nnz = runs, K, tuple(in_shape), tuple(out_shape), nnz
+        self.same_lon = True
 
 
 def runs_radix(nlon):
     """longitudes a lane owns in the run-form kernels (csrc/disco_runs.hip: N / R lanes in at most three waves), or None"""
-    if nlon % 4 == 0 and 2 <= nlon // 4 <= 192:
+    if nlon % 4 == 0 and nlon // 4 >= 2 and ((nlon // 4 + 63) // 64 <= 3 or (nlon // 4 + 63) // 64 == 6):
         return 4
     if nlon % 8 == 0 and 128 < nlon // 8 <= 192:
         return 8
@@ -416,8 +434,9 @@ def _runs_plan_bwd(L, planes, dtype):
     force_b = os.environ.get("MAKANI_AMD_DISCO_IMG", "") == "b"
     pref = os.environ.get("MAKANI_AMD_DISCO_BWD", "")             # "LG,img,PB" (experiments)
     order = [tuple(int(c) for c in pref.split(","))] if pref else [(4, 0, 4), (2, 0, 4), (4, 1, 4), (2, 1, 4), (4, 0, 2), (4, 1, 2)]
+    nw = (L.in_shape[1] // L.runs.R + 63) // 64
     for LG, img, pb in order:
-        if (img and dtype != torch.bfloat16) or (force_b and not img and dtype == torch.bfloat16):
+        if (img and dtype != torch.bfloat16) or (force_b and not img and dtype == torch.bfloat16) or nw * LG > 12:
             continue
         got = _runs_shape(L, planes, dtype, L.runs.max_rows_b(LG), img, pb)
         if got is not None:
@@ -497,6 +516,21 @@ class DiscoContractFn(torch.autograd.Function):
         return _contract_bwd(gy.contiguous(), ctx.lists), None
 
 
+class DiscoSumFn(torch.autograd.Function):
+    """out = sum_k psi_k (*) z_k, (B, O * K, nlat_in, nlon) -> (B, O, nlat_out, nlon): the contraction AFTER the channel mix
+    (``lists_t``: the transposed tensor's run lists, whose adjoint-shaped kernel is this map and whose forward-shaped kernel is
+    its adjoint)"""
+
+    @staticmethod
+    def forward(ctx, z, lists_t):
+        ctx.lists_t = lists_t
+        return _contract_bwd(z.contiguous(), lists_t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _contract_fwd(g.contiguous(), ctx.lists_t), None
+
+
 class DiscreteContinuousConvS2(nn.Module):
     def __init__(self, in_channels, out_channels, in_shape, out_shape, kernel_shape, basis_type="morlet",
                  basis_norm_mode="mean", groups=1, grid_in="equiangular", grid_out="equiangular", bias=True,
@@ -544,8 +578,34 @@ class DiscreteContinuousConvS2(nn.Module):
         bf16 = hip_conv_eligible(x)
         with torch.autocast(device_type="cuda", enabled=False):
             xc = x.to(torch.bfloat16) if bf16 else x.float()
-            y = DiscoContractFn.apply(xc, self._device_lists(x.device))           # (B, C * K, H, W)
+            L = self._device_lists(x.device)
+            if self._mix_first(L, xc):
+                return self._mix_then_contract(xc, L)
+            y = DiscoContractFn.apply(xc, L)                                      # (B, C * K, H, W)
             return self._channel_mix(y, bf16)
+
+    def _mix_first(self, L, xc):
+        """fewer output than input channels (FourCastNet3's decoders: 45 -> 5 per pressure level): mixing the channels first,
+        z[o, k] = sum_c w[o, c, k] x[c], and contracting afterwards, out[o] = sum_k psi_k (*) z[o, k], is the same linear map
+        with O * K instead of C * K plane contractions and without the (B, C * K, H, W) intermediate (22 GB fp32 in the decoder)"""
+        O, gs, _ = self.weight.shape
+        if O >= gs * self.groups or os.environ.get("MAKANI_AMD_DISCO_MIXFIRST", "1") != "1" or not _runs_enabled(L):
+            return False
+        Lt = L.transposed()
+        planes = xc.shape[0] * O
+        return Lt is not None and _runs_plan_bwd(Lt, planes, xc.dtype) is not None and (
+            _fused_plan(Lt, planes) is not None or _runs_plan_fwd(Lt, planes, xc.dtype) is not None)
+
+    def _mix_then_contract(self, xc, L):
+        B, Cc, H, W = xc.shape
+        O, gs, K = self.weight.shape
+        G = self.groups
+        w = self.weight.reshape(G, O // G, gs, K).to(xc.dtype)
+        z = torch.einsum("gock,bgcn->bgokn", w, xc.reshape(B, G, gs, H * W)).reshape(B, O * K, H, W)     # plane o * K + k
+        out = DiscoSumFn.apply(z, L.transposed())
+        if self.bias is not None:
+            out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
+        return out
 
     def _channel_mix(self, y, bf16):
         """out[o] = sum_{c, k} weight[o, c, k] y[c * K + k] (+ bias): a 1x1 convolution over the C * K channels"""

@@ -111,7 +111,7 @@ def test_disco_run_form_kernels_match_list_kernels(shape, grid, fac, planes, dty
     mod = pd.DiscreteContinuousConvS2(planes, 2, shape, shape, (3, 3), grid_in=grid, grid_out=grid, bias=False,
                                       theta_cutoff=_cutoff(shape[0], fac)).to("cuda:0")
     L = mod._device_lists(torch.device("cuda:0"))
-    assert L.runs is not None and L.runs.R == (8 if shape[1] > 768 else 4)
+    assert L.runs is not None and L.runs.R == 4
     x = torch.randn(1, planes, *shape, device="cuda:0").to(dtype)
     g = torch.randn(1, planes * 9, *shape, device="cuda:0").to(dtype)
     monkeypatch.setenv("MAKANI_AMD_DISCO", "lists")
