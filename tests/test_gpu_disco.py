@@ -71,6 +71,32 @@ def test_disco_conv_bf16_autocast():
     assert rel_l2(mod.weight.grad, ref.weight.grad) < 2e-2
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (24, 48)), (6, 12, (33, 64)), (12, 4, (24, 48))])
+def test_disco_conv_bf16_gradient_orders_agree(cin, cout, shape, monkeypatch):
+    """bf16, groups = 1, equal grids: the data gradient through the transposed one-in-K-out kernel + regrouped GEMM (DiscoConvFn),
+    the mix-first evaluation (fewer output than input channels) and the plain order (W^T g, then the K-in-one-out adjoint
+    kernel) are the same linear maps: outputs and all gradients agree to bf16 rounding, and with the fp64 oracle to 2e-2"""
+    ref, mod = _pair(cin, cout, shape, shape, "equiangular", "equiangular", 2.0, 1)
+    x = torch.randn(2, cin, *shape)
+    g = torch.randn(2, cout, *shape)
+    xr = x.clone().requires_grad_(True)
+    (ref(xr) * g).sum().backward()
+    res = {}
+    for mode in ("fused", "lists"):
+        monkeypatch.setenv("MAKANI_AMD_DISCO_ADJ", mode)
+        monkeypatch.setenv("MAKANI_AMD_DISCO_MIXFIRST", "1" if mode == "fused" else "0")
+        mod.zero_grad()
+        xd = x.to("cuda:0").requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yd = mod(xd)
+        (yd.float() * g.to("cuda:0")).sum().backward()
+        res[mode] = (yd.float(), xd.grad.float(), mod.weight.grad.clone(), mod.bias.grad.clone())
+        assert rel_l2(yd, ref(x)) < 2e-2 and rel_l2(xd.grad, xr.grad) < 2e-2
+        assert rel_l2(mod.weight.grad, ref.weight.grad) < 2e-2 and rel_l2(mod.bias.grad, ref.bias.grad) < 2e-2
+    for a, b in zip(res["fused"], res["lists"]):
+        assert rel_l2(a, b) < 1.5e-2
+
+
 @pytest.mark.parametrize("in_shape,out_shape,fac", [((721, 1440), (360, 720), 1.0), ((360, 720), (360, 720), 2.0)])
 def test_disco_contraction_properties_at_fcn3_grids(in_shape, out_shape, fac):
     """FourCastNet3's encoder (721x1440 -> 360x720) and local-block (360x720, doubled cutoff) operators, 3 planes:
