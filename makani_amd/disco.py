@@ -13,15 +13,17 @@ nlon_in]`` (s = nlon_in / nlon_out) followed by a dense channel mix ``out[o] = s
 pattern is the same for every output longitude, so the convolution tensor is kept as per-(output latitude, basis
 function) lists of (input latitude, input longitude, value) — 9 short lists per latitude instead of a COO tensor over
 the whole grid:
-  * forward (``csrc/disco.hip``): one workgroup per output latitude and group of 4 planes stages the <= 2 cutoff / dlat + 1
-    input latitude rows it needs in LDS (read once from HBM, coalesced), every lane owns output longitudes and walks the
-    lists (wave-uniform scalar loads) against the LDS rows; the result is written as (B, C * K, nlat_out, nlon_out), i.e.
-    as the NCHW activation the channel GEMM kernels of ``csrc/conv1x1.hip`` consume in place — the channel mix IS a
-    1x1 convolution with C * K input channels and runs on those kernels (bf16, fused bias) with their weight-gradient
-    kernel in backward;
-  * backward: the adjoint contraction as a deterministic gather, no atomics: on equal longitude counts (the local blocks,
-    the decoder) it is the same LDS-staged correlation as the forward kernel over the lists transposed per (input
-    latitude, basis function); the strided case (encoder) gathers per input point.
+  * equal longitude counts (local blocks, decoder; ``csrc/disco_runs.hip``): per (k, t, input row) the non-zeros form one
+    circular run in longitude, so the contraction is a 1-D circular correlation; a lane owns 4 consecutive output longitudes
+    and slides a register window over the row (de-interleaved LDS row image, filter values through the scalar cache, packed
+    fp32 FMAs); the forward kernel shares the window between all nine basis functions.  The result is written as (B, C * K,
+    nlat_out, nlon_out), i.e. as the NCHW activation the channel GEMM kernels of ``csrc/conv1x1.hip`` consume in place — the
+    channel mix IS a 1x1 convolution with C * K input channels and runs on those kernels with their weight-gradient kernel
+    in backward.  The two linear maps are evaluated in the cheaper order per layer: contraction first (O >= C), channel mix
+    first with ``sum_k psi_k (*) z_k`` afterwards (O < C: FourCastNet3's decoders), and the data gradient as
+    ``W regrouped x (psi^T (*) g)`` (``DiscoConvFn``), each through the same kernels on the tensor or its transpose;
+  * strided case (encoder, nlon_in = 2 nlon_out) and shapes the run form does not cover (``csrc/disco.hip``): lists in LDS,
+    a lane owns output longitudes 256 apart; adjoint as a deterministic gather (no atomics).
 The convolution tensor is computed in fp64 numpy at construction (vectorised over the input grid).  Filter basis: "morlet"
 (the one FourCastNet3's recipe selects, ``config/fourcastnet3.yaml:34``).
 """
