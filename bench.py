@@ -134,9 +134,9 @@ def roofline_of(family, members, prof, gemm_mode, traffic):
 
 def load_pmc_traffic():
     """HBM bytes per launch of every kernel family from the committed PMC passes of THIS command (rocprofv3 counters
-    cannot be collected from inside the timed run; profiles/r02c_pmc_hbm_traffic.json says how they were taken and
+    cannot be collected from inside the timed run; profiles/r02d_pmc_hbm_traffic.json (the newest of profiles/r02*_pmc_hbm_traffic.json) says how they were taken and
     tools/pmc_traffic.py rebuilds it — to be regenerated whenever a kernel of the family changes)"""
-    for name in ("r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):       # newest first
+    for name in ("r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):       # newest first
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return {k: v["hbm_bytes"] for k, v in json.load(fh).items() if isinstance(v, dict) and "hbm_bytes" in v}
