@@ -3,6 +3,7 @@ precompute agrees with the oracle, the drop-in modules keep the reference's inte
 (constructor, attributes, state_dict, error behaviour) and refuse to run without the HIP path."""
 import ctypes
 import json
+import math
 import os
 import re
 import sys
@@ -318,3 +319,86 @@ def test_modules_opt_out_of_torch_compile():
     compiled = torch.compile(net)
     with pytest.raises(RuntimeError, match="no CPU fallback"):       # reaches the HIP entry point, not a dynamo error
         compiled(torch.randn(1, 2, 16, 32))
+
+
+# --------------------------------------------------------------------------- #
+# DISCO list builders (host side of csrc/disco_runs.hip)
+# --------------------------------------------------------------------------- #
+def _synthetic_entries(N):
+    rng = np.random.default_rng(0)
+    ent = []
+
+    def add(t, k, row, lons):
+        for l in lons:
+            ent.append((t, k, row, l % N, rng.standard_normal()))
+    add(0, 0, 0, range(-3, 4))                  # a run that crosses longitude 0
+    add(0, 1, 0, range(-2, 5))
+    add(0, 2, 0, range(-3, 3))
+    add(0, 0, 1, range(N))                      # a whole latitude circle (polar row)
+    add(0, 1, 1, range(0, N, 2))                # gaps: many one-tap runs
+    add(1, 0, 2, [5, 6, 7])
+    add(1, 2, 2, [6, 7, 8, 12])                 # two runs in one row
+    add(2, 1, 0, [N - 1, 0])
+    t, k, row, lon, val = map(np.array, zip(*ent))
+    return t, k, row, lon, val.astype(np.float32)
+
+
+def test_disco_run_lists_reproduce_the_convolution_tensor():
+    """``_build_runs`` (per (segment, row): circular runs of consecutive longitudes, zero-padded to groups of R) and
+    ``_build_fused`` (per (latitude, row): the union over the basis functions, aligned to 4 longitudes, K x 4 values per group)
+    expand back to exactly the entries they were built from"""
+    from makani_amd import disco
+    N, K, R = 24, 3, 4
+    t, k, row, lon, val = _synthetic_entries(N)
+    dense = np.zeros((3, K, 3, N), np.float32)
+    dense[t, k, row, lon] = val
+    so, rn, vl = disco._build_runs(t * K + k, row, lon, val, 3 * K, N, R)
+    assert vl.size % R == 0 and np.all(vl[-R:] == 0) and so[-1] == len(rn)
+    rec = np.zeros_like(dense)
+    for s_ in range(3 * K):
+        for r in range(so[s_], so[s_ + 1]):
+            rw, js, vo, ng = rn[r]
+            assert vo % R == 0 and ng >= 1
+            for g in range(ng * R):
+                rec[s_ // K, s_ % K, rw, (js + g) % N] += vl[vo + g]
+    assert np.array_equal(rec, dense)
+    # the run that crosses longitude 0 is ONE run, a full circle is one run of N taps
+    seg0 = rn[so[0]:so[1]]
+    assert len(seg0) == 2 and sorted(int(x) for x in seg0[:, 3]) == [2, N // R]
+    so, rn, vl = disco._build_fused(t, k, row, lon, val, 3, K, N)
+    rec = np.zeros_like(dense)
+    for tt in range(3):
+        for r in range(so[tt], so[tt + 1]):
+            rw, slot, vo, ng = rn[r]
+            blk = vl[vo:vo + ng * K * 4].reshape(ng, K, 4)
+            for g in range(ng):
+                for kk in range(K):
+                    for tau in range(4):
+                        rec[tt, kk, rw, (slot * 4 + g * 4 + tau) % N] += blk[g, kk, tau]
+    assert np.array_equal(rec, dense)
+    assert np.all(vl[-K * 4:] == 0)
+
+
+def test_disco_lists_of_a_real_tensor_and_its_transpose():
+    """on a real convolution tensor: forward run lists, the adjoint's lists for latitude groups of 2 and 4 (image rows relative to
+    the group's first touched output latitude) and the transposed tensor's lists all carry every entry exactly once"""
+    from makani_amd import disco
+    shape = (12, 24)
+    psi = disco.convolution_tensor(shape, shape, [3, 3], basis_type="morlet", grid_in="equiangular", grid_out="equiangular",
+                                   theta_cutoff=3 * math.pi / 11, basis_norm_mode="mean")
+    L = disco._Lists(psi, shape, shape, "cpu")
+    assert L.runs is not None and L.runs.R == 4 and disco.runs_radix(1440) == 4 and disco.runs_radix(1152) == 8 and disco.runs_radix(36 * 4 + 2) is None
+    tot = float(np.abs(psi["v"]).sum())
+    assert abs(float(L.runs.f_vals.abs().sum()) - tot) < 1e-4 * tot
+    for LG in (2, 4):
+        so, rn, vl, t_lo, t_n, mr = L.runs.bwd(LG)
+        assert abs(float(vl.abs().sum()) - tot) < 1e-4 * tot and mr == int(t_n.max()) == L.runs.max_rows_b(LG)
+        assert int(rn[:, 0].max()) < mr and so.numel() == shape[0] * psi["K"] + 1
+    so, rn, vl, g_lo, g_n, mr = L.runs.fused(4)
+    assert abs(float(vl.abs().sum()) - tot) < 1e-4 * tot and mr == L.runs.fused_rows(4)
+    Lt = L.transposed()
+    assert Lt.in_shape == shape and Lt.out_shape == shape and abs(float(Lt.runs.f_vals.abs().sum()) - tot) < 1e-4 * tot
+    # transposing twice gives the forward lists back (same segments, same values)
+    k, t, i, j, v = Lt.runs._e
+    back = disco._RunLists(dict(k=k, t=i, i=t, j=(-j) % shape[1], v=v, K=psi["K"]), (shape, shape), "cpu")
+    assert torch.equal(back.f_seg, L.runs.f_seg) and torch.equal(back.f_runs, L.runs.f_runs) and torch.equal(back.f_vals, L.runs.f_vals)
