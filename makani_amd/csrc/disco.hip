@@ -273,6 +273,10 @@ __global__ __launch_bounds__(DNT) void resample_fwd_kernel(const T* __restrict__
 
 // adjoint: gx[i][j] = sum_{(t, wl) in lat_inv(i)} wl * sum_{(p, wp) in lon_inv(j)} wp * gy[t][p]
 //                     + [i is a polar row] (1 / nlon_in) * sum_{(t, wl) in pole_inv} wl * sum_p gy[t][p]
+// One workgroup per (input row, plane).  Every gradient row the input row receives from (2-4 of them when upsampling by 2) is
+// staged ONCE in LDS as fp32 with coalesced loads; the longitude stencils then gather from LDS.  (The first version gathered
+// from global memory, lat entries x lon entries = 16 scattered reads per input point: 6-11 ms per FourCastNet3 decoder call
+// depending on what the caches held; this form reads each gradient row twice in total.)
 template <typename T>
 __global__ __launch_bounds__(DNT) void resample_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, const int* __restrict__ lat_off,
                                                            const int* __restrict__ lat_t, const float* __restrict__ lat_wt,
@@ -280,31 +284,55 @@ __global__ __launch_bounds__(DNT) void resample_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ lon_wt, const int* __restrict__ pole_off,
                                                            const int* __restrict__ pole_t, const float* __restrict__ pole_wt,
                                                            int nlat_in, int nlon_in, int nlat_out, int nlon_out) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];       // nlon_out floats
     __shared__ float red[DNT / 64];
     const int i = blockIdx.x, pl = blockIdx.y, tid = threadIdx.x;
     const T* g = gy + (long long)pl * nlat_out * nlon_out;
+    constexpr int MAXQ = 8;                                              // input longitudes per thread: nlon_in <= 8 * 256
+    float acc[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) acc[q] = 0.f;
+    auto stage = [&](int t) {                                            // gradient row t -> LDS; returns this thread's partial row sum
+        const T* row = g + (long long)t * nlon_out;
+        float sacc = 0.f;
+        for (int p = tid; p < nlon_out; p += DNT) {
+            const float v = ldf(row + p);
+            rowbuf[p] = v;
+            sacc += v;
+        }
+        return sacc;
+    };
     float pole = 0.f;
     const int which = (i == 0) ? 0 : ((i == nlat_in - 1) ? 1 : -1);
     if (which >= 0) {
         for (int n = pole_off[which]; n < pole_off[which + 1]; ++n) {
-            const T* row = g + (long long)pole_t[n] * nlon_out;
             float sacc = 0.f;
+            const T* row = g + (long long)pole_t[n] * nlon_out;
             for (int p = tid; p < nlon_out; p += DNT) sacc += ldf(row + p);
             pole += pole_wt[n] * block_sum(sacc, red);
         }
         pole /= (float)nlon_in;
     }
     const int a0 = lat_off[i], a1 = lat_off[i + 1];
-    for (int j = tid; j < nlon_in; j += DNT) {
-        float acc = pole;
-        const int b0 = lon_off[j], b1 = lon_off[j + 1];
-        for (int n = a0; n < a1; ++n) {
-            const T* row = g + (long long)lat_t[n] * nlon_out;
-            float h = 0.f;
-            for (int m = b0; m < b1; ++m) h = fmaf(lon_wt[m], ldf(row + lon_p[m]), h);
-            acc = fmaf(lat_wt[n], h, acc);
+    for (int n = a0; n < a1; ++n) {
+        __syncthreads();                                                 // the previous row is consumed
+        (void)stage(lat_t[n]);
+        __syncthreads();
+        const float wl = lat_wt[n];
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int j = tid + q * DNT;
+            if (j < nlon_in) {
+                float h = 0.f;
+                for (int m = lon_off[j]; m < lon_off[j + 1]; ++m) h = fmaf(lon_wt[m], rowbuf[lon_p[m]], h);
+                acc[q] = fmaf(wl, h, acc[q]);
+            }
         }
-        stf(gx + ((long long)pl * nlat_in + i) * nlon_in + j, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int j = tid + q * DNT;
+        if (j < nlon_in) stf(gx + ((long long)pl * nlat_in + i) * nlon_in + j, acc[q] + pole);
     }
 }
 
@@ -441,13 +469,15 @@ extern "C" int mk_resample_bwd(const void* gy, void* gx, int dtype, const int* l
                                void* stream) {
     MK_REQUIRE(gy && gx && lat_off && lon_off && pole_off, "resample_bwd: null pointer");
     MK_REQUIRE(planes > 0 && planes <= 65535, "resample_bwd: bad plane count");
+    MK_REQUIRE(nlon_in <= 8 * DNT && nlon_out <= 15360, "resample_bwd: at most %d input / 15360 output longitudes", 8 * DNT);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nlat_in, planes), block(DNT);
+    const size_t lds = (size_t)nlon_out * sizeof(float);
     if (dtype == MK_F32)
-        hipLaunchKernelGGL(resample_bwd_kernel<float>, grid, block, 0, s, (const float*)gy, (float*)gx, lat_off, lat_t, lat_wt,
+        hipLaunchKernelGGL(resample_bwd_kernel<float>, grid, block, lds, s, (const float*)gy, (float*)gx, lat_off, lat_t, lat_wt,
                            lon_off, lon_p, lon_wt, pole_off, pole_t, pole_wt, nlat_in, nlon_in, nlat_out, nlon_out);
     else
-        hipLaunchKernelGGL(resample_bwd_kernel<u16>, grid, block, 0, s, (const u16*)gy, (u16*)gx, lat_off, lat_t, lat_wt, lon_off,
+        hipLaunchKernelGGL(resample_bwd_kernel<u16>, grid, block, lds, s, (const u16*)gy, (u16*)gx, lat_off, lat_t, lat_wt, lon_off,
                            lon_p, lon_wt, pole_off, pole_t, pole_wt, nlat_in, nlon_in, nlat_out, nlon_out);
     return mk_check_launch("mk_resample_bwd");
 }

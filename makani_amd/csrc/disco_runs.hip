@@ -338,8 +338,10 @@ __global__ __launch_bounds__(64 * NW * LG) void disco_fused_fwd_kernel(const T* 
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[k][r] = fv(0.f);
     const int r0 = seg_off[t], r1 = seg_off[t + 1];
+    i32x4 hnext = runs[min(r0, r1 - 1 < r0 ? r0 : r1 - 1)];
     for (int rr = r0; rr < r1; ++rr) {
-        const i32x4 h = runs[rr];                                  // {row, first slot (js / R), value offset, groups}
+        const i32x4 h = hnext;                                     // {row, first slot (js / R), value offset, groups}
+        hnext = runs[min(rr + 1, r1 - 1)];                         // the next header travels while this run is multiplied
         lds_cb* rowp = img + h[0] * ROWB;
         const float* vp = vals + h[2];
         const int ng = h[3];
