@@ -646,8 +646,10 @@ class DiscreteContinuousConvS2(nn.Module):
         B, Cc, H, W = xc.shape
         O, gs, K = self.weight.shape
         G = self.groups
-        w = self.weight.reshape(G, O // G, gs, K).to(xc.dtype)
-        z = torch.einsum("gock,bgcn->bgokn", w, xc.reshape(B, G, gs, H * W)).reshape(B, O * K, H, W)     # plane o * K + k
+        # z[b, g, (o, k), n] = sum_c w[g, o, c, k] x[b, g, c, n]: a batched GEMM that leaves z in place as planes o * K + k (an
+        # einsum would transpose the activations to put the batch last: two copies of the largest tensors of the decoder)
+        wm = self.weight.reshape(G, O // G, gs, K).permute(0, 1, 3, 2).reshape(1, G, (O // G) * K, gs).to(xc.dtype)
+        z = torch.matmul(wm, xc.reshape(B, G, gs, H * W)).reshape(B, O * K, H, W)
         out = DiscoSumFn.apply(z, L.transposed())
         if self.bias is not None:
             out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
@@ -664,8 +666,8 @@ class DiscreteContinuousConvS2(nn.Module):
         else:
             B, _, H, W = y.shape
             yg = y.reshape(B, self.groups, self.groupsize * self.kernel_size, H * W)
-            wg = self.weight.reshape(self.groups, O // self.groups, self.groupsize * self.kernel_size).to(y.dtype)
-            out = torch.einsum("gok,bgkn->bgon", wg, yg).reshape(B, O, H, W)
+            wg = self.weight.reshape(1, self.groups, O // self.groups, self.groupsize * self.kernel_size).to(y.dtype)
+            out = torch.matmul(wg, yg).reshape(B, O, H, W)                        # batched over (B, groups), output in place
         if self.bias is not None:
             out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
         return out

@@ -243,7 +243,10 @@ class NeuralOperatorBlock(nn.Module):
             dx = self.mlp(dx)
         dx = self.drop_path(dx)
         if hasattr(self, "skip"):
-            return self.skip(x[..., : self.out_chans, :, :]) + self.layer_scale(dx)
+            res = self.skip(x[..., : self.out_chans, :, :])
+            if isinstance(self.layer_scale, LayerScale):                          # skip + w[c] * dx in one pass
+                return torch.addcmul(res, dx, self.layer_scale.weight.view(1, -1, 1, 1).to(dx.dtype))
+            return res + self.layer_scale(dx)
         return dx
 
 
