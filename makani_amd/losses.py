@@ -426,3 +426,60 @@ class CRPSLoss(nn.Module):
         crps = CrpsFn.apply(forecasts, observations, self.quad_weight_split.reshape(-1), w,
                             _CRPS_TYPES[self.crps_type], self.alpha, self.eps)
         return self.quadrature._reduce(crps)
+
+
+class SpectralCRPSLoss(SpectralLpLoss):
+    """``SpectralCRPSLoss`` of ``makani/utils/losses/crps_loss.py:454-637`` (registered as "ensemble_spectral_crps"): the
+    ensemble CRPS of the ABSOLUTE VALUES of the spherical-harmonic coefficients, summed with the Parseval weights of
+    ``SpectralBaseLoss`` (m = 0 once, m > 0 twice, 1 / 4 pi).  ``forward(forecasts (B, E, C, H, W), observations (B, C, H, W),
+    spectral_weights=None) -> (B, C)``.  The transforms are the HIP SHT (fp32, autocast off, as the reference), the per-(l, m)
+    ensemble score and its weighted sum the HIP kernel of ``CRPSLoss`` (``csrc/crps.hip``) with the (l, m) plane in the place of
+    the grid.  Not built, as for ``CRPSLoss``: ``crps_type="cdf"``, weighted ensembles, the ensemble-parallel transpose; and
+    ``absolute=False`` (complex differences in the naive kernel)."""
+
+    def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
+                 channel_names: List[str], grid_type: str, lmax: Optional[int] = None, crps_type: str = "skillspread",
+                 spatial_distributed: Optional[bool] = False, ensemble_distributed: Optional[bool] = False,
+                 ensemble_weights: Optional[torch.Tensor] = None, absolute: Optional[bool] = True, alpha: Optional[float] = 1.0,
+                 eps: Optional[float] = 1.0e-6, **kwargs):
+        super().__init__(img_shape, crop_shape, crop_offset, channel_names, grid_type, spatial_distributed=spatial_distributed,
+                         lmax=lmax)
+        if ensemble_distributed:
+            raise NotImplementedError("the ensemble-parallel CRPS (transpose over the 'ensemble' group) is not built")
+        if ensemble_weights is not None:
+            raise NotImplementedError("currently only constant ensemble weights are supported")
+        if crps_type == "cdf":
+            raise NotImplementedError("crps_type='cdf' is not built (skillspread, naive skillspread, probability weighted "
+                                      "moment and gauss are)")
+        if crps_type not in ("skillspread", "probability weighted moment", "gauss"):     # (the reference's forward knows these and "cdf")
+            raise ValueError(f"Unknown CRPS crps_type {crps_type}")
+        if crps_type not in ("skillspread", "naive skillspread") and alpha < 1.0:
+            raise NotImplementedError("The alpha parameter (almost fair CRPS factor) is only supported for the skillspread kernels.")
+        if not absolute:
+            raise NotImplementedError("absolute=False (the naive kernel on complex coefficients) is not built")
+        self.crps_type, self.alpha, self.eps, self.absolute = crps_type, alpha, eps, absolute
+
+    @torch.compiler.disable(recursive=True)
+    def forward(self, forecasts: torch.Tensor, observations: torch.Tensor, spectral_weights: Optional[torch.Tensor] = None,
+                **kwargs) -> torch.Tensor:
+        from . import distributed as thd
+        if forecasts.dim() != 5:
+            raise ValueError(f"Error, forecasts tensor expected to have 5 dimensions but found {forecasts.dim()}.")
+        if spectral_weights is not None and spectral_weights.dim() != observations.dim():
+            raise ValueError("the weights have to have the same number of dimensions as observations")
+        dtype = forecasts.dtype
+        with torch.autocast(device_type=forecasts.device.type, enabled=False):
+            f = self.sht(forecasts.float()) / math.sqrt(4.0 * math.pi)
+            o = self.sht(observations.float()) / math.sqrt(4.0 * math.pi)
+        f, o = torch.abs(f).to(dtype), torch.abs(o).to(dtype)
+        B, E, Cc, L, M = f.shape
+        if E == 1:
+            w = self.lm_weights if spectral_weights is None else spectral_weights * self.lm_weights
+            crps = (torch.abs(o - f.squeeze(1)).float() * w).reshape(B, Cc, L * M).sum(dim=-1)
+        else:
+            w = spectral_weights.expand(B, Cc, L, M) if spectral_weights is not None else None
+            crps = CrpsFn.apply(f.contiguous(), o.contiguous(), self.lm_weights.reshape(-1).contiguous(), w, _CRPS_TYPES[self.crps_type],
+                                self.alpha, self.eps)
+        if self.spatial_distributed:
+            crps = thd.reduce_from_spatial_region(crps)
+        return crps

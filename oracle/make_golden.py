@@ -155,6 +155,40 @@ def crps_fixtures():
     print(f"crps_loss.npz: {os.path.getsize(path)/1e6:.2f} MB")
 
 
+def crps_spectral_fixtures():
+    """SpectralCRPSLoss (makani/utils/losses/crps_loss.py:454-637, the reference's own module on the restated SHT): the built
+    score types on the absolute values of the coefficients, with spectral weights, a truncated lmax, E = 1."""
+    SpectralCRPSLoss = ref_shims.import_reference_module("makani.utils.losses.crps_loss").SpectralCRPSLoss
+    cases = [
+        dict(img=(17, 32), grid="equiangular", E=4, crps_type="skillspread", alpha=1.0, wgt=False, lmax=None),
+        dict(img=(12, 24), grid="legendre-gauss", E=5, crps_type="skillspread", alpha=0.95, wgt=True, lmax=None),
+        dict(img=(17, 32), grid="equiangular", E=3, crps_type="probability weighted moment", alpha=1.0, wgt=False, lmax=9),
+        dict(img=(12, 24), grid="legendre-gauss", E=8, crps_type="gauss", alpha=1.0, wgt=True, lmax=None),
+        dict(img=(12, 24), grid="legendre-gauss", E=2, crps_type="skillspread", alpha=1.0, wgt=False, lmax=None),
+        dict(img=(17, 32), grid="equiangular", E=1, crps_type="skillspread", alpha=1.0, wgt=False, lmax=None),
+    ]
+    rec = {"cases": json.dumps(cases)}
+    for i, c in enumerate(cases):
+        torch.manual_seed(700 + i)
+        B, C = 2, 3
+        mod = SpectralCRPSLoss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0), channel_names=[str(k) for k in range(C)],
+                               grid_type=c["grid"], lmax=c["lmax"], crps_type=c["crps_type"], alpha=c["alpha"])
+        f = torch.randn(B, c["E"], C, *c["img"], requires_grad=True)
+        o = torch.randn(B, C, *c["img"])
+        L, M = mod.lm_weights.shape
+        # (the reference reshapes the product with lm_weights to (1, 1, L * M), crps_loss.py:578: weights per (l, m) only)
+        wgt = torch.rand(1, 1, L, M) + 0.5 if c["wgt"] else None
+        out = mod(f, o, wgt)
+        g = torch.randn_like(out)
+        (out * g).sum().backward()
+        rec[f"{i}_f"], rec[f"{i}_o"], rec[f"{i}_g"], rec[f"{i}_out"], rec[f"{i}_df"] = _np(f), _np(o), _np(g), _np(out), _np(f.grad)
+        if wgt is not None:
+            rec[f"{i}_wgt"] = _np(wgt)
+    path = os.path.join(OUT, "crps_spectral.npz")
+    np.savez_compressed(path, **rec)
+    print(f"crps_spectral.npz: {os.path.getsize(path)/1e6:.2f} MB")
+
+
 def fcn3_fixtures():
     """FourCastNet3 (makani/models/networks/fourcastnet3.py, the reference's own module) on top of the restated
     torch-harmonics operators: SHT (oracle/sht.py) and DISCO convolution / ResampleS2 (oracle/disco.py).  The DISCO
@@ -425,7 +459,7 @@ def main():
         raise SystemExit("reference tree not found; golden fixtures can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss", "stepper", "fcn3", "crps"]
+    which = sys.argv[1:] or ["contractions", "spectral_conv", "sfno", "loss", "stepper", "fcn3", "crps", "crps_spectral"]
     if "contractions" in which:
         contraction_fixtures()
     if "spectral_conv" in which:
@@ -442,6 +476,8 @@ def main():
         fcn3_fixtures()
     if "crps" in which:
         crps_fixtures()
+    if "crps_spectral" in which:
+        crps_spectral_fixtures()
 
 
 if __name__ == "__main__":
