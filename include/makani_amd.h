@@ -336,6 +336,18 @@ int mk_disco_fwd_runs(const void* x, void* y, int dtype, const int* seg_off, con
 int mk_disco_bwd_runs(const void* gy, void* gx, int dtype, const int* seg_off, const int* runs, const float* vals,
                       const int* t_lo, const int* t_n, int max_rows, int planes, int K, int nlat_in, int nlon, int nlat_out,
                       int R, int PB, int img_bf16, int lat_group, void* stream);
+/* Grouped channel mix with a handful of channels per group (csrc/groupmix.hip): the channel mixes of FourCastNet3's encoders /
+ * decoders (th.DiscreteContinuousConvS2 with groups > 1, fourcastnet3.py:189-205,356-381: 8-9 planes in and out per group).
+ *   mk_group_mix:        z (B*G, RG, N) = W (G, RG, CG) x (B*G, CG, N); dtype f32 | bf16, fp32 accumulation; the data gradient is
+ *                        the same call with the transposed weights.  N a multiple of 4 (f32) / 8 (bf16).
+ *   mk_group_mix_wgrad:  partial (B*G * mk_group_mix_blocks(N, dtype, B*G), RG * CG) = per-block sums of dz[r][n] x[c][n]; the caller
+ *                        adds the blocks of a group and the batch entries (deterministic).
+ *   mk_group_mix_supported: 1 for the instantiated (CG, RG) pairs (8 | 9 each). */
+int mk_group_mix_supported(int CG, int RG);
+int mk_group_mix_blocks(long long N, int dtype, int BG);
+int mk_group_mix(const void* x, const float* W, void* z, int dtype, int B, int G, int CG, int RG, long long N, void* stream);
+int mk_group_mix_wgrad(const void* x, const void* dz, float* partial, int dtype, int B, int G, int CG, int RG, long long N,
+                       void* stream);
 int mk_resample_fwd(const void* x, void* y, int dtype, const int* lat_a, const int* lat_b, const float* lat_w,
                     const int* lon_l, const int* lon_r, const float* lon_w, int planes, int nlat_in, int nlon_in,
                     int nlat_out, int nlon_out, void* stream);

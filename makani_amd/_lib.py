@@ -87,6 +87,10 @@ _SIGS = {
     "mk_disco_fwd_fused": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_disco_fwd_runs": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_disco_bwd_runs": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
+    "mk_group_mix_supported": ([c_int, c_int], c_int),
+    "mk_group_mix_blocks": ([c_ll, c_int, c_int], c_int),
+    "mk_group_mix": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_ll, c_vp], c_int),
+    "mk_group_mix_wgrad": ([c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_ll, c_vp], c_int),
     "mk_resample_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_resample_bwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_quad_lp_chunks": ([c_ll], c_int),

@@ -518,6 +518,57 @@ class DiscoContractFn(torch.autograd.Function):
         return _contract_bwd(gy.contiguous(), ctx.lists), None
 
 
+class GroupMixFn(torch.autograd.Function):
+    """z[b, g, r, n] = sum_c W[g, r, c] x[b, g, c, n] for 8-9 planes per group (``csrc/groupmix.hip``: one streaming pass instead
+    of M = 9 batched library GEMMs); x (B, G, CG, N) f32 | bf16, W (G, RG, CG)"""
+
+    @staticmethod
+    def supported(x, W):
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % vec == 0 and x.shape[0] * x.shape[1] <= 65535
+                and bool(lib().mk_group_mix_supported(W.shape[2], W.shape[1])))
+
+    @staticmethod
+    def forward(ctx, x, W):
+        B, G, CG, N = x.shape
+        RG = W.shape[1]
+        x = x.contiguous()
+        Wf = W.detach().to(x.dtype).float().contiguous()        # under bf16 autocast the reference multiplies bf16-rounded weights
+        z = torch.empty((B, G, RG, N), dtype=x.dtype, device=x.device)
+        with ops._timed(f"group_mix_c{CG}_r{RG}_n{N}", nbytes=float(x.element_size()) * (x.numel() + z.numel())):
+            check(lib().mk_group_mix(ptr(x), ptr(Wf), ptr(z), dtype_code(x), B, G, CG, RG, N, stream()), "mk_group_mix")
+        ctx.save_for_backward(x, Wf)
+        ctx.wdtype = W.dtype
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, Wf = ctx.saved_tensors
+        B, G, CG, N = x.shape
+        RG = Wf.shape[1]
+        gz = gz.contiguous()
+        gx = gW = None
+        if ctx.needs_input_grad[0]:
+            Wt = Wf.transpose(1, 2).contiguous()
+            gx = torch.empty_like(x)
+            with ops._timed(f"group_mix_c{RG}_r{CG}_n{N}", nbytes=float(x.element_size()) * (x.numel() + gz.numel())):
+                check(lib().mk_group_mix(ptr(gz), ptr(Wt), ptr(gx), dtype_code(x), B, G, RG, CG, N, stream()), "mk_group_mix")
+        if ctx.needs_input_grad[1]:
+            nb = lib().mk_group_mix_blocks(N, dtype_code(x), B * G)
+            part = torch.empty((B, G, nb, RG, CG), dtype=torch.float32, device=x.device)
+            with ops._timed(f"group_mix_wgrad_c{CG}_r{RG}_n{N}", nbytes=float(x.element_size()) * (x.numel() + gz.numel())):
+                check(lib().mk_group_mix_wgrad(ptr(x), ptr(gz), ptr(part), dtype_code(x), B, G, CG, RG, N, stream()), "mk_group_mix_wgrad")
+            gW = part.sum(dim=(0, 2)).to(ctx.wdtype)
+        return gx, gW
+
+
+def _group_mix(W, x):
+    """W (G, RG, CG) applied to x (B, G, CG, N): the HIP streaming kernel for FourCastNet3's group sizes, else a batched GEMM"""
+    if GroupMixFn.supported(x, W) and os.environ.get("MAKANI_AMD_GROUPMIX", "hip") == "hip":
+        return GroupMixFn.apply(x, W)
+    return torch.matmul(W.unsqueeze(0).to(x.dtype), x)
+
+
 class DiscoSumFn(torch.autograd.Function):
     """out = sum_k psi_k (*) z_k, (B, O * K, nlat_in, nlon) -> (B, O, nlat_out, nlon): the contraction AFTER the channel mix
     (``lists_t``: the transposed tensor's run lists, whose adjoint-shaped kernel is this map and whose forward-shaped kernel is
@@ -648,8 +699,8 @@ class DiscreteContinuousConvS2(nn.Module):
         G = self.groups
         # z[b, g, (o, k), n] = sum_c w[g, o, c, k] x[b, g, c, n]: a batched GEMM that leaves z in place as planes o * K + k (an
         # einsum would transpose the activations to put the batch last: two copies of the largest tensors of the decoder)
-        wm = self.weight.reshape(G, O // G, gs, K).permute(0, 1, 3, 2).reshape(1, G, (O // G) * K, gs).to(xc.dtype)
-        z = torch.matmul(wm, xc.reshape(B, G, gs, H * W)).reshape(B, O * K, H, W)
+        wm = self.weight.reshape(G, O // G, gs, K).permute(0, 1, 3, 2).reshape(G, (O // G) * K, gs)
+        z = _group_mix(wm, xc.reshape(B, G, gs, H * W)).reshape(B, O * K, H, W)
         out = DiscoSumFn.apply(z, L.transposed())
         if self.bias is not None:
             out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
@@ -666,8 +717,8 @@ class DiscreteContinuousConvS2(nn.Module):
         else:
             B, _, H, W = y.shape
             yg = y.reshape(B, self.groups, self.groupsize * self.kernel_size, H * W)
-            wg = self.weight.reshape(1, self.groups, O // self.groups, self.groupsize * self.kernel_size).to(y.dtype)
-            out = torch.matmul(wg, yg).reshape(B, O, H, W)                        # batched over (B, groups), output in place
+            wg = self.weight.reshape(self.groups, O // self.groups, self.groupsize * self.kernel_size)
+            out = _group_mix(wg, yg).reshape(B, O, H, W)                          # per (batch, group), output in place
         if self.bias is not None:
             out = out + self.bias.to(out.dtype).view(1, -1, 1, 1)
         return out

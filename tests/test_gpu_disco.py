@@ -71,6 +71,27 @@ def test_disco_conv_bf16_autocast():
     assert rel_l2(mod.weight.grad, ref.weight.grad) < 2e-2
 
 
+@pytest.mark.parametrize("CG,RG", [(9, 9), (9, 8), (8, 9), (8, 8)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)])
+def test_group_mix_kernel_matches_matmul(CG, RG, dtype, tol):
+    """csrc/groupmix.hip (the channel mix of FourCastNet3's grouped DISCO convolutions: 8-9 planes per group) against the fp64
+    batched product: forward, data gradient, weight gradient; ragged pixel count (not a multiple of the block's pass)"""
+    import makani_amd.disco as pd
+    torch.manual_seed(CG * 10 + RG)
+    B, G, N = 2, 5, 8 * 777
+    x = torch.randn(B, G, CG, N, device="cuda:0").to(dtype).requires_grad_(True)
+    W = (torch.randn(G, RG, CG, device="cuda:0") / 3).requires_grad_(True)
+    g = torch.randn(B, G, RG, N, device="cuda:0").to(dtype)
+    assert pd.GroupMixFn.supported(x, W)
+    z = pd._group_mix(W, x)
+    (z.float() * g.float()).sum().backward()
+    xr, Wr = x.detach().double().requires_grad_(True), W.detach().double().requires_grad_(True)
+    zr = torch.matmul(Wr.unsqueeze(0), xr)
+    (zr * g.double()).sum().backward()
+    assert z.dtype == dtype and rel_l2(z, zr) < tol
+    assert rel_l2(x.grad, xr.grad) < tol and rel_l2(W.grad, Wr.grad) < max(tol, 1e-5) and W.grad.dtype == torch.float32
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (24, 48)), (6, 12, (33, 64)), (12, 4, (24, 48))])
 def test_disco_conv_bf16_gradient_orders_agree(cin, cout, shape, monkeypatch):
     """bf16, groups = 1, equal grids: the data gradient through the transposed one-in-K-out kernel + regrouped GEMM (DiscoConvFn),
