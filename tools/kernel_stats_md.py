@@ -11,7 +11,7 @@ FAMILIES = {
              ("layout", r"weight_to_w|w_to_weight|slayout|complex_to"), ("torch glue", r"at::native|rocclr|Cijk")],
     "fcn3": [("DISCO contraction", r"disco_"), ("channel GEMM fwd/dgrad", r"conv_nn_"), ("channel GEMM wgrad", r"conv_wgrad_|reduce_splits"),
              ("SHT + dhconv (global blocks)", r"xc?gemm2?_kernel|fft_(fast_)?kernel|weight_to_w|w_to_weight|slayout|complex_to"),
-             ("resampling", r"resample_"), ("library GEMMs (grouped channel mix, fp32)", r"Cijk"), ("plane sums", r"plane_sum|sum_chunks"),
+             ("resampling", r"resample_"), ("grouped channel mix", r"group_mix"), ("library GEMMs (grouped channel mix, fp32)", r"Cijk"), ("plane sums", r"plane_sum|sum_chunks"),
              ("torch glue", r"at::native|rocclr")],
 }
 
