@@ -402,3 +402,70 @@ def test_disco_lists_of_a_real_tensor_and_its_transpose():
     k, t, i, j, v = Lt.runs._e
     back = disco._RunLists(dict(k=k, t=i, i=t, j=(-j) % shape[1], v=v, K=psi["K"]), (shape, shape), "cpu")
     assert torch.equal(back.f_seg, L.runs.f_seg) and torch.equal(back.f_runs, L.runs.f_runs) and torch.equal(back.f_vals, L.runs.f_vals)
+
+
+def _emulate_run_kernel(x, seg_off, runs, vals, seg, row0, nrows, R, lanes_per_wave=64):
+    """numpy model of csrc/disco_runs.hip for ONE segment: de-interleaved row image (class = lon % R, slot = lon // R, one
+    duplicate slot behind every class segment), a lane owns R consecutive output longitudes, every run streams blocks of R row
+    elements through a sliding window (block j of the stream: class (bm + j) % R of slot base + (bm + j) // R)"""
+    N = x.shape[1]
+    n4 = N // R
+    nw = (n4 + lanes_per_wave - 1) // lanes_per_wave
+    segs = lanes_per_wave * nw + 1                                   # slots per class segment (compile-time in the kernel)
+    img = np.zeros((nrows, R, segs))
+    for r in range(nrows):
+        for lon in range(N):
+            img[r, lon % R, lon // R] = x[row0 + r, lon]
+        img[r, :, n4] = img[r, :, 0]                                  # the duplicate slot
+    out = np.zeros(N)
+    for lane in range(n4):
+        acc = np.zeros(R)
+        for rr in range(seg_off[seg], seg_off[seg + 1]):
+            row, js, voff, ng = (int(v) for v in runs[rr])
+            bq, bm = js // R, js % R
+            slot = (lane + bq) % n4
+
+            def block(slot):
+                return [img[row, (bm + j) % R, slot + (bm + j) // R] for j in range(R)]
+            cur = block(slot)
+            for g in range(ng):
+                slot = (slot + 1) % n4
+                nxt = block(slot)
+                win = cur + nxt
+                for tau in range(R):
+                    for r in range(R):
+                        acc[r] += vals[voff + g * R + tau] * win[tau + r]
+                cur = nxt
+        out[lane * R:(lane + 1) * R] = acc
+    return out
+
+
+def test_disco_run_kernel_addressing_model():
+    """the addressing of the run-form kernel, restated in numpy on the device lists, reproduces the dense circular correlation
+    y[t][p] = sum_{i, j} psi[k][t][i][j] x[i][(j + p) mod N] — forward lists and the adjoint's lists (latitude groups of 2)"""
+    from makani_amd import disco
+    shape = (10, 24)
+    psi = disco.convolution_tensor(shape, shape, [3, 3], basis_type="morlet", grid_in="equiangular", grid_out="equiangular",
+                                   theta_cutoff=3.5 * math.pi / 9, basis_norm_mode="mean")
+    L = disco._Lists(psi, shape, shape, "cpu")
+    RL, K, N = L.runs, psi["K"], shape[1]
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(shape)
+    dense = np.zeros((K, shape[0], shape[0], N))
+    dense[psi["k"], psi["t"], psi["i"], psi["j"]] = psi["v"]
+    so, rn, vl = RL.f_seg.numpy(), RL.f_runs.numpy(), RL.f_vals.numpy()
+    lat_lo, lat_n = RL.lat_lo.numpy(), RL.lat_n.numpy()
+    for t, k in ((0, 0), (4, 3), (9, 8), (5, 1)):
+        ref = np.array([sum(dense[k, t, i, j] * x[i, (j + p) % N] for i in range(shape[0]) for j in range(N) if dense[k, t, i, j] != 0)
+                        for p in range(N)])
+        got = _emulate_run_kernel(x, so, rn, vl, t * K + k, int(lat_lo[t]), int(lat_n[t]), RL.R)
+        assert np.allclose(got, ref, atol=1e-6), (t, k)
+    # adjoint: gx[i][q] = sum_{k, t, j} psi[k][t][i][j] gy[k][t][(q - j) mod N], latitude groups of 2 share the image of a k
+    gy = rng.standard_normal((K, *shape))
+    so, rn, vl, t_lo, t_n, _ = (a.numpy() if hasattr(a, "numpy") else a for a in RL.bwd(2))
+    for i in (0, 3, 9):
+        ref = np.array([sum(dense[k, t, i, j] * gy[k, t, (q - j) % N] for k in range(K) for t in range(shape[0]) for j in range(N)
+                            if dense[k, t, i, j] != 0) for q in range(N)])
+        got = sum(_emulate_run_kernel(gy[k], so, rn, vl, i * K + k, int(t_lo[(i // 2) * K + k]), int(t_n[(i // 2) * K + k]), RL.R)
+                  for k in range(K))
+        assert np.allclose(got, ref, atol=1e-6), i
