@@ -23,10 +23,17 @@
 // carry is a compile-time constant, i.e. an immediate offset of the LDS read; per group a lane spends 3 integer instructions
 // (advance + wrap of its slot address) beside R reads and R * R * PB multiply-adds.
 //
-//   forward   workgroup = (output latitude t, PB planes); the x rows it touches are staged once; KG wave groups of NW waves
-//             share them and take the basis functions k = kg, kg + KG, ...
-//   adjoint   workgroup = (LG consecutive input latitudes, PB planes); for every k the gradient rows of gy[k] that those
-//             latitudes touch are staged (two barriers per k), wave group lg accumulates gx of latitude i0 + lg over all k.
+//   forward, all K basis functions per stream (disco_fused_fwd_kernel, the default for K = 9): workgroup = (LG consecutive
+//             output latitudes, 2 planes); the union of the x rows they touch is staged once; wave group lg of NW waves walks
+//             the (row) streams of latitude t0 + lg, every stream feeding the K accumulator sets of its lanes.
+//   forward, one stream per basis function (disco_runs_fwd_kernel): workgroup = (output latitude t, PB planes), WV waves take
+//             the (k, 64-lane longitude segment) items round-robin.
+//   adjoint / K planes in, one out (disco_runs_bwd_kernel): workgroup = (LG consecutive input latitudes, PB planes); for every k
+//             the gradient rows of gy[k] that those latitudes touch are staged (two barriers per k), wave group lg accumulates
+//             gx of latitude i0 + lg over all k.  The same kernel evaluates sum_k psi_k (*) z_k on the transposed tensor's lists.
+// Measured on FourCastNet3's local block (360 x 720, 677 planes, 570 GFLOP): fused forward 7.0 ms = 81 TFLOP/s fp32 (0.51 of
+// the packed-FMA vector peak; VALU issue 0.85 busy), per-k forward 10.4 ms, adjoint 13.1 ms; the list kernels of disco.hip 33 /
+// 59 ms.
 #include "common.h"
 
 namespace {
