@@ -469,3 +469,39 @@ def test_disco_run_kernel_addressing_model():
         got = sum(_emulate_run_kernel(gy[k], so, rn, vl, i * K + k, int(t_lo[(i // 2) * K + k]), int(t_n[(i // 2) * K + k]), RL.R)
                   for k in range(K))
         assert np.allclose(got, ref, atol=1e-6), i
+
+
+def test_c_abi_host_side_planning_functions():
+    """the planning entry points of the C ABI that need no GPU: which shapes the run-form DISCO kernels take (and with which
+    radix / planes per workgroup / latitude group), the grouped-mix instantiations, the weight-gradient workspace"""
+    import ctypes as C
+    from makani_amd._lib import lib, MK_BF16, MK_F32
+    L = lib()
+    R, PB = C.c_int(0), C.c_int(0)
+    # FourCastNet3's local block (720 longitudes, 10 image rows): R = 4, four planes of an fp32 image fit the LDS
+    assert L.mk_disco_runs_shape(720, 10, 677, MK_BF16, 0, C.byref(R), C.byref(PB)) == 1 and (R.value, PB.value) == (4, 4)
+    # 13 rows (four latitudes per workgroup) of four fp32 planes: 160 576 B, inside the 160 KB of a CU; 14 rows are not
+    PB.value = 4
+    assert L.mk_disco_runs_shape(720, 13, 677, MK_BF16, 0, C.byref(R), C.byref(PB)) == 1
+    PB.value = 4
+    assert L.mk_disco_runs_shape(720, 14, 677, MK_BF16, 0, C.byref(R), C.byref(PB)) == 0
+    PB.value = 0
+    assert L.mk_disco_runs_shape(720, 14, 677, MK_BF16, 0, C.byref(R), C.byref(PB)) == 1 and PB.value == 2
+    PB.value = 4
+    assert L.mk_disco_runs_shape(720, 14, 677, MK_BF16, 1, C.byref(R), C.byref(PB)) == 1          # bf16 image: half the bytes
+    # the decoder grid: 1440 longitudes = 360 lanes of R = 4 in six waves; 1152 longitudes fall to R = 8; odd counts to the lists
+    PB.value = 0
+    assert L.mk_disco_runs_shape(1440, 6, 585, MK_F32, 0, C.byref(R), C.byref(PB)) == 1 and R.value == 4
+    assert L.mk_disco_runs_shape(1152, 4, 8, MK_F32, 0, C.byref(R), C.byref(PB)) == 1 and R.value == 8
+    assert L.mk_disco_runs_shape(722, 4, 8, MK_F32, 0, C.byref(R), C.byref(PB)) == 0
+    assert L.mk_disco_runs_shape(720, 10, 1, MK_F32, 0, C.byref(R), C.byref(PB)) == 0                # a single plane: list kernels
+    LG = C.c_int(0)
+    assert L.mk_disco_fused_shape(720, 9, 13, 677, C.byref(LG), C.byref(PB)) == 1 and (LG.value, PB.value) == (4, 2)
+    assert L.mk_disco_fused_shape(1440, 9, 6, 585, C.byref(LG), C.byref(PB)) == 1 and LG.value == 2
+    assert L.mk_disco_fused_shape(720, 4, 13, 677, C.byref(LG), C.byref(PB)) == 0                    # K != 9: one stream per basis function
+    assert [L.mk_group_mix_supported(c, r) for c, r in ((9, 9), (9, 8), (8, 9), (8, 8), (9, 10), (3, 9))] == [1, 1, 1, 1, 0, 0]
+    assert L.mk_group_mix_blocks(1038240, MK_F32, 65) == 32 and L.mk_group_mix_blocks(64, MK_BF16, 4) == 1
+    # weight gradient workspace = splits x M x K: FourCastNet3's 677 x 6093 at 259 200 pixels is tiled 3 x 16 with 5 pixel splits
+    L.mk_conv1x1_wgrad_workspace.restype = C.c_longlong
+    assert L.mk_conv1x1_wgrad_workspace(677, 6093, 1, 259200) == 5 * 677 * 6093
+    assert L.mk_conv1x1_wgrad_workspace(384, 384, 1, 1038240) % (384 * 384) == 0
