@@ -38,7 +38,7 @@ import torch.nn as nn
 from . import _lib
 from . import legendre as _leg
 from . import ops
-from ._lib import check, dtype_code, lib, ptr, stream
+from ._lib import check, device_guard, dtype_code, lib, ptr, stream
 from .layers import hip_conv_eligible
 
 
@@ -657,6 +657,7 @@ class DiscreteContinuousConvS2(nn.Module):
         return _LIST_CACHE[key]
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
@@ -877,6 +878,7 @@ class DistributedDiscreteContinuousConvS2(DiscreteContinuousConvS2):
         return y.contiguous()
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
@@ -994,6 +996,7 @@ class ResampleS2(nn.Module):
                                         self.nlon_in, self.nlat_out, self.nlon_out, stream()), "mk_resample_bwd")
         return gx
 
+    @device_guard
     def forward(self, x):
         if self.skip_resampling:
             return x
@@ -1016,6 +1019,7 @@ class DistributedResampleS2(ResampleS2):
         self.lat_out_shapes = thd.compute_split_shapes(self.nlat_out, self.comm_size_polar)
         self.lon_out_shapes = thd.compute_split_shapes(self.nlon_out, self.comm_size_azimuth)
 
+    @device_guard
     def forward(self, x):
         from . import distributed as thd
         if self.skip_resampling:

@@ -23,6 +23,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from . import comm
+from ._lib import device_guard
 from . import distributed as thd
 from .disco import (DiscreteContinuousConvS2, DistributedDiscreteContinuousConvS2, DistributedResampleS2, ResampleS2)
 from .layers import MLP, ChannelLayerNorm, DropPath, EncoderDecoder, GeometricInstanceNormS2, InstanceNorm2d, PointwiseConv
@@ -422,6 +423,7 @@ class AtmoSphericNeuralOperatorNet(nn.Module):
             x = torch.where(self.water_channel_mask, w_full, x)
         return x
 
+    @device_guard
     def forward(self, x):
         if self.big_skip:
             residual = x[..., : self.n_out_chans, :, :].contiguous()

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, legendre
-from ._lib import check, dtype_code, lib, ptr, stream
+from ._lib import device_guard, check, dtype_code, lib, ptr, stream
 
 GRID_TO_QUADRATURE_RULE = {
     "euclidean": "uniform",
@@ -263,6 +263,7 @@ class SpectralLpLoss(nn.Module):
         return normp / (tar_normp + self.eps)
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None, **kwargs):
         return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)
 
@@ -335,6 +336,7 @@ class GeometricLpLoss(nn.Module):
         return norms
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, prd: torch.Tensor, tar: torch.Tensor, wgt: Optional[torch.Tensor] = None, **kwargs):
         return self.rel(prd, tar, wgt) if self.relative else self.abs(prd, tar, wgt)
 
@@ -411,6 +413,7 @@ class CRPSLoss(nn.Module):
         return len(self.channel_names)
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, forecasts: torch.Tensor, observations: torch.Tensor, spatial_weights: Optional[torch.Tensor] = None,
                 **kwargs) -> torch.Tensor:
         if forecasts.dim() != 5:
@@ -460,6 +463,7 @@ class SpectralCRPSLoss(SpectralLpLoss):
         self.crps_type, self.alpha, self.eps, self.absolute = crps_type, alpha, eps, absolute
 
     @torch.compiler.disable(recursive=True)
+    @device_guard
     def forward(self, forecasts: torch.Tensor, observations: torch.Tensor, spectral_weights: Optional[torch.Tensor] = None,
                 **kwargs) -> torch.Tensor:
         from . import distributed as thd
