@@ -216,11 +216,23 @@ def _host_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def _cpu_worker(cfg_name, mode):
+PARITY_SEED = 20260926
+
+
+def parity_input(cfg):
+    """the input of the in-run parity check: U[0, 1) from a seeded CPU generator, identical in the GPU process and in the
+    CPU child (DummyLoader-shaped, makani/utils/dataloaders/data_loader_dummy.py:264-277)"""
+    gen = torch.Generator().manual_seed(PARITY_SEED)
+    return torch.rand(1, cfg["inp_chans"], *cfg["inp_shape"], generator=gen)
+
+
+def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
     """child process: the oracle (the reference's model code restated over the restated torch-harmonics SHT), fp32, on
     the host cores.  Always: forward and forward+backward of ONE internal-grid block (seconds; also picks the thread
     count).  mode "fwd" (default): one FORWARD pass of the whole network at 721 x 1440.  mode "step": one full train
-    step (forward + backward + clip + AdamW) of the whole network — minutes of host time, opt-in."""
+    step (forward + backward + clip + AdamW) of the whole network — minutes of host time, opt-in.
+    ``state_path`` / ``out_path``: the timed forward pass runs with the GPU model's initial weights on ``parity_input``
+    and its output is kept — the same pass is the CPU timing sample AND the oracle side of ``parity_rel_l2``."""
     from oracle import sfno as osf
     from oracle import sht as osht
     cores = _host_cores()
@@ -258,11 +270,17 @@ def _cpu_worker(cfg_name, mode):
             "operator_type", "model_grid_type", "sht_grid_type")
     model = osf.SphericalFourierNeuralOperatorNet(**{k: cfg[k] for k in keys if k in cfg})
     inp, tar = torch.rand(1, cfg["inp_chans"], H, W), torch.rand(1, cfg["out_chans"], H, W)
+    if state_path:
+        model.load_state_dict(torch.load(state_path, map_location="cpu"), strict=True)
+        inp = parity_input(cfg)
     if mode != "step":
         with torch.no_grad():
             t0 = time.perf_counter()
             y = model(inp)
             rec.update(t_fwd=time.perf_counter() - t0, out_mean=float(y.mean()))
+        if out_path:
+            torch.save(y, out_path)
+            rec.update(parity_output=out_path)
         print(json.dumps(rec), flush=True)
         return
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
@@ -276,7 +294,47 @@ def _cpu_worker(cfg_name, mode):
     print(json.dumps(rec), flush=True)
 
 
-def cpu_baseline(cfg_name, timeout_s=240):
+class ParityProbe:
+    """In-run parity of the measured model against the oracle: before the first train step the GPU
+    model's forward output on ``parity_input`` is taken in fp32 and under bf16 autocast (the benchmark's precision) and its
+    initial weights are written to a scratch file; the CPU child that times the oracle's full-size forward pass loads
+    those weights, runs on the same input and keeps its output; ``finish`` reports both rel-L2 distances."""
+
+    def __init__(self, model, cfg, device):
+        import tempfile
+        self.dir = tempfile.mkdtemp(prefix="mk_parity_")
+        self.state_path = os.path.join(self.dir, "state.pt")
+        self.out_path = os.path.join(self.dir, "oracle_out.pt")
+        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, self.state_path)
+        x = parity_input(cfg).to(device)
+        was_training = model.training
+        model.eval()
+        with torch.no_grad():
+            self.y32 = model(x).float().cpu()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                self.y16 = model(x).float().cpu()
+        model.train(was_training)
+        del x
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()                       # peak_hbm_GB is the train loop's, not the probe's
+
+    def finish(self):
+        import shutil
+        out = None
+        try:
+            if os.path.exists(self.out_path):
+                yo = torch.load(self.out_path, map_location="cpu").double()
+                den = float(yo.norm())
+                out = dict(fp32=float((self.y32.double() - yo).norm()) / den, bf16_autocast=float((self.y16.double() - yo).norm()) / den,
+                           what="rel-L2 of the GPU model's forward output (initial weights of this run, seeded U[0,1) input, "
+                                "721x1440x73) against the CPU oracle's output of the pass timed as cpu_baseline; gates: "
+                                "fp32 <= 1e-4, bf16 autocast <= 2e-2 (BASELINE.md §3)")
+        finally:
+            shutil.rmtree(self.dir, ignore_errors=True)
+        return out
+
+
+def cpu_baseline(cfg_name, timeout_s=240, parity=None):
     """Reference-equivalent CPU path, timed in a child process on this host's cores, fp32 (kind "port": the oracle), on
     a bounded sample (about 30 s of host time): ONE forward pass of the whole network at 721 x 1440, measured, times the
     (forward+backward)/forward ratio measured on one internal-grid block; the optimizer is excluded (which favours the
@@ -291,8 +349,10 @@ def cpu_baseline(cfg_name, timeout_s=240):
         timeout_s = max(timeout_s, 1500)
     recs, err = [], None
     try:
-        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name, "--cpu-mode", mode],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name, "--cpu-mode", mode]
+        if parity is not None:
+            cmd += ["--cpu-state", parity.state_path, "--cpu-out", parity.out_path]
+        pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         try:
             so, _ = pr.communicate(timeout=timeout_s)
         except subprocess.TimeoutExpired:
@@ -369,6 +429,9 @@ def run_worker(args):
     B = 1
     model = build_model(args.config, device, seed=333)            # same seed on every rank -> same init
     opt = make_optimizer(model)
+    probe = None
+    if world == 1 and not args.no_cpu_baseline and args.config == "sfno_sc3_layers8_edim384":
+        probe = ParityProbe(model, cfg, device)                    # before the first update: the weights the oracle will load
     # mappings.py:321-525 (the model itself when world == 1); --zero: ZeRO-1 over the data group (reduce-scattered
     # gradients, sharded AdamW state, in-place parameter all-gather: makani_amd/optim.py)
     net = thd.init_gradient_reduction_hooks(model, device, zero=args.zero and dsize > 1)
@@ -536,7 +599,8 @@ def run_worker(args):
             out["fwd_sht"] = sht_bandwidth(device)
             print("[bench] fwd SHT done; CPU baseline", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config)
+            out["cpu_baseline"] = cpu_baseline(args.config, parity=probe)
+            out["parity_rel_l2"] = probe.finish() if probe is not None else None
         else:
             out["cpu_baseline"] = None
     if world > 1:
@@ -670,9 +734,11 @@ def main():
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-mode", default="fwd", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-state", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
-        _cpu_worker(args.cpu_worker, args.cpu_mode)
+        _cpu_worker(args.cpu_worker, args.cpu_mode, args.cpu_state, args.cpu_out)
         return
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.worker or (args.gpus <= 1 and env_world <= 1):

@@ -141,11 +141,15 @@ def device_guard(fn):
     import functools
 
     @functools.wraps(fn)
-    def wrapped(self, x, *args, **kwargs):
-        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
-            with torch.cuda.device(x.device):
-                return fn(self, x, *args, **kwargs)
-        return fn(self, x, *args, **kwargs)
+    def wrapped(self, *args, **kwargs):
+        # the first CUDA tensor among the positional, then the keyword arguments decides (model(x=inp), loss(prd=, tar=))
+        for a in (*args, *kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(self, *args, **kwargs)
+                break
+        return fn(self, *args, **kwargs)
 
     return wrapped
 

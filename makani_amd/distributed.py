@@ -644,8 +644,10 @@ def total_grad_norm(model, comm=None):
     replicated parameters count once."""
     c = comm or _comm
     groups = {}
+    from .optim import _check_live_shard
     for p in model.parameters():
         z = getattr(p, "_mk_zero", None)
+        _check_live_shard(p)
         if z is not None and z[0] is not None:          # ZeRO: this rank holds the reduced slice; the slices add up over "data"
             key = tuple(g for g in getattr(p, "sharded_dims_mp", []) if g is not None and c.get_size(g) > 1) + ("data",)
             groups.setdefault(key, []).append(z[0])

@@ -50,6 +50,16 @@ def _flat(t, like=None):
     return r
 
 
+def _check_live_shard(p):
+    """A ZeRO-sharded parameter whose reduced gradient shard was consumed by ``step()`` still carries the LOCAL, unreduced
+    gradient in ``p.grad``: a gradient norm computed from it would be wrong and differ per rank.  Norms are defined between
+    ``backward()`` and ``step()``."""
+    z = getattr(p, "_mk_zero", None)
+    if z is not None and z[0] is None and p.grad is not None:
+        raise RuntimeError("gradient norm requested after FusedAdamW.step() consumed the ZeRO gradient shard: p.grad holds "
+                           "this rank's unreduced gradient; take the norm between backward() and step()")
+
+
 class FusedAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` semantics (state keys ``step`` / ``exp_avg`` / ``exp_avg_sq``), executed by
     ``mk_adamw_step``.  ``step(max_grad_norm=...)`` folds makani's global-norm clipping
@@ -73,6 +83,7 @@ class FusedAdamW(torch.optim.Optimizer):
         for g in self.param_groups:
             for p in g["params"]:
                 z = self.zero_shard(p)
+                _check_live_shard(p)
                 if z is not None:
                     shards.append(z[0])
                     group = z[1]
@@ -95,9 +106,20 @@ class FusedAdamW(torch.optim.Optimizer):
     def _step_state(self, group, device):
         """device-side step counter + bias corrections of a parameter group (mk_adamw_advance)"""
         st = group.get("_mk_step_state")
-        if st is None or st.device != device:
-            st = torch.zeros(3, dtype=torch.float32, device=device)
-            group["_mk_step_state"] = st
+        if torch.is_tensor(st) and st.device == device and st.numel() == 3:
+            return st
+        # No counter on this device: a resumed run.  ``Optimizer.load_state_dict`` does not move param_group tensors to the
+        # device (makani loads checkpoints with map_location="cpu", driver.py:436/507), and checkpoints written by
+        # torch.optim.AdamW / the round-1 FusedAdamW hold no counter at all.  Restarting at zero would restart the bias
+        # correction (updates ~0.3x too small for thousands of steps at beta2 = 0.999), so the count is rebuilt from the
+        # saved counter or, failing that, from the per-parameter ``state["step"]`` mirror.
+        if torch.is_tensor(st) and st.numel() == 3:
+            step = float(st.reshape(-1)[0])
+        else:
+            steps = [float(self.state[p]["step"]) for p in group["params"] if "step" in self.state.get(p, {})]
+            step = max(steps) if steps else 0.0
+        st = torch.tensor([step, 0.0, 0.0], dtype=torch.float32, device=device)      # [1], [2] are rewritten by mk_adamw_advance
+        group["_mk_step_state"] = st
         return st
 
     @torch.no_grad()
@@ -130,17 +152,29 @@ class FusedAdamW(torch.optim.Optimizer):
                     gshard, zgroup, nranks, rank = z
                     pr = _flat(p).reshape(-1)
                     chunk = pr.numel() // nranks
+                    if gshard.numel() != chunk or p.grad is not None and p.grad.stride() != p.stride():
+                        raise RuntimeError("ZeRO gradient shard does not match the parameter (size or memory order)")
                     if not st:
                         st["step"] = 0
                         st["exp_avg"] = torch.zeros(chunk, dtype=torch.float32, device=p.device)
                         st["exp_avg_sq"] = torch.zeros(chunk, dtype=torch.float32, device=p.device)
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        full = _real(st[key])
+                        if full.numel() == pr.numel():       # a non-ZeRO checkpoint (full-size moments): keep this rank's slice
+                            st[key] = _flat(st[key], p).reshape(-1)[rank * chunk:(rank + 1) * chunk].clone()
+                        elif full.numel() != chunk:
+                            raise RuntimeError(f"ZeRO optimizer state of {full.numel()} elements does not fit a shard of {chunk}")
+                    if st.setdefault("zero_shard", (nranks, rank)) != (nranks, rank):
+                        raise RuntimeError(f"optimizer state belongs to ZeRO shard {st['zero_shard']}, this rank is {(nranks, rank)}: "
+                                           "sharded state must be saved and restored per data rank")
                     st["step"] += 1
                     mine = pr[rank * chunk:(rank + 1) * chunk]
                     _k_adamw(mine, gshard, st["exp_avg"], st["exp_avg_sq"], scale, group["lr"], b1, b2, group["eps"],
                              group["weight_decay"], sdev)
-                    if dist.get_backend(zgroup) == "gloo":           # (CPU tests) no in-place gather on gloo
-                        parts = [torch.empty_like(mine) for _ in range(nranks)]
-                        dist.all_gather(parts, mine.clone(), group=zgroup)
+                    if dist.get_backend(zgroup) == "gloo":           # (tests) gloo: no in-place gather, host memory only
+                        h = mine.cpu() if mine.is_cuda else mine.clone()
+                        parts = [torch.empty_like(h) for _ in range(nranks)]
+                        dist.all_gather(parts, h, group=zgroup)
                         pr.copy_(torch.cat(parts))
                     else:
                         dist.all_gather_into_tensor(pr, mine, group=zgroup)

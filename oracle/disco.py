@@ -176,8 +176,68 @@ def disco_contraction_dense(x, psi, nlon_out):
     return y.permute(3, 1, 2, 0).reshape(B, C, K, nlat_out, nlon_out)
 
 
+def _direct_fwd(x, idx, vals, in_shape, out_shape, K):
+    """y[b, c, k, t, p] = sum_e vals[e] x[b, c, i_e, (j_e + p * pscale) mod nlon_in] over the entries e = (k, t, i, j) of psi:
+    the defining quadrature sum, evaluated one output longitude at a time (gather + index_add, no dense psi, no roll)."""
+    nlat_in, nlon_in = in_shape
+    nlat_out, nlon_out = out_shape
+    pscale = nlon_in // nlon_out
+    B, C = x.shape[:2]
+    k, t, ij = idx
+    i, j = ij // nlon_in, ij % nlon_in
+    seg = k * nlat_out + t
+    xf = x.reshape(B * C, nlat_in, nlon_in)
+    y = torch.zeros(B * C, K * nlat_out, nlon_out, dtype=x.dtype)
+    for p in range(nlon_out):
+        contrib = vals * xf[:, i, (j + p * pscale) % nlon_in]
+        y[:, :, p] = torch.zeros(B * C, K * nlat_out, dtype=x.dtype).index_add_(1, seg, contrib)
+    return y.reshape(B, C, K, nlat_out, nlon_out)
+
+
+def _direct_adj(g, idx, vals, in_shape, out_shape, K):
+    """the adjoint of ``_direct_fwd``: gx[b, c, i_e, (j_e + p * pscale) mod nlon_in] += vals[e] g[b, c, k_e, t_e, p]"""
+    nlat_in, nlon_in = in_shape
+    nlat_out, nlon_out = out_shape
+    pscale = nlon_in // nlon_out
+    B, C = g.shape[:2]
+    k, t, ij = idx
+    i, j = ij // nlon_in, ij % nlon_in
+    seg = k * nlat_out + t
+    gf = g.reshape(B * C, K * nlat_out, nlon_out)
+    gx = torch.zeros(B * C, nlat_in * nlon_in, dtype=g.dtype)
+    for p in range(nlon_out):
+        gx.index_add_(1, i * nlon_in + (j + p * pscale) % nlon_in, vals * gf[:, seg, p])
+    return gx.reshape(B, C, nlat_in, nlon_in)
+
+
+class _DirectContraction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, vals, in_shape, out_shape, K):
+        ctx.save_for_backward(idx, vals)
+        ctx.meta = (in_shape, out_shape, K)
+        return _direct_fwd(x, idx, vals, in_shape, out_shape, K)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, vals = ctx.saved_tensors
+        return _direct_adj(g.contiguous(), idx, vals, *ctx.meta), None, None, None, None, None
+
+
+def disco_contraction_direct(x, psi_idx, psi_vals, in_shape, out_shape, kernel_size):
+    """The same contraction as ``disco_contraction_dense`` written as the defining sum over the entries of psi, with a
+    hand-written adjoint (no autograd graph per output longitude).  This is what makes FourCastNet3's real grids
+    (721 x 1440 -> 360 x 720, 360 x 720 with the doubled cutoff, 721 x 1440) tractable on the CPU: the dense form rolls a
+    (K, nlat_in, nlon_in, B * C) tensor once per output longitude and autograd keeps every rolled copy.  Pinned against the
+    dense form, forward and gradient, in ``tests/test_oracle_disco.py``."""
+    return _DirectContraction.apply(x, psi_idx, psi_vals.to(x.dtype), tuple(in_shape), tuple(out_shape), kernel_size)
+
+
 class DiscreteContinuousConvS2(nn.Module):
-    """``th.DiscreteContinuousConvS2`` (constructor, parameters and forward as published)."""
+    """``th.DiscreteContinuousConvS2`` (constructor, parameters and forward as published).  ``contraction``: "dense" — the
+    form of torch-harmonics' CPU path — or "direct" (``disco_contraction_direct``, the same sum, for large grids); a class
+    attribute so that test harnesses can switch every instance of a network at once."""
+
+    contraction = "dense"
 
     def __init__(self, in_channels, out_channels, in_shape, out_shape, kernel_shape, basis_type="morlet",
                  basis_norm_mode="mean", groups=1, grid_in="equiangular", grid_out="equiangular", bias=True,
@@ -210,7 +270,11 @@ class DiscreteContinuousConvS2(nn.Module):
                                        size=(self.kernel_size, self.nlat_out, self.nlat_in * self.nlon_in)).coalesce()
 
     def forward(self, x):
-        y = disco_contraction_dense(x, self.get_psi(x.dtype), self.nlon_out)
+        if self.contraction == "direct":
+            y = disco_contraction_direct(x, self.psi_idx, self.psi_vals, (self.nlat_in, self.nlon_in),
+                                         (self.nlat_out, self.nlon_out), self.kernel_size)
+        else:
+            y = disco_contraction_dense(x, self.get_psi(x.dtype), self.nlon_out)
         B, C, K, H, W = y.shape
         y = y.reshape(B, self.groups, self.groupsize, K, H, W)
         w = self.weight.reshape(self.groups, -1, self.weight.shape[1], self.weight.shape[2]).to(x.dtype)

@@ -230,6 +230,65 @@ def fcn3_fixtures():
         print(f"{name}: {os.path.getsize(path)/1e6:.2f} MB  |y|={y.abs().mean().item():.4f}")
 
 
+SUBSAMPLE = 7
+
+
+def seeded_field(seed, shape, kind):
+    """x / g of the large-grid fixtures are not stored: both sides regenerate them from a seeded CPU generator (same torch
+    build here and on the GPU box); the fixture holds their sums as a check"""
+    gen = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=gen) if kind == "rand" else torch.randn(shape, generator=gen)
+
+
+def fcn3_block_fixture():
+    """ONE processor block of FourCastNet3 at BASELINE config 4's internal grid (360 x 720 Gauss, local DISCO convolution with
+    the doubled cutoff, instance norms, MLP, layer scale, identity skip on the first out_chans channels) with reduced channel
+    counts: the reference's own ``NeuralOperatorBlock`` (makani/models/networks/fourcastnet3.py:421-638) over the restated
+    DISCO operator, evaluated with the entry-by-entry contraction (oracle.disco.disco_contraction_direct).  The fixture stores
+    the parameters, every parameter gradient, the norms of the output / input gradient and both fields on a stride-7 lattice
+    (the full fields would be 4 x 12 MB); x and g are regenerated from their seeds."""
+    from . import disco as _disco
+    from . import sht as _sht
+    mod = ref_shims.import_reference_module("makani.models.networks.fourcastnet3")
+    nlat, nlon, cin, cout = 360, 720, 12, 8
+    fwd = _sht.RealSHT(nlat, nlon, grid="legendre-gauss")
+    inv = _sht.InverseRealSHT(nlat, nlon, grid="legendre-gauss")
+    kwargs = dict(inp_chans=cin, out_chans=cout, conv_type="local", mlp_ratio=2.0, normalization_layer="instance_norm",
+                  skip="identity", layer_scale=True, use_mlp=True, kernel_shape=[3, 3], basis_type="morlet",
+                  basis_norm_mode="mean", bias=False)
+    old = _disco.DiscreteContinuousConvS2.contraction
+    _disco.DiscreteContinuousConvS2.contraction = "direct"
+    try:
+        torch.manual_seed(352)
+        blk = mod.NeuralOperatorBlock(fwd, inv, act_layer=torch.nn.GELU, **kwargs)
+        blk.train()
+        with torch.no_grad():                          # non-trivial affine parameters, biases and layer scale
+            for n, p_ in blk.named_parameters():
+                if n.endswith("bias"):
+                    p_.normal_(0.0, 0.1)
+                elif n.startswith("norm") or n.startswith("layer_scale"):
+                    p_.mul_(1.0 + 0.3 * torch.randn_like(p_))
+        x = seeded_field(3520, (1, cin, nlat, nlon), "rand").requires_grad_(True)
+        g = seeded_field(3521, (1, cout, nlat, nlon), "randn")
+        y = blk(x)
+        (y * g).sum().backward()
+    finally:
+        _disco.DiscreteContinuousConvS2.contraction = old
+    s = SUBSAMPLE
+    rec = {"kwargs": np.array(json.dumps(dict(kwargs, nlat=nlat, nlon=nlon, grid="legendre-gauss", x_seed=3520, g_seed=3521,
+                                             subsample=s))),
+           "x_sum": np.float64(x.detach().double().sum()), "g_sum": np.float64(g.double().sum()),
+           "y_sub": _np(y[..., ::s, ::s]), "gx_sub": _np(x.grad[..., ::s, ::s]),
+           "y_norm": np.float64(y.detach().double().norm()), "gx_norm": np.float64(x.grad.double().norm())}
+    for k, v in blk.state_dict().items():
+        rec["param/" + k] = _np(v)
+    for k, p_ in blk.named_parameters():
+        rec["grad/" + k] = _np(p_.grad)
+    path = os.path.join(OUT, "fcn3_local_block_360x720.npz")
+    np.savez_compressed(path, **rec)
+    print(f"fcn3_local_block_360x720.npz: {os.path.getsize(path)/1e6:.2f} MB  |y|={y.abs().mean().item():.4f}")
+
+
 def spectral_conv_fixtures():
     sc = ref_shims.import_reference_module("makani.models.common.spectral_convolution")
     th = sys.modules["torch_harmonics"]
@@ -474,6 +533,8 @@ def main():
         stepper_fixtures()
     if "fcn3" in which:
         fcn3_fixtures()
+    if "fcn3" in which or "fcn3_block" in which:
+        fcn3_block_fixture()
     if "crps" in which:
         crps_fixtures()
     if "crps_spectral" in which:

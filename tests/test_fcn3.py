@@ -78,3 +78,42 @@ def test_fcn3_bf16_autocast_runs_close_to_fp32():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = model(x)
     assert rel_l2(y.float(), torch.from_numpy(g["y"])) < 4e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp,tol", [(False, 1e-4), (True, 2e-2)])
+def test_fcn3_local_block_360x720_matches_reference_golden(amp, tol):
+    """one FourCastNet3 processor block at BASELINE config 4's internal grid (360 x 720 Gauss, local DISCO convolution with the
+    doubled cutoff, instance norms, MLP, layer scale; 12 -> 8 channels) against the reference's own NeuralOperatorBlock
+    (fourcastnet3.py:421-638; fixture: oracle/make_golden.py fcn3_block_fixture).  The fixture holds the fields on a stride-7
+    lattice plus their norms; weight gradients integrate over every pixel."""
+    import types
+    from makani_amd import fcn3
+    from oracle.make_golden import seeded_field
+    g = load_golden("fcn3_local_block_360x720.npz")
+    kw = json.loads(str(g["kwargs"]))
+    nlat, nlon, s = kw.pop("nlat"), kw.pop("nlon"), kw.pop("subsample")
+    tr = types.SimpleNamespace(nlat=nlat, nlon=nlon, grid=kw.pop("grid"))
+    xs, gs = kw.pop("x_seed"), kw.pop("g_seed")
+    blk = fcn3.NeuralOperatorBlock(tr, tr, act_layer=torch.nn.GELU, **kw)
+    blk.load_state_dict({k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}, strict=True)
+    blk = blk.to("cuda:0")
+    x = seeded_field(xs, (1, kw["inp_chans"], nlat, nlon), "rand")
+    gy = seeded_field(gs, (1, kw["out_chans"], nlat, nlon), "randn")
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6 * x.numel() and abs(float(gy.double().sum()) - float(g["g_sum"])) < 1e-3
+    xd = x.to("cuda:0").requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = blk(xd)
+    (y.float() * gy.to("cuda:0")).sum().backward()
+    e_y = rel_l2(y.float()[..., ::s, ::s], torch.from_numpy(g["y_sub"]))
+    e_gx = rel_l2(xd.grad[..., ::s, ::s], torch.from_numpy(g["gx_sub"]))
+    n_y = abs(float(y.double().norm()) - float(g["y_norm"])) / float(g["y_norm"])
+    n_gx = abs(float(xd.grad.double().norm()) - float(g["gx_norm"])) / float(g["gx_norm"])
+    print(f"FCN3 local block 360x720 amp={amp}: y {e_y:.2e} gx {e_gx:.2e} |y| {n_y:.2e} |gx| {n_gx:.2e}")
+    assert e_y < tol and e_gx < tol and n_y < tol and n_gx < tol
+    gmax = max(float(np.abs(g[k2]).max()) for k2 in g.files if k2.startswith("grad/"))
+    for k, p in blk.named_parameters():
+        ref = torch.from_numpy(g["grad/" + k])
+        e = rel_l2(p.grad, ref)
+        a = (p.grad.detach().cpu().float() - ref).abs().max().item()
+        assert e < 2 * tol or a < (1e-4 if not amp else 2e-2) * gmax, (k, e, a, gmax)

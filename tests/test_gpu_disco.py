@@ -217,3 +217,105 @@ def test_resample_fcn3_decoder_grid_adjoint():
     assert abs(lhs - rhs) / abs(lhs) < 1e-5
     c = mod._launch(torch.ones_like(x), False)
     assert (c - 1).abs().max() < 1e-5
+
+
+# --------------------------------------------------------------------------- #
+# HIP operators against the ORACLE at FourCastNet3's real grids (BASELINE config 4; reference call sites
+# makani/models/networks/fourcastnet3.py:189-205 encoder, :518-534 local block, :356-381 decoder): the template selection of
+# the run-form / fused kernels (latitude groups, planes per workgroup, waves per latitude circle) depends on the grid, so toy
+# grids do not cover it.  The oracle evaluates the defining sum entry by entry (oracle.disco.disco_contraction_direct, pinned
+# against the dense form in tests/test_oracle_disco.py).
+# --------------------------------------------------------------------------- #
+REAL_GRIDS = {
+    # name: (in_shape, out_shape, grid_in, grid_out, cutoff factor, cin, cout, batch)
+    "encoder_721x1440_to_360x720": ((721, 1440), (360, 720), "equiangular", "legendre-gauss", 1.0, 5, 8, 1),
+    "local_360x720_cutoff2": ((360, 720), (360, 720), "legendre-gauss", "legendre-gauss", 2.0, 6, 6, 2),
+    "decoder_721x1440": ((721, 1440), (721, 1440), "equiangular", "equiangular", 1.0, 9, 2, 1),
+}
+_REAL_CACHE = {}
+
+
+def _real_pair(name):
+    """(oracle outputs and gradients, product module, x, g) per grid; the oracle side is computed once per session"""
+    if name in _REAL_CACHE:
+        return _REAL_CACHE[name]
+    import makani_amd.disco as pd
+    from oracle import disco as od
+    in_shape, out_shape, gi, go, fac, cin, cout, B = REAL_GRIDS[name]
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 32)))
+    torch.manual_seed(21)
+    kw = dict(kernel_shape=(3, 3), basis_type="morlet", basis_norm_mode="mean", grid_in=gi, grid_out=go, groups=1, bias=True,
+              theta_cutoff=_cutoff(in_shape[0], fac))
+    ref = od.DiscreteContinuousConvS2(cin, cout, in_shape, out_shape, **kw)
+    ref.contraction = "direct"
+    with torch.no_grad():
+        ref.bias.normal_()
+    mod = pd.DiscreteContinuousConvS2(cin, cout, in_shape, out_shape, **kw)
+    mod.load_state_dict(ref.state_dict())
+    x = torch.randn(B, cin, *in_shape)
+    g = torch.randn(B, cout, *out_shape)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * g).sum().backward()
+    out = (dict(y=yr.detach(), gx=xr.grad, gw=ref.weight.grad, gb=ref.bias.grad), mod.to("cuda:0"), x, g)
+    _REAL_CACHE[name] = out
+    return out
+
+
+def _run_real(mod, x, g, amp):
+    mod.zero_grad()
+    xd = x.to("cuda:0").requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        yd = mod(xd)
+    (yd.float() * g.to("cuda:0")).sum().backward()
+    return dict(y=yd.float(), gx=xd.grad, gw=mod.weight.grad, gb=mod.bias.grad)
+
+
+@pytest.mark.parametrize("name", list(REAL_GRIDS))
+@pytest.mark.parametrize("variant", ["default", "runs_unfused", "lists"])
+def test_disco_conv_matches_oracle_at_fcn3_grids_fp32(name, variant, monkeypatch):
+    """forward, input gradient (the adjoint contraction), weight and bias gradient, fp32 <= 1e-5, through
+    the fused / run-form kernels (default), the per-basis-function run-form kernels and the list kernels"""
+    ref, mod, x, g = _real_pair(name)
+    if variant == "runs_unfused":
+        monkeypatch.setenv("MAKANI_AMD_DISCO_FUSED", "0")
+    elif variant == "lists":
+        monkeypatch.setenv("MAKANI_AMD_DISCO", "lists")
+    got = _run_real(mod, x, g, amp=False)
+    errs = {k: rel_l2(got[k], ref[k]) for k in ref}
+    print(f"DISCO {name} [{variant}] fp32 rel-L2 vs oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(v < 1e-5 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("name", list(REAL_GRIDS))
+@pytest.mark.parametrize("variant", ["default", "plain_order"])
+def test_disco_conv_matches_oracle_at_fcn3_grids_bf16(name, variant, monkeypatch):
+    """bf16 autocast (the benchmark's precision for FourCastNet3) <= 2e-2: the default evaluation orders (DiscoConvFn's
+    transposed-tensor data gradient, mix-first for the decoder) and the plain order (W^T g, then the K-in-one-out adjoint)"""
+    ref, mod, x, g = _real_pair(name)
+    if variant == "plain_order":
+        monkeypatch.setenv("MAKANI_AMD_DISCO_ADJ", "lists")
+        monkeypatch.setenv("MAKANI_AMD_DISCO_MIXFIRST", "0")
+    got = _run_real(mod, x, g, amp=True)
+    errs = {k: rel_l2(got[k], ref[k]) for k in ref}
+    print(f"DISCO {name} [{variant}] bf16 rel-L2 vs oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(v < 2e-2 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("nin,nout,gi,go", [((360, 720), (721, 1440), "legendre-gauss", "equiangular")])
+def test_resample_matches_oracle_at_fcn3_decoder_grid(nin, nout, gi, go):
+    """ResampleS2 360 x 720 Gauss -> 721 x 1440 equiangular (fourcastnet3.py:356-361), forward and adjoint vs the oracle"""
+    import makani_amd.disco as pd
+    from oracle import disco as od
+    torch.manual_seed(6)
+    ref = od.ResampleS2(*nin, *nout, grid_in=gi, grid_out=go)
+    mod = pd.ResampleS2(*nin, *nout, grid_in=gi, grid_out=go).to("cuda:0")
+    x = torch.randn(1, 3, *nin)
+    g = torch.randn(1, 3, *nout)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * g).sum().backward()
+    xd = x.to("cuda:0").requires_grad_(True)
+    yd = mod(xd)
+    (yd * g.to("cuda:0")).sum().backward()
+    assert rel_l2(yd, yr) < 1e-6 and rel_l2(xd.grad, xr.grad) < 1e-5

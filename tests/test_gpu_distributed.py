@@ -178,3 +178,80 @@ def _worker_rccl(rank, world, port):
 
 def test_rccl_collectives_of_the_grad_reducer_world1():
     mp.spawn(_worker_rccl, args=(1, _free_port()), nprocs=1, join=True)
+
+
+def _worker_ragged_gpu(rank, world, port, h, w, C):
+    """BASELINE configs[2] / [4] split sizes at the real grid THROUGH THE HIP BACKEND: 721 x 1440, lmax 240, mmax 241 over
+    h = 4 (lat [181, 181, 181, 178], l [60] * 4) and h4 w2 (lon [720, 720], m [121, 120]) with ragged plane counts; every
+    rank's shard of the distributed transform and of its gradient against the serial HIP transform AND the fp64 oracle
+    (split rule: makani/mpu/fft.py:50-51; tolerance of the reference's distributed tests: tests_distributed_layers.py:71-76)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd as ma
+        import makani_amd.comm as mcomm
+        import makani_amd.distributed as thd
+        from oracle import sht as osht
+        dev = torch.device("cuda:0")
+        _, ih, iw = mcomm.init(h, w)
+        assert thd.ensure_initialized() and thd._BACKEND is thd.HipBackend
+        nlat, nlon, lmax, mmax, B = 721, 1440, 240, 241, 1
+        kw = dict(lmax=lmax, mmax=mmax, grid="equiangular")
+        fwd = thd.DistributedRealSHT(nlat, nlon, **kw).to(dev)
+        inv = thd.DistributedInverseRealSHT(nlat, nlon, **kw).to(dev)
+        if h == 4:
+            assert fwd.lat_shapes == [181, 181, 181, 178] and fwd.l_shapes == [60, 60, 60, 60]
+        if w == 2:
+            assert fwd.lon_shapes == [720, 720] and fwd.m_shapes == [121, 120]
+        lat0, lon0 = sum(fwd.lat_shapes[:ih]), sum(fwd.lon_shapes[:iw])
+        l0, m0 = sum(fwd.l_shapes[:ih]), sum(fwd.m_shapes[:iw])
+        hl, wl, ll, ml = fwd.lat_shapes[ih], fwd.lon_shapes[iw], fwd.l_shapes[ih], fwd.m_shapes[iw]
+        torch.manual_seed(7)
+        x = torch.randn(B, C, nlat, nlon)
+        G = torch.randn(B, C, lmax, mmax, dtype=torch.complex64)
+        coef = torch.tril(torch.randn(B, C, lmax, mmax, dtype=torch.complex64))
+        gy = torch.randn(B, C, nlat, nlon)
+        # serial HIP transform and fp64 oracle on the whole field
+        S, I = ma.RealSHT(nlat, nlon, **kw).to(dev), ma.InverseRealSHT(nlat, nlon, **kw).to(dev)
+        xs = x.to(dev).requires_grad_(True)
+        cs = S(xs)
+        (torch.view_as_real(cs) * torch.view_as_real(G.to(dev))).sum().backward()
+        cfs = coef.to(dev).requires_grad_(True)
+        ys = I(cfs)
+        (ys * gy.to(dev)).sum().backward()
+        xo = x.double().requires_grad_(True)
+        co = osht.RealSHT(nlat, nlon, **kw)(xo)
+        (torch.view_as_real(co) * torch.view_as_real(G.to(torch.complex128))).sum().backward()
+        cfo = coef.to(torch.complex128).requires_grad_(True)
+        yo = osht.InverseRealSHT(nlat, nlon, **kw)(cfo)
+        (yo * gy.double()).sum().backward()
+        # this rank's shard through the distributed HIP transform
+        xl = x[..., lat0:lat0 + hl, lon0:lon0 + wl].to(dev).requires_grad_(True)
+        c = fwd(xl)
+        assert c.shape == (B, C, ll, ml) and c.dtype == torch.complex64
+        (torch.view_as_real(c) * torch.view_as_real(G[..., l0:l0 + ll, m0:m0 + ml].to(dev))).sum().backward()
+        cl = coef[..., l0:l0 + ll, m0:m0 + ml].to(dev).requires_grad_(True)
+        y = inv(cl)
+        assert y.shape == (B, C, hl, wl)
+        (y * gy[..., lat0:lat0 + hl, lon0:lon0 + wl].to(dev)).sum().backward()
+        sl_s, sl_g = (..., slice(l0, l0 + ll), slice(m0, m0 + ml)), (..., slice(lat0, lat0 + hl), slice(lon0, lon0 + wl))
+        tri = torch.tril(torch.ones(lmax, mmax))[l0:l0 + ll, m0:m0 + ml]           # gradients of the l < m entries are unspecified
+        pairs = {"fwd": (c, cs[sl_s], co[sl_s]), "fwd_gx": (xl.grad, xs.grad[sl_g], xo.grad[sl_g]),
+                 "inv": (y, ys[sl_g], yo[sl_g]),
+                 "inv_gc": (cl.grad.cpu() * tri, cfs.grad[sl_s].cpu() * tri, cfo.grad[sl_s] * tri)}
+        for k, (a, b_hip, b_or) in pairs.items():
+            e1, e2 = _rel(torch.view_as_real(a.detach().cpu()) if a.is_complex() else a.detach().cpu(),
+                          torch.view_as_real(b_hip.detach().cpu()) if b_hip.is_complex() else b_hip.detach().cpu()), \
+                     _rel(torch.view_as_real(a.detach().cpu()) if a.is_complex() else a.detach().cpu(),
+                          torch.view_as_real(b_or.detach()) if b_or.is_complex() else b_or.detach())
+            assert e1 < 1e-5 and e2 < 1e-5, (rank, k, e1, e2)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w,C", [(4, 1, 6), (4, 2, 5)])
+def test_distributed_sht_ragged_config3_splits_on_the_hip_backend(h, w, C):
+    mp.spawn(_worker_ragged_gpu, args=(h * w, _free_port(), h, w, C), nprocs=h * w, join=True)

@@ -177,3 +177,129 @@ def test_dhconv_c384_l240_m241_matches_contract_lwise():
     assert rel_l2(y, yo) < TOL_OP
     assert rel_l2(xd.grad.cpu() * tri, xo.grad * tri) < TOL_OP
     assert rel_l2(wd.grad, wo.grad) < TOL_OP
+
+
+# --------------------------------------------------------------------------- #
+# (iv) the whole network of BASELINE config 2 (sfno_sc3_layers8_edim384, 721 x 1440 x 73, B = 1): forward against the oracle
+#      (makani/models/networks/sfnonet.py:866-934; tolerances tests/distributed/tests_distributed_layers.py:71-76,539)
+# --------------------------------------------------------------------------- #
+CONFIG2 = dict(inp_shape=(721, 1440), out_shape=(721, 1440), inp_chans=73, out_chans=73, scale_factor=3, embed_dim=384,
+               num_layers=8, mlp_ratio=2, operator_type="dhconv", normalization_layer="instance_norm",
+               activation_function="gelu", big_skip=True, model_grid_type="equiangular", sht_grid_type="legendre-gauss")
+
+
+def _perturb_affine(mod, seed):
+    """non-trivial norm weights and biases (the initial ones are 1 / 0, which hides a wrong bias or affine path)"""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.1)
+            elif ".norm" in n or n.startswith("norm"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+
+
+@pytest.fixture(scope="module")
+def config2_pair():
+    import makani_amd as ma
+    from oracle import sfno as osf
+    _threads()
+    torch.manual_seed(333)
+    omod = osf.SphericalFourierNeuralOperatorNet(**CONFIG2)
+    _perturb_affine(omod, 7)
+    x = torch.rand(1, 73, 721, 1440)                    # DummyLoader-shaped U[0, 1) input (data_loader_dummy.py:264-277)
+    with torch.no_grad():
+        yo = omod(x)
+    model = ma.SphericalFourierNeuralOperatorNet(**CONFIG2)
+    model.load_state_dict(omod.state_dict(), strict=True)
+    del omod
+    return model.to(DEV).eval(), x, yo
+
+
+def test_sfno_config2_forward_721x1440_matches_oracle(config2_pair):
+    """all eight layers at the benchmark's size: encoder 73 -> 384, block 0 (721x1440 -> 240x480), six internal blocks,
+    block 7 (240x480 -> 721x1440, residual re-sampled through SHT -> iSHT), decoder 384 -> 73, big skip; fp32 <= 1e-4"""
+    model, x, yo = config2_pair
+    with torch.no_grad():
+        y = model(x.to(DEV))
+    assert y.shape == yo.shape and y.dtype == torch.float32
+    e = rel_l2(y, yo)
+    print(f"config 2 forward 721x1440 fp32 rel-L2 vs oracle: {e:.2e}")
+    assert e < TOL_E2E, e
+
+
+def test_sfno_config2_forward_721x1440_bf16_autocast_matches_oracle(config2_pair):
+    """the benchmark's precision (bf16 autocast, fp32 spectral path) against the fp32 oracle, whole network, <= 2e-2"""
+    model, x, yo = config2_pair
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = model(x.to(DEV))
+    e = rel_l2(y.float(), yo)
+    print(f"config 2 forward 721x1440 bf16 autocast rel-L2 vs fp32 oracle: {e:.2e}")
+    assert e < TOL_BF16, e
+
+
+# --------------------------------------------------------------------------- #
+# (v) the two blocks that change resolution, forward + every gradient at 384 channels:
+#     block 0 (721 x 1440 equiangular -> 240 x 480 Gauss; residual = iSHT(SHT(x)) on the internal grid) and
+#     block 7 (240 x 480 -> 721 x 1440; MLP, norms and skip at full resolution, residual re-sampled), sfnonet.py:676-700
+# --------------------------------------------------------------------------- #
+def _edge_block_pair(first):
+    import makani_amd as ma
+    from makani_amd.sfno import NeuralOperatorBlock
+    from makani_amd.layers import InstanceNorm2d
+    from functools import partial
+    from oracle import sfno as osf
+    from oracle import sht as osht
+    _threads()
+    torch.manual_seed(333 + int(first))
+    (hi, wi, gi), (ho, wo, go) = ((721, 1440, "equiangular"), (H, W, "legendre-gauss")) if first else \
+                                 ((H, W, "legendre-gauss"), (721, 1440, "equiangular"))
+    ot = osht.RealSHT(hi, wi, lmax=L, mmax=M, grid=gi).float()
+    oi = osht.InverseRealSHT(ho, wo, lmax=L, mmax=M, grid=go).float()
+    oblk = osf.NeuralOperatorBlock(ot, oi, E, "dhconv", 2, torch.nn.GELU, False)
+    _perturb_affine(oblk, 11)
+    norm = partial(InstanceNorm2d, num_features=E, eps=1e-6, affine=True, track_running_stats=False)
+    t = ma.RealSHT(hi, wi, lmax=L, mmax=M, grid=gi)
+    i = ma.InverseRealSHT(ho, wo, lmax=L, mmax=M, grid=go)
+    blk = NeuralOperatorBlock(t, i, E, filter_type="linear", operator_type="dhconv", mlp_ratio=2, act_layer=torch.nn.GELU,
+                              norm_layer=(norm, norm), inner_skip="none", outer_skip="linear", use_mlp=True)
+    blk.load_state_dict(oblk.state_dict(), strict=True)
+    blk = blk.to(DEV)
+    x = torch.rand(1, E, hi, wi) - 0.5
+    g = torch.randn(1, E, ho, wo)
+    xo = x.clone().requires_grad_(True)
+    yo = oblk(xo)
+    (yo * g).sum().backward()
+    ref = dict(y=yo.detach(), gx=xo.grad, grads={n: p.grad for n, p in oblk.named_parameters()})
+    del oblk, yo
+    return blk, x, g, ref
+
+
+@pytest.fixture(scope="module")
+def block0_pair():
+    return _edge_block_pair(True)
+
+
+@pytest.fixture(scope="module")
+def block7_pair():
+    return _edge_block_pair(False)
+
+
+def test_block0_721x1440_to_240x480_fp32_matches_oracle(block0_pair):
+    errs = _check_block(*block0_pair, amp=False, tol=TOL_E2E)
+    print("block 0 (721x1440 -> 240x480, 384 ch) fp32 rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
+def test_block0_721x1440_to_240x480_bf16_matches_oracle(block0_pair):
+    errs = _check_block(*block0_pair, amp=True, tol=TOL_BF16)
+    print("block 0 (721x1440 -> 240x480, 384 ch) bf16 rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
+def test_block7_240x480_to_721x1440_fp32_matches_oracle(block7_pair):
+    errs = _check_block(*block7_pair, amp=False, tol=TOL_E2E)
+    print("block 7 (240x480 -> 721x1440, 384 ch) fp32 rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
+def test_block7_240x480_to_721x1440_bf16_matches_oracle(block7_pair):
+    errs = _check_block(*block7_pair, amp=True, tol=TOL_BF16)
+    print("block 7 (240x480 -> 721x1440, 384 ch) bf16 rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})

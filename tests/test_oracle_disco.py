@@ -75,6 +75,28 @@ def test_dense_contraction_equals_direct_sum_and_is_equivariant(in_shape, out_sh
 
 
 @pytest.mark.parametrize("in_shape,out_shape,gi,go,fac", CASES)
+def test_direct_contraction_equals_dense_forward_and_gradient(in_shape, out_shape, gi, go, fac):
+    """oracle.disco.disco_contraction_direct (used at FourCastNet3's real grids, where the dense form is intractable on the
+    CPU) is the dense roll / bmm form of torch-harmonics' CPU path: outputs and input gradients agree to fp64 round-off,
+    and the module gives the same output, input gradient and weight gradient with either"""
+    torch.manual_seed(4)
+    m = od.DiscreteContinuousConvS2(2, 3, in_shape, out_shape, (3, 3), basis_type="morlet", grid_in=gi, grid_out=go, bias=True,
+                                    theta_cutoff=_cutoff(in_shape[0], fac)).double()
+    x = torch.randn(2, 2, *in_shape, dtype=torch.float64)
+    g = torch.randn(2, 3, *out_shape, dtype=torch.float64)
+    res = {}
+    for mode in ("dense", "direct"):
+        m.contraction = mode
+        m.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        (y * g).sum().backward()
+        res[mode] = (y.detach(), xr.grad, m.weight.grad.clone())
+    for a, b in zip(res["dense"], res["direct"]):
+        assert torch.allclose(a, b, atol=1e-12, rtol=1e-10)
+
+
+@pytest.mark.parametrize("in_shape,out_shape,gi,go,fac", CASES)
 @pytest.mark.parametrize("mode", ["mean", "individual"])
 def test_product_convolution_tensor_matches_oracle(in_shape, out_shape, gi, go, fac, mode):
     from makani_amd import disco as pd
