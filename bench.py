@@ -40,6 +40,35 @@ CONFIGS = {
     "sfno_debug": dict(inp_shape=(91, 180), out_shape=(91, 180), inp_chans=8, out_chans=8, scale_factor=3,
                        embed_dim=64, num_layers=4, mlp_ratio=2),
 }
+_LEVELS = [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]
+_FCN3_CHANS = ["u10m", "v10m", "u100m", "v100m", "t2m", "msl", "tcwv"] + [f"{v}{l}" for v in "uvztq" for l in _LEVELS]
+# auxiliary channels as makani's driver names them (makani/utils/features.py:20-67; driver.py:212-263): zenith angle, the 8
+# concatenated noise channels of the ensemble recipe (config/fourcastnet3.yaml:165-172), orography, the two land-sea masks
+_FCN3_AUX = ["xzen"] + [f"xnoise{i}" for i in range(8)] + ["xoro", "xlsml", "xlsms"]
+# BASELINE.json configs[3]: fcn3_sc2_edim45_layers10 (config/fourcastnet3.yaml:24-46), trained with the ensemble recipe of its
+# second pre-training stage (:174-202,254-262): ensemble_size 2, loss = fair CRPS ("skillspread") + 0.1 x spectral CRPS.
+# One sample = one initial condition = ensemble_size forward passes (the members are the model's batch).
+FCN3_CONFIGS = {
+    "fcn3_sc2_edim45_layers10": dict(
+        ensemble_size=2, lr=4e-4,
+        model=dict(inp_shape=(721, 1440), out_shape=(721, 1440), scale_factor=2, model_grid_type="equiangular",
+                   sht_grid_type="legendre-gauss", filter_basis_type="morlet", kernel_shape=(3, 3), channel_names=_FCN3_CHANS,
+                   aux_channel_names=_FCN3_AUX, atmo_embed_dim=45, surf_embed_dim=56, aux_embed_dim=36, num_layers=10,
+                   sfno_block_frequency=5, num_groups=1, normalization_layer="none", hard_thresholding_fraction=1.0, use_mlp=True,
+                   mlp_ratio=2, activation_function="gelu", big_skip=False, bias=False, encoder_mlp=False)),
+    # the same network on a small grid with few variables (plumbing / CI)
+    "fcn3_debug": dict(
+        ensemble_size=2, lr=4e-4,
+        model=dict(inp_shape=(65, 128), out_shape=(65, 128), scale_factor=2, filter_basis_type="morlet", kernel_shape=(3, 3),
+                   channel_names=["u10m", "t2m", "u500", "t500", "u850", "t850"], aux_channel_names=["xzen", "xnoise0", "xoro"],
+                   atmo_embed_dim=8, surf_embed_dim=8, aux_embed_dim=6, num_layers=4, sfno_block_frequency=2,
+                   normalization_layer="none", use_mlp=True, mlp_ratio=2, big_skip=False)),
+}
+for _k, _v in FCN3_CONFIGS.items():
+    CONFIGS[_k] = dict(kind="fcn3", inp_shape=_v["model"]["inp_shape"], out_shape=_v["model"]["out_shape"],
+                       inp_chans=len(_v["model"]["channel_names"]) + len(_v["model"]["aux_channel_names"]),
+                       out_chans=len(_v["model"]["channel_names"]), **_v)
+PEAK_F32_VALU_TF = 157.3      # packed fp32 FMA on the vector ALUs (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0    # dense
 PEAK_HBM_GBS = 8000.0
@@ -60,6 +89,7 @@ def kernel_family(name):
     """Launch names of the channel GEMMs carry their shape (``conv1x1_wgrad_m384_k768_n115200``): one kernel symbol,
     nine shapes per step.  The family is what rocprofv3 aggregates under one kernel name."""
     import re
+    name = re.sub(r"_\d+x\d+_p\d+$", "", name)          # disco_fwd_360x720_p1354 -> disco_fwd
     return re.sub(r"_m\d+_k\d+_n\d+$", "", name)
 
 
@@ -111,6 +141,16 @@ def roofline_of(family, members, prof, gemm_mode, traffic):
         base["shapes"] = members
     if not flops:
         return dict(base, bound="hbm", achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gb / PEAK_HBM_GBS, 4))
+    if family.startswith(("disco", "resample", "group_mix")):
+        # sliding-window contractions on the vector ALUs (no matrix-core shape): priced against the packed-fp32 FMA peak when
+        # their arithmetic intensity is above the VALU ridge (157.3 TF / 8 TB/s = 20 flop/B), else against HBM
+        if flops / (PEAK_F32_VALU_TF * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9):
+            return dict(base, bound="valu", achieved=round(tf, 2), peak=PEAK_F32_VALU_TF, unit="TFLOP/s",
+                        frac=round(tf / PEAK_F32_VALU_TF, 4), GBps=round(gb, 1),
+                        note="fp32 multiply-adds of the convolution tensor's entries (2 x nnz x planes x longitudes) on the "
+                             "vector ALUs against the packed-FMA peak; no MFMA shape exists for a sparse circular correlation")
+        return dict(base, bound="hbm", achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gb / PEAK_HBM_GBS, 4),
+                    TFLOPs=round(tf, 1))
     if family.startswith("conv1x1"):
         if flops / (PEAK_BF16_MFMA_TF * 1e12) < nbytes / (PEAK_HBM_GBS * 1e9):      # below the ridge: HBM is the roof
             return dict(base, bound="hbm", achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -132,11 +172,14 @@ def roofline_of(family, members, prof, gemm_mode, traffic):
                      f"{PEAK_BF16_MFMA_TF:.0f} TF is the matrix-pipe utilisation (SURVEY.md §8d)")
 
 
-def load_pmc_traffic():
+def load_pmc_traffic(fcn3=False):
     """HBM bytes per launch of every kernel family from the committed PMC passes of THIS command (rocprofv3 counters
     cannot be collected from inside the timed run; profiles/r02d_pmc_hbm_traffic.json (the newest of profiles/r02*_pmc_hbm_traffic.json) says how they were taken and
     tools/pmc_traffic.py rebuilds it — to be regenerated whenever a kernel of the family changes)"""
-    for name in ("r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):       # newest first
+    names = (("r03_pmc_hbm_traffic_fcn3.json",) if fcn3 else
+             ("r03_pmc_hbm_traffic.json", "r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json",
+              "r02_pmc_hbm_traffic.json"))
+    for name in names:       # newest first
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return {k: v["hbm_bytes"] for k, v in json.load(fh).items() if isinstance(v, dict) and "hbm_bytes" in v}
@@ -159,16 +202,34 @@ def parse_parallelism(par):
 def build_model(cfg_name, device, seed):
     import makani_amd as ma
     torch.manual_seed(seed)
-    model = ma.SphericalFourierNeuralOperatorNet(**CONFIGS[cfg_name]).to(device)
-    return model
+    cfg = CONFIGS[cfg_name]
+    if cfg.get("kind") == "fcn3":
+        return ma.AtmoSphericNeuralOperatorNet(**cfg["model"]).to(device)
+    return ma.SphericalFourierNeuralOperatorNet(**cfg).to(device)
 
 
-def make_optimizer(model):
-    # AdamW, betas (0.9, 0.95), lr 1e-3, weight decay 0 (config/sfnonet.yaml:50-54,114-117) as one fused
-    # HIP pass per tensor; complex64 spectral weights are updated through their real view.
+def make_optimizer(model, lr=1e-3):
+    # AdamW, betas (0.9, 0.95), lr 1e-3, weight decay 0 (config/sfnonet.yaml:50-54,114-117; FourCastNet3: lr 4e-4,
+    # config/fourcastnet3.yaml:254-262) as one fused HIP pass per tensor; complex64 spectral weights through their real view.
     from makani_amd.optim import FusedAdamW
     params = [p for p in model.parameters() if p.requires_grad]
-    return FusedAdamW(params, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
+    return FusedAdamW(params, lr=lr, betas=(0.9, 0.95), weight_decay=0.0)
+
+
+def make_ensemble_loss(H, W, channels, device, spatial):
+    """FourCastNet3's second-stage loss (config/fourcastnet3.yaml:180-193): "ensemble_crps" (fair CRPS, crps_type
+    "skillspread") + 0.1 x "ensemble_spectral_crps", uniform channel weights, mean over (B, C); both on the HIP path
+    (makani_amd.CRPSLoss / SpectralCRPSLoss: csrc/crps.hip, the HIP SHT).  pred: (E, C, H, W) — the ensemble members are the
+    model's batch —, tar: (1, C, H, W)."""
+    import makani_amd as ma
+    kw = dict(img_shape=(H, W), crop_shape=(H, W), crop_offset=(0, 0), channel_names=[f"c{i}" for i in range(channels)],
+              grid_type="equiangular", crps_type="skillspread", spatial_distributed=spatial)
+    crps, scrps = ma.CRPSLoss(**kw).to(device), ma.SpectralCRPSLoss(**kw).to(device)
+
+    def loss(pred, tar):
+        f = pred.float().unsqueeze(0)
+        return (crps(f, tar) + 0.1 * scrps(f, tar)).mean()
+    return loss
 
 
 def train_step(model, opt, inp, tar, loss_fn, amp, sharded_clip):
@@ -281,6 +342,12 @@ def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
         if out_path:
             torch.save(y, out_path)
             rec.update(parity_output=out_path)
+            print(json.dumps(rec), flush=True)
+            # the reference's own arithmetic under op-by-op bf16 autocast (CPU), same weights and input: the yardstick for the
+            # GPU path's bf16 distance from the fp32 result
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+                yb = model(inp).double()
+            rec.update(oracle_bf16_rel_l2=float((yb - y.double()).norm() / y.double().norm()))
         print(json.dumps(rec), flush=True)
         return
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)
@@ -303,6 +370,7 @@ class ParityProbe:
     def __init__(self, model, cfg, device):
         import tempfile
         self.dir = tempfile.mkdtemp(prefix="mk_parity_")
+        self.oracle_bf16 = None
         self.state_path = os.path.join(self.dir, "state.pt")
         self.out_path = os.path.join(self.dir, "oracle_out.pt")
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, self.state_path)
@@ -326,9 +394,12 @@ class ParityProbe:
                 yo = torch.load(self.out_path, map_location="cpu").double()
                 den = float(yo.norm())
                 out = dict(fp32=float((self.y32.double() - yo).norm()) / den, bf16_autocast=float((self.y16.double() - yo).norm()) / den,
+                           oracle_bf16_autocast=self.oracle_bf16,
                            what="rel-L2 of the GPU model's forward output (initial weights of this run, seeded U[0,1) input, "
-                                "721x1440x73) against the CPU oracle's output of the pass timed as cpu_baseline; gates: "
-                                "fp32 <= 1e-4, bf16 autocast <= 2e-2 (BASELINE.md §3)")
+                                "721x1440x73, all 8 layers) against the fp32 CPU oracle's output of the pass timed as "
+                                "cpu_baseline; oracle_bf16_autocast = the same distance for the oracle itself under op-by-op CPU "
+                                "bf16 autocast (the reference's own bf16 arithmetic).  Gates: fp32 <= 1e-4 (BASELINE.md §3); bf16 "
+                                "autocast <= the oracle's own bf16 distance (2e-2 holds per block, not through 8 bf16 layers)")
         finally:
             shutil.rmtree(self.dir, ignore_errors=True)
         return out
@@ -367,6 +438,8 @@ def cpu_baseline(cfg_name, timeout_s=240, parity=None):
     if not recs:
         return dict(value=None, unit="samples/s", cores=None, kind="port", sample=f"CPU baseline unavailable: {err}")
     rec = recs[-1]
+    if parity is not None:
+        parity.oracle_bf16 = rec.get("oracle_bf16_rel_l2")
     who = f"oracle fp32 on {rec['threads']} host threads ({rec['cores']} cores visible; the faster of 32 / 64 threads on one block)"
     if "t_step" in rec:
         return dict(value=1.0 / rec["t_step"], unit="samples/s", cores=rec["threads"], kind="port",
@@ -389,8 +462,11 @@ def cpu_baseline(cfg_name, timeout_s=240, parity=None):
                 ms_per_step=step * 1e3, measured="one block, extrapolated")
 
 
-def default_parallelism(world):
-    """the north-star split over ALL GPUs of the node (BASELINE.json: h_parallel=4, w_parallel=2 at 8 GPUs)"""
+def default_parallelism(world, cfg_name="sfno_sc3_layers8_edim384"):
+    """the north-star split over ALL GPUs of the node (BASELINE.json: h_parallel=4, w_parallel=2 at 8 GPUs); FourCastNet3
+    (configs[3]): "8 MI355X, h=2 w=2 + data-parallel" """
+    if CONFIGS.get(cfg_name, {}).get("kind") == "fcn3":
+        return {1: "dp", 2: "h2w1", 4: "h2w2", 8: "h2w2"}.get(world, "dp")
     return {1: "dp", 2: "h2w1", 4: "h4w1", 8: "h4w2"}.get(world, "dp")
 
 
@@ -416,7 +492,7 @@ def run_worker(args):
     import makani_amd.distributed as thd
 
     # ---- process-group tree: world -> data x (h x w), as makani/utils/comm.py:114-201 ----
-    par = args.parallelism if args.parallelism != "auto" else default_parallelism(world)
+    par = args.parallelism if args.parallelism != "auto" else default_parallelism(world, args.config)
     ph, pw = parse_parallelism(par)
     msize = ph * pw
     if world % msize:
@@ -427,8 +503,12 @@ def run_worker(args):
     cfg = CONFIGS[args.config]
     H, W = cfg["inp_shape"]
     B = 1
+    fcn3 = cfg.get("kind") == "fcn3"
+    E = cfg["ensemble_size"] if fcn3 else 1                        # ensemble members ride in the model's batch dimension
+    if fcn3 and args.multistep_count > 1:
+        raise SystemExit("--multistep-count applies to the SFNO workloads")
     model = build_model(args.config, device, seed=333)            # same seed on every rank -> same init
-    opt = make_optimizer(model)
+    opt = make_optimizer(model, lr=cfg.get("lr", 1e-3))
     probe = None
     if world == 1 and not args.no_cpu_baseline and args.config == "sfno_sc3_layers8_edim384":
         probe = ParityProbe(model, cfg, device)                    # before the first update: the weights the oracle will load
@@ -439,12 +519,24 @@ def run_worker(args):
         from makani_amd.stepper import MultiStepWrapper
         net = MultiStepWrapper(net, n_future=args.multistep_count - 1, multistep_checkpoint=args.multistep_checkpoint).train()
     torch.manual_seed(333 + d_idx)                                 # DummyLoader: fixed U[0,1) tensors on device
-    inp = torch.rand(B, cfg["inp_chans"], H, W, device=device)
+    inp = torch.rand(B * E, cfg["inp_chans"], H, W, device=device)
+    if fcn3:
+        # one initial condition per sample: the state and static channels are shared by the members, the noise channels are
+        # drawn per member (fixed synthetic draws, resident like the rest of the input; makani samples them per step from a
+        # spherical diffusion process in its preprocessor, outside this path)
+        names = cfg["model"]["channel_names"] + cfg["model"]["aux_channel_names"]
+        shared = [i for i, n in enumerate(names) if not n.startswith("xnoise")]
+        inp[:, shared] = inp[:1, shared]
+        noise = [i for i, n in enumerate(names) if n.startswith("xnoise")]
+        inp[:, noise] = torch.randn(B * E, len(noise), H, W, device=device)
     tar = torch.rand(B, cfg["out_chans"] * args.multistep_count, H, W, device=device)
-    loss_fn = make_loss(H, W, cfg["out_chans"] * args.multistep_count, device, msize > 1)
+    if fcn3:
+        loss_fn = make_ensemble_loss(H, W, cfg["out_chans"], device, msize > 1)
+    else:
+        loss_fn = make_loss(H, W, cfg["out_chans"] * args.multistep_count, device, msize > 1)
     if msize > 1:                                                  # this rank's lat/lon shard (dataloaders shard likewise)
-        lat0, lon0 = sum(model.trans_down.lat_shapes[:ih]), sum(model.trans_down.lon_shapes[:iw])
-        hl, wl = model.inp_shape_loc
+        lats, lons = thd.compute_split_shapes(H, ph), thd.compute_split_shapes(W, pw)
+        lat0, lon0, hl, wl = sum(lats[:ih]), sum(lons[:iw]), lats[ih], lons[iw]
         inp = inp[..., lat0:lat0 + hl, lon0:lon0 + wl].contiguous()
         tar = tar[..., lat0:lat0 + hl, lon0:lon0 + wl].contiguous()
     amp = not args.fp32
@@ -547,7 +639,7 @@ def run_worker(args):
         if not (dom_family and any(m in prof for m in dom_members)):
             dom_family, dom_members = dominant_family(prof)
         kernels = kernel_table(warm_prof, prof, event_steps)
-        pmc = load_pmc_traffic() if (args.config == "sfno_sc3_layers8_edim384" and msize == 1) else {}
+        pmc = load_pmc_traffic(fcn3) if (args.config in ("sfno_sc3_layers8_edim384", "fcn3_sc2_edim45_layers10") and msize == 1) else {}
         roofline = roofline_of(dom_family, dom_members, prof, ops.GEMM_MODE, pmc.get(dom_family)) if dom_family else None
         # the runners-up, from the fully profiled warm-up step (one launch set, not an average over the timed steps)
         others = []
@@ -560,7 +652,8 @@ def run_worker(args):
                 others.append(roofline_of(f, sorted(fams[f]), warm_prof, ops.GEMM_MODE, pmc.get(f)))
         hip_ms = sum(v["ms_per_step"] for v in kernels.values())
         out = {
-            "metric": f"SFNO train samples/sec at {H}x{W}x{cfg['inp_chans']}ch",
+            "metric": (f"FourCastNet3 train samples/sec at {H}x{W}x{cfg['out_chans']}ch" if fcn3 else
+                       f"SFNO train samples/sec at {H}x{W}x{cfg['inp_chans']}ch"),
             "value": dsize * B * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
@@ -573,6 +666,8 @@ def run_worker(args):
             "dtype": "bf16" if amp else "f32",
             "data": "synthetic",
             "config": {"workload": args.config, "grid": f"{H}x{W}", "channels": cfg["inp_chans"],
+                       **({"ensemble_size": E, "loss": "ensemble_crps (skillspread) + 0.1 x ensemble_spectral_crps",
+                           "state_channels": cfg["out_chans"], "aux_channels": cfg["inp_chans"] - cfg["out_chans"]} if fcn3 else {}),
                        "global_batch": dsize * B, "parallelism": f"dp{dsize}" + (f"_h{ph}w{pw}" if msize > 1 else ""),
                        "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32",
                        "multistep_count": args.multistep_count,
@@ -679,7 +774,7 @@ def launch(args):
     rank = int(os.environ.get("RANK", "0")) if under_torchrun else 0
     ranks = [rank] if under_torchrun else list(range(world))
     base_port = int(os.environ.get("MASTER_PORT", "0")) if under_torchrun else 0
-    head = args.parallelism if args.parallelism != "auto" else default_parallelism(world)
+    head = args.parallelism if args.parallelism != "auto" else default_parallelism(world, args.config)
     phases = [head] + (["dp"] if (head != "dp" and not args.no_secondary) else [])
     timeout_s = int(os.environ.get("MAKANI_AMD_BENCH_PHASE_TIMEOUT", "1500"))
     results, errors = {}, {}
@@ -711,7 +806,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="sfno_sc3_layers8_edim384", choices=list(CONFIGS))
+    ap.add_argument("--config", default="sfno_sc3_layers8_edim384", choices=list(CONFIGS),
+                    help="sfno_sc3_layers8_edim384 = BASELINE configs[1] (the headline; with --multistep-count 4: configs[4]); "
+                         "fcn3_sc2_edim45_layers10 = configs[3] (FourCastNet3, ensemble CRPS recipe); *_debug = small stand-ins")
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (not the BASELINE metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sht-metric", action="store_true")

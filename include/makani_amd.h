@@ -278,13 +278,16 @@ int mk_grad_clip_coef(const MkAdamTensor* tensors, int count, float max_norm, fl
 /* ---- ensemble CRPS on the sphere -----------------------------------------------------------------------------------
  * Pointwise score over the ensemble dimension fused with the quadrature over the plane: replaces the kernels of
  * makani/utils/losses/crps_loss.py:124-275 ("skillspread" = type 0, the default of CRPSLoss :277-452; "probability weighted
- * moment" = 1; "naive skillspread" = 2; "gauss" = 3), the weighted sum of :435-438 and their autograd.
+ * moment" = 1; "naive skillspread" = 2; "gauss" = 3) and the piecewise-integrated "cdf" form of :55-122 (type 4: members in
+ * rank order, optional per-member ensemble weights `ens_w` (E) — `self.ensemble_weights[idx]` of :392-396), the weighted sum
+ * of :435-438 and their autograd.
  * f: (B, E, C, hw) forecasts, obs: (B, C, hw), q: (hw) quadrature weights, w: optional (B, C, hw) spatial weights.
  * grad == 0: partial[(B * C) * mk_crps_chunks(hw)] chunk sums of q * w * crps (the caller adds the chunks of a plane);
- * grad == 1: gf (shape / dtype of f) = gout[b * C + c] * q * w * d crps / d f_e.  2 <= E <= 32 (2-8, 10, 12, 16, 20, 24, 32). */
+ * grad == 1: gf (shape / dtype of f) = gout[b * C + c] * q * w * d crps / d f_e.  Any 2 <= E <= 32 (members live in registers). */
 int mk_crps_chunks(long long hw);
 int mk_crps(const void* f, int f_dtype, const void* obs, int o_dtype, const float* q, const float* w, const float* gout,
-            float* partial, void* gf, int B, int E, int C, long long hw, int type, float alpha, float eps, int grad, void* stream);
+            float* partial, void* gf, int B, int E, int C, long long hw, int type, float alpha, float eps, int grad,
+            const float* ens_w, void* stream);
 
 /* ---- DISCO convolution and S2 resampling (FourCastNet3's local operators) ----------------------------------------
  * Replace th.DiscreteContinuousConvS2's sparse contraction and th.ResampleS2 [torch-harmonics, un-vendored; call sites

@@ -11,7 +11,12 @@
 // One thread owns one point: the E <= 32 members live in registers, ranks come from E^2 comparisons (ordinal ranks with the
 // stable tie order of torch.argsort, as rankdata() of the reference), everything else is a handful of flops: the kernel reads
 // (E + 1) values and, in backward, writes E — HBM-bound.  A NaN observation scores 0 and yields zero gradients, as the
-// reference's masking does.
+// reference's masking does.  "cdf" (crps_loss.py:55-122, the form FourCastNet3's first pre-training stage uses,
+// config/fourcastnet3.yaml:151-163): the members are put in rank order and the piecewise integral of (F - H)^2 is accumulated
+// exactly as the reference's loop does (same branch conditions), optionally with per-member ensemble weights; its gradient
+// is the derivative of that loop with respect to the sorted members, scattered back through the ranks.
+// Ensemble sizes: every E in 2..32 — the kernels are instantiated for EM in {2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32} and run
+// any E <= EM with the surplus members predicated off.
 #include "common.h"
 
 namespace {
@@ -28,30 +33,36 @@ __device__ __forceinline__ float ldv<u16>(const u16* p) { return bf16_to_f32(*p)
 __device__ __forceinline__ void stv(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stv(u16* p, float v) { *p = f32_to_bf16(v); }
 
-enum { CRPS_SKILLSPREAD = 0, CRPS_PWM = 1, CRPS_NAIVE = 2, CRPS_GAUSS = 3 };
+enum { CRPS_SKILLSPREAD = 0, CRPS_PWM = 1, CRPS_NAIVE = 2, CRPS_GAUSS = 3, CRPS_CDF = 4 };
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-// score of one point and (GRAD) its derivative with respect to every member, written back into f[]
-template <int E, bool GRAD>
-__device__ __forceinline__ float crps_point(float (&f)[E], float obs, int type, float alpha, float eps) {
-    const bool masked = type != CRPS_GAUSS && obs != obs;      // NaN observation (the gauss kernel of the reference does not mask)
+// score of one point and (GRAD) its derivative with respect to every member, written back into f[].
+// EM = compiled capacity, E <= EM = members present (members e >= E are ignored; callers load them as zeros).
+// ew: per-member ensemble weights of the "cdf" form (nullptr = uniform)
+template <int EM, bool GRAD>
+__device__ __forceinline__ float crps_point(float (&f)[EM], int E, float obs, int type, float alpha, float eps,
+                                            const float* __restrict__ ew) {
+    const bool masked = type != CRPS_GAUSS && type != CRPS_CDF && obs != obs;      // NaN observation (gauss / cdf of the reference do not mask)
     const float o = masked ? 0.f : obs;
     const float inv_e = 1.f / (float)E;
     float skill = 0.f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) skill += fabsf(o - f[e]);
+    for (int e = 0; e < EM; ++e)
+        if (e < E) skill += fabsf(o - f[e]);
     skill *= inv_e;
     float score;
-    float g[E];
+    float g[EM];
     if (type == CRPS_GAUSS) {
         float mu = 0.f;
 #pragma unroll
-        for (int e = 0; e < E; ++e) mu += f[e];
+        for (int e = 0; e < EM; ++e)
+            if (e < E) mu += f[e];
         mu *= inv_e;
         float var = 0.f;
 #pragma unroll
-        for (int e = 0; e < E; ++e) var += (f[e] - mu) * (f[e] - mu);
+        for (int e = 0; e < EM; ++e)
+            if (e < E) var += (f[e] - mu) * (f[e] - mu);
         var *= inv_e;
         const float sraw = sqrtf(var);
         const float sigma = fmaxf(sraw, eps);
@@ -62,34 +73,84 @@ __device__ __forceinline__ float crps_point(float (&f)[E], float obs, int type, 
         if (GRAD) {
             const float dmu = -cdf2m1, dsig = 2.f * pdf - 0.5641895835477563f;
 #pragma unroll
-            for (int e = 0; e < E; ++e)
+            for (int e = 0; e < EM; ++e)
                 g[e] = dmu * inv_e + ((sraw > eps) ? dsig * (f[e] - mu) * inv_e / sigma : 0.f);
         }
     } else {
         // ordinal ranks 1..E: members smaller than f_e, plus equal members that come before e
         float acc = 0.f;               // sum_e (2 r_e - E - 1) f_e   (skillspread / naive)   or   sum_e (r_e - 1) f_e   (pwm)
         float mean = 0.f;
-        float coef[E];
+        float coef[EM];
+        int rank[EM];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
+        for (int e = 0; e < EM; ++e) {
             int r = 1;
             float ssum = 0.f;          // sum_j sign(f_e - f_j)   (naive form: zero contribution from ties)
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                r += (f[j] < f[e] || (f[j] == f[e] && j < e)) ? 1 : 0;
-                ssum += sgn(f[e] - f[j]);
+            for (int j = 0; j < EM; ++j) {
+                if (j < E) {
+                    r += (f[j] < f[e] || (f[j] == f[e] && j < e)) ? 1 : 0;
+                    ssum += sgn(f[e] - f[j]);
+                }
             }
+            rank[e] = r;
             coef[e] = (type == CRPS_PWM) ? (float)(r - 1) : ((type == CRPS_NAIVE) ? ssum : (float)(2 * r - E - 1));
-            acc += coef[e] * f[e];
-            mean += f[e];
+            if (e < E) {
+                acc += coef[e] * f[e];
+                mean += f[e];
+            }
         }
         mean *= inv_e;
-        if (type == CRPS_PWM) {
+        if (type == CRPS_CDF) {
+            // members (and their weights) in rank order; then the reference's loop (crps_loss.py:84-117), prev_forecast of the
+            // first step is the constant 0, forecast_cdf advances by w_n / sum(w)
+            float total = 0.f;
+#pragma unroll
+            for (int e = 0; e < EM; ++e)
+                if (e < E) total += ew ? ew[e] : 1.f;
+            float obs_cdf = 0.f, fc = 0.f, prev = 0.f, integ = 0.f, last = 0.f;
+            float gs[EM];              // gradient with respect to the n-th sorted member
+#pragma unroll
+            for (int n = 0; n < EM; ++n) {
+                gs[n] = 0.f;
+                if (n < E) {
+                    float fo = 0.f, wn = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EM; ++e) {
+                        const bool hit = e < E && rank[e] == n + 1;
+                        fo = hit ? f[e] : fo;
+                        wn = hit ? (ew ? ew[e] : 1.f) : wn;
+                    }
+                    const bool cond = (obs < fo) && fabsf(obs_cdf) < 1.0e-7f;
+                    const float d = fc - obs_cdf;
+                    integ += cond ? ((obs - prev) * fc * fc + (fo - obs) * (fc - 1.f) * (fc - 1.f)) : ((fo - prev) * d * d);
+                    if (GRAD) {
+                        gs[n] = cond ? (fc - 1.f) * (fc - 1.f) : d * d;
+                        const float gp = cond ? -fc * fc : -d * d;
+                        if (n > 0) gs[n - 1] += gp;
+                    }
+                    obs_cdf = cond ? 1.f : obs_cdf;
+                    fc += wn / total;
+                    prev = fo;
+                    last = fo;
+                }
+            }
+            score = integ + fmaxf(obs - last, 0.f);
+            if (GRAD) {
+#pragma unroll
+                for (int e = 0; e < EM; ++e) {
+                    float ge = 0.f;
+#pragma unroll
+                    for (int n = 0; n < EM; ++n) ge = (n < E && rank[e] == n + 1) ? gs[n] : ge;
+                    g[e] = ge - ((rank[e] == E && obs > last) ? 1.f : 0.f);
+                }
+            }
+        } else if (type == CRPS_PWM) {
             const float c1 = 1.f / (float)(E * (E - 1));
             score = skill + mean - 2.f * acc * c1;
             if (GRAD) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) g[e] = sgn(f[e] - o) * inv_e + inv_e - 2.f * coef[e] * c1;
+                for (int e = 0; e < EM; ++e) g[e] = sgn(f[e] - o) * inv_e + inv_e - 2.f * coef[e] * c1;
             }
         } else {
             // espread = 2 mean((2r - E - 1) f) (E - 1 + alpha) / (E (E - 1));  naive: sum_ij |f_i - f_j| (E - 1 + alpha) / (E^2 (E - 1))
@@ -97,22 +158,23 @@ __device__ __forceinline__ float crps_point(float (&f)[E], float obs, int type, 
             score = skill - acc * inv_e * c;
             if (GRAD) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) g[e] = sgn(f[e] - o) * inv_e - coef[e] * inv_e * c;
+                for (int e = 0; e < EM; ++e) g[e] = sgn(f[e] - o) * inv_e - coef[e] * inv_e * c;
             }
         }
     }
     if (GRAD) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) f[e] = masked ? 0.f : g[e];
+        for (int e = 0; e < EM; ++e) f[e] = masked ? 0.f : g[e];
     }
     return masked ? 0.f : score;
 }
 
 // grid: (chunks, planes = B * C).  Forward: partial[plane][chunk]; backward: gf written in place of the loop.
-template <typename TF, typename TO, int E, bool GRAD>
+template <typename TF, typename TO, int EM, bool GRAD>
 __global__ __launch_bounds__(CNT) void crps_kernel(const TF* __restrict__ f, const TO* __restrict__ obs, const float* __restrict__ q,
                                                    const float* __restrict__ w, const float* __restrict__ gout, float* __restrict__ partial,
-                                                   TF* __restrict__ gf, int C, long long hw, int type, float alpha, float eps) {
+                                                   TF* __restrict__ gf, int E, int C, long long hw, int type, float alpha, float eps,
+                                                   const float* __restrict__ ew) {
     __shared__ float red[CNT / 64];
     const int plane = blockIdx.y, b = plane / C, c = plane % C;
     const long long estride = (long long)C * hw;
@@ -122,15 +184,16 @@ __global__ __launch_bounds__(CNT) void crps_kernel(const TF* __restrict__ f, con
     const float go = GRAD ? gout[plane] : 0.f;
     float sum = 0.f;
     for (long long p = (long long)blockIdx.x * CNT + threadIdx.x; p < hw; p += (long long)gridDim.x * CNT) {
-        float v[E];
+        float v[EM];
 #pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = ldv(fp + e * estride + p);
-        const float s = crps_point<E, GRAD>(v, ldv(op + p), type, alpha, eps);
+        for (int e = 0; e < EM; ++e) v[e] = (e < E) ? ldv(fp + e * estride + p) : 0.f;
+        const float s = crps_point<EM, GRAD>(v, E, ldv(op + p), type, alpha, eps, ew);
         const float wt = q[p] * (wp ? wp[p] : 1.f);
         if (GRAD) {
             TF* gp = gf + ((long long)b * E * C + c) * hw;
 #pragma unroll
-            for (int e = 0; e < E; ++e) stv(gp + e * estride + p, go * wt * v[e]);
+            for (int e = 0; e < EM; ++e)
+                if (e < E) stv(gp + e * estride + p, go * wt * v[e]);
         } else {
             sum += wt * s;
         }
@@ -149,21 +212,19 @@ __global__ __launch_bounds__(CNT) void crps_kernel(const TF* __restrict__ f, con
 
 template <typename TF, typename TO, bool GRAD>
 int launch_e(int E, dim3 grid, hipStream_t s, const TF* f, const TO* obs, const float* q, const float* w, const float* gout,
-             float* partial, TF* gf, int C, long long hw, int type, float alpha, float eps) {
-#define MK_CRPS_E(N)                                                                                                           \
-    case N:                                                                                                                    \
-        hipLaunchKernelGGL((crps_kernel<TF, TO, N, GRAD>), grid, dim3(CNT), 0, s, f, obs, q, w, gout, partial, gf, C, hw, type, \
-                           alpha, eps);                                                                                        \
-        break
-    switch (E) {
-        MK_CRPS_E(2); MK_CRPS_E(3); MK_CRPS_E(4); MK_CRPS_E(5); MK_CRPS_E(6); MK_CRPS_E(7); MK_CRPS_E(8); MK_CRPS_E(10); MK_CRPS_E(12);
-        MK_CRPS_E(16); MK_CRPS_E(20); MK_CRPS_E(24); MK_CRPS_E(32);
-        default:
-            mk_set_error("crps: ensemble size %d is not instantiated (2-8, 10, 12, 16, 20, 24, 32)", E);
-            return MK_EUNSUP;
+             float* partial, TF* gf, int C, long long hw, int type, float alpha, float eps, const float* ew) {
+#define MK_CRPS_E(N)                                                                                                              \
+    if (E <= N) {                                                                                                                 \
+        hipLaunchKernelGGL((crps_kernel<TF, TO, N, GRAD>), grid, dim3(CNT), 0, s, f, obs, q, w, gout, partial, gf, E, C, hw, type, \
+                           alpha, eps, ew);                                                                                       \
+        return mk_check_launch("mk_crps");                                                                                        \
     }
+    // the smallest instantiated capacity that holds E members
+    MK_CRPS_E(2) MK_CRPS_E(3) MK_CRPS_E(4) MK_CRPS_E(5) MK_CRPS_E(6) MK_CRPS_E(7) MK_CRPS_E(8) MK_CRPS_E(10) MK_CRPS_E(12)
+    MK_CRPS_E(16) MK_CRPS_E(20) MK_CRPS_E(24) MK_CRPS_E(32)
 #undef MK_CRPS_E
-    return mk_check_launch("mk_crps");
+    mk_set_error("crps: ensemble size %d exceeds the register-resident limit of 32 members", E);
+    return MK_EUNSUP;
 }
 
 }  // namespace
@@ -175,18 +236,20 @@ extern "C" int mk_crps_chunks(long long hw) {
 
 // grad == 0: partial (planes * mk_crps_chunks(hw)) f32 receives the chunk sums (the caller adds them up);
 // grad == 1: gf (same shape and dtype as f) receives gout[plane] * q * w * dcrps/df
+// ens_w: optional (E,) f32 per-member weights, used by type 4 ("cdf") only
 extern "C" int mk_crps(const void* f, int f_dtype, const void* obs, int o_dtype, const float* q, const float* w, const float* gout,
                        float* partial, void* gf, int B, int E, int C, long long hw, int type, float alpha, float eps, int grad,
-                       void* stream) {
+                       const float* ens_w, void* stream) {
     MK_REQUIRE(f && obs && q && B > 0 && E >= 2 && E <= MAXE && C > 0 && hw > 0, "crps: bad arguments (2 <= E <= 32)");
-    MK_REQUIRE(type >= 0 && type <= 3, "crps: unknown score type %d", type);
+    MK_REQUIRE(type >= 0 && type <= 4, "crps: unknown score type %d", type);
+    MK_REQUIRE(!ens_w || type == CRPS_CDF, "crps: ensemble weights are defined for the cdf form only");
     MK_REQUIRE(grad ? (gout && gf) : (partial != nullptr), "crps: missing output");
     MK_REQUIRE((long long)B * C <= 65535, "crps: too many planes");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)mk_crps_chunks(hw), (unsigned)(B * C));
 #define MK_CRPS_GO(TF, TO)                                                                                                          \
-    return grad ? launch_e<TF, TO, true>(E, grid, s, (const TF*)f, (const TO*)obs, q, w, gout, partial, (TF*)gf, C, hw, type, alpha, eps) \
-                : launch_e<TF, TO, false>(E, grid, s, (const TF*)f, (const TO*)obs, q, w, gout, partial, (TF*)gf, C, hw, type, alpha, eps)
+    return grad ? launch_e<TF, TO, true>(E, grid, s, (const TF*)f, (const TO*)obs, q, w, gout, partial, (TF*)gf, C, hw, type, alpha, eps, ens_w) \
+                : launch_e<TF, TO, false>(E, grid, s, (const TF*)f, (const TO*)obs, q, w, gout, partial, (TF*)gf, C, hw, type, alpha, eps, ens_w)
     if (f_dtype == MK_F32 && o_dtype == MK_F32) MK_CRPS_GO(float, float);
     if (f_dtype == MK_BF16 && o_dtype == MK_F32) MK_CRPS_GO(u16, float);
     if (f_dtype == MK_BF16 && o_dtype == MK_BF16) MK_CRPS_GO(u16, u16);

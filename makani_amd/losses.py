@@ -344,24 +344,29 @@ class GeometricLpLoss(nn.Module):
 # --------------------------------------------------------------------------- #
 # ensemble CRPS (makani/utils/losses/crps_loss.py:277-452)
 # --------------------------------------------------------------------------- #
-_CRPS_TYPES = {"skillspread": 0, "probability weighted moment": 1, "naive skillspread": 2, "gauss": 3}
+_CRPS_TYPES = {"skillspread": 0, "probability weighted moment": 1, "naive skillspread": 2, "gauss": 3, "cdf": 4}
+MAX_ENSEMBLE = 32          # members of a grid point live in registers (csrc/crps.hip)
 
 
 class CrpsFn(torch.autograd.Function):
     """out[b, c] = sum_p q[p] * w[b, c, p] * crps(obs[b, c, p], forecasts[b, :, c, p]); gradient w.r.t. the forecasts"""
 
     @staticmethod
-    def forward(ctx, forecasts, obs, q, wgt, ctype, alpha, eps):
+    def forward(ctx, forecasts, obs, q, wgt, ctype, alpha, eps, ens_w=None):
         B, E, Cc, H, W = forecasts.shape
+        if E > MAX_ENSEMBLE:
+            raise NotImplementedError(f"ensemble size {E}: the HIP CRPS kernels hold the members of a point in registers "
+                                      f"(2 <= E <= {MAX_ENSEMBLE})")
         hw = H * W
         f, o = _prep(forecasts), _prep(obs)
         w = wgt.float().contiguous() if wgt is not None else None
         ch = lib().mk_crps_chunks(hw)
         partial = torch.empty((B * Cc, ch), dtype=torch.float32, device=f.device)
         check(lib().mk_crps(ptr(f), dtype_code(f), ptr(o), dtype_code(o), ptr(q), ptr(w), None, ptr(partial), None, B, E, Cc, hw,
-                            ctype, float(alpha), float(eps), 0, stream()), "mk_crps")
+                            ctype, float(alpha), float(eps), 0, ptr(ens_w), stream()), "mk_crps")
         ctx.save_for_backward(f, o, q, w if w is not None else torch.empty(0, device=f.device))
         ctx.meta = (ctype, alpha, eps, w is not None, forecasts.dtype)
+        ctx.ens_w = ens_w
         return partial.sum(dim=1).reshape(B, Cc)
 
     @staticmethod
@@ -372,16 +377,23 @@ class CrpsFn(torch.autograd.Function):
         gf = torch.empty_like(f)
         go = g.float().contiguous()
         check(lib().mk_crps(ptr(f), dtype_code(f), ptr(o), dtype_code(o), ptr(q), ptr(w) if has_w else None, ptr(go), None,
-                            ptr(gf), B, E, Cc, H * W, ctype, float(alpha), float(eps), 1, stream()), "mk_crps")
-        return gf.to(dt), None, None, None, None, None, None
+                            ptr(gf), B, E, Cc, H * W, ctype, float(alpha), float(eps), 1, ptr(ctx.ens_w), stream()), "mk_crps")
+        return gf.to(dt), None, None, None, None, None, None, None
+
+
+def _ens_w(w, E):
+    if w is not None and w.numel() != E:
+        raise ValueError(f"ensemble_weights holds {w.numel()} entries for an ensemble of {E}")
+    return w
 
 
 class CRPSLoss(nn.Module):
     """``CRPSLoss`` of ``makani/utils/losses/crps_loss.py:277-452``: ``forward(forecasts (B, E, C, H, W), observations
     (B, C, H, W), spatial_weights=None) -> (B, C)``, the quadrature-weighted ensemble CRPS.  Score and quadrature are one HIP
     kernel (``csrc/crps.hip``), the gradient with respect to the forecasts one more.  Built: ``crps_type`` "skillspread"
-    (default, with the almost-fair factor ``alpha``), "naive skillspread", "probability weighted moment", "gauss";
-    constant ensemble weights; the "cdf" form, weighted ensembles and the ensemble-parallel transpose are not."""
+    (default, with the almost-fair factor ``alpha``), "naive skillspread", "probability weighted moment", "gauss" and "cdf"
+    (:55-122, with optional per-member ``ensemble_weights``, the only form in which the reference uses them); any ensemble
+    size 2..32.  Not built: the ensemble-parallel transpose."""
 
     def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
                  channel_names: List[str], grid_type: str, crps_type: str = "skillspread",
@@ -396,16 +408,15 @@ class CRPSLoss(nn.Module):
         self.spatial_distributed = self.quadrature.distributed
         if ensemble_distributed:
             raise NotImplementedError("the ensemble-parallel CRPS (transpose over the 'ensemble' group) is not built")
-        if ensemble_weights is not None:
+        if ensemble_weights is not None and crps_type != "cdf":      # the reference uses them in the cdf form only (:392-396)
             raise NotImplementedError("currently only constant ensemble weights are supported")
-        if crps_type == "cdf":
-            raise NotImplementedError("crps_type='cdf' is not built (skillspread, naive skillspread, probability weighted "
-                                      "moment and gauss are)")
         if crps_type not in _CRPS_TYPES:
             raise ValueError(f"Unknown CRPS crps_type {crps_type}")
         if crps_type not in ("skillspread", "naive skillspread") and alpha < 1.0:
             raise NotImplementedError("The alpha parameter (almost fair CRPS factor) is only supported for the skillspread kernels.")
         self.crps_type, self.alpha, self.eps = crps_type, alpha, eps
+        self.register_buffer("ensemble_weights", None if ensemble_weights is None else ensemble_weights.float().reshape(-1).contiguous(),
+                             persistent=False)
         self.register_buffer("quad_weight_split", self.quadrature.quad_weight.reshape(1, 1, -1).contiguous(), persistent=False)
 
     @property
@@ -427,7 +438,7 @@ class CRPSLoss(nn.Module):
             return crps
         w = spatial_weights.expand(B, Cc, H, W) if spatial_weights is not None else None
         crps = CrpsFn.apply(forecasts, observations, self.quad_weight_split.reshape(-1), w,
-                            _CRPS_TYPES[self.crps_type], self.alpha, self.eps)
+                            _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, E))
         return self.quadrature._reduce(crps)
 
 
@@ -437,8 +448,7 @@ class SpectralCRPSLoss(SpectralLpLoss):
     ``SpectralBaseLoss`` (m = 0 once, m > 0 twice, 1 / 4 pi).  ``forward(forecasts (B, E, C, H, W), observations (B, C, H, W),
     spectral_weights=None) -> (B, C)``.  The transforms are the HIP SHT (fp32, autocast off, as the reference), the per-(l, m)
     ensemble score and its weighted sum the HIP kernel of ``CRPSLoss`` (``csrc/crps.hip``) with the (l, m) plane in the place of
-    the grid.  Not built, as for ``CRPSLoss``: ``crps_type="cdf"``, weighted ensembles, the ensemble-parallel transpose; and
-    ``absolute=False`` (complex differences in the naive kernel)."""
+    the grid.  Not built: the ensemble-parallel transpose and ``absolute=False`` (complex differences in the naive kernel)."""
 
     def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
                  channel_names: List[str], grid_type: str, lmax: Optional[int] = None, crps_type: str = "skillspread",
@@ -449,18 +459,17 @@ class SpectralCRPSLoss(SpectralLpLoss):
                          lmax=lmax)
         if ensemble_distributed:
             raise NotImplementedError("the ensemble-parallel CRPS (transpose over the 'ensemble' group) is not built")
-        if ensemble_weights is not None:
+        if ensemble_weights is not None and crps_type != "cdf":
             raise NotImplementedError("currently only constant ensemble weights are supported")
-        if crps_type == "cdf":
-            raise NotImplementedError("crps_type='cdf' is not built (skillspread, naive skillspread, probability weighted "
-                                      "moment and gauss are)")
-        if crps_type not in ("skillspread", "probability weighted moment", "gauss"):     # (the reference's forward knows these and "cdf")
+        if crps_type not in ("cdf", "skillspread", "probability weighted moment", "gauss"):     # what the reference's forward knows
             raise ValueError(f"Unknown CRPS crps_type {crps_type}")
         if crps_type not in ("skillspread", "naive skillspread") and alpha < 1.0:
             raise NotImplementedError("The alpha parameter (almost fair CRPS factor) is only supported for the skillspread kernels.")
         if not absolute:
             raise NotImplementedError("absolute=False (the naive kernel on complex coefficients) is not built")
         self.crps_type, self.alpha, self.eps, self.absolute = crps_type, alpha, eps, absolute
+        self.register_buffer("ensemble_weights", None if ensemble_weights is None else ensemble_weights.float().reshape(-1).contiguous(),
+                             persistent=False)
 
     @torch.compiler.disable(recursive=True)
     @device_guard
@@ -483,7 +492,7 @@ class SpectralCRPSLoss(SpectralLpLoss):
         else:
             w = spectral_weights.expand(B, Cc, L, M) if spectral_weights is not None else None
             crps = CrpsFn.apply(f.contiguous(), o.contiguous(), self.lm_weights.reshape(-1).contiguous(), w, _CRPS_TYPES[self.crps_type],
-                                self.alpha, self.eps)
+                                self.alpha, self.eps, _ens_w(self.ensemble_weights, E))
         if self.spatial_distributed:
             crps = thd.reduce_from_spatial_region(crps)
         return crps

@@ -127,13 +127,23 @@ def crps_fixtures():
         # E = 1 (the reference's own E = 1 branch fails with spatial weights: crps_loss.py:375-437 leaves
         # spatial_weights_split unbound)
         dict(img=(17, 32), grid="equiangular", E=1, crps_type="skillspread", alpha=1.0, wgt=False, nan=False, ties=False),
+        # round 3: the "cdf" form (crps_loss.py:55-122; FourCastNet3's first pre-training stage), plain and with per-member
+        # ensemble weights + ties + spatial weights, and ensemble sizes between the instantiated register capacities
+        dict(img=(12, 24), grid="legendre-gauss", E=6, crps_type="cdf", alpha=1.0, wgt=False, nan=False, ties=False),
+        dict(img=(19, 36), grid="equiangular", E=9, crps_type="cdf", alpha=1.0, wgt=True, nan=False, ties=True, ens_w=True),
+        dict(img=(12, 24), grid="legendre-gauss", E=2, crps_type="cdf", alpha=1.0, wgt=False, nan=False, ties=False),
+        dict(img=(12, 24), grid="legendre-gauss", E=14, crps_type="skillspread", alpha=1.0, wgt=False, nan=False, ties=False),
+        dict(img=(12, 24), grid="legendre-gauss", E=27, crps_type="probability weighted moment", alpha=1.0, wgt=False, nan=False, ties=False),
     ]
     rec = {"cases": json.dumps(cases)}
     for i, c in enumerate(cases):
         torch.manual_seed(500 + i)
         B, C = 2, 3
+        ens_w = torch.rand(c["E"]) + 0.5 if c.get("ens_w") else None
         mod = CRPSLoss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0), channel_names=[str(k) for k in range(C)],
-                       grid_type=c["grid"], crps_type=c["crps_type"], alpha=c["alpha"])
+                       grid_type=c["grid"], crps_type=c["crps_type"], alpha=c["alpha"], ensemble_weights=ens_w)
+        if ens_w is not None:
+            rec[f"{i}_ens_w"] = _np(ens_w)
         f = torch.randn(B, c["E"], C, *c["img"])
         if c["ties"]:
             f[:, 1] = f[:, 0]                      # two equal members everywhere: ordinal ranks break the tie by position
@@ -166,6 +176,7 @@ def crps_spectral_fixtures():
         dict(img=(12, 24), grid="legendre-gauss", E=8, crps_type="gauss", alpha=1.0, wgt=True, lmax=None),
         dict(img=(12, 24), grid="legendre-gauss", E=2, crps_type="skillspread", alpha=1.0, wgt=False, lmax=None),
         dict(img=(17, 32), grid="equiangular", E=1, crps_type="skillspread", alpha=1.0, wgt=False, lmax=None),
+        dict(img=(12, 24), grid="legendre-gauss", E=5, crps_type="cdf", alpha=1.0, wgt=True, lmax=None),      # round 3
     ]
     rec = {"cases": json.dumps(cases)}
     for i, c in enumerate(cases):

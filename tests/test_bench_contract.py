@@ -130,3 +130,29 @@ def test_roofline_report_on_a_synthetic_profile():
     assert t["adamw"]["launches_per_step"] == 8 and t["dhconv_dgrad"]["launches_per_step"] == 8
     pm = bench.load_pmc_traffic()
     assert pm.get("dhconv_dgrad", 0) > 0 and all(isinstance(v, (int, float)) for v in pm.values())
+
+
+@pytest.mark.gpu
+def test_bench_fcn3_workload_runs_the_ensemble_recipe():
+    """--config fcn3_debug: the FourCastNet3 workload of BASELINE configs[3] on a small grid — ensemble members in the model's
+    batch, fair CRPS + 0.1 x spectral CRPS, clip + FusedAdamW; the roofline object names a kernel of the step"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "fcn3_debug", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("FourCastNet3 train samples/sec") and d["unit"] == "samples/s" and d["value"] > 0
+    assert d["config"]["workload"] == "fcn3_debug" and d["config"]["ensemble_size"] == 2 and d["config"]["global_batch"] == 1
+    assert d["final_loss"] == d["final_loss"] and d["roofline"]["bound"] in ("hbm", "mfma", "valu")
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+
+
+def test_roofline_prices_the_disco_contraction_against_the_vector_peak():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.kernel_family("disco_fwd_360x720_p1354") == "disco_fwd"
+    prof = {"disco_fwd_360x720_p1354": _rec(8, 7.0, 2.0 * 1354 * 720 * 585036, 2.0 * 1354 * 259200 * 10)}
+    r = bench.roofline_of("disco_fwd", ["disco_fwd_360x720_p1354"], prof, "x6", None)
+    assert r["bound"] == "valu" and r["peak"] == 157.3 and abs(r["achieved"] - 2.0 * 1354 * 720 * 585036 / 7.0e-3 / 1e12) < 0.01
+    assert bench.default_parallelism(8, "fcn3_sc2_edim45_layers10") == "h2w2" and bench.default_parallelism(8) == "h4w2"

@@ -18,12 +18,14 @@ def test_crps_constructor_contract():
     assert abs(float(m.quad_weight_split.sum()) - 1.0) < 1e-6
     with pytest.raises(ValueError):
         ma.CRPSLoss(crps_type="nonsense", **kw)
-    with pytest.raises(NotImplementedError):
-        ma.CRPSLoss(crps_type="cdf", **kw)
+    assert ma.CRPSLoss(crps_type="cdf", **kw).crps_type == "cdf"
+    assert ma.CRPSLoss(crps_type="cdf", ensemble_weights=torch.ones(4), **kw).ensemble_weights.shape == (4,)
     with pytest.raises(NotImplementedError):
         ma.CRPSLoss(crps_type="gauss", alpha=0.9, **kw)
     with pytest.raises(NotImplementedError):
-        ma.CRPSLoss(ensemble_weights=torch.ones(4), **kw)
+        ma.CRPSLoss(crps_type="cdf", alpha=0.9, **kw)
+    with pytest.raises(NotImplementedError):
+        ma.CRPSLoss(ensemble_weights=torch.ones(4), **kw)            # skillspread: constant weights only (crps_loss.py:408-410)
     with pytest.raises(ValueError):
         m(torch.zeros(2, 2, 9, 16), torch.zeros(2, 2, 9, 16))          # forecasts need the ensemble dimension
 
@@ -35,9 +37,10 @@ def test_crps_matches_reference_golden():
     cases = json.loads(str(g["cases"]))
     for i, c in enumerate(cases):
         C = g[f"{i}_o"].shape[1]
+        ens_w = torch.from_numpy(g[f"{i}_ens_w"]) if f"{i}_ens_w" in g.files else None
         mod = ma.CRPSLoss(img_shape=tuple(c["img"]), crop_shape=tuple(c["img"]), crop_offset=(0, 0),
                           channel_names=[str(k) for k in range(C)], grid_type=c["grid"], crps_type=c["crps_type"],
-                          alpha=c["alpha"]).to("cuda:0")
+                          alpha=c["alpha"], ensemble_weights=ens_w).to("cuda:0")
         f = torch.from_numpy(g[f"{i}_f"]).to("cuda:0").requires_grad_(True)
         o = torch.from_numpy(g[f"{i}_o"]).to("cuda:0")
         w = torch.from_numpy(g[f"{i}_wgt"]).to("cuda:0") if f"{i}_wgt" in g.files else None
@@ -47,6 +50,28 @@ def test_crps_matches_reference_golden():
         assert torch.isfinite(out).all(), c
         assert rel_l2(out, torch.from_numpy(g[f"{i}_out"])) < 1e-5, (c, out, g[f"{i}_out"])
         assert rel_l2(f.grad, torch.from_numpy(g[f"{i}_df"])) < 1e-5, c
+
+
+@pytest.mark.gpu
+def test_crps_cdf_equals_fair_score_identity_and_large_ensemble_errors():
+    """the piecewise-integrated "cdf" score is the classic ensemble CRPS  mean|f - o| - sum_ij |f_i - f_j| / (2 E^2)  (the
+    "naive skillspread" form with alpha = 0 differs from it by the factor (E - 1) / E on the spread), for every ensemble size
+    2..32; more than 32 members raise"""
+    import makani_amd as ma
+    torch.manual_seed(9)
+    kw = dict(img_shape=(16, 32), crop_shape=(16, 32), crop_offset=(0, 0), channel_names=["a", "b"], grid_type="equiangular")
+    cdf = ma.CRPSLoss(crps_type="cdf", **kw).to("cuda:0")
+    q = cdf.quad_weight_split.reshape(16, 32)
+    for E in (2, 3, 9, 11, 17, 31, 32):
+        f = torch.randn(1, E, 2, 16, 32, device="cuda:0", dtype=torch.float64)
+        o = torch.randn(1, 2, 16, 32, device="cuda:0", dtype=torch.float64)
+        skill = (f - o.unsqueeze(1)).abs().mean(dim=1)
+        spread = (f.unsqueeze(1) - f.unsqueeze(2)).abs().sum(dim=(1, 2)) / (2.0 * E * E)
+        ref = ((skill - spread) * q).sum(dim=(-2, -1))
+        got = cdf(f.float(), o.float())
+        assert rel_l2(got, ref) < 1e-5, (E, got, ref)
+    with pytest.raises(NotImplementedError):
+        cdf(torch.zeros(1, 33, 2, 16, 32, device="cuda:0"), torch.zeros(1, 2, 16, 32, device="cuda:0"))
 
 
 @pytest.mark.gpu
@@ -77,7 +102,8 @@ def test_spectral_crps_constructor_contract():
     assert m.crps_type == "skillspread" and m.absolute and m.lm_weights.shape == (m.sht.lmax, m.sht.mmax) == (11, 11)     # the grid's bandlimit
     assert torch.allclose(m.lm_weights[:, 0], torch.full((11,), 1.0 / (4 * np.pi))) and torch.allclose(m.lm_weights[:, 1:], torch.full((11, 10), 2.0 / (4 * np.pi)))
     assert ma.SpectralCRPSLoss(lmax=7, **kw).lm_weights.shape == (7, 7)
-    for bad, exc in ((dict(crps_type="naive skillspread"), ValueError), (dict(crps_type="cdf"), NotImplementedError),
+    assert ma.SpectralCRPSLoss(crps_type="cdf", **kw).crps_type == "cdf"
+    for bad, exc in ((dict(crps_type="naive skillspread"), ValueError),
                      (dict(absolute=False), NotImplementedError), (dict(crps_type="gauss", alpha=0.9), NotImplementedError),
                      (dict(ensemble_weights=torch.ones(4)), NotImplementedError), (dict(ensemble_distributed=True), NotImplementedError)):
         with pytest.raises(exc):
