@@ -674,7 +674,7 @@ def run_worker(args):
                        "multistep_checkpoint": bool(args.multistep_checkpoint),
                        "collectives": (dist.get_backend() if world > 1 else None),
                        "launch": ("hipGraph replay of the captured step" if graph is not None else "eager"),
-                       "channel_gemm": os.environ.get("MAKANI_AMD_CONV", "hip")},
+                       "channel_gemm": "hip (csrc/conv1x1.hip)"},
             "roofline": roofline,
             "roofline_runners_up": others,
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),

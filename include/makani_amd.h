@@ -275,6 +275,21 @@ int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_sca
 long long mk_grad_norm_workspace(const MkAdamTensor* tensors, int count);
 int mk_grad_clip_coef(const MkAdamTensor* tensors, int count, float max_norm, float* partial, float* out, void* stream);
 
+/* ---- layer norm over the channels of an NCHW tensor ------------------------------------------------------------------
+ * Replaces DistributedLayerNorm (makani/mpu/layer_norm.py:256-290: nn.LayerNorm(C) between two transposes of the NCHW
+ * activation; `normalization_layer="layer_norm"`, makani/models/networks/sfnonet.py:609-613, fourcastnet3.py:95-96) and its
+ * autograd without the transposes.  x, y, gy, gx: (B, C, P) planes (P = H * W grid points); stats: (B, 2, P) f32 = [mean,
+ * rstd] per grid point; gamma / beta: (C) f32 or NULL.  dtypes: x f32 -> y f32; x bf16 -> y f32 (nn.LayerNorm under
+ * autocast) or bf16; gy has y's dtype, gx has x's.
+ * wgrad: partial[(2, C, mk_chan_layernorm_chunks(C, P))] = per-chunk sums of gy * xhat (dgamma) and gy (dbeta). */
+int mk_chan_layernorm_chunks(int C, long long P);
+int mk_chan_layernorm_fwd(const void* x, int x_dtype, void* y, int y_dtype, float* stats, const float* gamma, const float* beta,
+                          int B, int C, long long P, float eps, void* stream);
+int mk_chan_layernorm_bwd(const void* x, int x_dtype, const void* gy, int g_dtype, void* gx, const float* stats,
+                          const float* gamma, int B, int C, long long P, void* stream);
+int mk_chan_layernorm_wgrad(const void* x, int x_dtype, const void* gy, int g_dtype, const float* stats, float* partial, int B,
+                            int C, long long P, void* stream);
+
 /* ---- ensemble CRPS on the sphere -----------------------------------------------------------------------------------
  * Pointwise score over the ensemble dimension fused with the quadrature over the plane: replaces the kernels of
  * makani/utils/losses/crps_loss.py:124-275 ("skillspread" = type 0, the default of CRPSLoss :277-452; "probability weighted

@@ -63,6 +63,10 @@ _SIGS = {
     "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp, c_f, c_vp], c_int),
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
     "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_int, c_ll, c_ll, c_int, c_int, c_vp], c_int),
+    "mk_chan_layernorm_chunks": ([c_int, c_ll], c_int),
+    "mk_chan_layernorm_fwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_f, c_vp], c_int),
+    "mk_chan_layernorm_bwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp], c_int),
+    "mk_chan_layernorm_wgrad": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_ll, c_vp], c_int),
     "mk_bias_gelu_fwd": ([c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),
     "mk_conv1x1_nn": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
     "mk_conv1x1_wgrad_workspace": ([c_int, c_int, c_int, c_ll], c_ll),

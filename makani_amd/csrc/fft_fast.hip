@@ -528,6 +528,9 @@ int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, con
         // two workgroups per CU: 14-16 % slower)
         case 1440: return launch<720, 10, 9, 8, 16, 512, 1>(MK_FFT_ARGS);
         case 480: return launch<240, 10, 6, 4, 32, 512, 2>(MK_FFT_ARGS);   // 32 rows: whole 128-byte lines on the F side (irfft +7 %)
+        // FourCastNet3's internal grid (360 x 720, full spectrum mmax = 361: fourcastnet3.py:503-504); round 2 ran it on the
+        // generic kernel at 0.11 of the HBM rate
+        case 720: return launch<360, 10, 6, 6, 16, 256, 3>(MK_FFT_ARGS);
         case 360: return launch<180, 6, 6, 5, 16, 256, 3>(MK_FFT_ARGS);
         case 128: return launch<64, 4, 4, 4, 16, 256, 4>(MK_FFT_ARGS);
         case 72: return launch<36, 6, 6, 1, 16, 256, 4>(MK_FFT_ARGS);

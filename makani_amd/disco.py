@@ -563,10 +563,11 @@ class GroupMixFn(torch.autograd.Function):
 
 
 def _group_mix(W, x):
-    """W (G, RG, CG) applied to x (B, G, CG, N): the HIP streaming kernel for FourCastNet3's group sizes, else a batched GEMM"""
-    if GroupMixFn.supported(x, W) and os.environ.get("MAKANI_AMD_GROUPMIX", "hip") == "hip":
+    """W (G, RG, CG) applied to x (B, G, CG, N): the HIP streaming kernel for FourCastNet3's group sizes (8-9 planes per
+    group), else the package's fp32 GEMM engine batched over (sample, group) — never a library GEMM"""
+    if GroupMixFn.supported(x, W):
         return GroupMixFn.apply(x, W)
-    return torch.matmul(W.unsqueeze(0).to(x.dtype), x)
+    return ops.GroupMmFn.apply(x, W)
 
 
 class DiscoSumFn(torch.autograd.Function):

@@ -7,7 +7,8 @@ State-dict layout and initialisation follow
 Everything here runs on HIP kernels under bf16 autocast: the channel GEMMs (1x1 convolutions on the NCHW
 planes, forward / data gradient / weight gradient) on the LDS-DMA ring kernels of ``csrc/conv1x1.hip`` with the
 bias, GELU, gelu' and skip-connection work in their epilogues, instance norm (+GELU) in ``csrc/pointwise.hip``.
-Without autocast (fp32 parity runs) the GEMMs are plain library GEMMs — DESIGN.md §5.
+Without autocast (fp32 parity runs) the GEMMs run on the fp32 GEMM engine of the Legendre transforms (``ops.chan_gemm_f32``):
+no library GEMM in the product — DESIGN.md §5.
 """
 import math
 import os
@@ -18,15 +19,14 @@ import torch.nn as nn
 from . import ops
 
 
-_HIP_NN = os.environ.get("MAKANI_AMD_CONV", "hip") == "hip"
 _DEFER_BIAS = os.environ.get("MAKANI_AMD_DEFER_BIAS", "1") != "0"
 
 
 def hip_conv_eligible(x) -> bool:
     """bf16 compute (autocast or bf16 tensors), pixel count % 8 == 0: forward / data-gradient channel GEMMs run on the
-    HIP kernels of csrc/conv1x1.hip (LDS-DMA ring kernel, fused bias / GELU / gelu' / skip epilogues).
-    ``MAKANI_AMD_CONV=lib`` routes them to the library GEMM instead (A/B measurements); fp32 always goes there."""
-    if not _HIP_NN or not x.is_cuda or x.dim() != 4 or (x.shape[-1] * x.shape[-2]) % 8 != 0:
+    bf16 kernels of csrc/conv1x1.hip (LDS-DMA ring kernels, fused bias / GELU / gelu' / skip epilogues); everything else
+    (fp32 parity runs, ragged toy grids) on the package's fp32 GEMM engine (``ops.ConvMmFn``).  No library GEMM either way."""
+    if not x.is_cuda or x.dim() != 4 or (x.shape[-1] * x.shape[-2]) % 8 != 0:
         return False
     if torch.is_autocast_enabled("cuda"):
         return torch.get_autocast_dtype("cuda") == torch.bfloat16
@@ -273,12 +273,15 @@ class ChannelLayerNorm(nn.Module):
     """``DistributedLayerNorm`` of ``makani/mpu/layer_norm.py:256-290`` (``normalization_layer="layer_norm"``): a layer
     norm over the CHANNELS of an NCHW tensor, one statistic per grid point — the same on a lat/lon shard as on the full
     grid, so the spatially parallel network uses this class unchanged.  State-dict keys ``norm.weight`` / ``norm.bias``
-    as the reference.  Runs on torch's layer-norm kernel over a channels-last view (this option is not on the
-    benchmarked path; the instance norms are the HIP kernels)."""
+    as the reference (the ``nn.LayerNorm`` submodule only holds the parameters); the arithmetic is the HIP kernel of
+    ``csrc/chan_layernorm.hip`` on the NCHW planes themselves — no transposes, no library layer norm.  Output dtype: float32
+    under autocast (torch runs ``layer_norm`` in fp32 there, which is what the reference module returns), else the input's."""
 
     def __init__(self, normalized_shape, eps=1e-05, elementwise_affine=True, bias=True):
         super().__init__()
         self.norm = nn.LayerNorm(normalized_shape, eps=eps, elementwise_affine=elementwise_affine, bias=bias)
+        if len(self.norm.normalized_shape) != 1:
+            raise ValueError("ChannelLayerNorm normalises over the channel dimension: normalized_shape must be one integer")
         if elementwise_affine:
             self.norm.weight.is_shared_mp = ["model"]
             self.norm.weight.sharded_dims_mp = [None]
@@ -286,5 +289,13 @@ class ChannelLayerNorm(nn.Module):
                 self.norm.bias.is_shared_mp = ["model"]
                 self.norm.bias.sharded_dims_mp = [None]
 
+    @torch.compiler.disable(recursive=True)
     def forward(self, x):
-        return torch.transpose(self.norm(torch.transpose(x, 1, 3)), 1, 3).contiguous()
+        if x.dim() != 4 or x.shape[1] != self.norm.normalized_shape[0]:
+            raise ValueError(f"expected (B, {self.norm.normalized_shape[0]}, H, W), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("makani_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        out_dtype = torch.float32 if torch.is_autocast_enabled("cuda") else x.dtype
+        return ops.ChannelLayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype)

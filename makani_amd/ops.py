@@ -769,6 +769,52 @@ class InstanceNormFn(torch.autograd.Function):
         return gx, (s[1] if g is not None else None), (s[0] if b is not None else None), None, None, gpb, None, None
 
 
+class ChannelLayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the channel dimension of an NCHW tensor (DistributedLayerNorm, makani/mpu/layer_norm.py:256-290)
+    without the two transposes: csrc/chan_layernorm.hip.  ``out_dtype``: float32 under autocast (layer_norm is an fp32 op of
+    torch's autocast policy), else the input dtype."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        P = H * W
+        y = torch.empty((B, Cc, H, W), dtype=out_dtype, device=x.device)
+        stats = torch.empty((B, 2, P), dtype=torch.float32, device=x.device)
+        g = gamma.float().contiguous() if gamma is not None else None
+        b = beta.float().contiguous() if beta is not None else None
+        with _timed(f"chan_layernorm_fwd_n{P}", nbytes=float(x.numel()) * (2 * x.element_size() + y.element_size())):
+            check(lib().mk_chan_layernorm_fwd(ptr(x), dtype_code(x), ptr(y), dtype_code(y), ptr(stats), ptr(g), ptr(b), B, Cc, P,
+                                              float(eps), stream()), "mk_chan_layernorm_fwd")
+        ctx.save_for_backward(x, stats, g)
+        ctx.has = (gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, g = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        P = H * W
+        gy = gy.contiguous()
+        if gy.dtype not in (torch.float32, x.dtype):
+            gy = gy.float()
+        gx = dg = db = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            with _timed(f"chan_layernorm_bwd_n{P}", nbytes=float(x.numel()) * (3 * x.element_size() + 2 * gy.element_size())):
+                check(lib().mk_chan_layernorm_bwd(ptr(x), dtype_code(x), ptr(gy), dtype_code(gy), ptr(gx), ptr(stats), ptr(g), B, Cc, P,
+                                                  stream()), "mk_chan_layernorm_bwd")
+        if (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[1] and ctx.needs_input_grad[2]):
+            ch = lib().mk_chan_layernorm_chunks(Cc, P)
+            part = torch.empty((2, Cc, ch), dtype=torch.float32, device=x.device)
+            check(lib().mk_chan_layernorm_wgrad(ptr(x), dtype_code(x), ptr(gy), dtype_code(gy), ptr(stats), ptr(part), B, Cc, P,
+                                                stream()), "mk_chan_layernorm_wgrad")
+            sums = part.sum(dim=2)
+            dg = sums[0] if ctx.has[0] else None
+            db = sums[1] if ctx.has[1] else None
+        return gx, dg, db, None, None
+
+
 class BiasGeluFn(torch.autograd.Function):
     """y = gelu(x + bias[c]) on NCHW (bias may be None)."""
 
@@ -967,45 +1013,130 @@ def weight_operands(weight, need_t=False):
     return pad_weight_bf16(w2), (pad_weight_bf16(w2.t()) if need_t else None)
 
 
+def _pad_last(t, mult):
+    """zero-pad the last dimension to a multiple of ``mult`` (a copy only when it is ragged)"""
+    r = (-t.shape[-1]) % mult
+    return t if r == 0 else torch.nn.functional.pad(t, (0, r))
+
+
+def chan_gemm_f32(w: torch.Tensor, x: torch.Tensor, out: torch.Tensor = None, accumulate: bool = False, transposed: bool = False):
+    """out[b, g] (+)= W[g] x[b, g] (or W[g]^T x[b, g]) in fp32 on the package's own GEMM engine (the split-bf16 / exact-fp32
+    MFMA kernels of csrc/xgemm.hip / sgemm.hip, the engine of the Legendre transforms; ``MAKANI_AMD_GEMM`` picks the
+    arithmetic): the fp32 form of the 1x1 convolutions and of the grouped channel mixes (parity runs without autocast; under
+    bf16 autocast the LDS-DMA kernels of csrc/conv1x1.hip / the streaming kernel of csrc/groupmix.hip run instead).
+    w (M, K) with x (B, K | M, N), or w (G, M, K) with x (B, G, K | M, N); fp32, pixel index contiguous."""
+    grouped = w.dim() == 3
+    w3 = w if grouped else w.unsqueeze(0)
+    x4 = x if grouped else x.unsqueeze(1)
+    o4 = None if out is None else (out if grouped else out.unsqueeze(1))
+    B, G, Kx, N = x4.shape
+    Gw, M, K = w3.shape
+    rows, kdim = (K, M) if transposed else (M, K)
+    assert Gw == G and Kx == kdim and x4.dtype == torch.float32 and w3.dtype == torch.float32
+    if N % 4:                                   # ragged pixel count (toy grids): operate on zero-padded planes
+        r = chan_gemm_f32(w3, _pad_last(x4, 4), None if o4 is None else _pad_last(o4, 4), accumulate, transposed)[..., :N]
+        if o4 is None:
+            r = r.contiguous()
+            return r if grouped else r[:, 0]
+        o4.copy_(r)
+        return out
+    wp = _pad_last(w3.contiguous(), 4)          # (G, M, K4): 16-byte rows
+    K4 = wp.shape[2]
+    x4 = x4.contiguous()
+    if o4 is None:
+        o4 = torch.empty((B, G, rows, N), dtype=torch.float32, device=x4.device)
+        accumulate = False
+    assert o4.is_contiguous()
+    a = dict(a_row=1, a_k=K4) if transposed else dict(a_row=K4, a_k=1)
+    g = _gemm(A=wp.data_ptr(), B=x4.data_ptr(), C=o4.data_ptr(), a_batch=0, a_inner=M * K4, **a,
+              b_batch=G * kdim * N, b_inner=kdim * N, b_col=1, b_k=N, c_batch=G * rows * N, c_inner=rows * N, c_row=N,
+              M=rows, N=N, K=kdim, batch=B * G, inner=G, beta=1 if accumulate else 0)
+    with _timed(f"conv1x1_f32_m{rows}_k{kdim}_n{N}", flops=2.0 * B * G * M * K * N,
+                nbytes=4.0 * B * G * N * (M + K) * (1 + int(accumulate))):
+        _run_gemm(g, False, "chan_gemm_f32")
+    if out is not None:
+        return out
+    return o4 if grouped else o4[:, 0]
+
+
+def chan_wgrad_f32(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW[g][m][k] = sum_{b, n} gy[b, g, m, n] x[b, g, k, n] in fp32 on the same engine: the pixel sum is cut into slabs that
+    run as batch entries (each a k-major / k-major GEMM), their partial products are added up afterwards.
+    gy (B, M, N), x (B, K, N) -> (M, K); or gy (B, G, M, N), x (B, G, K, N) -> (G, M, K)."""
+    grouped = gy.dim() == 4
+    gy4 = gy if grouped else gy.unsqueeze(1)
+    x4 = x if grouped else x.unsqueeze(1)
+    B, G, M, N = gy4.shape
+    K = x4.shape[2]
+    if N % 4:
+        gy4, x4 = _pad_last(gy4, 4), _pad_last(x4, 4)
+        N = gy4.shape[-1]
+    gy4, x4 = gy4.contiguous(), x4.contiguous()
+    ns = 1
+    for cand in range(min(256, max(1, N // 2048)), 0, -1):      # slabs of >= 2048 pixels whose length is a multiple of 4
+        if N % (4 * cand) == 0:
+            ns = cand
+            break
+    chunk = N // ns
+    Kp = round4(K)
+    part = torch.empty((B, G, ns, M, Kp), dtype=torch.float32, device=gy4.device)
+    for b in range(B):
+        g = _gemm(A=gy4[b].data_ptr(), B=x4[b].data_ptr(), C=part[b].data_ptr(), a_batch=M * N, a_inner=chunk, a_row=N, a_k=1,
+                  b_batch=K * N, b_inner=chunk, b_col=N, b_k=1, c_batch=ns * M * Kp, c_inner=M * Kp, c_row=Kp,
+                  M=M, N=K, K=chunk, batch=G * ns, inner=ns)
+        with _timed(f"conv1x1_f32_wgrad_m{M}_k{K}_n{N}", flops=2.0 * G * M * K * N, nbytes=4.0 * G * N * (M + K)):
+            _run_gemm(g, False, "chan_wgrad_f32")
+    dW = part.sum(dim=(0, 2))[..., :K]
+    return dW if grouped else dW[0]
+
+
+class GroupMmFn(torch.autograd.Function):
+    """z[b, g] = W[g] x[b, g] for arbitrary group sizes in fp32 (the group sizes the streaming kernel of csrc/groupmix.hip is
+    not instantiated for): forward, data gradient and weight gradient on the fp32 GEMM engine."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return chan_gemm_f32(W.detach().float(), x.float()).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, W = ctx.saved_tensors
+        gz = gz.contiguous().float()
+        gx = chan_gemm_f32(W.detach().float(), gz, transposed=True).to(x.dtype) if ctx.needs_input_grad[0] else None
+        gW = chan_wgrad_f32(gz, x.float()).to(W.dtype) if ctx.needs_input_grad[1] else None
+        return gx, gW
+
+
 class ConvMmFn(torch.autograd.Function):
-    """y = W x (+ residual) with the forward / data-gradient products issued as plain library GEMMs
-    (hipBLASLt through torch.mm: measured 2x faster than the round-1 HIP NN kernel on these
-    pixel-contiguous shapes) and the weight gradient on the HIP split-pixel kernel
-    (mk_conv1x1_wgrad: 1.1-3.7x faster than the library on these huge-K shapes)."""
+    """y = W x (+ residual) for everything the bf16 LDS-DMA kernels do not take (fp32 tensors: parity runs without
+    autocast; bf16 planes whose pixel count is not a multiple of 8): forward, data gradient and weight gradient on the
+    package's fp32 GEMM engine (``chan_gemm_f32`` / ``chan_wgrad_f32``) — no library GEMM anywhere in the product."""
 
     @staticmethod
     def forward(ctx, x, weight, residual, residual_is_fresh=False):
         B, K, H, W = x.shape
         M = weight.shape[0]
-        w = cast_weight(weight, x.dtype).view(M, K)
         N = H * W
+        w2 = weight.detach().reshape(M, K).float()
+        xf = x if x.dtype == torch.float32 else x.float()
         # with a residual the product may accumulate INTO it (beta = 1, no 88-800 MB copy of the residual first), which
         # autograd is told through mark_dirty.  That is only legal when no upstream node saved that tensor for its own
         # backward (a ReLU saves its output, an instance norm or a GEMM of this package does not), which this function
         # cannot see: the caller has to vouch for it with ``residual_is_fresh``; otherwise the output is a new tensor.
-        # Outputs are allocated in their final shape (never views of a temporary) so that they can be the
-        # in-place target of a later call.
-        inplace = (residual_is_fresh and residual is not None and residual.is_contiguous() and residual.dtype == x.dtype
-                   and not residual._is_view() and not (residual.is_leaf and residual.requires_grad))
-        out = residual if inplace else torch.empty((B, M, H, W), dtype=x.dtype, device=x.device)
-        if B == 1:
-            x2, o2 = x.reshape(K, N), out.view(M, N)
-            if residual is None:
-                torch.mm(w, x2, out=o2)
-            elif inplace:
-                o2.addmm_(w, x2)
-            else:
-                torch.addmm(residual.reshape(M, N).to(x.dtype), w, x2, out=o2)
+        inplace = (residual_is_fresh and residual is not None and residual.is_contiguous() and residual.dtype == torch.float32
+                   and x.dtype == torch.float32 and N % 4 == 0 and not residual._is_view()
+                   and not (residual.is_leaf and residual.requires_grad))
+        if inplace:
+            out = residual
+            chan_gemm_f32(w2, xf.reshape(B, K, N), out.view(B, M, N), accumulate=True)
+        elif residual is not None:
+            out = residual.float().clone(memory_format=torch.contiguous_format)
+            chan_gemm_f32(w2, xf.reshape(B, K, N), out.view(B, M, N), accumulate=True)
+            out = out.to(x.dtype)
         else:
-            wb = w.unsqueeze(0).expand(B, -1, -1)
-            x3, o3 = x.reshape(B, K, N), out.view(B, M, N)
-            if residual is None:
-                torch.bmm(wb, x3, out=o3)
-            elif inplace:
-                o3.baddbmm_(wb, x3)
-            else:
-                torch.baddbmm(residual.reshape(B, M, N).to(x.dtype), wb, x3, out=o3)
-        ctx.save_for_backward(x, weight, w if w.dtype != weight.dtype else None)
+            out = chan_gemm_f32(w2, xf.reshape(B, K, N)).view(B, M, H, W).to(x.dtype)
+        ctx.save_for_backward(x, weight)
         ctx.has_res = residual is not None
         if inplace:
             ctx.mark_dirty(residual)
@@ -1013,24 +1144,20 @@ class ConvMmFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, wc = ctx.saved_tensors
+        x, weight = ctx.saved_tensors
         B, K, H, W = x.shape
         M = weight.shape[0]
         N = H * W
         gy = gy.contiguous()
         gx = gw = gr = None
         if ctx.needs_input_grad[0]:
-            # W^T as a transposed view of the (already cast) forward operand: the library GEMM takes it as is
-            wt = (wc if wc is not None and wc.dtype == gy.dtype else weight.view(M, K).to(gy.dtype)).t()
-            if B == 1:
-                gx = torch.mm(wt, gy.reshape(M, N)).view(B, K, H, W)
-            else:
-                gx = torch.bmm(wt.unsqueeze(0).expand(B, -1, -1), gy.reshape(B, M, N)).view(B, K, H, W)
+            gx = chan_gemm_f32(weight.detach().reshape(M, K).float(), gy.float().reshape(B, M, N), transposed=True)
+            gx = gx.view(B, K, H, W).to(x.dtype)
         if ctx.needs_input_grad[1]:
             if gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and N % 8 == 0:
                 gw = conv1x1_wgrad(gy, x).view_as(weight)
             else:
-                gw = torch.einsum("bmn,bkn->mk", gy.reshape(B, M, N).float(), x.reshape(B, K, N).float()).view_as(weight).to(weight.dtype)
+                gw = chan_wgrad_f32(gy.float().reshape(B, M, N), x.float().reshape(B, K, N)).reshape(weight.shape).to(weight.dtype)
         if ctx.has_res and ctx.needs_input_grad[2]:
             gr = gy
         return gx, gw, gr, None

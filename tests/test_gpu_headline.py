@@ -97,16 +97,6 @@ def test_block_240x480x384_bf16_autocast_matches_oracle(block_pair):
     print("block 240x480x384 bf16 rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
 
 
-def test_block_240x480x384_hip_channel_gemm_matches_oracle(block_pair, monkeypatch):
-    """the same block with every forward / data-gradient channel GEMM on the hand-written HIP kernel and its fused
-    bias+GELU / gelu' / skip epilogues (MAKANI_AMD_CONV=hip), bf16 autocast"""
-    from makani_amd import layers
-    blk, x, g, ref = block_pair
-    monkeypatch.setattr(layers, "_HIP_NN", True)
-    errs = _check_block(blk, x, g, ref, amp=True, tol=TOL_BF16)
-    print("block 240x480x384 bf16 (HIP channel GEMM) rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()})
-
-
 # --------------------------------------------------------------------------- #
 # (ii) channel-GEMM weight gradient at 1 038 240 pixels (the dominant kernel, in the regime of its pixel split)
 # --------------------------------------------------------------------------- #

@@ -556,3 +556,78 @@ def test_fused_adamw_device_step_counter_matches_host_steps():
     assert st[0].item() == 5.0 and abs(st[1].item() - 1.0 / (1 - 0.9 ** 5)) < 1e-5
     for pa, pb in zip(a, b):
         assert rel_l2(pa, pb) < 2e-6
+
+
+@pytest.mark.parametrize("B,Cc,H,W", [(1, 384, 240, 480), (2, 45, 33, 64), (2, 7, 5, 9), (1, 384, 31, 45)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16_autocast", "bf16"])
+def test_channel_layernorm_matches_torch_layernorm(B, Cc, H, W, mode):
+    """csrc/chan_layernorm.hip (no transposes, no library layer norm) against nn.LayerNorm over the channels in fp64 — the
+    reference module (makani/mpu/layer_norm.py:256-290): output, input gradient, dgamma, dbeta; vector (P % 4 == 0) and scalar
+    pixel paths; fp32, bf16 under autocast (fp32 output, as torch's layer_norm autocast policy) and plain bf16"""
+    from makani_amd.layers import ChannelLayerNorm
+    DEV = _dev()
+    torch.manual_seed(B * 100 + Cc)
+    m = ChannelLayerNorm(Cc, eps=1e-6).to(DEV)
+    with torch.no_grad():
+        m.norm.weight.normal_(1.0, 0.3)
+        m.norm.bias.normal_(0.0, 0.3)
+    x = torch.randn(B, Cc, H, W, device=DEV) * 2.0 + 5.0            # a large common mean: the shifted moments matter
+    g = torch.randn(B, Cc, H, W, device=DEV)
+    xin = (x if mode == "fp32" else x.bfloat16()).detach().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "bf16_autocast"):
+        y = m(xin)
+    assert y.dtype == (torch.bfloat16 if mode == "bf16" else torch.float32)
+    (y.float() * g).sum().backward()
+    ref = torch.nn.LayerNorm(Cc, eps=1e-6).to(DEV).double()
+    ref.load_state_dict({k: v.double() for k, v in m.norm.state_dict().items()})
+    xr = xin.detach().double().requires_grad_(True)
+    yr = torch.transpose(ref(torch.transpose(xr, 1, 3)), 1, 3)
+    (yr * g.double()).sum().backward()
+    tol = 1e-5 if mode == "fp32" else (2e-5 if mode == "bf16_autocast" else 6e-3)
+    assert rel_l2(y, yr) < tol
+    assert rel_l2(xin.grad, xr.grad) < (tol if mode == "fp32" else 6e-3)
+    assert rel_l2(m.norm.weight.grad, ref.weight.grad) < max(tol, 2e-5) and rel_l2(m.norm.bias.grad, ref.bias.grad) < max(tol, 2e-5)
+
+
+@pytest.mark.parametrize("B,G,M,K,N", [(1, 1, 384, 384, 115200), (2, 1, 73, 384, 2664), (1, 1, 384, 73, 16380), (2, 3, 10, 27, 2048),
+                                       (1, 1, 16, 5, 45), (2, 2, 9, 7, 333)])
+def test_fp32_channel_gemm_engine_matches_fp64(B, G, M, K, N):
+    """ops.chan_gemm_f32 / chan_wgrad_f32 / ConvMmFn / GroupMmFn: the fp32 1x1 convolutions and grouped channel mixes on the
+    package's own GEMM engine (no library GEMM in the product): forward, accumulate-into, data gradient
+    (transposed weight), weight gradient with the pixel sum split into slabs; channel counts that are not multiples of 4,
+    pixel counts that are not multiples of 4 (zero-padded planes); fp32 op tolerance 1e-5 against fp64"""
+    from makani_amd import ops
+    DEV = _dev()
+    torch.manual_seed(M + K)
+    grouped = G > 1
+    W = (torch.randn(G, M, K, device=DEV) / math.sqrt(K))
+    x = torch.randn(B, G, K, N, device=DEV)
+    gy = torch.randn(B, G, M, N, device=DEV)
+    yr = torch.matmul(W.double().unsqueeze(0), x.double())
+    w_, x_, g_ = (W, x, gy) if grouped else (W[0], x[:, 0], gy[:, 0])
+    y = ops.chan_gemm_f32(w_, x_)
+    assert rel_l2(y.reshape(yr.shape), yr) < 1e-5
+    acc = gy.clone()
+    a_ = acc if grouped else acc[:, 0].contiguous()
+    ops.chan_gemm_f32(w_, x_, a_, accumulate=True)
+    assert rel_l2(a_.reshape(yr.shape), yr + gy.double()) < 1e-5
+    gx = ops.chan_gemm_f32(w_, g_, transposed=True)
+    assert rel_l2(gx.reshape(x.shape), torch.matmul(W.double().transpose(1, 2).unsqueeze(0), gy.double())) < 1e-5
+    dW = ops.chan_wgrad_f32(g_, x_)
+    assert rel_l2(dW.reshape(W.shape), torch.einsum("bgmn,bgkn->gmk", gy.double(), x.double())) < 1e-5
+    if grouped:
+        xg, Wg = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        z = ops.GroupMmFn.apply(xg, Wg)
+        (z * gy).sum().backward()
+        assert rel_l2(z, yr) < 1e-5 and rel_l2(xg.grad, torch.matmul(W.double().transpose(1, 2).unsqueeze(0), gy.double())) < 1e-5
+        assert rel_l2(Wg.grad, torch.einsum("bgmn,bgkn->gmk", gy.double(), x.double())) < 1e-5
+    else:
+        H = 9 if N % 9 == 0 else 1
+        x4 = x[:, 0].reshape(B, K, H, N // H).clone().requires_grad_(True)
+        w4 = W[0].reshape(M, K, 1, 1).clone().requires_grad_(True)
+        r4 = gy[:, 0].reshape(B, M, H, N // H).clone().requires_grad_(True)
+        y4 = ops.ConvMmFn.apply(x4, w4, r4, False)
+        (y4 * gy[:, 0].reshape(y4.shape)).sum().backward()
+        assert rel_l2(y4.reshape(B, 1, M, N), yr + gy.double()) < 1e-5 and torch.equal(r4.grad, gy[:, 0].reshape(r4.shape))
+        assert rel_l2(x4.grad.reshape(B, 1, K, N), torch.matmul(W.double().transpose(1, 2).unsqueeze(0), gy.double())) < 1e-5
+        assert rel_l2(w4.grad.reshape(1, M, K), torch.einsum("bgmn,bgkn->gmk", gy.double(), x.double())) < 1e-5
