@@ -118,6 +118,31 @@ int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* twiddle, co
                   int B, int C, int Cp, int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq,
                   void* stream);
 
+/* Segmented addressing for the distributed transforms (makani_amd/distributed.py; the reference schedule: torch-harmonics'
+ * DistributedRealSHT / DistributedInverseRealSHT [un-vendored], in-tree twin makani/mpu/fft.py:148-182,214-249 with the
+ * split / all_to_all / cat of makani/mpu/mappings.py:38-67).  Instead of packing send chunks and concatenating received ones
+ * in separate passes, the FFT kernels address both of their sides through this descriptor:
+ *   F side = per-peer slabs: slab (jw, ih) = orders m in [m_off[jw], m_off[jw+1]) x rows in [r_off[ih], r_off[ih+1]) of every
+ *     latitude of the call, latitude outermost: [lat][m][re/im][row] at F + base[jw][ih] (floats).  nw / nh = number of
+ *     m ranges / row ranges (<= MK_FFT_SEG_MAX); r_off and base entries are multiples of 4.
+ *   x side = every row (plane, latitude) of nlon points cut into `xseg` equal pieces; piece j of all rows at
+ *     x + j * x_stride elements, rows of a piece [plane][lat][nlon / xseg] (xseg <= 1: whole rows, as mk_rfft_rows).
+ * One batch entry; C planes; implemented by the specialised row lengths only (mk_fft_seg_supported). */
+#define MK_FFT_SEG_MAX 8
+typedef struct MkFftSeg {
+    int nw, nh;
+    int m_off[MK_FFT_SEG_MAX + 1];
+    int r_off[MK_FFT_SEG_MAX + 1];
+    long long base[MK_FFT_SEG_MAX][MK_FFT_SEG_MAX];
+    int xseg;
+    long long x_stride;
+} MkFftSeg;
+int mk_fft_seg_supported(int nlon);
+int mk_rfft_rows_seg(const void* x, int x_dtype, float* F, const float* twiddle, int C, int nlat, int nlon, int mmax,
+                     float w_dc, float w_pos, float w_nyq, const MkFftSeg* seg, void* stream);
+int mk_irfft_rows_seg(const float* F, void* x, int x_dtype, const float* twiddle, int C, int nlat, int nlon, int mmax,
+                      float w_dc, float w_pos, float w_nyq, const MkFftSeg* seg, void* stream);
+
 /* ---- layout changes ------------------------------------------------------------
  * complex64 dhconv parameter (Cin, Cout, L) [makani/models/common/spectral_convolution.py:164-193]
  * <-> W-layout, and S-layout <-> complex64 (rows, L, M) tensors at the RealSHT API boundary. */

@@ -38,6 +38,15 @@ class MkGemm(C.Structure):
     ]
 
 
+MK_FFT_SEG_MAX = 8
+
+
+class MkFftSeg(C.Structure):
+    """mirrors `struct MkFftSeg` of include/makani_amd.h"""
+    _fields_ = [("nw", c_int), ("nh", c_int), ("m_off", c_int * (MK_FFT_SEG_MAX + 1)), ("r_off", c_int * (MK_FFT_SEG_MAX + 1)),
+                ("base", (c_ll * MK_FFT_SEG_MAX) * MK_FFT_SEG_MAX), ("xseg", c_int), ("x_stride", c_ll)]
+
+
 _SIGS = {
     "mk_version": ([], c_int),
     "mk_sgemm_batched": ([C.POINTER(MkGemm), c_vp], c_int),
@@ -50,6 +59,9 @@ _SIGS = {
                       c_f, c_f, c_f, c_vp], c_int),
     "mk_irfft_rows": ([c_vp, c_vp, c_int, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                        c_f, c_f, c_f, c_vp], c_int),
+    "mk_fft_seg_supported": ([c_int], c_int),
+    "mk_rfft_rows_seg": ([c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, C.POINTER(MkFftSeg), c_vp], c_int),
+    "mk_irfft_rows_seg": ([c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, C.POINTER(MkFftSeg), c_vp], c_int),
     "mk_weight_to_wlayout": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_wlayout_to_weight_grad": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_slayout_to_complex": ([c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),

@@ -17,7 +17,7 @@
 #include "fft_common.h"
 
 int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, const float* twiddle, int B, int C, int Cp,
-                         int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, void* stream);
+                         int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, const MkFftSeg* seg, void* stream);
 
 static bool use_fast_fft() {
     static int v = -1;
@@ -290,7 +290,7 @@ extern "C" int mk_rfft_rows(const void* x, int x_dtype, float* F, const float* t
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "rfft: mmax=%d out of range for nlon=%d", mmax, nlon);
     MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "rfft: bad dtype %d", x_dtype);
     if (use_fast_fft()) {
-        const int frc = mk_fft_fast_dispatch(false, x, F, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, w_dc, w_pos, w_nyq, stream);
+        const int frc = mk_fft_fast_dispatch(false, x, F, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, w_dc, w_pos, w_nyq, nullptr, stream);
         if (frc != -1000) return frc;
     }
     RadixList rl;
@@ -327,7 +327,7 @@ extern "C" int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* 
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "irfft: mmax=%d out of range for nlon=%d", mmax, nlon);
     MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "irfft: bad dtype %d", x_dtype);
     if (use_fast_fft()) {
-        const int frc = mk_fft_fast_dispatch(true, F, x, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, w_dc, w_pos, w_nyq, stream);
+        const int frc = mk_fft_fast_dispatch(true, F, x, x_dtype, twiddle, B, C, Cp, nlat, nlon, mmax, w_dc, w_pos, w_nyq, nullptr, stream);
         if (frc != -1000) return frc;
     }
     RadixList rl;
@@ -352,4 +352,36 @@ extern "C" int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* 
         MK_REQUIRE(false, "irfft: bad dtype %d", x_dtype);
     }
     return mk_check_launch("mk_irfft_rows");
+}
+
+
+// ---- segmented variants (distributed transforms): only the specialised kernels of fft_fast.hip implement them ----------
+extern "C" int mk_fft_seg_supported(int nlon) {
+    return nlon == 1440 || nlon == 720 || nlon == 480 || nlon == 360 || nlon == 128 || nlon == 72;
+}
+
+extern "C" int mk_rfft_rows_seg(const void* x, int x_dtype, float* F, const float* twiddle, int C, int nlat, int nlon, int mmax,
+                                float w_dc, float w_pos, float w_nyq, const MkFftSeg* seg, void* stream) {
+    MK_REQUIRE(x && F && twiddle && seg, "rfft_seg: null pointer");
+    MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "rfft_seg: mmax=%d out of range for nlon=%d", mmax, nlon);
+    MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "rfft_seg: bad dtype %d", x_dtype);
+    const int rc = mk_fft_fast_dispatch(false, x, F, x_dtype, twiddle, 1, C, (C + 3) / 4 * 4, nlat, nlon, mmax, w_dc, w_pos, w_nyq, seg, stream);
+    if (rc == -1000) {
+        mk_set_error("rfft_seg: nlon=%d has no specialised kernel (mk_fft_seg_supported)", nlon);
+        return MK_EUNSUP;
+    }
+    return rc;
+}
+
+extern "C" int mk_irfft_rows_seg(const float* F, void* x, int x_dtype, const float* twiddle, int C, int nlat, int nlon, int mmax,
+                                 float w_dc, float w_pos, float w_nyq, const MkFftSeg* seg, void* stream) {
+    MK_REQUIRE(x && F && twiddle && seg, "irfft_seg: null pointer");
+    MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "irfft_seg: mmax=%d out of range for nlon=%d", mmax, nlon);
+    MK_REQUIRE(x_dtype == MK_F32 || x_dtype == MK_BF16, "irfft_seg: bad dtype %d", x_dtype);
+    const int rc = mk_fft_fast_dispatch(true, F, x, x_dtype, twiddle, 1, C, (C + 3) / 4 * 4, nlat, nlon, mmax, w_dc, w_pos, w_nyq, seg, stream);
+    if (rc == -1000) {
+        mk_set_error("irfft_seg: nlon=%d has no specialised kernel (mk_fft_seg_supported)", nlon);
+        return MK_EUNSUP;
+    }
+    return rc;
 }

@@ -22,6 +22,46 @@ struct Rounds {
     static constexpr int value = (ITEMS + NT - 1) / NT;
 };
 
+// ---- segmented addressing (distributed transforms, makani_amd/distributed.py) -------------------------------------------
+// SEG kernels address both sides of the transform through an MkFftSeg descriptor (include/makani_amd.h) so that the
+// all-to-all exchanges around the transform need no pack / unpack pass:
+//   * F side: per-peer slabs.  Slab (jw, ih) holds the orders m in [m_off[jw], m_off[jw+1]) and the rows (planes) in
+//     [r_off[ih], r_off[ih+1]) of every latitude of this call, LATITUDE OUTERMOST: [lat][m][re/im][row] at F + base[jw][ih].
+//     The forward transform writes the send buffers of the (h x w) exchange this way (one contiguous slab per destination
+//     rank, and — latitude being outermost — the slabs of the ranks of one polar group concatenate into the Legendre
+//     operand by landing next to each other); the inverse transform reads its receive buffers the same way.
+//   * x side: a row (plane, latitude) of nlon points cut into `xseg` equal pieces, piece j of all rows at x + j * x_stride
+//     (the pieces the planes <-> longitude exchange delivers / collects, one buffer per azimuth peer).
+struct SegTab {                 // LDS copy of the F-side tables
+    long long base[MK_FFT_SEG_MAX * MK_FFT_SEG_MAX];
+    int m_off[MK_FFT_SEG_MAX + 1];
+    int r_off[MK_FFT_SEG_MAX + 1];
+};
+
+template <int NT>
+__device__ __forceinline__ void seg_fill(SegTab* t, const MkFftSeg& sg, int tid) {
+    for (int q = tid; q < MK_FFT_SEG_MAX * MK_FFT_SEG_MAX; q += NT) t->base[q] = sg.base[q / MK_FFT_SEG_MAX][q % MK_FFT_SEG_MAX];
+    for (int q = tid; q <= MK_FFT_SEG_MAX; q += NT) {
+        t->m_off[q] = sg.m_off[q < sg.nw ? q : sg.nw];
+        t->r_off[q] = sg.r_off[q < sg.nh ? q : sg.nh];
+    }
+}
+
+__device__ __forceinline__ int seg_find(const int* off, int n, int v) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < MK_FFT_SEG_MAX; ++k) j += (k < n && v >= off[k]) ? 1 : 0;
+    return j;
+}
+
+// float offset of (m, latitude klat, re plane, row pr) from F, and the distance to the im plane
+__device__ __forceinline__ long long seg_f_offset(const SegTab* t, int nw, int nh, int m, long long klat, long long pr, int* im_stride) {
+    const int jw = seg_find(t->m_off, nw, m), ih = seg_find(t->r_off, nh, (int)pr);
+    const int Mj = t->m_off[jw + 1] - t->m_off[jw], Pi = t->r_off[ih + 1] - t->r_off[ih];
+    *im_stride = Pi;
+    return t->base[jw * MK_FFT_SEG_MAX + ih] + ((klat * Mj + (m - t->m_off[jw])) * 2) * Pi + (pr - t->r_off[ih]);
+}
+
 // One in-place Stockham pass of radix R (Ns = product of earlier radices) over RB rows, split into
 // its load half and its twiddle + butterfly + store half so that the loads of the NEXT work item can
 // be issued early (software prefetch) and so that load and store may alias the same LDS buffer
@@ -172,42 +212,51 @@ struct RowVec<u16> {
     static constexpr int PAIRS = 4;
 };
 
-template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
                                                             const float2* __restrict__ tw_g, int C, int Cp,
                                                             long long rows, long long planes, int nlat, int mmax,
                                                             int ngr, long long nitems, float w_dc, float w_pos,
-                                                            float w_nyq) {
+                                                            float w_nyq, const MkFftSeg sg) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
     constexpr int N = 2 * N2, LS = row_stride(N2, RB, false);
     constexpr int VP = RowVec<T>::PAIRS, VROW = N2 / VP;        // vectors per row
     static_assert(N2 % VP == 0 && LS % 2 == 0 && RB % 4 == 0, "vector layout");
     using Tb = Tables<N2, R1, R2, R3, MCAP>;        // mmax <= MCAP
     __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
+    __shared__ SegTab segtab_s;
+    SegTab* segtab = &segtab_s;
     float2* buf = smem;
     float2* tw2 = smem + RB * LS;
     float2* tw3 = tw2 + Tb::T2;
     float2* twu = tw3 + Tb::T3;
     const int tid = threadIdx.x;
     Tb::template fill<NT>(tw2, tw_g, tid);
+    if constexpr (SEG) seg_fill<NT>(segtab, sg, tid);
 
     const ItemRange it = my_items(nitems);
     auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
     auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
     // work item = one latitude x RB consecutive (batch, channel) planes (k-major F layout, see fft.hip)
-    const long long rstride = (long long)nlat * N;              // distance between the rows of an item
+    // SEG: the row of a plane is cut into sg.xseg equal pieces in separate buffers (see SegTab): per (lane, q) the piece and
+    // the offset inside it are fixed, only the (plane, latitude) part moves with the item
+    const int xseg = SEG ? max(1, sg.xseg) : 1;
+    const int vpp = VROW / xseg;                                 // vectors per piece
+    const long long wl = (long long)N / xseg;                    // points per piece
+    const long long rstride = (long long)nlat * wl;             // distance between the rows of an item (inside a piece)
     constexpr int NV = (RB * VROW + NT - 1) / NT;
     uint4 rawv[NV];
     auto prefetch = [&](long long itm) {
         const long long kl_ = itm / ngr;
         const long long p0_ = (itm - kl_ * ngr) * RB;
         const int nr_ = (int)min((long long)RB, planes - p0_);
-        const T* xr_ = x + (p0_ * nlat + kl_) * (long long)N;
+        const T* xr_ = x + (p0_ * nlat + kl_) * wl;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int idx = tid + q * NT;
             const int row = idx / VROW, c = idx % VROW;
-            rawv[q] = (row < nr_) ? *reinterpret_cast<const uint4*>(xr_ + (long long)row * rstride + c * (2 * VP))
+            const long long coff = SEG ? (long long)(c / vpp) * sg.x_stride + (long long)(c % vpp) * (2 * VP) : (long long)c * (2 * VP);
+            rawv[q] = (row < nr_) ? *reinterpret_cast<const uint4*>(xr_ + (long long)row * rstride + coff)
                                   : make_uint4(0, 0, 0, 0);
         }
     };
@@ -263,9 +312,16 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
                 const float2 X2 = untangle_one<N2>(z + 2 * LS, twu, m, w_dc, w_pos, w_nyq);
                 const float2 X3 = untangle_one<N2>(z + 3 * LS, twu, m, w_dc, w_pos, w_nyq);
                 const long long pr = p0 + r0;
-                float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
-                *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
-                *reinterpret_cast<float4*>(o + rows) = make_float4(X0.y, X1.y, X2.y, X3.y);
+                if constexpr (SEG) {
+                    int ims;
+                    float* o = F + seg_f_offset(segtab, sg.nw, sg.nh, m, klat, pr, &ims);
+                    *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
+                    *reinterpret_cast<float4*>(o + ims) = make_float4(X0.y, X1.y, X2.y, X3.y);
+                } else {
+                    float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
+                    *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
+                    *reinterpret_cast<float4*>(o + rows) = make_float4(X0.y, X1.y, X2.y, X3.y);
+                }
             }
         } else {
             for (int idx = tid; idx < mmax * RB; idx += NT) {
@@ -288,12 +344,12 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
 
 // MCAP: compile-time bound on mmax (N2/3+1 for the 3x-truncated spectra of the scale-3 model, else N2+1);
 // it sizes the registers that carry the next item's spectrum.
-template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __restrict__ F, T* __restrict__ x,
                                                              const float2* __restrict__ tw_g, int C, int Cp,
                                                              long long rows, long long planes, int nlat, int mmax,
                                                              int ngr, long long nitems, float w_dc, float w_pos,
-                                                             float w_nyq) {
+                                                             float w_nyq, const MkFftSeg sg) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
     constexpr int N = 2 * N2, LS = row_stride(N2, RB, true);
     // PRUNED (mmax <= N2/2): the spectrum is zero for mmax <= m <= N2 - mmax ... N2, which the kernel never
@@ -301,16 +357,21 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     constexpr bool PRUNED = MCAP <= N2 / 2;
     using Tb = Tables<N2, R1, R2, R3, PRUNED ? MCAP : N2 + 1>;
     __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
+    __shared__ SegTab segtab_s;
+    SegTab* segtab = &segtab_s;
     float2* buf = smem;
     float2* tw2 = smem + RB * LS;
     float2* tw3 = tw2 + Tb::T2;
     float2* twu = tw3 + Tb::T3;
     const int tid = threadIdx.x;
     Tb::template fill<NT>(tw2, tw_g, tid);
+    if constexpr (SEG) seg_fill<NT>(segtab, sg, tid);
     __syncthreads();
 
     const ItemRange it = my_items(nitems);
-    const long long rstride = (long long)nlat * N;
+    const int xseg = SEG ? max(1, sg.xseg) : 1;                  // x rows cut into xseg pieces in separate buffers (see SegTab)
+    const int wl = N / xseg;                                     // points per piece
+    const long long rstride = (long long)nlat * wl;
     const bool vec = (C % 4 == 0) || (planes == C);
     // the next item's half spectrum X[m], m < mmax, rides in registers while this one is transformed:
     // vec: float4 = 4 rows per (m, re/im);  scalar fallback: one (row, m) pair per slot
@@ -328,9 +389,16 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
             if (m < mmax && r0 < nr_) {
                 const long long pr = p0_ + r0;
-                const float* sp = F + ((long long)m * nlat + kl_) * 2 * rows + (pr / C) * Cp + (pr % C);
-                a = *reinterpret_cast<const float4*>(sp);
-                b = *reinterpret_cast<const float4*>(sp + rows);
+                if constexpr (SEG) {
+                    int ims;
+                    const float* sp = F + seg_f_offset(segtab, sg.nw, sg.nh, m, kl_, pr, &ims);
+                    a = *reinterpret_cast<const float4*>(sp);
+                    b = *reinterpret_cast<const float4*>(sp + ims);
+                } else {
+                    const float* sp = F + ((long long)m * nlat + kl_) * 2 * rows + (pr / C) * Cp + (pr % C);
+                    a = *reinterpret_cast<const float4*>(sp);
+                    b = *reinterpret_cast<const float4*>(sp + rows);
+                }
             }
             sre[q] = a;
             sim[q] = b;
@@ -341,7 +409,7 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         const long long klat = item / ngr;
         const long long p0 = (item - klat * ngr) * RB;
         const int nr = (int)min((long long)RB, planes - p0);
-        T* xr = x + (p0 * nlat + klat) * (long long)N;
+        T* xr = x + (p0 * nlat + klat) * (long long)wl;
 
         if constexpr (PRUNED) {
             // registers -> pre-twiddled pairs (m, N2-m) with X[N2-m] = 0:  Zs[m] and Zs[N2-m] from X[m] alone
@@ -427,7 +495,14 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         // the last pass writes its rows straight to global memory (staging them through LDS for 16-byte
         // stores measured 10 % slower: the extra round trip costs more than the narrower stores)
         auto st_global = [&](int row, int pos, float2 val) {
-            if (row < nr) store_pair<T>(xr + (long long)row * rstride + 2 * pos, val.x, -val.y);     // conj
+            long long e = 2 * pos;
+            if constexpr (SEG) {
+                int j = 0;
+#pragma unroll
+                for (int k = 1; k < MK_FFT_SEG_MAX; ++k) j += (k < xseg && 2 * pos >= k * wl) ? 1 : 0;
+                e = (long long)j * sg.x_stride + (2 * pos - j * wl);
+            }
+            if (row < nr) store_pair<T>(xr + (long long)row * rstride + e, val.x, -val.y);     // conj
         };
         if constexpr (PRUNED) {
             const int z0 = mmax, z1 = N2 - mmax;               // never-written (zero) positions, inclusive
@@ -449,10 +524,10 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     }
 }
 
-template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 int launch_inverse(const float* in, T* out, const float2* tw, int C, int Cp, long long rows, long long planes, int nlat,
-                   int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, hipStream_t s) {
-    auto kern = irfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, MCAP, T>;
+                   int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, const MkFftSeg& sg, hipStream_t s) {
+    auto kern = irfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, MCAP, T, SEG>;
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
@@ -462,14 +537,14 @@ int launch_inverse(const float* in, T* out, const float2* tw, int C, int Cp, lon
     long long grid = 256ll * per_cu;            // persistent: every workgroup resident, contiguous item ranges
     if (grid > nitems) grid = nitems;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems,
-                       w_dc, w_pos, w_nyq);
+                       w_dc, w_pos, w_nyq, sg);
     return mk_check_launch("mk_irfft_rows(fast)");
 }
 
-template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T>
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 int launch_forward(const T* in, float* out, const float2* tw, int C, int Cp, long long rows, long long planes, int nlat,
-                   int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, hipStream_t s) {
-    auto kern = rfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, MCAP, T>;
+                   int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, const MkFftSeg& sg, hipStream_t s) {
+    auto kern = rfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, MCAP, T, SEG>;
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
@@ -479,45 +554,67 @@ int launch_forward(const T* in, float* out, const float2* tw, int C, int Cp, lon
     long long grid = 256ll * per_cu;
     if (grid > nitems) grid = nitems;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems,
-                       w_dc, w_pos, w_nyq);
+                       w_dc, w_pos, w_nyq, sg);
     return mk_check_launch("mk_rfft_rows(fast)");
 }
 
-template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS>
-int launch(bool inverse, const void* in, void* out, int dtype, const float2* tw, int B, int C, int Cp, int nlat, int mmax,
-           float w_dc, float w_pos, float w_nyq, hipStream_t s) {
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, bool SEG>
+int launch_seg(bool inverse, const void* in, void* out, int dtype, const float2* tw, int B, int C, int Cp, int nlat, int mmax,
+               float w_dc, float w_pos, float w_nyq, const MkFftSeg& sg, hipStream_t s) {
     const long long planes = (long long)B * C;
     const int ngr = (int)((planes + RB - 1) / RB);
     const long long nitems = (long long)nlat * ngr;
     const long long rows = (long long)B * Cp;
     MK_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "fft: x and F must be 16-byte aligned");
     constexpr int M3 = N2 / 3 + 1, MF = N2 + 1;
-#define MK_FFT_TAIL tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq, s
+#define MK_FFT_TAIL tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq, sg, s
     const bool vec = (C % 4 == 0) || (B == 1);
+    if (SEG) {
+        // per-peer slabs: rows in groups of 4 (float4 F access), row ranges on multiples of 4, x pieces of whole 16-byte vectors
+        MK_REQUIRE(vec && B == 1, "fft(seg): one batch entry (the planes are the rows)");
+        MK_REQUIRE(sg.nw >= 1 && sg.nw <= MK_FFT_SEG_MAX && sg.nh >= 1 && sg.nh <= MK_FFT_SEG_MAX, "fft(seg): 1..%d peers per direction", MK_FFT_SEG_MAX);
+        MK_REQUIRE(sg.m_off[0] == 0 && sg.m_off[sg.nw] == mmax && sg.r_off[0] == 0 && sg.r_off[sg.nh] >= C, "fft(seg): ranges must cover m < mmax and every row");
+        for (int i = 0; i <= sg.nh; ++i) MK_REQUIRE(sg.r_off[i] % 4 == 0, "fft(seg): row ranges must start on multiples of 4");
+        for (int j = 0; j < sg.nw; ++j)
+            for (int i = 0; i < sg.nh; ++i) MK_REQUIRE(sg.base[j][i] % 4 == 0, "fft(seg): slab offsets must be multiples of 4 floats");
+        const int xs = sg.xseg < 1 ? 1 : sg.xseg;
+        const int ev = dtype == MK_F32 ? 4 : 8;
+        MK_REQUIRE(xs <= MK_FFT_SEG_MAX && (2 * N2) % xs == 0 && ((2 * N2) / xs) % ev == 0 && (xs == 1 || sg.x_stride % ev == 0),
+                   "fft(seg): x pieces must be equal and hold whole 16-byte vectors");
+    }
     if (!inverse) {
         if (mmax <= M3) {
-            if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, M3, float>((const float*)in, (float*)out, MK_FFT_TAIL);
-            return launch_forward<N2, R1, R2, R3, RB, NT, WGS, M3, u16>((const u16*)in, (float*)out, MK_FFT_TAIL);
+            if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, M3, float, SEG>((const float*)in, (float*)out, MK_FFT_TAIL);
+            return launch_forward<N2, R1, R2, R3, RB, NT, WGS, M3, u16, SEG>((const u16*)in, (float*)out, MK_FFT_TAIL);
         }
-        if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, MF, float>((const float*)in, (float*)out, MK_FFT_TAIL);
-        return launch_forward<N2, R1, R2, R3, RB, NT, WGS, MF, u16>((const u16*)in, (float*)out, MK_FFT_TAIL);
+        if (dtype == MK_F32) return launch_forward<N2, R1, R2, R3, RB, NT, WGS, MF, float, SEG>((const float*)in, (float*)out, MK_FFT_TAIL);
+        return launch_forward<N2, R1, R2, R3, RB, NT, WGS, MF, u16, SEG>((const u16*)in, (float*)out, MK_FFT_TAIL);
     }
     if (mmax <= M3 && vec) {      // truncated spectrum (pruned transform; it needs the float4 F access)
-        if (dtype == MK_F32) return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, float>((const float*)in, (float*)out, MK_FFT_TAIL);
-        return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, u16>((const float*)in, (u16*)out, MK_FFT_TAIL);
+        if (dtype == MK_F32) return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, float, SEG>((const float*)in, (float*)out, MK_FFT_TAIL);
+        return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, M3, u16, SEG>((const float*)in, (u16*)out, MK_FFT_TAIL);
     }
-    if (dtype == MK_F32) return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, MF, float>((const float*)in, (float*)out, MK_FFT_TAIL);
-    return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, MF, u16>((const float*)in, (u16*)out, MK_FFT_TAIL);
+    if (dtype == MK_F32) return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, MF, float, SEG>((const float*)in, (float*)out, MK_FFT_TAIL);
+    return launch_inverse<N2, R1, R2, R3, RB, NT, WGS, MF, u16, SEG>((const float*)in, (u16*)out, MK_FFT_TAIL);
 #undef MK_FFT_TAIL
+}
+
+template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS>
+int launch(bool inverse, const void* in, void* out, int dtype, const float2* tw, int B, int C, int Cp, int nlat, int mmax,
+           float w_dc, float w_pos, float w_nyq, const MkFftSeg* sg, hipStream_t s) {
+    if (sg) return launch_seg<N2, R1, R2, R3, RB, NT, WGS, true>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, *sg, s);
+    MkFftSeg none = {};
+    return launch_seg<N2, R1, R2, R3, RB, NT, WGS, false>(inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, none, s);
 }
 
 }  // namespace
 
-#define MK_FFT_ARGS inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, s
+#define MK_FFT_ARGS inverse, in, out, dtype, tw, B, C, Cp, nlat, mmax, w_dc, w_pos, w_nyq, seg, s
 
 // returns -1000 if nlon has no specialised kernel (caller falls through to the generic one)
+// seg != nullptr: segmented addressing of both sides (distributed transforms), see SegTab
 int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, const float* twiddle, int B, int C, int Cp,
-                         int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, void* stream) {
+                         int nlat, int nlon, int mmax, float w_dc, float w_pos, float w_nyq, const MkFftSeg* seg, void* stream) {
     const float2* tw = reinterpret_cast<const float2*>(twiddle);
     hipStream_t s = (hipStream_t)stream;
     //                         N2  radices   RB   NT  WG/CU
