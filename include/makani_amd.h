@@ -126,7 +126,9 @@ int mk_irfft_rows(const float* F, void* x, int x_dtype, const float* twiddle, co
  *     latitude of the call, latitude outermost: [lat][m][re/im][row] at F + base[jw][ih] (floats).  nw / nh = number of
  *     m ranges / row ranges (<= MK_FFT_SEG_MAX); r_off and base entries are multiples of 4.
  *   x side = every row (plane, latitude) of nlon points cut into `xseg` equal pieces; piece j of all rows at
- *     x + j * x_stride elements, rows of a piece [plane][lat][nlon / xseg] (xseg <= 1: whole rows, as mk_rfft_rows).
+ *     x + j * x_stride elements, rows of a piece [plane][x_nlat][nlon / xseg] (xseg <= 1: whole rows, as mk_rfft_rows).
+ *   A call may transform a latitude sub-range (chunked overlap of transform and exchange): nlat = its length, x and the slab
+ *   offsets point at its first latitude, x_nlat = latitudes per plane of the x buffers.
  * One batch entry; C planes; implemented by the specialised row lengths only (mk_fft_seg_supported). */
 #define MK_FFT_SEG_MAX 8
 typedef struct MkFftSeg {
@@ -136,6 +138,8 @@ typedef struct MkFftSeg {
     long long base[MK_FFT_SEG_MAX][MK_FFT_SEG_MAX];
     int xseg;
     long long x_stride;
+    int x_nlat; /* latitudes per plane in the x buffers (the call may cover a sub-range: x then points at its first latitude);
+                   0 = nlat of the call */
 } MkFftSeg;
 int mk_fft_seg_supported(int nlon);
 int mk_rfft_rows_seg(const void* x, int x_dtype, float* F, const float* twiddle, int C, int nlat, int nlon, int mmax,

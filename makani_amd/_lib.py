@@ -44,7 +44,7 @@ MK_FFT_SEG_MAX = 8
 class MkFftSeg(C.Structure):
     """mirrors `struct MkFftSeg` of include/makani_amd.h"""
     _fields_ = [("nw", c_int), ("nh", c_int), ("m_off", c_int * (MK_FFT_SEG_MAX + 1)), ("r_off", c_int * (MK_FFT_SEG_MAX + 1)),
-                ("base", (c_ll * MK_FFT_SEG_MAX) * MK_FFT_SEG_MAX), ("xseg", c_int), ("x_stride", c_ll)]
+                ("base", (c_ll * MK_FFT_SEG_MAX) * MK_FFT_SEG_MAX), ("xseg", c_int), ("x_stride", c_ll), ("x_nlat", c_int)]
 
 
 _SIGS = {

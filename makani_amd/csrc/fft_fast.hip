@@ -243,14 +243,15 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
     const int xseg = SEG ? max(1, sg.xseg) : 1;
     const int vpp = VROW / xseg;                                 // vectors per piece
     const long long wl = (long long)N / xseg;                    // points per piece
-    const long long rstride = (long long)nlat * wl;             // distance between the rows of an item (inside a piece)
+    const long long xnl = (SEG && sg.x_nlat > 0) ? sg.x_nlat : nlat;      // latitudes per plane in the x buffers
+    const long long rstride = xnl * wl;                          // distance between the rows of an item (inside a piece)
     constexpr int NV = (RB * VROW + NT - 1) / NT;
     uint4 rawv[NV];
     auto prefetch = [&](long long itm) {
         const long long kl_ = itm / ngr;
         const long long p0_ = (itm - kl_ * ngr) * RB;
         const int nr_ = (int)min((long long)RB, planes - p0_);
-        const T* xr_ = x + (p0_ * nlat + kl_) * wl;
+        const T* xr_ = x + (p0_ * xnl + kl_) * wl;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int idx = tid + q * NT;
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     const ItemRange it = my_items(nitems);
     const int xseg = SEG ? max(1, sg.xseg) : 1;                  // x rows cut into xseg pieces in separate buffers (see SegTab)
     const int wl = N / xseg;                                     // points per piece
-    const long long rstride = (long long)nlat * wl;
+    const long long xnl = (SEG && sg.x_nlat > 0) ? sg.x_nlat : nlat;      // latitudes per plane in the x buffers
+    const long long rstride = xnl * wl;
     const bool vec = (C % 4 == 0) || (planes == C);
     // the next item's half spectrum X[m], m < mmax, rides in registers while this one is transformed:
     // vec: float4 = 4 rows per (m, re/im);  scalar fallback: one (row, m) pair per slot
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         const long long klat = item / ngr;
         const long long p0 = (item - klat * ngr) * RB;
         const int nr = (int)min((long long)RB, planes - p0);
-        T* xr = x + (p0 * nlat + klat) * (long long)wl;
+        T* xr = x + (p0 * xnl + klat) * (long long)wl;
 
         if constexpr (PRUNED) {
             // registers -> pre-twiddled pairs (m, N2-m) with X[N2-m] = 0:  Zs[m] and Zs[N2-m] from X[m] alone

@@ -21,6 +21,7 @@ Local compute goes through a small backend object.  The product backend is the H
 (``HipBackend``) — there is no CPU fallback; tests inject the CPU oracle to verify the
 exchange schedule with gloo.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -154,12 +155,12 @@ def _exchange(recv, send, group):
     hr = [torch.empty(t.shape, dtype=t.dtype) if on_gpu else t for t in recv]
     ops_ = []
     for peer in range(len(send)):
-        if peer == me:
+        if peer == me or (hs[peer].numel() == 0 and hr[peer].numel() == 0):      # (empty slabs: nothing to post)
             continue
         gp = dist.get_global_rank(group, peer)
         ops_.append(dist.P2POp(dist.isend, hs[peer], gp, group=group))
         ops_.append(dist.P2POp(dist.irecv, hr[peer], gp, group=group))
-    for req in dist.batch_isend_irecv(ops_):
+    for req in (dist.batch_isend_irecv(ops_) if ops_ else ()):
         req.wait()
     if on_gpu:
         for peer in range(len(send)):
@@ -255,7 +256,36 @@ def reduce_from_spatial_region(x):
 
 
 class HipBackend:
-    """Local compute on the HIP library (the product path)."""
+    """Local compute on the HIP library (the product path).  ``segmented``: the four operations of the fused schedule
+    (makani_amd/dist_pipeline.py) are available — FFTs that address their operands per peer, Legendre GEMMs on the
+    latitude-major operand."""
+    segmented = True
+
+    @staticmethod
+    def seg_supported(nlon):
+        return ops.fft_seg_supported(nlon)
+
+    @staticmethod
+    def _seg(p, a):
+        base = [[p.base[j][i] + a * p.m_shapes[j] * 2 * p.sub[p.iw][i] for i in range(p.h)] for j in range(p.w)]
+        return ops.fft_seg_desc(p.m_shapes, p.sub[p.iw], base, xseg=p.w, x_stride=p.pw[p.iw] * p.hl * p.wl, x_nlat=p.hl)
+
+    @staticmethod
+    def rfft_seg(xbuf, a, b, fs, p, w):
+        """latitudes [a, b) of the pieces ``xbuf`` (w, P_w, lat_loc, lon piece) -> the per-peer slabs of the flat buffer ``fs``"""
+        ops.rfft_rows_seg(xbuf, a * p.wl, fs, p.pw[p.iw], b - a, p.nlon, p.M, w, HipBackend._seg(p, a))
+
+    @staticmethod
+    def irfft_seg(fr, a, b, xbuf, p, w):
+        ops.irfft_rows_seg(fr, xbuf, a * p.wl, p.pw[p.iw], b - a, p.nlon, p.M, w, HipBackend._seg(p, a))
+
+    @staticmethod
+    def analysis_lm(G, matT, L, m_off):
+        return ops.legendre_analysis(G, matT, L, m_off, lat_major=True)
+
+    @staticmethod
+    def synthesis_lm(T, mat, nlat, m_off):
+        return ops.legendre_synthesis(T, mat, nlat, m_off, lat_major=True)
 
     @staticmethod
     def rfft(x4, mmax, w):
@@ -275,13 +305,6 @@ class HipBackend:
 
 
 _BACKEND = HipBackend
-
-
-def set_backend(backend):
-    """Test hook: replace the local-compute backend (tests inject the CPU oracle to check the
-    exchange schedule with gloo).  The default and only product backend is ``HipBackend``."""
-    global _BACKEND
-    _BACKEND = backend
 
 
 def _offsets(sizes):
@@ -307,6 +330,15 @@ class _DistBase:
     def _plane_shapes(self, planes):
         return compute_split_shapes(planes, self.comm_size_azimuth), compute_split_shapes(planes, self.comm_size_polar)
 
+    def _plan(self, planes):
+        """sizes and slab offsets of the fused schedule for this plane count (makani_amd/dist_pipeline.py), cached"""
+        from . import dist_pipeline as dp
+        plans = self.__dict__.setdefault("_plans", {})
+        key = (planes, os.environ.get("MAKANI_AMD_DIST_CHUNKS", "2"))
+        if key not in plans:
+            plans[key] = dp.Plan(self, planes)
+        return plans[key]
+
 
 class DistributedRealSHT(RealSHT, _DistBase):
     """``thd.DistributedRealSHT``: local ``(B, C, nlat_loc, nlon_loc)`` -> local ``(B, C, l_loc, m_loc)``.
@@ -329,6 +361,9 @@ class DistributedRealSHT(RealSHT, _DistBase):
         if x4.shape[-2] != hl or x4.shape[-1] != wl:
             raise ValueError(f"expected local shape (..., {hl}, {wl}), got {tuple(x4.shape)}")
         P = B * C
+        from . import dist_pipeline as dp
+        if dp.eligible(self, x4.dtype):              # the fused schedule: per-peer addressing in the FFTs, one h x w exchange
+            return dp.DistAnalysisFn.apply(x4.reshape(P, hl, wl), self, self._plan(P))
         pw, ph = self._plane_shapes(P)
         x = x4.reshape(1, P, hl, wl)
         # (w) planes <-> lon
@@ -367,8 +402,12 @@ class DistributedInverseRealSHT(InverseRealSHT, _DistBase):
         if B > 1 and C % 4:            # S holds round4(C) planes per sample: transform the zero planes too, drop them at the end
             C = C + (-C) % 4
         P = B * C
-        pw, ph = self._plane_shapes(P)
         hl, wl = self.lat_shapes[self.comm_rank_polar], self.lon_shapes[self.comm_rank_azimuth]
+        from . import dist_pipeline as dp
+        if dp.eligible(self, out_dtype):
+            x = dp.DistSynthesisFn.apply(S, self, self._plan(P), out_dtype)
+            return x.reshape(B, C, hl, wl)[:, :Cc]
+        pw, ph = self._plane_shapes(P)
         # (h) planes <-> l
         S = transpose(S, 3, ph, 0, self.l_shapes, polar_group(), pad_dims=(3,))       # (L, M_loc, 2, round4(P_h))
         F = _BACKEND.synthesis(S, self.pct, self.pct_t, self.nlat, self.m_off)        # (M_loc, nlat, 2, round4(P_h))

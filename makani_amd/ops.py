@@ -230,6 +230,57 @@ def irfft_rows(F: torch.Tensor, B: int, Cc: int, nlon: int, out_dtype, w) -> tor
     return x
 
 
+def fft_seg_desc(m_shapes, r_shapes, base, xseg=1, x_stride=0, x_nlat=0):
+    """MkFftSeg (include/makani_amd.h): per-peer F slabs (m ranges x row ranges, ``base[jw][ih]`` float offsets) and x rows
+    cut into ``xseg`` pieces ``x_stride`` elements apart"""
+    sg = _lib.MkFftSeg()
+    sg.nw, sg.nh = len(m_shapes), len(r_shapes)
+    if sg.nw > _lib.MK_FFT_SEG_MAX or sg.nh > _lib.MK_FFT_SEG_MAX:
+        raise ValueError(f"at most {_lib.MK_FFT_SEG_MAX} peers per direction")
+    off = 0
+    for j, n in enumerate(m_shapes):
+        sg.m_off[j] = off
+        off += n
+    for j in range(len(m_shapes), _lib.MK_FFT_SEG_MAX + 1):
+        sg.m_off[j] = off
+    off = 0
+    for i, n in enumerate(r_shapes):
+        sg.r_off[i] = off
+        off += n
+    for i in range(len(r_shapes), _lib.MK_FFT_SEG_MAX + 1):
+        sg.r_off[i] = off
+    for j in range(sg.nw):
+        for i in range(sg.nh):
+            sg.base[j][i] = int(base[j][i])
+    sg.xseg, sg.x_stride, sg.x_nlat = int(xseg), int(x_stride), int(x_nlat)
+    return sg
+
+
+def fft_seg_supported(nlon: int) -> bool:
+    return bool(lib().mk_fft_seg_supported(int(nlon)))
+
+
+def rfft_rows_seg(x_ptr_tensor: torch.Tensor, x_off: int, F: torch.Tensor, planes: int, nlat: int, nlon: int, mmax: int, w, sg):
+    """truncated rFFT of ``planes`` rows x ``nlat`` latitudes read from the pieces of ``x`` (element offset ``x_off`` = first
+    latitude of the call) into the per-peer slabs of the flat fp32 buffer ``F`` (csrc/fft_fast.hip, SEG kernels)"""
+    plan = fft_plan(nlon, F.device)
+    xa = C.c_void_p(x_ptr_tensor.data_ptr() + x_off * x_ptr_tensor.element_size())
+    nbytes = planes * nlat * (nlon * x_ptr_tensor.element_size() + mmax * 8)
+    with _timed(f"rfft_{nlon}", nbytes=nbytes):
+        check(lib().mk_rfft_rows_seg(xa, dtype_code(x_ptr_tensor), ptr(F), ptr(plan.twiddle), planes, nlat, nlon, mmax,
+                                     w[0], w[1], w[2], C.byref(sg), stream()), "mk_rfft_rows_seg")
+
+
+def irfft_rows_seg(F: torch.Tensor, x_ptr_tensor: torch.Tensor, x_off: int, planes: int, nlat: int, nlon: int, mmax: int, w, sg):
+    """the inverse: per-peer slabs of ``F`` -> pieces of ``x`` (zero-padded spectrum, Im of m = 0 dropped)"""
+    plan = fft_plan(nlon, F.device)
+    xa = C.c_void_p(x_ptr_tensor.data_ptr() + x_off * x_ptr_tensor.element_size())
+    nbytes = planes * nlat * (nlon * x_ptr_tensor.element_size() + mmax * 8)
+    with _timed(f"irfft_{nlon}", nbytes=nbytes):
+        check(lib().mk_irfft_rows_seg(ptr(F), xa, dtype_code(x_ptr_tensor), ptr(plan.twiddle), planes, nlat, nlon, mmax,
+                                      w[0], w[1], w[2], C.byref(sg), stream()), "mk_irfft_rows_seg")
+
+
 # --------------------------------------------------------------------------- #
 # Legendre GEMMs (real, batched over m).  Both operands are row-contiguous ("k-major"):
 #   analysis   S[l][j]   = sum_k  matT[m][k][l] * F[m][k][j]          j = (ri, row)
@@ -286,15 +337,20 @@ def _presplit_ok() -> bool:
     return GEMM_GEN == "2" and GEMM_MODE != "fp32"
 
 
-def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 0) -> torch.Tensor:
-    """S[l][m][ri][row] = sum_k matT[m][k][l] F[m][k][ri][row]      (rows l >= m only)."""
-    M, nlat, _, R = F.shape
+def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 0, lat_major: bool = False) -> torch.Tensor:
+    """S[l][m][ri][row] = sum_k matT[m][k][l] F[m][k][ri][row]      (rows l >= m only).
+    ``lat_major``: F is (nlat, M, 2, R) — latitude outermost, the layout in which the slabs the ranks of a polar group send
+    concatenate by landing next to each other (makani_amd/dist_pipeline.py); only the operand strides change."""
+    if lat_major:
+        nlat, M, _, R = F.shape
+    else:
+        M, nlat, _, R = F.shape
     Mm, nk, Lp = matT.shape
     assert Mm == M and nk == nlat and Lp >= L and F.is_contiguous() and matT.is_contiguous()
     S = torch.empty((L, M, 2, R), dtype=torch.float32, device=F.device)
     g = _gemm(A=matT.data_ptr(), B=F.data_ptr(), C=S.data_ptr(),
               a_batch=nlat * Lp, a_row=1, a_k=Lp,
-              b_batch=nlat * 2 * R, b_col=1, b_k=2 * R,
+              b_batch=2 * R if lat_major else nlat * 2 * R, b_col=1, b_k=M * 2 * R if lat_major else 2 * R,
               c_batch=2 * R, c_row=M * 2 * R,
               M=L, N=2 * R, K=nlat, batch=M, tri_mode=_lib.TRI_ROW_GE, tri_off=m_off)
     # dense-formulation work (SURVEY.md §8d): 2 * (2R) * nlat * L * M flops
@@ -308,16 +364,16 @@ def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 
     return S
 
 
-def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int = 0) -> torch.Tensor:
-    """F[m][k][ri][row] = sum_{l >= m} mat[m][l][k] S[l][m][ri][row]."""
+def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int = 0, lat_major: bool = False) -> torch.Tensor:
+    """F[m][k][ri][row] = sum_{l >= m} mat[m][l][k] S[l][m][ri][row].  ``lat_major``: F is written as (nlat, M, 2, R)."""
     L, M, _, R = S.shape
     Mm, Lm, kp = mat.shape
     assert Mm == M and Lm == L and kp >= nlat and S.is_contiguous() and mat.is_contiguous()
-    F = torch.empty((M, nlat, 2, R), dtype=torch.float32, device=S.device)
+    F = torch.empty((nlat, M, 2, R) if lat_major else (M, nlat, 2, R), dtype=torch.float32, device=S.device)
     g = _gemm(A=mat.data_ptr(), B=S.data_ptr(), C=F.data_ptr(),
               a_batch=L * kp, a_row=1, a_k=kp,
               b_batch=2 * R, b_col=1, b_k=M * 2 * R,
-              c_batch=nlat * 2 * R, c_row=2 * R,
+              c_batch=2 * R if lat_major else nlat * 2 * R, c_row=M * 2 * R if lat_major else 2 * R,
               M=nlat, N=2 * R, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
     pre = _presplit_ok()
     b = polar_band(mat, 2) if pre else None                      # mat = (m, l, latitude): the band clips the output rows

@@ -64,6 +64,59 @@ class OracleBackend:
         return torch.einsum("lmir,mlk->mkir", S, mat[:, :, :nlat].to(S.dtype))
 
 
+class OracleSegBackend(OracleBackend):
+    """the four operations of the fused schedule (makani_amd/dist_pipeline.py) in torch on the CPU: FFTs that read the
+    longitude pieces of a row and scatter / gather the per-peer slabs [lat][m][re/im][row] of the flat exchange buffer,
+    Legendre transforms on the latitude-major operand — what csrc/fft_fast.hip (SEG kernels) and the GEMM engine do"""
+    segmented = True
+
+    @staticmethod
+    def seg_supported(nlon):
+        return True
+
+    @staticmethod
+    def _slabs(p, a, b):
+        out, r0 = [], 0
+        roff = [0]
+        for n in p.sub[p.iw]:
+            roff.append(roff[-1] + n)
+        moff = [0]
+        for n in p.m_shapes:
+            moff.append(moff[-1] + n)
+        for i in range(p.h):
+            for j in range(p.w):
+                row = p.m_shapes[j] * 2 * p.sub[p.iw][i]
+                out.append((j, i, p.base[j][i] + a * row, p.base[j][i] + b * row, moff[j], moff[j + 1], roff[i], roff[i + 1]))
+        return out
+
+    @staticmethod
+    def rfft_seg(xbuf, a, b, fs, p, w):
+        Pw = p.pw[p.iw]
+        x = xbuf[:, :, a:b, :].permute(1, 2, 0, 3).reshape(1, Pw, b - a, p.nlon)
+        F = OracleBackend.rfft(x, p.M, w)                                           # (M, nl, 2, round4(Pw))
+        rows = sum(p.sub[p.iw])
+        F = torch.nn.functional.pad(F, (0, rows - F.shape[-1]))
+        for j, i, f0, f1, m0, m1, r0, r1 in OracleSegBackend._slabs(p, a, b):
+            fs[f0:f1] = F[m0:m1, :, :, r0:r1].permute(1, 0, 2, 3).reshape(-1).to(fs.dtype)
+
+    @staticmethod
+    def irfft_seg(fr, a, b, xbuf, p, w):
+        Pw, nl = p.pw[p.iw], b - a
+        F = torch.zeros((p.M, nl, 2, sum(p.sub[p.iw])), dtype=fr.dtype)
+        for j, i, f0, f1, m0, m1, r0, r1 in OracleSegBackend._slabs(p, a, b):
+            F[m0:m1, :, :, r0:r1] = fr[f0:f1].reshape(nl, m1 - m0, 2, r1 - r0).permute(1, 0, 2, 3)
+        x = OracleBackend.irfft(F, Pw, p.nlon, xbuf.dtype, w)[0]                    # (Pw, nl, nlon)
+        xbuf[:, :, a:b, :] = x.reshape(Pw, nl, p.w, p.wl).permute(2, 0, 1, 3)
+
+    @staticmethod
+    def analysis_lm(G, matT, L, m_off):
+        return torch.einsum("mkl,kmir->lmir", matT[:, :, :L].to(G.dtype), G).contiguous()
+
+    @staticmethod
+    def synthesis_lm(T, mat, nlat, m_off):
+        return torch.einsum("lmir,mlk->kmir", T, mat[:, :, :nlat].to(T.dtype)).contiguous()
+
+
 def _s_planes(B, C):
     """S layout: plane b * Cp + c with Cp = round4(C) when B > 1 (every sample's channels padded), round4(C) planes for B == 1"""
     return B * (C + (-C) % 4) if B > 1 else C + (-C) % 4
@@ -82,7 +135,7 @@ def _complex_to_s(c):
     return torch.nn.functional.pad(S, (0, (-C) % 4)).reshape(L, M, 2, -1).contiguous()
 
 
-def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C):
+def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C, fused=False, chunks="2"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -99,12 +152,15 @@ def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C):
             g = dist.new_group([i * w + j for j in range(w)])
             if i == ih:
                 wg = g
-        thd.init(hg if h > 1 else None, wg if w > 1 else None)
-        thd.set_backend(OracleBackend)
+        thd.init(hg if h > 1 else None, wg if w > 1 else None, dist.group.WORLD)
+        thd._BACKEND = OracleSegBackend if fused else OracleBackend      # test-only: the CPU stand-in for the HIP kernels
+        os.environ["MAKANI_AMD_DIST_CHUNKS"] = chunks
         torch.manual_seed(7)
         x = torch.randn(B, C, nlat, nlon, dtype=torch.float64)
         fwd = thd.DistributedRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
         inv = thd.DistributedInverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
+        from makani_amd import dist_pipeline as dp
+        assert dp.eligible(fwd, x.dtype) == fused and dp.eligible(inv, x.dtype) == fused
         assert fwd.lat_shapes == thd.compute_split_shapes(nlat, h) and fwd.m_shapes == thd.compute_split_shapes(mmax, w)
         lat0, lon0 = sum(fwd.lat_shapes[:ih]), sum(fwd.lon_shapes[:iw])
         l0, m0 = sum(fwd.l_shapes[:ih]), sum(fwd.m_shapes[:iw])
@@ -152,6 +208,23 @@ def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C):
 def test_distributed_sht_schedule_matches_serial(h, w, nlat, nlon, lmax, mmax, grid, B, C):
     world = h * w
     mp.spawn(_worker_sht, args=(world, _free_port(), h, w, nlat, nlon, lmax, mmax, grid, B, C), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("h,w", [(2, 1), (1, 2), (2, 2), (4, 2), (3, 1)])
+@pytest.mark.parametrize("nlat,nlon,lmax,mmax,grid,B,C", [(33, 64, 16, 17, "equiangular", 1, 6), (12, 24, 12, 13, "legendre-gauss", 2, 8),
+                                                    (12, 24, 12, 13, "legendre-gauss", 2, 3), (19, 48, 10, 11, "equiangular", 1, 1)])
+def test_fused_distributed_sht_schedule_matches_serial(h, w, nlat, nlon, lmax, mmax, grid, B, C):
+    """the fused schedule of makani_amd/dist_pipeline.py (per-peer slabs written / read by the FFT, ONE h x w all-to-all between
+    FFT and Legendre transform, latitude-major Legendre operand, plane blocks): forward and backward of both transforms against
+    the serial oracle, incl. ragged plane blocks (fewer planes than ranks, padded sub-blocks) and empty slabs"""
+    world = h * w
+    mp.spawn(_worker_sht, args=(world, _free_port(), h, w, nlat, nlon, lmax, mmax, grid, B, C, True), nprocs=world, join=True)
+
+
+def test_fused_distributed_sht_latitude_chunks():
+    """steps (2)+(3) cut into latitude chunks (MAKANI_AMD_DIST_CHUNKS): every rank enters the same number of collectives even
+    when the ranks' latitude counts differ (ragged 130 -> [44, 43, 43]...)"""
+    mp.spawn(_worker_sht, args=(4, _free_port(), 2, 2, 130, 48, 20, 21, "equiangular", 1, 5, True, "2"), nprocs=4, join=True)
 
 
 def _worker_dp(rank, world, port):
@@ -251,7 +324,7 @@ def test_group_tree_and_model_parallel_grad_reduction(world, ph, pw):
     mp.spawn(_worker_tree, args=(world, _free_port(), ph, pw), nprocs=world, join=True)
 
 
-def _worker_ragged(rank, world, port, h, w, C):
+def _worker_ragged(rank, world, port, h, w, C, fused=False):
     """BASELINE configs[2] / [4] split sizes at the real grid: 721 x 1440, lmax 240, mmax 241 over h = 4 (lat
     [181, 181, 181, 178], l [60] * 4) and w = 2 (lon [720, 720], m [121, 120]), reduced channel count"""
     sys.path.insert(0, ROOT)
@@ -264,7 +337,7 @@ def _worker_ragged(rank, world, port, h, w, C):
         from oracle import sht as osht
         _, ih, iw = mcomm.init(h, w)
         assert thd.ensure_initialized()
-        thd.set_backend(OracleBackend)
+        thd._BACKEND = OracleSegBackend if fused else OracleBackend
         nlat, nlon, lmax, mmax, B = 721, 1440, 240, 241, 1
         fwd = thd.DistributedRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid="equiangular")
         inv = thd.DistributedInverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid="equiangular")
@@ -299,10 +372,11 @@ def _worker_ragged(rank, world, port, h, w, C):
 
 
 @pytest.mark.parametrize("h,w,C", [(4, 1, 6), (4, 2, 5)])
-def test_distributed_sht_ragged_config3_splits(h, w, C):
+@pytest.mark.parametrize("fused", [False, True])
+def test_distributed_sht_ragged_config3_splits(h, w, C, fused):
     """h = 4 (BASELINE configs[2]) and h4 w2 (configs[4]) at 721 x 1440 with ragged plane counts (6 planes over 4 ranks ->
-    [1, 1, 1, 3]; 5 over 2 -> [3, 2])"""
-    mp.spawn(_worker_ragged, args=(h * w, _free_port(), h, w, C), nprocs=h * w, join=True)
+    [1, 1, 1, 3]; 5 over 2 -> [3, 2]); transpose-by-transpose and fused schedule"""
+    mp.spawn(_worker_ragged, args=(h * w, _free_port(), h, w, C, fused), nprocs=h * w, join=True)
 
 
 def test_parse_parallelism():

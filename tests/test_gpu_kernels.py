@@ -631,3 +631,78 @@ def test_fp32_channel_gemm_engine_matches_fp64(B, G, M, K, N):
         assert rel_l2(y4.reshape(B, 1, M, N), yr + gy.double()) < 1e-5 and torch.equal(r4.grad, gy[:, 0].reshape(r4.shape))
         assert rel_l2(x4.grad.reshape(B, 1, K, N), torch.matmul(W.double().transpose(1, 2).unsqueeze(0), gy.double())) < 1e-5
         assert rel_l2(w4.grad.reshape(1, M, K), torch.einsum("bgmn,bgkn->gmk", gy.double(), x.double())) < 1e-5
+
+
+@pytest.mark.parametrize("nlat,nlon,mmax,Cc,m_shapes,r_shapes,xseg", [
+    (181, 1440, 241, 192, [121, 120], [48, 48, 48, 48], 2),        # BASELINE configs[4] on one rank: h4 w2, 192 planes
+    (45, 1440, 241, 37, [241], [12, 12, 12, 4], 1),                # h4 w1, ragged planes (37 -> 40 rows in sub-blocks of 4)
+    (60, 480, 241, 96, [121, 120], [48, 48], 2),                   # internal grid, full spectrum
+    (23, 720, 361, 20, [91, 90, 90, 90], [8, 12], 2),              # FourCastNet3's internal grid
+    (9, 72, 13, 6, [7, 6], [4, 4], 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segmented_fft_kernels_match_plain_kernels(nlat, nlon, mmax, Cc, m_shapes, r_shapes, xseg, dtype):
+    """mk_rfft_rows_seg / mk_irfft_rows_seg (csrc/fft_fast.hip, SEG kernels: rows read from / written to `xseg` longitude
+    pieces, the F side addressed as per-peer slabs [lat][m][re/im][row]) against the plain kernels on the same data: bit-identical
+    values, only the addresses differ; incl. a latitude sub-range call (chunked overlap)"""
+    from makani_amd import ops
+    DEV = _dev()
+    torch.manual_seed(nlat + Cc)
+    w = (2.0 * math.pi / nlon, 2.0 * math.pi / nlon, 2.0 * math.pi / nlon)
+    x = torch.randn(1, Cc, nlat, nlon, device=DEV).to(dtype)
+    Cp = ops.round4(Cc)
+    F = ops.rfft_rows(x, mmax, Cp, w)                                                  # (M, nlat, 2, Cp)
+    wl = nlon // xseg
+    xbuf = x[0].reshape(Cc, nlat, xseg, wl).permute(2, 0, 1, 3).contiguous()          # pieces [j][plane][lat][wl]
+    rows = sum(r_shapes)
+    assert rows >= Cc and len(m_shapes) <= 8 and sum(m_shapes) == mmax
+    moff, roff = [0], [0]
+    for n in m_shapes:
+        moff.append(moff[-1] + n)
+    for n in r_shapes:
+        roff.append(roff[-1] + n)
+
+    def desc(a, b):
+        base, off = [[0] * len(r_shapes) for _ in m_shapes], 0
+        for i in range(len(r_shapes)):
+            for j in range(len(m_shapes)):
+                base[j][i] = off + a * m_shapes[j] * 2 * r_shapes[i]
+                off += nlat * m_shapes[j] * 2 * r_shapes[i]
+        return ops.fft_seg_desc(m_shapes, r_shapes, base, xseg=xseg, x_stride=Cc * nlat * wl, x_nlat=nlat), off
+
+    def slabs(fs):
+        """flat slab buffer -> (M, nlat, 2, rows)"""
+        out, off = torch.zeros(mmax, nlat, 2, rows, device=DEV), 0
+        for i in range(len(r_shapes)):
+            for j in range(len(m_shapes)):
+                n = nlat * m_shapes[j] * 2 * r_shapes[i]
+                out[moff[j]:moff[j + 1], :, :, roff[i]:roff[i + 1]] = fs[off:off + n].reshape(nlat, m_shapes[j], 2, r_shapes[i]).permute(1, 0, 2, 3)
+                off += n
+        return out
+
+    _, total = desc(0, nlat)
+    fs = torch.full((total,), float("nan"), device=DEV)
+    cuts = [0, nlat // 3, nlat]                                                       # two latitude chunks
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sg, _ = desc(a, b)
+        ops.rfft_rows_seg(xbuf, a * wl, fs, Cc, b - a, nlon, mmax, w, sg)
+    got = slabs(fs)
+    assert torch.equal(got[..., :Cc], F[..., :Cc])
+    assert not torch.isnan(got[..., :Cp]).any()                                       # pad rows of a started group of 4 are zeros
+    # inverse: slabs -> longitude pieces
+    xr = ops.irfft_rows(F, 1, Cc, nlon, dtype, w)
+    fr = torch.zeros((total,), device=DEV)
+    off = 0
+    for i in range(len(r_shapes)):
+        for j in range(len(m_shapes)):
+            n = nlat * m_shapes[j] * 2 * r_shapes[i]
+            src = torch.zeros(m_shapes[j], nlat, 2, r_shapes[i], device=DEV)
+            hi = min(roff[i + 1], Cp)
+            if hi > roff[i]:
+                src[..., :hi - roff[i]] = F[moff[j]:moff[j + 1], :, :, roff[i]:hi]
+            fr[off:off + n] = src.permute(1, 0, 2, 3).reshape(-1)
+            off += n
+    xo = torch.full((xseg, Cc, nlat, wl), float("nan"), device=DEV).to(dtype)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sg, _ = desc(a, b)
+        ops.irfft_rows_seg(fr, xo, a * wl, Cc, b - a, nlon, mmax, w, sg)
+    assert torch.equal(xo.permute(1, 2, 0, 3).reshape(1, Cc, nlat, nlon), xr)
