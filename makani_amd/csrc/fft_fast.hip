@@ -352,6 +352,7 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                                                              int ngr, long long nitems, float w_dc, float w_pos,
                                                              float w_nyq, const MkFftSeg sg) {
     static_assert(R1 * R2 * R3 == N2, "radix product");
+    static_assert(N2 <= 1024, "the piece index of the SEG stores is a multiply-shift valid for rows of at most 2048 points");
     constexpr int N = 2 * N2, LS = row_stride(N2, RB, true);
     // PRUNED (mmax <= N2/2): the spectrum is zero for mmax <= m <= N2 - mmax ... N2, which the kernel never
     // touches: no zero fill, the pre-twiddle runs on the loaded registers, the first pass substitutes zeros
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     const ItemRange it = my_items(nitems);
     const int xseg = SEG ? max(1, sg.xseg) : 1;                  // x rows cut into xseg pieces in separate buffers (see SegTab)
     const int wl = N / xseg;                                     // points per piece
+    const unsigned wl_magic = ((1u << 24) + (unsigned)wl - 1u) / (unsigned)wl;
     const long long xnl = (SEG && sg.x_nlat > 0) ? sg.x_nlat : nlat;      // latitudes per plane in the x buffers
     const long long rstride = xnl * wl;
     const bool vec = (C % 4 == 0) || (planes == C);
@@ -499,10 +501,9 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         auto st_global = [&](int row, int pos, float2 val) {
             long long e = 2 * pos;
             if constexpr (SEG) {
-                int j = 0;
-#pragma unroll
-                for (int k = 1; k < MK_FFT_SEG_MAX; ++k) j += (k < xseg && 2 * pos >= k * wl) ? 1 : 0;
-                e = (long long)j * sg.x_stride + (2 * pos - j * wl);
+                // piece j = e / wl by a multiply-shift that is exact for e < 2 N2 <= 2^11 and wl >= 8 (e * wl < 2^24)
+                const unsigned j = ((unsigned)(2 * pos) * wl_magic) >> 24;
+                e = (long long)j * sg.x_stride + (2 * pos - (int)j * wl);
             }
             if (row < nr) store_pair<T>(xr + (long long)row * rstride + e, val.x, -val.y);     // conj
         };

@@ -16,6 +16,40 @@ Reference call sites (all of FourCastNet3's local operators, SURVEY.md §8f item
   * ``fourcastnet3.py:518-534``  the "local" blocks (theta_cutoff doubled)
   * ``fourcastnet3.py:46-50``    the cutoff heuristic ``(kernel_shape[0] + 1) * 0.5 * pi / (nlat - 1)``
 
+Which torch-harmonics release each function restates, and what is known to have changed up to the reference's pin
+----------------------------------------------------------------------------------------------------------------
+The reference requires ``torch-harmonics >= 0.9.0`` at commit 887006c ("main as of 2026-08-04").  Neither that
+commit nor any release of the package is in this image and there is no network, so NOTHING below could be diffed against the
+pinned sources: the restatement follows the published algorithm as the author of this file knows it from the public 0.7.4 -
+0.8.0 releases, function by function:
+
+  ``MorletFilterBasis.compute_support_vals``   filter_basis.py as introduced in 0.7.4 (Hann window cos^2(pi r / 2 r_cutoff) times
+      sin / cos products in x = r sin(phi), y = r cos(phi), basis index k = m * kernel_shape[1] + n); unchanged in 0.7.5 / 0.8.0.
+  ``rotated_coordinates``                      convolution.py::_precompute_convolution_tensor_s2, 0.7.x - 0.8.0: YZY Euler rotation
+      (alpha = -theta_out, beta = lon_in, gamma = theta_in), normalisation of (x, y, z) before arccos / atan2 (added in 0.7.4),
+      phi wrapped to [0, 2 pi).
+  ``precompute_convolution_tensor``            the same function: support ``theta <= theta_cutoff * (1 + theta_eps)``, theta_eps = 1e-3
+      (0.7.4+; earlier releases compared against theta_cutoff itself), quadrature weights ``w / nlon_in / 2`` (0.7.5 / 0.8.0;
+      0.7.3 and earlier used ``2 pi w / nlon_in`` and normalised differently: NOT restated).
+  ``normalize_convolution_tensor``             convolution.py::_normalize_convolution_tensor_s2 of 0.7.5 / 0.8.0: modes "none",
+      "individual", "mean", "support", ``eps = 1e-9``, ``merge_quadrature`` multiplies the weights into psi.  (0.7.4 had the
+      "individual" / "mean" / "none" modes only; "support" came with 0.7.5.)
+  ``disco_contraction_dense``                  _disco_s2_contraction_torch (0.6 - 0.8.0): roll by ``pscale`` columns + bmm per output
+      longitude.  ``disco_contraction_direct`` is this file's equivalent form (see its docstring).
+  ``DiscreteContinuousConvS2``                 convolution.py of 0.7.5 / 0.8.0: weight (out, in / groups, kernel_size) with scale
+      sqrt(1 / groupsize / kernel_size), bias zeros, default theta_cutoff pi / (nlat_out - 1), einsum "bgckxy,gock->bgoxy".
+  ``ResampleS2``                               resample.py of 0.7.5 / 0.8.0, mode "bilinear": pole extension by the longitude mean
+      of the polar rows, ``searchsorted(side="right") - 1`` indices, lerp in latitude then longitude.
+
+Known or suspected changes between 0.8.0 and the pin that this file does NOT reflect because they could not be read here:
+additional filter bases ("harmonic" is the reference classes' DEFAULT argument, makani/models/networks/fourcastnet3.py:175,315,495,660; the
+FourCastNet3 recipe itself uses "morlet", config/fourcastnet3.yaml:34 — only "morlet" is restated and built), a "bilinear-
+spherical" resampling mode, optimised CUDA contraction kernels (which do not change results), and possibly further
+``basis_norm_mode`` values.  Whether the normalisation constants of the restated modes changed after 0.8.0 CANNOT be known
+from inside this container; if they did, every fixture built on this file (``tests/golden/fcn3_*.npz``) inherits the
+difference as one per-basis-function scale of psi — which FourCastNet3's learned weights absorb, but a checkpoint trained
+on the reference would not transfer bit-for-bit.  This is the open end of the "parity unpinned" statement above.
+
 Conventions of the restated algorithm:
   * ``psi[k, t, i * nlon_in + j]`` = value of filter basis function k, centred on the output point (latitude t,
     longitude 0), at input point (latitude i, longitude j); the centre is moved to longitude p by rolling the input by

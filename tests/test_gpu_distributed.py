@@ -171,6 +171,13 @@ def _worker_rccl(rank, world, port):
         thd._exchange(recv, send, dist.group.WORLD)
         torch.cuda.synchronize()
         assert torch.equal(recv[0], send[0])
+        # ... and as the fused schedule issues it: asynchronous, contiguous views of differing shapes
+        from makani_amd import dist_pipeline as dp
+        big = torch.arange(24.0, device=dev)
+        out = torch.zeros(2, 3, 4, device=dev)
+        dp._exchange_async([out[0:2]], [big], dist.group.WORLD).wait()
+        torch.cuda.synchronize()
+        assert torch.equal(out.reshape(-1), big)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -180,7 +187,7 @@ def test_rccl_collectives_of_the_grad_reducer_world1():
     mp.spawn(_worker_rccl, args=(1, _free_port()), nprocs=1, join=True)
 
 
-def _worker_ragged_gpu(rank, world, port, h, w, C):
+def _worker_ragged_gpu(rank, world, port, h, w, C, fused=True):
     """BASELINE configs[2] / [4] split sizes at the real grid THROUGH THE HIP BACKEND: 721 x 1440, lmax 240, mmax 241 over
     h = 4 (lat [181, 181, 181, 178], l [60] * 4) and h4 w2 (lon [720, 720], m [121, 120]) with ragged plane counts; every
     rank's shard of the distributed transform and of its gradient against the serial HIP transform AND the fp64 oracle
@@ -188,6 +195,7 @@ def _worker_ragged_gpu(rank, world, port, h, w, C):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(4)
+    os.environ["MAKANI_AMD_DIST_FUSED"] = "1" if fused else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import makani_amd as ma
@@ -205,6 +213,8 @@ def _worker_ragged_gpu(rank, world, port, h, w, C):
             assert fwd.lat_shapes == [181, 181, 181, 178] and fwd.l_shapes == [60, 60, 60, 60]
         if w == 2:
             assert fwd.lon_shapes == [720, 720] and fwd.m_shapes == [121, 120]
+        from makani_amd import dist_pipeline as dp
+        assert dp.eligible(fwd, torch.float32) == fused and dp.eligible(inv, torch.float32) == fused      # which schedule runs
         lat0, lon0 = sum(fwd.lat_shapes[:ih]), sum(fwd.lon_shapes[:iw])
         l0, m0 = sum(fwd.l_shapes[:ih]), sum(fwd.m_shapes[:iw])
         hl, wl, ll, ml = fwd.lat_shapes[ih], fwd.lon_shapes[iw], fwd.l_shapes[ih], fwd.m_shapes[iw]
@@ -252,6 +262,8 @@ def _worker_ragged_gpu(rank, world, port, h, w, C):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w,C", [(4, 1, 6), (4, 2, 5)])
-def test_distributed_sht_ragged_config3_splits_on_the_hip_backend(h, w, C):
-    mp.spawn(_worker_ragged_gpu, args=(h * w, _free_port(), h, w, C), nprocs=h * w, join=True)
+@pytest.mark.parametrize("h,w,C,fused", [(4, 1, 6, True), (4, 2, 5, True), (4, 2, 5, False), (2, 2, 48, True)])
+def test_distributed_sht_ragged_config3_splits_on_the_hip_backend(h, w, C, fused):
+    """fused = the schedule of makani_amd/dist_pipeline.py (segmented FFT kernels, one h x w exchange, latitude-major Legendre
+    operand, two latitude chunks); not fused = transpose by transpose"""
+    mp.spawn(_worker_ragged_gpu, args=(h * w, _free_port(), h, w, C, fused), nprocs=h * w, join=True)

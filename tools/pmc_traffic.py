@@ -1,6 +1,6 @@
 """HBM bytes per launch of the bench's kernel families from two rocprofv3 PMC passes of the SAME bench command
 (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, summarised per kernel symbol by tools/pmc_summary.py).
-   python tools/pmc_traffic.py fetch.md write.md out.json
+   python tools/pmc_traffic.py fetch.md write.md out.json [sfno|fcn3]
 FETCH_SIZE counts KiB and reports half of a coalesced 16 B/lane read stream on gfx950 (MI355X_MICROARCH.md, HBM): x2,
 except for the inverse FFTs whose F-side reads are 32/64-byte runs (uncalibrated, taken as is: a lower bound).
 WRITE_SIZE is KiB, calibrated on kernels of known traffic in the same runs (weight_to_w writes 283.1 MB = 2.765e5 KiB)."""
@@ -23,6 +23,17 @@ FAMILIES = [          # (family, regex on the kernel symbol, fetch correction)
 ]
 
 
+FAMILIES_FCN3 = [     # bench.py --config fcn3_sc2_edim45_layers10
+    ("disco_fwd", r"^disco_(fused_fwd|runs_fwd|fwd)_kernel", 2),
+    ("disco_bwd", r"^disco_(runs_bwd|bwd_same|bwd)_kernel", 2),
+    ("conv1x1_nn", r"^conv_nn_(astat|ring)?_?kernel", 2),
+    ("conv1x1_wgrad", r"^conv_wgrad_(ring_)?kernel", 2),
+    ("resample_bwd", r"^resample_bwd", 2),
+    ("resample_fwd", r"^resample_fwd", 2),
+    ("group_mix", r"^group_mix_kernel", 2),
+]
+
+
 def table(path):
     out = {}
     for line in open(path):
@@ -33,7 +44,10 @@ def table(path):
     return out
 
 
-def main(fetch_md, write_md, out_json):
+def main(fetch_md, write_md, out_json, kind="sfno"):
+    global FAMILIES
+    if kind == "fcn3":
+        FAMILIES = FAMILIES_FCN3
     F, W = table(fetch_md), table(write_md)
     res = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two separate passes over `python bench.py --steps 2 --warmup 1 "
                       "--graph off` (the bench workload itself: sfno_sc3_layers8_edim384, 721x1440, B=1, bf16 autocast), MI355X",
@@ -59,4 +73,4 @@ def main(fetch_md, write_md, out_json):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
