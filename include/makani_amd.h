@@ -332,6 +332,11 @@ int mk_crps_chunks(long long hw);
 int mk_crps(const void* f, int f_dtype, const void* obs, int o_dtype, const float* q, const float* w, const float* gout,
             float* partial, void* gf, int B, int E, int C, long long hw, int type, float alpha, float eps, int grad,
             const float* ens_w, void* stream);
+/* The "naive skillspread" score on COMPLEX members — SpectralCRPSLoss(absolute=False), makani/utils/losses/crps_loss.py:205-243,
+ * 536-545: |.| is the complex modulus.  f (B, E, C, hw) and obs (B, C, hw) complex64 (re, im interleaved); gf like f (torch's
+ * complex-gradient convention); q / w / gout / partial as mk_crps. */
+int mk_crps_complex(const void* f, const void* obs, const float* q, const float* w, const float* gout, float* partial, void* gf,
+                    int B, int E, int C, long long hw, float alpha, int grad, void* stream);
 
 /* ---- DISCO convolution and S2 resampling (FourCastNet3's local operators) ----------------------------------------
  * Replace th.DiscreteContinuousConvS2's sparse contraction and th.ResampleS2 [torch-harmonics, un-vendored; call sites

@@ -95,6 +95,7 @@ _SIGS = {
     "mk_spec_lp_bwd": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_int, c_f, c_f, c_f, c_vp], c_int),
     "mk_crps_chunks": ([c_ll], c_int),
     "mk_crps": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_ll, c_int, c_f, c_f, c_int, c_vp, c_vp], c_int),
+    "mk_crps_complex": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_ll, c_f, c_int, c_vp], c_int),
     "mk_disco_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_disco_bwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),
     "mk_disco_bwd_same": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp], c_int),

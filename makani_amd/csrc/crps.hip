@@ -210,6 +210,79 @@ __global__ __launch_bounds__(CNT) void crps_kernel(const TF* __restrict__ f, con
     }
 }
 
+// "naive skillspread" on COMPLEX members (SpectralCRPSLoss(absolute=False), crps_loss.py:205-243,536-545: the score of the
+// spherical-harmonic coefficients themselves instead of their absolute values): |.| is the complex modulus,
+//   crps = mean_e |o - f_e| - (E - 1 + alpha) / (2 E^2 (E - 1)) sum_{i,j} |f_i - f_j|,
+// gradient in torch's convention (d / d re + i d / d im; the derivative of |z| is z / |z|, 0 at z = 0).
+// f: (B, E, C, hw) complex64 (re, im interleaved), obs: (B, C, hw) complex64; gf like f.
+template <int EM, bool GRAD>
+__global__ __launch_bounds__(CNT) void crps_cplx_kernel(const float2* __restrict__ f, const float2* __restrict__ obs,
+                                                        const float* __restrict__ q, const float* __restrict__ w,
+                                                        const float* __restrict__ gout, float* __restrict__ partial,
+                                                        float2* __restrict__ gf, int E, int C, long long hw, float alpha) {
+    __shared__ float red[CNT / 64];
+    const int plane = blockIdx.y, b = plane / C, c = plane % C;
+    const long long estride = (long long)C * hw;
+    const float2* fp = f + ((long long)b * E * C + c) * hw;
+    const float2* op = obs + (long long)plane * hw;
+    const float* wp = w ? w + (long long)plane * hw : nullptr;
+    const float go = GRAD ? gout[plane] : 0.f;
+    const float inv_e = 1.f / (float)E;
+    const float coef = ((float)E - 1.f + alpha) / (float)((long long)E * E * (E - 1));
+    float sum = 0.f;
+    for (long long p = (long long)blockIdx.x * CNT + threadIdx.x; p < hw; p += (long long)gridDim.x * CNT) {
+        float2 v[EM];
+#pragma unroll
+        for (int e = 0; e < EM; ++e) v[e] = (e < E) ? fp[e * estride + p] : make_float2(0.f, 0.f);
+        float2 o = op[p];
+        const bool masked = (o.x != o.x) || (o.y != o.y);
+        if (masked) o = make_float2(0.f, 0.f);
+        float skill = 0.f, spread = 0.f;
+        float2 g[EM];
+#pragma unroll
+        for (int e = 0; e < EM; ++e) {
+            g[e] = make_float2(0.f, 0.f);
+            if (e < E) {
+                const float dx = v[e].x - o.x, dy = v[e].y - o.y;
+                const float r = sqrtf(dx * dx + dy * dy);
+                skill += r;
+                if (GRAD && r > 0.f) g[e] = make_float2(dx / r * inv_e, dy / r * inv_e);
+#pragma unroll
+                for (int j = 0; j < EM; ++j) {
+                    if (j < E && j != e) {
+                        const float ex = v[e].x - v[j].x, ey = v[e].y - v[j].y;
+                        const float rr = sqrtf(ex * ex + ey * ey);
+                        spread += rr;
+                        if (GRAD && rr > 0.f) {
+                            g[e].x -= coef * ex / rr;
+                            g[e].y -= coef * ey / rr;
+                        }
+                    }
+                }
+            }
+        }
+        const float wt = q[p] * (wp ? wp[p] : 1.f);
+        if (GRAD) {
+            float2* gp = gf + ((long long)b * E * C + c) * hw;
+#pragma unroll
+            for (int e = 0; e < EM; ++e)
+                if (e < E) gp[e * estride + p] = masked ? make_float2(0.f, 0.f) : make_float2(go * wt * g[e].x, go * wt * g[e].y);
+        } else {
+            sum += masked ? 0.f : wt * (skill * inv_e - 0.5f * coef * spread);
+        }
+    }
+    if (!GRAD) {
+        for (int o2 = 32; o2 > 0; o2 >>= 1) sum += __shfl_down(sum, o2, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < CNT / 64; ++i) t += red[i];
+            partial[(long long)plane * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
 template <typename TF, typename TO, bool GRAD>
 int launch_e(int E, dim3 grid, hipStream_t s, const TF* f, const TO* obs, const float* q, const float* w, const float* gout,
              float* partial, TF* gf, int C, long long hw, int type, float alpha, float eps, const float* ew) {
@@ -257,4 +330,28 @@ extern "C" int mk_crps(const void* f, int f_dtype, const void* obs, int o_dtype,
 #undef MK_CRPS_GO
     mk_set_error("crps: unsupported dtype combination");
     return MK_EINVAL;
+}
+
+// The complex "naive skillspread" score (see crps_cplx_kernel): f (B, E, C, hw) and obs (B, C, hw) complex64, q / w / gout /
+// partial / gf as mk_crps (gf complex64).  2 <= E <= 32.
+extern "C" int mk_crps_complex(const void* f, const void* obs, const float* q, const float* w, const float* gout, float* partial,
+                               void* gf, int B, int E, int C, long long hw, float alpha, int grad, void* stream) {
+    MK_REQUIRE(f && obs && q && B > 0 && E >= 2 && E <= MAXE && C > 0 && hw > 0, "crps_complex: bad arguments (2 <= E <= 32)");
+    MK_REQUIRE(grad ? (gout && gf) : (partial != nullptr), "crps_complex: missing output");
+    MK_REQUIRE((long long)B * C <= 65535, "crps_complex: too many planes");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)mk_crps_chunks(hw), (unsigned)(B * C));
+#define MK_CX(N)                                                                                                                     \
+    if (E <= N) {                                                                                                                    \
+        if (grad)                                                                                                                    \
+            hipLaunchKernelGGL((crps_cplx_kernel<N, true>), grid, dim3(CNT), 0, s, (const float2*)f, (const float2*)obs, q, w, gout,  \
+                               partial, (float2*)gf, E, C, hw, alpha);                                                               \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((crps_cplx_kernel<N, false>), grid, dim3(CNT), 0, s, (const float2*)f, (const float2*)obs, q, w, gout, \
+                               partial, (float2*)gf, E, C, hw, alpha);                                                               \
+        return mk_check_launch("mk_crps_complex");                                                                                   \
+    }
+    MK_CX(2) MK_CX(4) MK_CX(8) MK_CX(16) MK_CX(32)
+#undef MK_CX
+    return MK_EUNSUP;
 }

@@ -381,6 +381,40 @@ class CrpsFn(torch.autograd.Function):
         return gf.to(dt), None, None, None, None, None, None, None
 
 
+class CrpsComplexFn(torch.autograd.Function):
+    """the "naive skillspread" score of COMPLEX members (``mk_crps_complex``): forecasts (B, E, C, L, M) complex64,
+    obs (B, C, L, M) complex64 -> (B, C); gradient with respect to the forecasts"""
+
+    @staticmethod
+    def forward(ctx, forecasts, obs, q, wgt, alpha):
+        B, E, Cc, H, W = forecasts.shape
+        if E > MAX_ENSEMBLE:
+            raise NotImplementedError(f"ensemble size {E}: the HIP CRPS kernels hold the members of a point in registers "
+                                      f"(2 <= E <= {MAX_ENSEMBLE})")
+        hw = H * W
+        f = torch.view_as_real(forecasts.to(torch.complex64).contiguous())
+        o = torch.view_as_real(obs.to(torch.complex64).contiguous())
+        w = wgt.float().contiguous() if wgt is not None else None
+        ch = lib().mk_crps_chunks(hw)
+        partial = torch.empty((B * Cc, ch), dtype=torch.float32, device=f.device)
+        check(lib().mk_crps_complex(ptr(f), ptr(o), ptr(q), ptr(w), None, ptr(partial), None, B, E, Cc, hw, float(alpha), 0, stream()),
+              "mk_crps_complex")
+        ctx.save_for_backward(f, o, q, w if w is not None else torch.empty(0, device=f.device))
+        ctx.meta = (alpha, w is not None)
+        return partial.sum(dim=1).reshape(B, Cc)
+
+    @staticmethod
+    def backward(ctx, g):
+        f, o, q, w = ctx.saved_tensors
+        alpha, has_w = ctx.meta
+        B, E, Cc, H, W, _ = f.shape
+        gf = torch.empty_like(f)
+        go = g.float().contiguous()
+        check(lib().mk_crps_complex(ptr(f), ptr(o), ptr(q), ptr(w) if has_w else None, ptr(go), None, ptr(gf), B, E, Cc, H * W,
+                                    float(alpha), 1, stream()), "mk_crps_complex")
+        return torch.view_as_complex(gf), None, None, None, None
+
+
 def _ens_w(w, E):
     if w is not None and w.numel() != E:
         raise ValueError(f"ensemble_weights holds {w.numel()} entries for an ensemble of {E}")
@@ -448,7 +482,8 @@ class SpectralCRPSLoss(SpectralLpLoss):
     ``SpectralBaseLoss`` (m = 0 once, m > 0 twice, 1 / 4 pi).  ``forward(forecasts (B, E, C, H, W), observations (B, C, H, W),
     spectral_weights=None) -> (B, C)``.  The transforms are the HIP SHT (fp32, autocast off, as the reference), the per-(l, m)
     ensemble score and its weighted sum the HIP kernel of ``CRPSLoss`` (``csrc/crps.hip``) with the (l, m) plane in the place of
-    the grid.  Not built: the ensemble-parallel transpose and ``absolute=False`` (complex differences in the naive kernel)."""
+    the grid; ``absolute=False`` scores the complex coefficients themselves with the naive skill / spread kernel
+    (``mk_crps_complex``).  Not built: the ensemble-parallel transpose."""
 
     def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
                  channel_names: List[str], grid_type: str, lmax: Optional[int] = None, crps_type: str = "skillspread",
@@ -465,8 +500,8 @@ class SpectralCRPSLoss(SpectralLpLoss):
             raise ValueError(f"Unknown CRPS crps_type {crps_type}")
         if crps_type not in ("skillspread", "naive skillspread") and alpha < 1.0:
             raise NotImplementedError("The alpha parameter (almost fair CRPS factor) is only supported for the skillspread kernels.")
-        if not absolute:
-            raise NotImplementedError("absolute=False (the naive kernel on complex coefficients) is not built")
+        if not absolute and crps_type != "skillspread":              # crps_loss.py:540-545
+            raise ValueError(f"the non-absolute path only works with the naive 'skillspread' CRPS kernel, but got crps_type {crps_type}")
         self.crps_type, self.alpha, self.eps, self.absolute = crps_type, alpha, eps, absolute
         self.register_buffer("ensemble_weights", None if ensemble_weights is None else ensemble_weights.float().reshape(-1).contiguous(),
                              persistent=False)
@@ -484,8 +519,13 @@ class SpectralCRPSLoss(SpectralLpLoss):
         with torch.autocast(device_type=forecasts.device.type, enabled=False):
             f = self.sht(forecasts.float()) / math.sqrt(4.0 * math.pi)
             o = self.sht(observations.float()) / math.sqrt(4.0 * math.pi)
-        f, o = torch.abs(f).to(dtype), torch.abs(o).to(dtype)
+        if self.absolute:
+            f, o = torch.abs(f).to(dtype), torch.abs(o).to(dtype)
         B, E, Cc, L, M = f.shape
+        if not self.absolute and E > 1:        # the naive kernel on the complex coefficients themselves (crps_loss.py:605-608)
+            w = spectral_weights.expand(B, Cc, L, M) if spectral_weights is not None else None
+            crps = CrpsComplexFn.apply(f, o, self.lm_weights.reshape(-1).contiguous(), w, self.alpha)
+            return thd.reduce_from_spatial_region(crps) if self.spatial_distributed else crps
         if E == 1:
             w = self.lm_weights if spectral_weights is None else spectral_weights * self.lm_weights
             crps = (torch.abs(o - f.squeeze(1)).float() * w).reshape(B, Cc, L * M).sum(dim=-1)

@@ -42,6 +42,19 @@ def _real(t):
     return torch.view_as_real(t) if t.is_complex() else t
 
 
+def invalidate_weight_shadows(module_or_params):
+    """Drop the bf16 weight / transposed-weight images ``FusedAdamW`` wrote for the channel GEMMs.  They are keyed on the
+    parameter's autograd version and storage address, which every torch-level change bumps (``copy_``, ``load_state_dict``,
+    optimizers, in-place ops on the parameter) — but a write THROUGH ``param.data`` (``p.data.mul_(0.5)``, some EMA / weight
+    surgery utilities) bypasses the version counter and cannot be seen.  Call this after such a write; the next forward
+    re-casts the weights, the next optimizer step re-creates the images."""
+    params = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
+    for p in params:
+        for a in ("_mk_shadow", "_mk_shadow_t", "_mk_shadow_version", "_mk_shadow_ptr"):
+            if hasattr(p, a):
+                delattr(p, a)
+
+
 def _flat(t, like=None):
     """fp32 view of ``t`` in memory order for the element-wise kernels; ``like``: a tensor it must share strides with"""
     r = dense_view(_real(t))

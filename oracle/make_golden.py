@@ -177,13 +177,17 @@ def crps_spectral_fixtures():
         dict(img=(12, 24), grid="legendre-gauss", E=2, crps_type="skillspread", alpha=1.0, wgt=False, lmax=None),
         dict(img=(17, 32), grid="equiangular", E=1, crps_type="skillspread", alpha=1.0, wgt=False, lmax=None),
         dict(img=(12, 24), grid="legendre-gauss", E=5, crps_type="cdf", alpha=1.0, wgt=True, lmax=None),      # round 3
+        # absolute=False: the naive skill / spread kernel on the complex coefficients themselves (crps_loss.py:536-545,605-608)
+        dict(img=(17, 32), grid="equiangular", E=4, crps_type="skillspread", alpha=0.95, wgt=True, lmax=None, absolute=False),
+        dict(img=(12, 24), grid="legendre-gauss", E=7, crps_type="skillspread", alpha=1.0, wgt=False, lmax=8, absolute=False),
     ]
     rec = {"cases": json.dumps(cases)}
     for i, c in enumerate(cases):
         torch.manual_seed(700 + i)
         B, C = 2, 3
         mod = SpectralCRPSLoss(img_shape=c["img"], crop_shape=c["img"], crop_offset=(0, 0), channel_names=[str(k) for k in range(C)],
-                               grid_type=c["grid"], lmax=c["lmax"], crps_type=c["crps_type"], alpha=c["alpha"])
+                               grid_type=c["grid"], lmax=c["lmax"], crps_type=c["crps_type"], alpha=c["alpha"],
+                               absolute=c.get("absolute", True))
         f = torch.randn(B, c["E"], C, *c["img"], requires_grad=True)
         o = torch.randn(B, C, *c["img"])
         L, M = mod.lm_weights.shape

@@ -102,9 +102,9 @@ def test_spectral_crps_constructor_contract():
     assert m.crps_type == "skillspread" and m.absolute and m.lm_weights.shape == (m.sht.lmax, m.sht.mmax) == (11, 11)     # the grid's bandlimit
     assert torch.allclose(m.lm_weights[:, 0], torch.full((11,), 1.0 / (4 * np.pi))) and torch.allclose(m.lm_weights[:, 1:], torch.full((11, 10), 2.0 / (4 * np.pi)))
     assert ma.SpectralCRPSLoss(lmax=7, **kw).lm_weights.shape == (7, 7)
-    assert ma.SpectralCRPSLoss(crps_type="cdf", **kw).crps_type == "cdf"
+    assert ma.SpectralCRPSLoss(crps_type="cdf", **kw).crps_type == "cdf" and not ma.SpectralCRPSLoss(absolute=False, **kw).absolute
     for bad, exc in ((dict(crps_type="naive skillspread"), ValueError),
-                     (dict(absolute=False), NotImplementedError), (dict(crps_type="gauss", alpha=0.9), NotImplementedError),
+                     (dict(absolute=False, crps_type="gauss"), ValueError), (dict(crps_type="gauss", alpha=0.9), NotImplementedError),
                      (dict(ensemble_weights=torch.ones(4)), NotImplementedError), (dict(ensemble_distributed=True), NotImplementedError)):
         with pytest.raises(exc):
             ma.SpectralCRPSLoss(**bad, **kw)
@@ -123,7 +123,7 @@ def test_spectral_crps_matches_reference_golden():
         C = g[f"{i}_o"].shape[1]
         mod = ma.SpectralCRPSLoss(img_shape=tuple(c["img"]), crop_shape=tuple(c["img"]), crop_offset=(0, 0),
                                   channel_names=[str(k) for k in range(C)], grid_type=c["grid"], lmax=c["lmax"],
-                                  crps_type=c["crps_type"], alpha=c["alpha"]).to("cuda:0")
+                                  crps_type=c["crps_type"], alpha=c["alpha"], absolute=c.get("absolute", True)).to("cuda:0")
         f = torch.from_numpy(g[f"{i}_f"]).to("cuda:0").requires_grad_(True)
         o = torch.from_numpy(g[f"{i}_o"]).to("cuda:0")
         w = torch.from_numpy(g[f"{i}_wgt"]).to("cuda:0") if f"{i}_wgt" in g.files else None

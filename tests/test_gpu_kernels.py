@@ -535,6 +535,18 @@ def test_bf16_weight_shadow_is_exact_and_invalidated_by_inplace_updates():
         ref = torch.einsum("oi,bihw->bohw", wf, x.to(torch.bfloat16).float())
         assert rel_l2(y, ref) < 1e-2
         assert rel_l2(xr.grad, wf.sum(0).view(1, -1, 1, 1).expand_as(x)) < 1e-2
+        # a write THROUGH param.data is invisible to the version counter: the images stay "valid" until they are dropped by hand
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            conv(x).float().square().mean().backward()
+        opt.step()
+        sh2 = conv.weight._mk_shadow
+        conv.weight.data.mul_(0.5)
+        assert ops.weight_operands(conv.weight)[0].data_ptr() == sh2.data_ptr()            # stale, undetected
+        from makani_amd.optim import invalidate_weight_shadows
+        invalidate_weight_shadows(conv)
+        A, _ = ops.weight_operands(conv.weight)
+        assert A.data_ptr() != sh2.data_ptr() and torch.equal(A[:, :cin], conv.weight.detach().view(cout, cin).to(torch.bfloat16))
 
 
 def test_fused_adamw_device_step_counter_matches_host_steps():
