@@ -784,14 +784,42 @@ def launch(args):
     base_port = int(os.environ.get("MASTER_PORT", "0")) if under_torchrun else 0
     head = args.parallelism if args.parallelism != "auto" else default_parallelism(world, args.config)
     phases = [head] + (["dp"] if (head != "dp" and not args.no_secondary) else [])
-    timeout_s = int(os.environ.get("MAKANI_AMD_BENCH_PHASE_TIMEOUT", "1500"))
+    timeout_s = int(os.environ.get("MAKANI_AMD_BENCH_PHASE_TIMEOUT", "600"))
     results, errors = {}, {}
-    for i, par in enumerate(phases):
-        port = (base_port + 1 + i) if under_torchrun else _free_port()
-        res, err = _run_phase(args, par, ranks, world, port, timeout_s)
-        results[par], errors[par] = res, err
-        if rank == 0:
-            print(f"[bench] phase {par}: {'ok' if res and not err else 'FAILED: ' + str(err)}", file=sys.stderr, flush=True)
+    if under_torchrun:                         # the copies of this script agree on each phase's outcome over a host-side group
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s + 300))
+    nport = 0
+    for par in phases:
+        # the spatial split runs the fused exchange schedule (makani_amd/dist_pipeline.py); should that phase fail — its RCCL
+        # branches with more than one rank cannot be exercised in the development environment — it is repeated once with the
+        # transpose-by-transpose schedule before the data-parallel measurement is reported instead
+        attempts = [None] if par == "dp" else [None, "0"]
+        for fused in attempts:
+            nport += 1
+            port = (base_port + nport) if under_torchrun else _free_port()
+            if fused is not None:
+                os.environ["MAKANI_AMD_DIST_FUSED"] = fused
+            res, err = _run_phase(args, par, ranks, world, port, timeout_s)
+            if fused is not None:
+                os.environ.pop("MAKANI_AMD_DIST_FUSED", None)
+                if res is not None and not err:
+                    res["note"] = "the fused exchange schedule failed; this line ran the transpose-by-transpose schedule (MAKANI_AMD_DIST_FUSED=0)"
+            results[par], errors[par] = res, err
+            ok = err is None and (rank != 0 or res is not None)
+            if under_torchrun:                 # every rank's copy of this script must take the same decision about a retry
+                flag = torch.tensor([1 if ok else 0])
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(flag.item())
+                if not ok and errors[par] is None:
+                    errors[par] = "another rank's worker failed"
+            if rank == 0:
+                tag = par + (" (MAKANI_AMD_DIST_FUSED=0)" if fused is not None else "")
+                print(f"[bench] phase {tag}: {'ok' if ok else 'FAILED: ' + str(errors[par])}", file=sys.stderr, flush=True)
+            if ok:
+                break
+    if under_torchrun:
+        dist.destroy_process_group()
     if rank != 0:
         return None
     out = results.get(head) if not errors.get(head) else None
