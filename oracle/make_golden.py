@@ -304,6 +304,49 @@ def fcn3_block_fixture():
     print(f"fcn3_local_block_360x720.npz: {os.path.getsize(path)/1e6:.2f} MB  |y|={y.abs().mean().item():.4f}")
 
 
+def fcn3_real_grid_fixture():
+    """The WHOLE FourCastNet3 network at BASELINE config 4's grids (721 x 1440 equiangular in / out, 360 x 720 Gauss inside:
+    DISCO encoders 721x1440 -> 360x720, one global (SHT) and two local (DISCO, doubled cutoff) processor blocks, bilinear
+    ResampleS2 + DISCO decoders at 721 x 1440) with reduced channel counts (2 pressure levels x 3 variables + 2 surface
+    variables, 2 auxiliary channels, embedding 4 / 4 / 4): the reference's own ``AtmoSphericNeuralOperatorNet``
+    (makani/models/networks/fourcastnet3.py) over the restated operators, DISCO contractions evaluated entry by entry.
+    Stored like the block fixture: parameters, every parameter gradient, norms and stride-7 lattices of y and gx; x and g are
+    regenerated from their seeds.  Takes ~10 minutes of CPU."""
+    from . import disco as _disco
+    FCN3 = ref_shims.import_reference_module("makani.models.networks.fourcastnet3").AtmoSphericNeuralOperatorNet
+    chans = ["u500", "v500", "t500", "u850", "v850", "t850", "u10m", "t2m"]
+    kwargs = dict(inp_shape=(721, 1440), out_shape=(721, 1440), scale_factor=2, model_grid_type="equiangular", sht_grid_type="legendre-gauss",
+                  filter_basis_type="morlet", kernel_shape=[3, 3], channel_names=chans, aux_channel_names=["xzen", "xoro"],
+                  atmo_embed_dim=4, surf_embed_dim=4, aux_embed_dim=4, num_layers=3, sfno_block_frequency=3,
+                  normalization_layer="none", use_mlp=True, mlp_ratio=2, activation_function="gelu", big_skip=False, bias=False,
+                  encoder_mlp=False)
+    old = _disco.DiscreteContinuousConvS2.contraction
+    _disco.DiscreteContinuousConvS2.contraction = "direct"
+    try:
+        torch.manual_seed(353)
+        model = FCN3(**kwargs)
+        model.train()
+        nin = len(chans) + 2
+        x = seeded_field(3530, (1, nin, 721, 1440), "rand").requires_grad_(True)
+        g = seeded_field(3531, (1, len(chans), 721, 1440), "randn")
+        y = model(x)
+        (y * g).sum().backward()
+    finally:
+        _disco.DiscreteContinuousConvS2.contraction = old
+    st = SUBSAMPLE
+    rec = {"kwargs": np.array(json.dumps(dict(kwargs, x_seed=3530, g_seed=3531, subsample=st))),
+           "x_sum": np.float64(x.detach().double().sum()), "g_sum": np.float64(g.double().sum()),
+           "y_sub": _np(y[..., ::st, ::st]), "gx_sub": _np(x.grad[..., ::st, ::st]),
+           "y_norm": np.float64(y.detach().double().norm()), "gx_norm": np.float64(x.grad.double().norm())}
+    for k, v in model.state_dict().items():
+        rec["param/" + k] = _np(v)
+    for k, p_ in model.named_parameters():
+        rec["grad/" + k] = _np(p_.grad)
+    path = os.path.join(OUT, "fcn3_config4_grids_721x1440.npz")
+    np.savez_compressed(path, **rec)
+    print(f"fcn3_config4_grids_721x1440.npz: {os.path.getsize(path)/1e6:.2f} MB  |y|={y.abs().mean().item():.4f}")
+
+
 def spectral_conv_fixtures():
     sc = ref_shims.import_reference_module("makani.models.common.spectral_convolution")
     th = sys.modules["torch_harmonics"]
@@ -550,6 +593,8 @@ def main():
         fcn3_fixtures()
     if "fcn3" in which or "fcn3_block" in which:
         fcn3_block_fixture()
+    if "fcn3_real" in which:                     # (minutes of CPU: not part of the default set)
+        fcn3_real_grid_fixture()
     if "crps" in which:
         crps_fixtures()
     if "crps_spectral" in which:
