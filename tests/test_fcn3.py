@@ -163,5 +163,5 @@ def test_fcn3_whole_network_at_config4_grids_matches_reference_golden(amp, tol):
         else:
             a = (p.grad.detach().cpu().float() - ref).abs().max().item()
         assert e < 2 * tol or a < (1e-4 if not amp else 4e-2) * gmax, (k, e, a, gmax)
-        worst = max(worst, e if a >= (1e-4 if not amp else 4e-2) * gmax else 0.0)
-    print(f"    worst parameter-gradient rel-L2: {worst:.2e}")
+        worst = max(worst, e)
+    print(f"    largest parameter-gradient rel-L2: {worst:.2e}")
