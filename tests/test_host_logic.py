@@ -505,3 +505,42 @@ def test_c_abi_host_side_planning_functions():
     L.mk_conv1x1_wgrad_workspace.restype = C.c_longlong
     assert L.mk_conv1x1_wgrad_workspace(677, 6093, 1, 259200) == 5 * 677 * 6093
     assert L.mk_conv1x1_wgrad_workspace(384, 384, 1, 1038240) % (384 * 384) == 0
+
+
+def test_fused_schedule_plan_invariants():
+    """makani_amd.dist_pipeline.Plan (host logic of the fused h x w exchange schedule): the plane blocks / sub-blocks partition
+    the planes, every slab offset is a multiple of 4 floats (16-byte vectors), every rank of a configuration cuts the same
+    number of latitude chunks, and a sender's slab for a destination has the size that destination expects from it"""
+    import types
+    from makani_amd import dist_pipeline as dp
+    from makani_amd.distributed import compute_split_shapes as css
+
+    def plans(h, w, nlat, nlon, L, M, P):
+        out = {}
+        for ih in range(h):
+            for iw in range(w):
+                T = types.SimpleNamespace(comm_size_polar=h, comm_size_azimuth=w, comm_rank_polar=ih, comm_rank_azimuth=iw, nlat=nlat,
+                                          nlon=nlon, lmax=L, mmax=M, lat_shapes=css(nlat, h), lon_shapes=css(nlon, w),
+                                          l_shapes=css(L, h), m_shapes=css(M, w))
+                out[(ih, iw)] = dp.Plan(T, P)
+        return out
+
+    for (h, w, nlat, nlon, L, M, P) in [(4, 2, 721, 1440, 240, 241, 384), (4, 2, 721, 1440, 240, 241, 5), (2, 2, 240, 480, 240, 241, 73),
+                                        (3, 1, 19, 48, 10, 11, 1), (1, 2, 33, 64, 16, 17, 6), (8, 1, 721, 1440, 240, 241, 96)]:
+        ps = plans(h, w, nlat, nlon, L, M, P)
+        p0 = ps[(0, 0)]
+        assert sum(p0.pw) == P and len({p.nc for p in ps.values()}) == 1
+        for j in range(w):
+            assert sum(p0.valid[j]) == p0.pw[j] and all(s % 4 == 0 for s in p0.sub[j]) and sum(p0.sub[j]) >= p0.pw[j]
+            assert all(0 <= p0.valid[j][i] <= p0.sub[j][i] for i in range(h))
+        for (ih, iw), p in ps.items():
+            assert all(p.base[j][i] % 4 == 0 for j in range(w) for i in range(h))
+            assert p.f_total == sum(p.slab[j][i] for j in range(w) for i in range(h))
+            c = p.chunks(p.hl)
+            assert c[0] == 0 and c[-1] == p.hl and all(a <= b for a, b in zip(c[:-1], c[1:]))
+            for i in range(h):
+                for j in range(w):
+                    # what (ih, iw) sends to (i, j) in step (3): its latitudes x M(j) x 2 x sub(iw, i); what (i, j) expects from
+                    # (ih, iw): lat(ih) x M_loc(j) x 2 x sub(iw, i) rows of its block G[iw]
+                    q = ps[(i, j)]
+                    assert p.slab[j][i] == p.hl * q.Ml * 2 * q.sub[iw][i] == q.lat[ih] * q.Ml * 2 * p.sub[iw][i]
