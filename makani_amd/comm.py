@@ -70,9 +70,11 @@ def _register(name, group, members, rank):
     _GROUPS[name] = (group if len(members) > 1 else None, len(members), members.index(rank) if rank in members else 0)
 
 
-def init(h: int = 1, w: int = 1):
+def init(h: int = 1, w: int = 1, ensemble: int = 1):
     """Build ``data x (h x w)`` over the current world.  Every rank creates every group in the same order
-    (``dist.new_group`` is collective over the world) and keeps its own.  Groups of one rank are ``None``."""
+    (``dist.new_group`` is collective over the world) and keeps its own.  Groups of one rank are ``None``.
+    ``ensemble``: the data group is ``batch x ensemble`` (makani's ``data_parallel_names = ["ensemble", "batch"]``,
+    ``makani/utils/comm.py:114-201``): data index d = batch index * ensemble + ensemble index."""
     global _SOURCE
     reset()
     world, rank = get_world_size(), get_world_rank()
@@ -80,6 +82,8 @@ def init(h: int = 1, w: int = 1):
     if world % msize:
         raise ValueError(f"world size {world} is not a multiple of h*w = {msize}")
     dsize = world // msize
+    if ensemble < 1 or dsize % ensemble:
+        raise ValueError(f"the data group of {dsize} ranks cannot be split into ensembles of {ensemble}")
     d_idx, m_idx = rank // msize, rank % msize
     ih, iw = m_idx // w, m_idx % w
 
@@ -108,7 +112,19 @@ def init(h: int = 1, w: int = 1):
         g = make(members)
         if m == m_idx:
             mine["data"] = (g, members)
-    for name in ("h", "w", "spatial", "data"):
+    nb = dsize // ensemble
+    for m in range(msize):
+        for ib in range(nb):                                 # ensemble groups: same model rank, same batch index
+            members = [(ib * ensemble + ie) * msize + m for ie in range(ensemble)]
+            g = make(members)
+            if rank in members:
+                mine["ensemble"] = (g, members)
+        for ie in range(ensemble):                           # batch groups: same model rank, same ensemble index
+            members = [(ib * ensemble + ie) * msize + m for ib in range(nb)]
+            g = make(members)
+            if rank in members:
+                mine["batch"] = (g, members)
+    for name in ("h", "w", "spatial", "data", "ensemble", "batch"):
         g, members = mine[name]
         _register(name, g, members, rank)
     _GROUPS["model"] = _GROUPS["spatial"]            # no matmul / feature parallelism on this path: model = h x w

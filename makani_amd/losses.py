@@ -415,6 +415,75 @@ class CrpsComplexFn(torch.autograd.Function):
         return torch.view_as_complex(gf), None, None, None, None
 
 
+class _EnsembleTransposeFn(torch.autograd.Function):
+    """``distributed_transpose(forecasts, (-1, 0), ensemble_shapes, "ensemble")`` of ``crps_loss.py:362-366,566-570``: every
+    rank of the ensemble group holds E_loc members on all N points and ends up with ALL members on its share of the points
+    (``compute_split_shapes(N, n)``).  x (B, E_loc, C, N) -> (B, E_loc * n, C, N_loc); backward is the reverse exchange."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        from . import distributed as thd
+        n, me = dist.get_world_size(group), dist.get_rank(group)
+        B, El, Cc, N = x.shape
+        sizes = thd.compute_split_shapes(N, n)
+        off = [0]
+        for v in sizes:
+            off.append(off[-1] + v)
+        send = [x[..., off[r]:off[r + 1]].contiguous() for r in range(n)]
+        recv = [torch.empty((B, El, Cc, sizes[me]), dtype=x.dtype, device=x.device) for _ in range(n)]
+        thd._exchange(recv, send, group)
+        ctx.meta = (group, n, me, sizes, off, N)
+        return torch.cat(recv, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import distributed as thd
+        group, n, me, sizes, off, N = ctx.meta
+        B, E, Cc, Nl = g.shape
+        El = E // n
+        send = [g[:, r * El:(r + 1) * El].contiguous() for r in range(n)]
+        recv = [torch.empty((B, El, Cc, sizes[r]), dtype=g.dtype, device=g.device) for r in range(n)]
+        thd._exchange(recv, send, group)
+        return torch.cat(recv, dim=3), None
+
+
+def _ensemble_split(forecasts, obs, q, wgt):
+    """the ensemble-parallel path of the CRPS losses: (forecasts with ALL members on this rank's share of the points, that
+    share of the observations / quadrature weights / spatial weights, the group).  forecasts (B, E_loc, C, N) etc."""
+    import torch.distributed as dist
+    from . import comm as _comm
+    from . import distributed as thd
+    group = _comm.get_group("ensemble")
+    n, me = dist.get_world_size(group), dist.get_rank(group)
+    N = forecasts.shape[-1]
+    sizes = thd.compute_split_shapes(N, n)
+    a = sum(sizes[:me])
+    b = a + sizes[me]
+    f = _EnsembleTransposeFn.apply(forecasts, group)
+    return f, obs[..., a:b].contiguous(), q[..., a:b].contiguous(), (wgt[..., a:b].contiguous() if wgt is not None else None), group
+
+
+class _ReduceFromGroupFn(torch.autograd.Function):
+    """``reduce_from_parallel_region``: SUM all-reduce forward, identity backward"""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        from . import ops
+        y = x.clone()
+        ops._all_reduce_sum(y, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def _ensemble_active(flag) -> bool:
+    from . import comm as _comm
+    return bool(flag) and _comm.is_distributed("ensemble") and _comm.get_size("ensemble") > 1
+
+
 def _ens_w(w, E):
     if w is not None and w.numel() != E:
         raise ValueError(f"ensemble_weights holds {w.numel()} entries for an ensemble of {E}")
@@ -427,7 +496,8 @@ class CRPSLoss(nn.Module):
     kernel (``csrc/crps.hip``), the gradient with respect to the forecasts one more.  Built: ``crps_type`` "skillspread"
     (default, with the almost-fair factor ``alpha``), "naive skillspread", "probability weighted moment", "gauss" and "cdf"
     (:55-122, with optional per-member ``ensemble_weights``, the only form in which the reference uses them); any ensemble
-    size 2..32.  Not built: the ensemble-parallel transpose."""
+    size 2..32; ``ensemble_distributed=True`` with a split "ensemble" group (``makani_amd.comm.init(h, w, ensemble=n)`` or
+    makani's own tree) trades the members for a share of the grid points before scoring, as the reference does."""
 
     def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
                  channel_names: List[str], grid_type: str, crps_type: str = "skillspread",
@@ -440,8 +510,7 @@ class CRPSLoss(nn.Module):
         self.quadrature = GridQuadrature(grid_to_quadrature_rule(grid_type), img_shape=img_shape, crop_shape=crop_shape,
                                          crop_offset=crop_offset, normalize=True, distributed=spatial_distributed)
         self.spatial_distributed = self.quadrature.distributed
-        if ensemble_distributed:
-            raise NotImplementedError("the ensemble-parallel CRPS (transpose over the 'ensemble' group) is not built")
+        self.ensemble_distributed = _ensemble_active(ensemble_distributed)                # crps_loss.py:305-307
         if ensemble_weights is not None and crps_type != "cdf":      # the reference uses them in the cdf form only (:392-396)
             raise NotImplementedError("currently only constant ensemble weights are supported")
         if crps_type not in _CRPS_TYPES:
@@ -467,11 +536,21 @@ class CRPSLoss(nn.Module):
             raise ValueError(f"the weights have to have the same number of dimensions (found {spatial_weights.dim()}) as "
                              f"observations (found {observations.dim()}).")
         B, E, Cc, H, W = forecasts.shape
-        if E == 1:            # |obs - forecast| under the quadrature (crps_loss.py:375-377)
+        if E == 1 and not self.ensemble_distributed:            # |obs - forecast| under the quadrature (crps_loss.py:375-377)
             crps = self.quadrature.lp(forecasts.squeeze(1), observations, spatial_weights, 1.0).reshape(B, Cc)
             return crps
         w = spatial_weights.expand(B, Cc, H, W) if spatial_weights is not None else None
-        crps = CrpsFn.apply(forecasts, observations, self.quad_weight_split.reshape(-1), w,
+        q = self.quad_weight_split.reshape(-1)
+        if self.ensemble_distributed:
+            # members are spread over the ensemble group: trade them for a share of the grid points (crps_loss.py:362-373),
+            # score that share with all members, sum the shares (:441-442)
+            f, o, q, w, group = _ensemble_split(forecasts.reshape(B, E, Cc, H * W), observations.reshape(B, Cc, H * W), q,
+                                                w.reshape(B, Cc, H * W) if w is not None else None)
+            E = f.shape[1]
+            crps = CrpsFn.apply(f.unsqueeze(-1), o.unsqueeze(-1), q, w.unsqueeze(-1) if w is not None else None,
+                                _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, E))
+            return self.quadrature._reduce(_ReduceFromGroupFn.apply(crps, group))
+        crps = CrpsFn.apply(forecasts, observations, q, w,
                             _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, E))
         return self.quadrature._reduce(crps)
 
@@ -483,7 +562,7 @@ class SpectralCRPSLoss(SpectralLpLoss):
     spectral_weights=None) -> (B, C)``.  The transforms are the HIP SHT (fp32, autocast off, as the reference), the per-(l, m)
     ensemble score and its weighted sum the HIP kernel of ``CRPSLoss`` (``csrc/crps.hip``) with the (l, m) plane in the place of
     the grid; ``absolute=False`` scores the complex coefficients themselves with the naive skill / spread kernel
-    (``mk_crps_complex``).  Not built: the ensemble-parallel transpose."""
+    (``mk_crps_complex``); ``ensemble_distributed=True`` as in ``CRPSLoss`` (absolute values only)."""
 
     def __init__(self, img_shape: Tuple[int, int], crop_shape: Tuple[int, int], crop_offset: Tuple[int, int],
                  channel_names: List[str], grid_type: str, lmax: Optional[int] = None, crps_type: str = "skillspread",
@@ -492,8 +571,7 @@ class SpectralCRPSLoss(SpectralLpLoss):
                  eps: Optional[float] = 1.0e-6, **kwargs):
         super().__init__(img_shape, crop_shape, crop_offset, channel_names, grid_type, spatial_distributed=spatial_distributed,
                          lmax=lmax)
-        if ensemble_distributed:
-            raise NotImplementedError("the ensemble-parallel CRPS (transpose over the 'ensemble' group) is not built")
+        self.ensemble_distributed = _ensemble_active(ensemble_distributed)
         if ensemble_weights is not None and crps_type != "cdf":
             raise NotImplementedError("currently only constant ensemble weights are supported")
         if crps_type not in ("cdf", "skillspread", "probability weighted moment", "gauss"):     # what the reference's forward knows
@@ -522,6 +600,16 @@ class SpectralCRPSLoss(SpectralLpLoss):
         if self.absolute:
             f, o = torch.abs(f).to(dtype), torch.abs(o).to(dtype)
         B, E, Cc, L, M = f.shape
+        if self.ensemble_distributed:            # crps_loss.py:566-581: members <-> (l, m) points over the ensemble group
+            if not self.absolute:
+                raise NotImplementedError("the ensemble-parallel spectral CRPS is built for absolute=True")
+            w = (spectral_weights.expand(B, Cc, L, M).reshape(B, Cc, L * M) if spectral_weights is not None else None)
+            fe, oe, qe, we, group = _ensemble_split(f.reshape(B, E, Cc, L * M), o.reshape(B, Cc, L * M),
+                                                    self.lm_weights.reshape(-1).contiguous(), w)
+            crps = CrpsFn.apply(fe.unsqueeze(-1), oe.unsqueeze(-1), qe, we.unsqueeze(-1) if we is not None else None,
+                                _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, fe.shape[1]))
+            crps = _ReduceFromGroupFn.apply(crps, group)
+            return thd.reduce_from_spatial_region(crps) if self.spatial_distributed else crps
         if not self.absolute and E > 1:        # the naive kernel on the complex coefficients themselves (crps_loss.py:605-608)
             w = spectral_weights.expand(B, Cc, L, M) if spectral_weights is not None else None
             crps = CrpsComplexFn.apply(f, o, self.lm_weights.reshape(-1).contiguous(), w, self.alpha)

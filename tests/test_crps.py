@@ -103,9 +103,10 @@ def test_spectral_crps_constructor_contract():
     assert torch.allclose(m.lm_weights[:, 0], torch.full((11,), 1.0 / (4 * np.pi))) and torch.allclose(m.lm_weights[:, 1:], torch.full((11, 10), 2.0 / (4 * np.pi)))
     assert ma.SpectralCRPSLoss(lmax=7, **kw).lm_weights.shape == (7, 7)
     assert ma.SpectralCRPSLoss(crps_type="cdf", **kw).crps_type == "cdf" and not ma.SpectralCRPSLoss(absolute=False, **kw).absolute
+    assert not ma.SpectralCRPSLoss(ensemble_distributed=True, **kw).ensemble_distributed      # no split "ensemble" group: serial, as the reference
     for bad, exc in ((dict(crps_type="naive skillspread"), ValueError),
                      (dict(absolute=False, crps_type="gauss"), ValueError), (dict(crps_type="gauss", alpha=0.9), NotImplementedError),
-                     (dict(ensemble_weights=torch.ones(4)), NotImplementedError), (dict(ensemble_distributed=True), NotImplementedError)):
+                     (dict(ensemble_weights=torch.ones(4)), NotImplementedError)):
         with pytest.raises(exc):
             ma.SpectralCRPSLoss(**bad, **kw)
     with pytest.raises(ValueError):
@@ -139,3 +140,58 @@ def test_spectral_crps_matches_reference_golden():
             # reference's autograd returns NaN for the whole gradient (0 * inf in the derivative of the standard deviation);
             # the HIP kernel's gradient is finite (the score at zero spread has the subgradient 0), the VALUE is pinned above
             assert c["crps_type"] == "gauss"
+
+
+def _worker_ensemble(rank, world, port):
+    """ensemble_distributed=True (crps_loss.py:305-307,362-373,441-442,566-581): 2 batch entries x 2 ensemble ranks on one GPU,
+    three members per rank: value and forecast gradient of CRPSLoss (every score type) and SpectralCRPSLoss against the
+    serial modules on the gathered ensemble"""
+    import os, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd as ma
+        import makani_amd.comm as mcomm
+        dev = "cuda:0"
+        mcomm.init(1, 1, ensemble=2)
+        ie, ib = mcomm.get_rank("ensemble"), mcomm.get_rank("batch")
+        assert (mcomm.get_size("ensemble"), mcomm.get_size("batch"), mcomm.get_size("data")) == (2, 2, 4) and rank == ib * 2 + ie
+        torch.manual_seed(3)
+        img, C, El = (19, 36), 3, 3
+        f_all = torch.randn(2, 2 * El, C, *img)
+        o_all = torch.randn(2, C, *img)
+        g_all = torch.randn(2, C)
+        w_all = torch.rand(2, C, *img) + 0.5
+        kw = dict(img_shape=img, crop_shape=img, crop_offset=(0, 0), channel_names=[str(k) for k in range(C)], grid_type="equiangular")
+        cases = [(ma.CRPSLoss, t, True) for t in ("skillspread", "cdf", "probability weighted moment", "gauss", "naive skillspread")]
+        cases += [(ma.SpectralCRPSLoss, "skillspread", False), (ma.SpectralCRPSLoss, "cdf", False)]
+        for cls, ctype, use_w in cases:
+            ser = cls(crps_type=ctype, **kw).to(dev)
+            par = cls(crps_type=ctype, ensemble_distributed=True, **kw).to(dev)
+            assert par.ensemble_distributed and not ser.ensemble_distributed
+            fs = f_all[ib:ib + 1].to(dev).requires_grad_(True)
+            o, g = o_all[ib:ib + 1].to(dev), g_all[ib:ib + 1].to(dev)
+            w = w_all[ib:ib + 1].to(dev) if use_w else None
+            ref = ser(fs, o, w)
+            (ref * g).sum().backward()
+            fl = f_all[ib:ib + 1, ie * El:(ie + 1) * El].to(dev).requires_grad_(True)
+            out = par(fl, o, w)
+            (out * g).sum().backward()
+            assert rel_l2(out, ref) < 1e-5, (cls.__name__, ctype, out, ref)
+            assert rel_l2(fl.grad, fs.grad[:, ie * El:(ie + 1) * El]) < 2e-5, (cls.__name__, ctype)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ensemble_parallel_crps_matches_serial():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_ensemble, args=(4, port), nprocs=4, join=True)
