@@ -98,6 +98,15 @@ class Plan:
 def eligible(T, x_dtype) -> bool:
     """the fused schedule needs the specialised FFT kernels, equal longitude pieces of whole 16-byte vectors and at most
     MK_FFT_SEG_MAX peers per direction; anything else runs the transpose-by-transpose schedule of distributed.py"""
+    from . import distributed as thd
+    key = (x_dtype, os.environ.get("MAKANI_AMD_DIST_FUSED", "1"), id(thd._BACKEND))
+    cache = T.__dict__.setdefault("_fused_ok", {})
+    if key not in cache:
+        cache[key] = _eligible(T, x_dtype)
+    return cache[key]
+
+
+def _eligible(T, x_dtype) -> bool:
     from . import _lib
     from . import distributed as thd
     if os.environ.get("MAKANI_AMD_DIST_FUSED", "1") != "1":
