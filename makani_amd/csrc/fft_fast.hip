@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
     constexpr int NV = (RB * VROW + NT - 1) / NT;
     uint4 rawv[NV];
     auto prefetch = [&](long long itm) {
-        const long long kl_ = itm / ngr;
+        const long long kl_ = (unsigned)itm / (unsigned)ngr;             // (nitems < 2^31: 32-bit division)
         const long long p0_ = (itm - kl_ * ngr) * RB;
         const int nr_ = (int)min((long long)RB, planes - p0_);
         const T* xr_ = x + (p0_ * xnl + kl_) * wl;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
     }
     __syncthreads();
     for (long long item = it.begin; item < it.end; ++item) {
-        const long long klat = item / ngr;
+        const long long klat = (unsigned)item / (unsigned)ngr;
         const long long p0 = (item - klat * ngr) * RB;
         const int nr = (int)min((long long)RB, planes - p0);
 
@@ -319,7 +319,9 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
                     *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
                     *reinterpret_cast<float4*>(o + ims) = make_float4(X0.y, X1.y, X2.y, X3.y);
                 } else {
-                    float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
+                    // vec: C % 4 == 0 (then Cp == C) or one batch entry — either way plane pr IS row pr of the F layout
+                    // (the general (pr / C) * Cp + pr % C costs two 64-bit divisions per lane and store)
+                    float* o = F + ((long long)m * nlat + klat) * 2 * rows + pr;
                     *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
                     *reinterpret_cast<float4*>(o + rows) = make_float4(X0.y, X1.y, X2.y, X3.y);
                 }
@@ -383,26 +385,29 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     constexpr int NQ1 = (MCAP * RB + NT - 1) / NT;
     float4 sre[NQ4], sim[NQ4];
     auto prefetch = [&](long long itm) {
-        const long long kl_ = itm / ngr;
+        const long long kl_ = (unsigned)itm / (unsigned)ngr;             // (nitems < 2^31: 32-bit division)
         const long long p0_ = (itm - kl_ * ngr) * RB;
         const int nr_ = (int)min((long long)RB, planes - p0_);
 #pragma unroll
         for (int q = 0; q < NQ4; ++q) {
             const int idx = tid + q * NT;
             const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (m < mmax && r0 < nr_) {
-                const long long pr = p0_ + r0;
-                if constexpr (SEG) {
-                    int ims;
-                    const float* sp = F + seg_f_offset(segtab, sg.nw, sg.nh, m, kl_, pr, &ims);
-                    a = *reinterpret_cast<const float4*>(sp);
-                    b = *reinterpret_cast<const float4*>(sp + ims);
-                } else {
-                    const float* sp = F + ((long long)m * nlat + kl_) * 2 * rows + (pr / C) * Cp + (pr % C);
-                    a = *reinterpret_cast<const float4*>(sp);
-                    b = *reinterpret_cast<const float4*>(sp + rows);
-                }
+            // Unconditional loads from clamped (always valid) positions: a load under a lane condition, or a select on the
+            // loaded value, makes hipcc wait for the memory round trip on the spot instead of leaving the loads in flight
+            // during the passes of the current item.  Entries with m >= mmax or rows >= nr are zeroed where they are USED
+            // (the same conditions are re-evaluated there for this item).
+            const int mc = min(m, mmax - 1);
+            const long long pr = p0_ + ((r0 < nr_) ? r0 : 0);
+            float4 a, b;
+            if constexpr (SEG) {
+                int ims;
+                const float* sp = F + seg_f_offset(segtab, sg.nw, sg.nh, mc, kl_, pr, &ims);
+                a = *reinterpret_cast<const float4*>(sp);
+                b = *reinterpret_cast<const float4*>(sp + ims);
+            } else {
+                const float* sp = F + ((long long)mc * nlat + kl_) * 2 * rows + pr;      // (float4 access: plane pr = row pr)
+                a = *reinterpret_cast<const float4*>(sp);
+                b = *reinterpret_cast<const float4*>(sp + rows);
             }
             sre[q] = a;
             sim[q] = b;
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     };
     if ((vec || PRUNED) && it.begin < it.end) prefetch(it.begin);
     for (long long item = it.begin; item < it.end; ++item) {
-        const long long klat = item / ngr;
+        const long long klat = (unsigned)item / (unsigned)ngr;
         const long long p0 = (item - klat * ngr) * RB;
         const int nr = (int)min((long long)RB, planes - p0);
         T* xr = x + (p0 * xnl + klat) * (long long)wl;
@@ -569,6 +574,7 @@ int launch_seg(bool inverse, const void* in, void* out, int dtype, const float2*
     const long long nitems = (long long)nlat * ngr;
     const long long rows = (long long)B * Cp;
     MK_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "fft: x and F must be 16-byte aligned");
+    MK_REQUIRE(nitems < (1ll << 31), "fft: too many (latitude, row group) items");
     constexpr int M3 = N2 / 3 + 1, MF = N2 + 1;
 #define MK_FFT_TAIL tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq, sg, s
     const bool vec = (C % 4 == 0) || (B == 1);
