@@ -10,10 +10,12 @@
 //   * index arithmetic is by constants, loops are fully unrolled;
 //   * persistent workgroups own a CONTIGUOUS range of (plane, latitude-group) items, so the
 //     RB-float runs they write to / read from the lat-major F-layout are adjacent in time and
-//     address (they merge in the XCD's L2), and the twiddle table is staged into LDS once.
+//     address (they merge in the XCD's L2), and the twiddle table is staged into LDS once;
+//   * complex values are register PAIRS worked on by the packed fp32 instructions (fft_packed.h): the kernels are bound
+//     by VALU issue, and the packed butterflies need about half the instructions of the struct-of-two-floats form.
 #include <stdlib.h>
 
-#include "fft_common.h"
+#include "fft_packed.h"
 
 namespace {
 
@@ -74,7 +76,7 @@ struct PassShape {
 };
 
 template <int N2, int R, int RB, int NT>
-using PassRegs = float2[PassShape<N2, R, RB, NT>::NR][R];
+using PassRegs = cf[PassShape<N2, R, RB, NT>::NR][R];
 
 template <int N2, int R, int RB, int NT, typename LoadFn>
 __device__ __forceinline__ void pass_load(PassRegs<N2, R, RB, NT>& v, LoadFn load, int tid) {
@@ -93,7 +95,7 @@ __device__ __forceinline__ void pass_load(PassRegs<N2, R, RB, NT>& v, LoadFn loa
 // tp: this pass's twiddles, tp[(r-1)*NS + k] = exp(-2 pi i k r / (NS R)): consecutive lanes (k) read
 // consecutive LDS words
 template <int N2, int R, int NS, int RB, int NT, typename StoreFn>
-__device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB, NT>& v, const float2* __restrict__ tp,
+__device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB, NT>& v, const cf* __restrict__ tp,
                                                    StoreFn store, int tid) {
     using S = PassShape<N2, R, RB, NT>;
 #pragma unroll
@@ -106,17 +108,17 @@ __device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB, NT>& v, c
 #pragma unroll
                 for (int r = 1; r < R; ++r) v[q][r] = cmul(v[q][r], tp[(r - 1) * NS + k]);
             }
-            Dft<R>::run(v[q]);
+            PDft<R>::run(v[q]);
             const int j0 = (j - k) * R + k;
 #pragma unroll
-            for (int o = 0; o < R; ++o) store(row, j0 + o * NS, v[q][Dft<R>::loc(o)]);
+            for (int o = 0; o < R; ++o) store(row, j0 + o * NS, v[q][PDft<R>::loc(o)]);
         }
     }
 }
 
 template <int N2, int R, int NS, int RB, int NT, bool SYNC_BETWEEN, typename LoadFn, typename StoreFn>
-__device__ __forceinline__ void fft_pass(const float2* __restrict__ tp, LoadFn load, StoreFn store, int tid) {
-    float2 v[PassShape<N2, R, RB, NT>::NR][R];
+__device__ __forceinline__ void fft_pass(const cf* __restrict__ tp, LoadFn load, StoreFn store, int tid) {
+    cf v[PassShape<N2, R, RB, NT>::NR][R];
     pass_load<N2, R, RB, NT>(v, load, tid);
     if (SYNC_BETWEEN) __syncthreads();
     pass_compute_store<N2, R, NS, RB, NT>(v, tp, store, tid);
@@ -134,7 +136,7 @@ __device__ __forceinline__ ItemRange my_items(long long nitems) {
     return r;
 }
 
-// LDS row stride (in float2).  The step that moves between the [row][m] LDS image and the
+// LDS row stride (in complex values).  The step that moves between the [row][m] LDS image and the
 // [m][row] global image touches LDS with the row index fastest across lanes, so the stride decides its
 // bank pattern (MI355X_MICROARCH.md, LDS): ds_read_b64 works on 32-lane groups over 64 banks, ds_write_b64
 // on 16-lane groups over 32 banks.
@@ -158,7 +160,7 @@ struct Tables {
     static constexpr int U = UN;
     static constexpr int SIZE = T2 + T3 + U;
     template <int NT>
-    __device__ static __forceinline__ void fill(float2* t, const float2* __restrict__ tw_g, int tid) {
+    __device__ static __forceinline__ void fill(cf* t, const cf* __restrict__ tw_g, int tid) {
         constexpr int N = 2 * N2;
         for (int q = tid; q < T2; q += NT) {
             const int r = q / R1 + 1, k = q % R1;
@@ -179,26 +181,33 @@ struct Tables {
 //     in flight (in registers) during the passes of the current one;
 //   * the F side is touched as float4 = 4 consecutive rows of one (m, latitude, re/im).
 // X[m] of one real row from the N2-point complex FFT Z of its (even, odd) pairs, truncated spectrum weights applied
+// per order m: the positions of the pair (Z[m], Z[N2 - m]), the twiddle U[m] and the weights of the two output components
 template <int N2>
-__device__ __forceinline__ float2 untangle_one(const float2* __restrict__ zrow, const float2* __restrict__ twu, int m,
-                                               float w_dc, float w_pos, float w_nyq) {
-    const int ma = (m == N2) ? 0 : m;
-    const int mb = (m == 0 || m == N2) ? 0 : N2 - m;
-    const float2 A = zrow[ma];
-    const float2 Bc = cconj(zrow[mb]);
-    const float2 u = cadd(A, Bc), t = csub(A, Bc);
-    const float2 wt = cmul(twu[m], t);
-    const float2 X = make_float2(0.5f * (u.x + wt.y), 0.5f * (u.y - wt.x));
-    const bool edge = (m == 0) || (m == N2);
-    const float w = (m == 0) ? w_dc : ((m == N2) ? w_nyq : w_pos);
-    return make_float2(w * X.x, edge ? 0.f : w * X.y);
-}
+struct Untangle {
+    int ma, mb;
+    cf tw, hw;         // hw = (w / 2, edge ? 0 : w / 2): X = (u + (-i) U t) / 2, scaled by the truncated-spectrum weight w
+    __device__ __forceinline__ Untangle(const cf* __restrict__ twu, int m, float w_dc, float w_pos, float w_nyq) {
+        ma = (m == N2) ? 0 : m;
+        mb = (m == 0 || m == N2) ? 0 : N2 - m;
+        tw = twu[m];
+        const bool edge = (m == 0) || (m == N2);
+        const float w = 0.5f * ((m == 0) ? w_dc : ((m == N2) ? w_nyq : w_pos));
+        hw = cf_make(w, edge ? 0.f : w);
+    }
+    // unscaled X[m] of one row
+    __device__ __forceinline__ cf raw(const cf* __restrict__ zrow) const {
+        const cf A = zrow[ma], B = zrow[mb];
+        const cf u = add_conj(A, B), t = sub_conj(A, B);
+        return add_mi(u, cmul(t, tw));
+    }
+};
 
+// weights of the two components of X[m] on the way into the inverse transform
 template <int N2>
-__device__ __forceinline__ float2 weighted_one(int m, float re, float im, float w_dc, float w_pos, float w_nyq) {
+__device__ __forceinline__ cf inverse_weights(int m, float w_dc, float w_pos, float w_nyq) {
     const bool edge = (m == 0) || (m == N2);
     const float w = (m == 0) ? w_dc : ((m == N2) ? w_nyq : 0.5f * w_pos);
-    return make_float2(w * re, edge ? 0.f : w * im);
+    return cf_make(w, edge ? 0.f : w);
 }
 
 template <typename T>
@@ -214,7 +223,7 @@ struct RowVec<u16> {
 
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
-                                                            const float2* __restrict__ tw_g, int C, int Cp,
+                                                            const cf* __restrict__ tw_g, int C, int Cp,
                                                             long long rows, long long planes, int nlat, int mmax,
                                                             int ngr, long long nitems, float w_dc, float w_pos,
                                                             float w_nyq, const MkFftSeg sg) {
@@ -223,20 +232,20 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
     constexpr int VP = RowVec<T>::PAIRS, VROW = N2 / VP;        // vectors per row
     static_assert(N2 % VP == 0 && LS % 2 == 0 && RB % 4 == 0, "vector layout");
     using Tb = Tables<N2, R1, R2, R3, MCAP>;        // mmax <= MCAP
-    __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
+    __shared__ __attribute__((aligned(16))) cf smem[RB * LS + Tb::SIZE];
     __shared__ SegTab segtab_s;
     SegTab* segtab = &segtab_s;
-    float2* buf = smem;
-    float2* tw2 = smem + RB * LS;
-    float2* tw3 = tw2 + Tb::T2;
-    float2* twu = tw3 + Tb::T3;
+    cf* buf = smem;
+    cf* tw2 = smem + RB * LS;
+    cf* tw3 = tw2 + Tb::T2;
+    cf* twu = tw3 + Tb::T3;
     const int tid = threadIdx.x;
     Tb::template fill<NT>(tw2, tw_g, tid);
     if constexpr (SEG) seg_fill<NT>(segtab, sg, tid);
 
     const ItemRange it = my_items(nitems);
-    auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
-    auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
+    auto st_lds = [&](int row, int pos, cf val) { buf[row * LS + pos] = val; };
+    auto ld_lds = [&](int row, int pos) -> cf { return buf[row * LS + pos]; };
     // work item = one latitude x RB consecutive (batch, channel) planes (k-major F layout, see fft.hip)
     // SEG: the row of a plane is cut into sg.xseg equal pieces in separate buffers (see SegTab): per (lane, q) the piece and
     // the offset inside it are fixed, only the (plane, latitude) part moves with the item
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
                                   : make_uint4(0, 0, 0, 0);
         }
     };
-    auto commit = [&]() {                                       // registers -> work buffer as float2 pairs
+    auto commit = [&]() {                                       // registers -> work buffer as fp32 pairs
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int idx = tid + q * NT;
@@ -307,30 +316,32 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
             for (int idx = tid; idx < mmax * (RB / 4); idx += NT) {
                 const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
                 if (r0 >= nr) continue;
-                const float2* z = buf + r0 * LS;                                    // rows >= nr hold zeros
-                const float2 X0 = untangle_one<N2>(z, twu, m, w_dc, w_pos, w_nyq);
-                const float2 X1 = untangle_one<N2>(z + LS, twu, m, w_dc, w_pos, w_nyq);
-                const float2 X2 = untangle_one<N2>(z + 2 * LS, twu, m, w_dc, w_pos, w_nyq);
-                const float2 X3 = untangle_one<N2>(z + 3 * LS, twu, m, w_dc, w_pos, w_nyq);
+                const cf* z = buf + r0 * LS;                                        // rows >= nr hold zeros
+                const Untangle<N2> un(twu, m, w_dc, w_pos, w_nyq);
+                const cf R0 = un.raw(z), R1_ = un.raw(z + LS), R2_ = un.raw(z + 2 * LS), R3_ = un.raw(z + 3 * LS);
+                // the scaling is scalar on purpose: its results are the components of the two 16-byte stores
+                const float4 Xre = make_float4(R0.x * un.hw.x, R1_.x * un.hw.x, R2_.x * un.hw.x, R3_.x * un.hw.x);
+                const float4 Xim = make_float4(R0.y * un.hw.y, R1_.y * un.hw.y, R2_.y * un.hw.y, R3_.y * un.hw.y);
                 const long long pr = p0 + r0;
                 if constexpr (SEG) {
                     int ims;
                     float* o = F + seg_f_offset(segtab, sg.nw, sg.nh, m, klat, pr, &ims);
-                    *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
-                    *reinterpret_cast<float4*>(o + ims) = make_float4(X0.y, X1.y, X2.y, X3.y);
+                    *reinterpret_cast<float4*>(o) = Xre;
+                    *reinterpret_cast<float4*>(o + ims) = Xim;
                 } else {
                     // vec: C % 4 == 0 (then Cp == C) or one batch entry — either way plane pr IS row pr of the F layout
                     // (the general (pr / C) * Cp + pr % C costs two 64-bit divisions per lane and store)
                     float* o = F + ((long long)m * nlat + klat) * 2 * rows + pr;
-                    *reinterpret_cast<float4*>(o) = make_float4(X0.x, X1.x, X2.x, X3.x);
-                    *reinterpret_cast<float4*>(o + rows) = make_float4(X0.y, X1.y, X2.y, X3.y);
+                    *reinterpret_cast<float4*>(o) = Xre;
+                    *reinterpret_cast<float4*>(o + rows) = Xim;
                 }
             }
         } else {
             for (int idx = tid; idx < mmax * RB; idx += NT) {
                 const int r = idx % RB, m = idx / RB;
                 if (r >= nr) continue;
-                const float2 X = untangle_one<N2>(buf + r * LS, twu, m, w_dc, w_pos, w_nyq);
+                const Untangle<N2> un(twu, m, w_dc, w_pos, w_nyq);
+                const cf X = un.raw(buf + r * LS) * un.hw;
                 const long long pr = p0 + r;
                 float* o = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
                 o[0] = X.x;
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict_
 // it sizes the registers that carry the next item's spectrum.
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __restrict__ F, T* __restrict__ x,
-                                                             const float2* __restrict__ tw_g, int C, int Cp,
+                                                             const cf* __restrict__ tw_g, int C, int Cp,
                                                              long long rows, long long planes, int nlat, int mmax,
                                                              int ngr, long long nitems, float w_dc, float w_pos,
                                                              float w_nyq, const MkFftSeg sg) {
@@ -360,13 +371,13 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     // touches: no zero fill, the pre-twiddle runs on the loaded registers, the first pass substitutes zeros
     constexpr bool PRUNED = MCAP <= N2 / 2;
     using Tb = Tables<N2, R1, R2, R3, PRUNED ? MCAP : N2 + 1>;
-    __shared__ __attribute__((aligned(16))) float2 smem[RB * LS + Tb::SIZE];
+    __shared__ __attribute__((aligned(16))) cf smem[RB * LS + Tb::SIZE];
     __shared__ SegTab segtab_s;
     SegTab* segtab = &segtab_s;
-    float2* buf = smem;
-    float2* tw2 = smem + RB * LS;
-    float2* tw3 = tw2 + Tb::T2;
-    float2* twu = tw3 + Tb::T3;
+    cf* buf = smem;
+    cf* tw2 = smem + RB * LS;
+    cf* tw3 = tw2 + Tb::T2;
+    cf* twu = tw3 + Tb::T3;
     const int tid = threadIdx.x;
     Tb::template fill<NT>(tw2, tw_g, tid);
     if constexpr (SEG) seg_fill<NT>(segtab, sg, tid);
@@ -427,18 +438,20 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                 const int idx = tid + q * NT;
                 const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
                 if (m < mmax) {
-                    const bool live = r0 < nr;
-                    const float2 tw = twu[m];
+                    // rows >= nr were loaded from a clamped (valid) position: zero weights instead of a select per value
+                    const cf wv = (r0 < nr) ? inverse_weights<N2>(m, w_dc, w_pos, w_nyq) : cf_make(0.f, 0.f);
+                    const cf tw = twu[m];
                     const float re[4] = {sre[q].x, sre[q].y, sre[q].z, sre[q].w};
                     const float im[4] = {sim[q].x, sim[q].y, sim[q].z, sim[q].w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float2 Xa = live ? weighted_one<N2>(m, re[i], im[i], w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                        const float2 wt = cmul(cconj(tw), Xa);
-                        buf[(r0 + i) * LS + m] = make_float2(Xa.x - wt.y, -(Xa.y + wt.x));
+                        const cf Xa = cf_make(wv.x * re[i], wv.y * im[i]);
+                        const cf Xc = cf_make(Xa.x, -Xa.y);
+                        const cf wt = cmulc(Xa, tw);                           // conj(U) X
+                        buf[(r0 + i) * LS + m] = Xc - wt.yx;                   // conj(X + i conj(U) X)
                         if (m != 0) {
-                            const float2 w2 = cmul(tw, cconj(Xa));
-                            buf[(r0 + i) * LS + N2 - m] = make_float2(Xa.x - w2.y, -(-Xa.y + w2.x));
+                            const cf w2 = cmul(Xc, tw);                        // U conj(X)
+                            buf[(r0 + i) * LS + N2 - m] = Xa - w2.yx;          // conj(conj(X) + i U conj(X))
                         }
                     }
                 }
@@ -453,11 +466,11 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                     const int idx = tid + q * NT;
                     const int r0 = (idx % (RB / 4)) * 4, m = idx / (RB / 4);
                     if (m < mmax) {
-                        const bool live = r0 < nr;
-                        buf[(r0 + 0) * LS + m] = live ? weighted_one<N2>(m, sre[q].x, sim[q].x, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                        buf[(r0 + 1) * LS + m] = live ? weighted_one<N2>(m, sre[q].y, sim[q].y, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                        buf[(r0 + 2) * LS + m] = live ? weighted_one<N2>(m, sre[q].z, sim[q].z, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
-                        buf[(r0 + 3) * LS + m] = live ? weighted_one<N2>(m, sre[q].w, sim[q].w, w_dc, w_pos, w_nyq) : make_float2(0.f, 0.f);
+                        const cf wv = (r0 < nr) ? inverse_weights<N2>(m, w_dc, w_pos, w_nyq) : cf_make(0.f, 0.f);
+                        buf[(r0 + 0) * LS + m] = cf_make(wv.x * sre[q].x, wv.y * sim[q].x);
+                        buf[(r0 + 1) * LS + m] = cf_make(wv.x * sre[q].y, wv.y * sim[q].y);
+                        buf[(r0 + 2) * LS + m] = cf_make(wv.x * sre[q].z, wv.y * sim[q].z);
+                        buf[(r0 + 3) * LS + m] = cf_make(wv.x * sre[q].w, wv.y * sim[q].w);
                     }
                 }
             } else {
@@ -466,17 +479,17 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                     const int idx = tid + q * NT;
                     const int r = idx % RB, m = idx / RB;
                     if (m < mmax) {
-                        float2 X = make_float2(0.f, 0.f);
+                        cf X = cf_make(0.f, 0.f);
                         if (r < nr) {
                             const long long pr = p0 + r;
                             const float* sp = F + ((long long)m * nlat + klat) * 2 * rows + (pr / C) * Cp + (pr % C);
-                            X = weighted_one<N2>(m, sp[0], sp[rows], w_dc, w_pos, w_nyq);
+                            X = cf_make(sp[0], sp[rows]) * inverse_weights<N2>(m, w_dc, w_pos, w_nyq);
                         }
                         buf[r * LS + m] = X;
                     }
                 }
             }
-            for (int idx = tid + mmax * RB; idx < (N2 + 1) * RB; idx += NT) buf[(idx % RB) * LS + idx / RB] = make_float2(0.f, 0.f);
+            for (int idx = tid + mmax * RB; idx < (N2 + 1) * RB; idx += NT) buf[(idx % RB) * LS + idx / RB] = cf_make(0.f, 0.f);
             __syncthreads();
             if (vec && item + 1 < it.end) prefetch(item + 1);      // in flight during the pre-twiddle and the passes
 
@@ -484,26 +497,25 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
             for (int idx = tid; idx < RB * (N2 / 2 + 1); idx += NT) {
                 const int row = idx / (N2 / 2 + 1), j = idx % (N2 / 2 + 1);
                 const int j2 = N2 - j;                         // partner (j = 0 pairs with N2, j = N2/2 with itself)
-                const float2 Xa = buf[row * LS + j], Xb = buf[row * LS + j2];
+                const cf Xa = buf[row * LS + j], Xb = buf[row * LS + j2];
+                const cf ua = add_conj(Xa, Xb), ub = add_conj(Xb, Xa);             // ub = conj(ua)
                 {
-                    const float2 u = cadd(Xa, cconj(Xb)), t = csub(Xa, cconj(Xb));
-                    const float2 wt = cmul(cconj(twu[j]), t);
-                    buf[row * LS + j] = make_float2(u.x - wt.y, -(u.y + wt.x));
+                    const cf wt = cmulc(sub_conj(Xa, Xb), twu[j]);
+                    buf[row * LS + j] = ub - wt.yx;                                // conj(ua + i wt)
                 }
                 if (j != 0 && j2 != j) {
-                    const float2 u = cadd(Xb, cconj(Xa)), t = csub(Xb, cconj(Xa));
-                    const float2 wt = cmul(cconj(twu[j2]), t);
-                    buf[row * LS + j2] = make_float2(u.x - wt.y, -(u.y + wt.x));
+                    const cf wt = cmulc(sub_conj(Xb, Xa), twu[j2]);
+                    buf[row * LS + j2] = ua - wt.yx;
                 }
             }
             __syncthreads();
         }
 
-        auto ld_lds = [&](int row, int pos) -> float2 { return buf[row * LS + pos]; };
-        auto st_lds = [&](int row, int pos, float2 val) { buf[row * LS + pos] = val; };
+        auto ld_lds = [&](int row, int pos) -> cf { return buf[row * LS + pos]; };
+        auto st_lds = [&](int row, int pos, cf val) { buf[row * LS + pos] = val; };
         // the last pass writes its rows straight to global memory (staging them through LDS for 16-byte
         // stores measured 10 % slower: the extra round trip costs more than the narrower stores)
-        auto st_global = [&](int row, int pos, float2 val) {
+        auto st_global = [&](int row, int pos, cf val) {
             long long e = 2 * pos;
             if constexpr (SEG) {
                 // piece j = e / wl by a multiply-shift that is exact for e < 2 N2 <= 2^11 and wl >= 8 (e * wl < 2^24)
@@ -514,8 +526,8 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         };
         if constexpr (PRUNED) {
             const int z0 = mmax, z1 = N2 - mmax;               // never-written (zero) positions, inclusive
-            fft_pass<N2, R1, 1, RB, NT, true>(tw2, [&](int row, int pos) -> float2 {
-                return (pos >= z0 && pos <= z1) ? make_float2(0.f, 0.f) : buf[row * LS + pos];
+            fft_pass<N2, R1, 1, RB, NT, true>(tw2, [&](int row, int pos) -> cf {
+                return (pos >= z0 && pos <= z1) ? cf_make(0.f, 0.f) : buf[row * LS + pos];
             }, st_lds, tid);
         } else {
             fft_pass<N2, R1, 1, RB, NT, true>(tw2, ld_lds, st_lds, tid);
@@ -544,7 +556,7 @@ int launch_inverse(const float* in, T* out, const float2* tw, int C, int Cp, lon
     }
     long long grid = 256ll * per_cu;            // persistent: every workgroup resident, contiguous item ranges
     if (grid > nitems) grid = nitems;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, reinterpret_cast<const cf*>(tw), C, Cp, rows, planes, nlat, mmax, ngr, nitems,
                        w_dc, w_pos, w_nyq, sg);
     return mk_check_launch("mk_irfft_rows(fast)");
 }
@@ -561,7 +573,7 @@ int launch_forward(const T* in, float* out, const float2* tw, int C, int Cp, lon
     }
     long long grid = 256ll * per_cu;
     if (grid > nitems) grid = nitems;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, tw, C, Cp, rows, planes, nlat, mmax, ngr, nitems,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, s, in, out, reinterpret_cast<const cf*>(tw), C, Cp, rows, planes, nlat, mmax, ngr, nitems,
                        w_dc, w_pos, w_nyq, sg);
     return mk_check_launch("mk_rfft_rows(fast)");
 }
