@@ -1,4 +1,3 @@
-# round-3 call 17: packed-fp32 FFT butterflies: FFT / SHT tests, then same-box A/B against the previous library
+# round-3 call 22: dead-row waves skipped (ds) against the same sources without it (pk4) and the earlier build (pk2)
 mkdir -p gpurun_out/r03l
-timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "fft or sht" 2>&1 | tail -5
-timeout 600 python tools/ab.py run base pk -- python tools/microbench.py fft 2>&1 | tee gpurun_out/r03l/ab_fft_packed.txt
+timeout 600 python tools/ab.py run pk2 pk4 ds -- python tools/microbench.py dhconv 2>&1 | grep -v gen1 | tee gpurun_out/r03l/ab_deadrows.txt

@@ -30,8 +30,10 @@ using gemm::validate;
 using namespace xsplit;
 
 constexpr int NT2 = 512;
-// timing diagnostics (tools/ab.py variants; results are WRONG with any of them): 1 = no limb split / LDS stores in the
-// main loop, 2 = no MFMA segment, 3 = no global loads in the main loop
+// timing diagnostics (tools/ab.py variants; results are WRONG with any of them), a bit mask: 1 = no limb split / LDS stores in
+// the main loop, 2 = no MFMA segment, 4 = no global loads in the main loop, 8 = (complex kernel) operand fragments read
+// from LDS in the first k-step only, 16 = (complex kernel) no result stores, 32 = (complex kernel) s_memtime stamps at the
+// segment boundaries of every k-step, summed per wave group into g_x2_diag (read with mk_x2_diag_read; tools/x2_diag.py)
 #ifndef MK_X2_DIAG
 #define MK_X2_DIAG 0
 #endif
@@ -53,6 +55,20 @@ constexpr int NT2 = 512;
 #endif
 #ifndef MK_X2_ILV             // limb products issued round-robin over the independent accumulators
 #define MK_X2_ILV 1
+#endif
+
+#if MK_X2_DIAG & 32
+// [group][0 produce, 1 fragment reads, 2 MFMA segment, 3 barrier, 4 prologue, 5 epilogue, 6 whole kernel, 7 waves]
+__device__ unsigned long long g_x2_diag[2][8];
+#define MK_X2_STAMP(k)                                              \
+    do {                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        dg[k] += t_ - tprev;                                        \
+        tprev = t_;                                                 \
+    } while (0)
+#else
+#define MK_X2_STAMP(k)
 #endif
 
 __device__ __forceinline__ void prio_hi() {
@@ -165,6 +181,7 @@ struct Stage2 {
     static_assert(NV >= 1, "tile too small");
     f32x4 v[NV];
     unsigned keep;              // KC: 4 bits per vector = elements inside [klo, khi), applied when the tile is stored
+    bool interior;              // uniform: the tile lies inside [klo, khi) (then no element masks are applied)
     const float* p0[NV];        // address of every vector at k = 0
     unsigned ok;                // bit q: the row(s) of vector q exist
     long long kstride;          // floats per unit of k
@@ -197,7 +214,7 @@ struct Stage2 {
     template <bool ILV>
     __device__ __forceinline__ void load(int k0, int klo, int khi, int tid) {
         const long long koff = (long long)k0 * kstride;
-        const bool interior = k0 >= klo && k0 + BK <= khi;      // uniform
+        interior = k0 >= klo && k0 + BK <= khi;                 // uniform
         keep = 0u;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -232,35 +249,16 @@ struct Stage2 {
         }
     }
 
-    template <int NP, int PLANE>
-    __device__ static __forceinline__ void split_store(u16* lds, int off, float r0, float r1, float r2, float r3) {
-        float r[4] = {r0, r1, r2, r3};
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            u16 h[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const __bf16 hb = (__bf16)r[e];
-                h[e] = __builtin_bit_cast(u16, hb);
-                r[e] -= (float)hb;
-            }
-            const uint2 pk = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-            *reinterpret_cast<uint2*>(lds + pl * PLANE + off) = pk;
-        }
-    }
-
     // split into NP bf16 limbs and store; limb plane p lives at lds + p * PLANE (elements)
     template <int NP, int PLANE>
     __device__ __forceinline__ void store(u16* lds, int tid, float sign) const {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            float r[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                r[e] = v[q][e] * sign;
-                if constexpr (KC) r[e] = ((keep >> (4 * q + e)) & 1u) ? r[e] : 0.f;
+            f32x4 r = v[q] * sign;
+            if constexpr (KC) {
+                if (!interior) r = mask4(r, keep >> (4 * q));
             }
-            split_store<NP, PLANE>(lds, lds_off(tid + q * NT2), r[0], r[1], r[2], r[3]);
+            split_store4<NP, PLANE>(lds, lds_off(tid + q * NT2), r.xy, r.zw);
         }
     }
 
@@ -269,19 +267,17 @@ struct Stage2 {
     __device__ __forceinline__ void store_ilv(u16* lre, u16* lim, int tid, float sign) const {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            float re[4] = {v[q][0], v[q][2], v2[q][0], v2[q][2]};
-            float im[4] = {v[q][1] * sign, v[q][3] * sign, v2[q][1] * sign, v2[q][3] * sign};
+            f32x4 re = {v[q][0], v[q][2], v2[q][0], v2[q][2]};
+            f32x4 im = f32x4{v[q][1], v[q][3], v2[q][1], v2[q][3]} * sign;
             if constexpr (KC) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool kp = (keep >> (4 * q + e)) & 1u;
-                    re[e] = kp ? re[e] : 0.f;
-                    im[e] = kp ? im[e] : 0.f;
+                if (!interior) {
+                    re = mask4(re, keep >> (4 * q));
+                    im = mask4(im, keep >> (4 * q));
                 }
             }
             const int off = lds_off(tid + q * NT2);
-            split_store<NP, PLANE>(lre, off, re[0], re[1], re[2], re[3]);
-            split_store<NP, PLANE>(lim, off, im[0], im[1], im[2], im[3]);
+            split_store4<NP, PLANE>(lre, off, re.xy, re.zw);
+            split_store4<NP, PLANE>(lim, off, im.xy, im.zw);
         }
     }
 };
@@ -301,6 +297,11 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2, cs = wave & 3;
     const int l31 = lane & 31, lh = lane >> 5;
+#if MK_X2_DIAG & 32
+    unsigned long long dg[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+    const unsigned long long tstart = tprev;
+#endif
     const long long bo = c.b / p.inner, bi = c.b % p.inner;
     const float* Ab = p.A + bo * p.a_batch + bi * p.a_inner;
     const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
@@ -363,12 +364,38 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
             sbi[d].template store<NP, PLB>(Bim, tid, sgn_b);
         }
     };
+#if MK_X2_DIAG & 8
+    bf16x8 d_br[NP], d_bim[NP], d_ar[2][NP], d_ai[2][NP];
+    bool d_have = false;
+#endif
     auto compute = [&](int buf) {
         const u16* Are = smem + buf * STG;
         const u16* Aim = Are + NP * PLA;
         const u16* Bre = Aim + NP * PLA;
         const u16* Bim = Bre + NP * PLB;
         if (!live[0]) return;                               // row tile g + 2 is dead whenever row tile g is
+#if MK_X2_DIAG & 8
+        if (!d_have) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                d_br[pl] = frag<BN, B_KC>(Bre + pl * PLB, cs * 32, lane);
+                d_bim[pl] = frag<BN, B_KC>(Bim + pl * PLB, cs * 32, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    d_ar[j][pl] = frag<BM, A_KC>(Are + pl * PLA, (grp + 2 * j) * 32, lane);
+                    d_ai[j][pl] = frag<BM, A_KC>(Aim + pl * PLA, (grp + 2 * j) * 32, lane);
+                }
+            }
+            d_have = true;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!live[j]) continue;
+            prio_hi();
+            cmma_split<NP>(d_ar[j], d_ai[j], d_br, d_bim, cre[j], cng[j], cim[j]);
+            prio_lo();
+        }
+#else
         bf16x8 br[NP], bim[NP];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
@@ -385,14 +412,17 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
                 ai[pl] = frag<BM, A_KC>(Aim + pl * PLA, (grp + 2 * j) * 32, lane);
             }
             // (ar + i ai)(br + i bi): re = ar br - ai bi (second part accumulated apart), im = ar bi + ai br
+            MK_X2_STAMP(1);
             prio_hi();
             cmma_split<NP>(ar, ai, br, bim, cre[j], cng[j], cim[j]);
             prio_lo();
+            MK_X2_STAMP(2);
         }
+#endif
     };
     auto produce = [&](auto set, int i) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
-        if (MK_X2_DIAG != 1 && i + 1 < nk) st(set, (i + 1) & 1);
-        if (MK_X2_DIAG != 3 && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
+        if (!(MK_X2_DIAG & 1) && i + 1 < nk) st(set, (i + 1) & 1);
+        if (!(MK_X2_DIAG & 4) && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
     };
 
     using S0 = std::integral_constant<int, 0>;
@@ -406,22 +436,33 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
     __syncthreads();
     auto step = [&](auto set, int i) {
 #if MK_X2_MIDBAR
-        if (grp == 0) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+        if (grp == 0) { if (!(MK_X2_DIAG & 2)) compute(i & 1); } else produce(set, i);
         __syncthreads();
-        if (grp == 1) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+        if (grp == 1) { if (!(MK_X2_DIAG & 2)) compute(i & 1); } else produce(set, i);
 #else
         // one barrier per k-step; the groups run the two segments in opposite order, so that on every SIMD one wave
-        // starts on the matrix pipe while its partner starts on the VALU / memory path
+        // starts on the matrix pipe while its partner starts on the VALU / memory path.
+        // (`grp` is a per-lane value to the compiler, so the two orders are laid out one after the other under exec masks;
+        // hipcc's wait-count pass then takes the loads of the masked-off path for the newest ones in flight on the same
+        // staging registers and every split waits for ALL loads in flight (vmcnt(3..0)): the effective prefetch distance is
+        // one k-step.  Branching on readfirstlane(grp) gives exact counts but the register allocator then spills the
+        // accumulators (384-612 bytes of scratch in every instantiation); making split and loads unconditional (main loop
+        // without the last step) removes one vmcnt(0) per step and measured 16 % SLOWER.  The kernel is bound by the bytes a
+        // CU ingests per clock: 32 KB per k-step against 3072 MFMA cycles per SIMD, tools/x2_diag.py)
         if (grp == 0) {
             produce(set, i);
-            if (MK_X2_DIAG != 2) compute(i & 1);
+            MK_X2_STAMP(0);
+            if (!(MK_X2_DIAG & 2)) compute(i & 1);
         } else {
-            if (MK_X2_DIAG != 2) compute(i & 1);
+            if (!(MK_X2_DIAG & 2)) compute(i & 1);
             produce(set, i);
+            MK_X2_STAMP(0);
         }
 #endif
         __syncthreads();
+        MK_X2_STAMP(3);
     };
+    MK_X2_STAMP(4);
     for (int i = 0; i < nk; i += 2) {                       // step i splits tile i + 1, which rides in set (i + 1) % D
         step(S1{}, i);
         if (i + 1 < nk) step(S0{}, i + 1);
@@ -435,7 +476,7 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = c.i0 + (grp + 2 * j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < c.Meff && col < p.N) {
+            if (row < c.Meff && col < p.N && (!(MK_X2_DIAG & 16) || p.K == -12345)) {
                 float* dr = Cb + (long long)row * p.c_row + (long long)col * p.c_col;
                 float* di = dr + p.c_im;
                 float vr = cre[j][r] - cng[j][r], vi = cim[j][r];
@@ -452,6 +493,16 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
             }
         }
     }
+#if MK_X2_DIAG & 32
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MK_X2_STAMP(5);
+    dg[6] = tprev - tstart;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_x2_diag[grp][k], dg[k]);
+        atomicAdd(&g_x2_diag[grp][7], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -574,8 +625,8 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
         }
     };
     auto produce = [&](auto set, int i) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
-        if (MK_X2_DIAG != 1 && i + 1 < nk) st(set, (i + 1) & 1);
-        if (MK_X2_DIAG != 3 && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
+        if (!(MK_X2_DIAG & 1) && i + 1 < nk) st(set, (i + 1) & 1);
+        if (!(MK_X2_DIAG & 4) && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
     };
 
     using S0 = std::integral_constant<int, 0>;
@@ -589,17 +640,17 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     __syncthreads();
     auto step = [&](auto set, int i) {
 #if MK_X2_MIDBAR
-        if (grp == 0) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+        if (grp == 0) { if (!(MK_X2_DIAG & 2)) compute(i & 1); } else produce(set, i);
         __syncthreads();
-        if (grp == 1) { if (MK_X2_DIAG != 2) compute(i & 1); } else produce(set, i);
+        if (grp == 1) { if (!(MK_X2_DIAG & 2)) compute(i & 1); } else produce(set, i);
 #else
         // one barrier per k-step; the groups run the two segments in opposite order, so that on every SIMD one wave
         // starts on the matrix pipe while its partner starts on the VALU / memory path
         if (grp == 0) {
             produce(set, i);
-            if (MK_X2_DIAG != 2) compute(i & 1);
+            if (!(MK_X2_DIAG & 2)) compute(i & 1);
         } else {
-            if (MK_X2_DIAG != 2) compute(i & 1);
+            if (!(MK_X2_DIAG & 2)) compute(i & 1);
             produce(set, i);
         }
 #endif
@@ -672,6 +723,17 @@ int launch_cplx2(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t 
 }
 
 }  // namespace
+
+#if MK_X2_DIAG & 32
+extern "C" int mk_x2_diag_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x2_diag), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_x2_diag), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream) {
     bool a_kc, b_kc, b_ilv;

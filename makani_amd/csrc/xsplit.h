@@ -13,6 +13,41 @@ constexpr int PK = 24;   // pitch (elements) of [row][k] limb tiles: 48 B -> con
 
 __device__ __forceinline__ bool in_range(int k, int lo, int hi) { return k >= lo && k < hi; }
 
+// ---- the limb split on packed instructions ---------------------------------------------------------------------------
+// Four consecutive fp32 values (two register pairs) -> NP bf16 limbs each, limb p of the four as one 8-byte LDS store in
+// plane p.  Per pair and limb: one v_cvt_pk_bf16_f32 (round to nearest even, result already packed for the store), two
+// integer instructions that widen the two limbs back to fp32, one v_pk_add_f32 for the residual: 5 VALU instructions per
+// value for three limbs.  The element-at-a-time form of the same arithmetic compiled to 9 (one conversion per element
+// with the second source unused, scalar subtractions, a re-pack) and dominated the engines, which are bound by VALU issue.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t limb_pair(f32x2 a) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2)); }
+__device__ __forceinline__ f32x2 widen_pair(uint32_t p) {
+    const f32x2 r = {__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)};
+    return r;
+}
+
+template <int NP, int PLANE>
+__device__ __forceinline__ void split_store4(u16* lds, int off, f32x2 a, f32x2 b) {
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        const uint32_t pa = limb_pair(a), pb = limb_pair(b);
+        *reinterpret_cast<uint2*>(lds + pl * PLANE + off) = make_uint2(pa, pb);
+        if (pl + 1 < NP) {
+            a -= widen_pair(pa);
+            b -= widen_pair(pb);
+        }
+    }
+}
+
+// element masks of a vector (4 bits of `keep`): only tiles cut by the contraction range carry them
+__device__ __forceinline__ f32x4 mask4(f32x4 r, unsigned bits) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = ((bits >> e) & 1u) ? r[e] : 0.f;
+    return r;
+}
+
 // fp32 tile staging registers (same addressing as sgemm.hip's TileStage)
 template <int ROWS, bool KC, int NT = 256>
 struct Stage {
@@ -21,6 +56,7 @@ struct Stage {
     f32x4 v[NV];
     unsigned keep;      // KC: 4 bits per vector = elements inside [klo, khi); applied when the tile is stored, NOT
                         // on the freshly loaded registers (that would put an s_waitcnt right behind every load)
+    bool interior;      // uniform: the tile lies inside [klo, khi), no element masks to apply
     // loop-invariant addressing, set up once per tile by init(): pointer of every vector at k = 0 and whether its
     // row exists.  Inside the k-loop a load is then "pointer + uniform offset" (the 64-bit index arithmetic and the
     // row checks done per load used to cost as much as a third of the kernel)
@@ -81,7 +117,8 @@ struct Stage {
     __device__ __forceinline__ void load_ilv(Stage& im, int k0, int klo, int khi, int tid) {
         const long long koff = (long long)k0 * kstride;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        if (k0 >= klo && k0 + BK <= khi) {
+        interior = im.interior = k0 >= klo && k0 + BK <= khi;
+        if (interior) {
             keep = im.keep = 0xffffffffu;
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
@@ -118,7 +155,8 @@ struct Stage {
     // tile [k0, k0 + BK) of the operand, zero outside [klo, khi)
     __device__ __forceinline__ void load(int k0, int klo, int khi, int tid) {
         const long long koff = (long long)k0 * kstride;                 // uniform
-        if (k0 >= klo && k0 + BK <= khi) {                              // interior tile (uniform branch)
+        interior = k0 >= klo && k0 + BK <= khi;
+        if (interior) {                                                 // interior tile (uniform branch)
             keep = 0xffffffffu;
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
@@ -167,24 +205,11 @@ struct Stage {
                 const int kk = f / RQ, rq = f % RQ;
                 off = kk * PR + rq * 4;
             }
-            float r[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                r[e] = v[q][e] * sign;
-                if constexpr (KC) r[e] = ((keep >> (4 * q + e)) & 1u) ? r[e] : 0.f;
+            f32x4 r = v[q] * sign;
+            if constexpr (KC) {
+                if (!interior) r = mask4(r, keep >> (4 * q));
             }
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                u16 h[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const __bf16 hb = (__bf16)r[e];
-                    h[e] = __builtin_bit_cast(u16, hb);
-                    r[e] -= (float)hb;
-                }
-                const uint2 pk = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<uint2*>(lds + pl * PLANE + off) = pk;
-            }
+            split_store4<NP, PLANE>(lds, off, r.xy, r.zw);
         }
     }
 };
