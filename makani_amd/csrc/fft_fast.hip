@@ -2,11 +2,10 @@
 //
 // Same contract as the generic kernels in fft.hip, but everything that decides speed is a
 // compile-time constant:
-//   * the complex length N2 = nlon/2 is factored into 2-3 LARGE radices (720 = 10*9*8,
-//     240 = 10*6*4) whose butterflies run entirely in registers (Dft<R>, fft_common.h), so a row
+//   * the complex length N2 = nlon/2 is factored into 2-3 LARGE radices (720 = 30*24,
+//     240 = 10*6*4) whose butterflies run entirely in registers (PDft<R>, fft_packed.h), so a row
 //     crosses LDS only between passes (in place: read -> barrier -> write);
-//   * the first pass of the forward transform reads its operands straight from global memory and
-//     the last pass of the inverse transform writes rows straight to global memory;
+//   * the last pass of the inverse transform writes rows straight to global memory;
 //   * index arithmetic is by constants, loops are fully unrolled;
 //   * persistent workgroups own a CONTIGUOUS range of (plane, latitude-group) items, so the
 //     RB-float runs they write to / read from the lat-major F-layout are adjacent in time and
@@ -16,6 +15,14 @@
 #include <stdlib.h>
 
 #include "fft_packed.h"
+
+// 1440 points as TWO passes (720 = 30 x 24, both radices in registers) instead of three (10 x 9 x 8): a quarter less LDS
+// traffic and one barrier pair less per item; same box: rfft 0.529 -> 0.491 ms, irfft 0.461 -> 0.431 (profiles/r03_ab_fft_2pass.txt).
+// The same idea at 480 points (240 = 16 x 15) helps the forward kernel by 3 % and costs the inverse 22 % (its last pass stores
+// straight to global memory, and with 16 instead of 60 consecutive lanes per run the stores fall apart): not taken.
+#ifndef MK_FFT_1440_2PASS
+#define MK_FFT_1440_2PASS 1
+#endif
 
 namespace {
 
@@ -644,7 +651,11 @@ int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, con
         // forcing 3 workgroups/CU on the 8-row forward 1440 kernel spills (2.6x slower)
         // 16 rows / 512 threads, one workgroup per CU: the F side is touched in 64-byte runs (8 rows / 256 threads,
         // two workgroups per CU: 14-16 % slower)
+#if MK_FFT_1440_2PASS
+        case 1440: return launch<720, 30, 24, 1, 16, 512, 1>(MK_FFT_ARGS);
+#else
         case 1440: return launch<720, 10, 9, 8, 16, 512, 1>(MK_FFT_ARGS);
+#endif
         case 480: return launch<240, 10, 6, 4, 32, 512, 2>(MK_FFT_ARGS);   // 32 rows: whole 128-byte lines on the F side (irfft +7 %)
         // FourCastNet3's internal grid (360 x 720, full spectrum mmax = 361: fourcastnet3.py:503-504); round 2 ran it on the
         // generic kernel at 0.11 of the HBM rate

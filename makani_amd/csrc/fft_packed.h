@@ -106,10 +106,11 @@ struct PDft {
     __host__ __device__ static constexpr int loc(int o) { return o; }
 };
 
+// RA and RB may themselves be composite (PDft<RA> / PDft<RB> report where their output bins end up)
 template <int RA, int RB>
 struct PDftComp {
     static constexpr int R = RA * RB;
-    __host__ __device__ static constexpr int loc(int o) { return RB * (o % RA) + (o / RA); }
+    __host__ __device__ static constexpr int loc(int o) { return RB * (o % RA) + PDft<RB>::loc(o / RA); }
     __device__ static __forceinline__ void run(cf* v) {
         // n = RB*a + b, k = k1 + RA*k2
 #pragma unroll
@@ -117,9 +118,9 @@ struct PDftComp {
             cf t[RA];
 #pragma unroll
             for (int a = 0; a < RA; ++a) t[a] = v[RB * a + b];
-            pdft_small<RA>(t);
+            PDft<RA>::run(t);
 #pragma unroll
-            for (int k1 = 0; k1 < RA; ++k1) v[RB * k1 + b] = t[k1];
+            for (int k1 = 0; k1 < RA; ++k1) v[RB * k1 + b] = t[PDft<RA>::loc(k1)];
         }
 #pragma unroll
         for (int k1 = 1; k1 < RA; ++k1)
@@ -127,7 +128,7 @@ struct PDftComp {
             for (int b = 1; b < RB; ++b)
                 v[RB * k1 + b] = cmul_const(v[RB * k1 + b], RootTable<R>::re[(b * k1) % R], RootTable<R>::im[(b * k1) % R]);
 #pragma unroll
-        for (int k1 = 0; k1 < RA; ++k1) pdft_small<RB>(v + RB * k1);
+        for (int k1 = 0; k1 < RA; ++k1) PDft<RB>::run(v + RB * k1);
     }
 };
 template <> struct PDft<6> : PDftComp<2, 3> {};
@@ -137,3 +138,7 @@ template <> struct PDft<10> : PDftComp<2, 5> {};
 template <> struct PDft<12> : PDftComp<3, 4> {};
 template <> struct PDft<15> : PDftComp<3, 5> {};
 template <> struct PDft<16> : PDftComp<4, 4> {};
+template <> struct PDft<18> : PDftComp<2, 9> {};
+template <> struct PDft<20> : PDftComp<4, 5> {};
+template <> struct PDft<24> : PDftComp<4, 6> {};
+template <> struct PDft<30> : PDftComp<5, 6> {};
