@@ -228,6 +228,10 @@ struct RowVec<u16> {
     static constexpr int PAIRS = 4;
 };
 
+// WGS: the second __launch_bounds__ argument, which in HIP is the minimum number of WAVES per SIMD (not workgroups per CU).
+// For the 256-thread kernels the two coincide; the 512-thread 480-point kernel asks for 2 and therefore runs ONE workgroup per
+// CU (130 / 169 registers).  Asking for 4 (two workgroups per CU, 128 registers) was measured: forward bf16 0.076 -> 0.071 ms,
+// everything else spills (inverse bf16 0.083 -> 0.103 ms): profiles/r03_ab_fft_launch_bounds.txt
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 __global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
                                                             const cf* __restrict__ tw_g, int C, int Cp,
