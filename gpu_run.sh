@@ -1,3 +1,4 @@
-# round-3 call 26: 480-point FFT with two workgroups per CU actually requested (launch bounds = waves per SIMD)
-mkdir -p gpurun_out/r03m
-timeout 600 python tools/ab.py run cur lb -- python tools/microbench.py fft 2>&1 | tee gpurun_out/r03m/ab_fft_lb.txt
+# round-3 call 27: final bench line + rocprofv3 kernel trace + PMC passes of the default bench command
+bash tools/profile_round.sh r03n > gpurun_out/r03n_profile.log 2>&1
+tail -3 gpurun_out/r03n_profile.log
+grep '^{' gpurun_out/r03n/bench.json | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline'], d['parity_rel_l2'])"
