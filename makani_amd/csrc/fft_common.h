@@ -1,7 +1,6 @@
 // Shared device helpers of the FFT kernels (gfx950).
 #pragma once
 #include "common.h"
-#include "fft_consts.h"
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -77,48 +76,3 @@ template <>
 __device__ __forceinline__ void store_pair<u16>(u16* p, float a, float b) {
     *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
 }
-
-
-// ---- in-register DFTs of composite size (Cooley-Tukey on two small factors) ----------------
-// Dft<R>::run(v) transforms v[0..R) in place; output bin o ends up at v[Dft<R>::loc(o)].
-template <int R>
-struct Dft {
-    __device__ static __forceinline__ void run(float2* v) { dft_small<R>(v); }
-    __host__ __device__ static constexpr int loc(int o) { return o; }
-};
-
-template <int RA, int RB>
-struct DftComp {
-    static constexpr int R = RA * RB;
-    __host__ __device__ static constexpr int loc(int o) { return RB * (o % RA) + (o / RA); }
-    __device__ static __forceinline__ void run(float2* v) {
-        // n = RB*a + b, k = k1 + RA*k2
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            float2 t[RA];
-#pragma unroll
-            for (int a = 0; a < RA; ++a) t[a] = v[RB * a + b];
-            dft_small<RA>(t);
-#pragma unroll
-            for (int k1 = 0; k1 < RA; ++k1) v[RB * k1 + b] = t[k1];
-        }
-#pragma unroll
-        for (int k1 = 1; k1 < RA; ++k1)
-#pragma unroll
-            for (int b = 1; b < RB; ++b) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const float2 w = make_float2(RootTable<R>::re[(b * k1) % R], RootTable<R>::im[(b * k1) % R]);
-                v[RB * k1 + b] = cmul(v[RB * k1 + b], w);
-            }
-#pragma unroll
-        for (int k1 = 0; k1 < RA; ++k1) dft_small<RB>(v + RB * k1);
-    }
-};
-template <> struct Dft<6> : DftComp<2, 3> {};
-template <> struct Dft<8> : DftComp<2, 4> {};
-template <> struct Dft<9> : DftComp<3, 3> {};
-template <> struct Dft<10> : DftComp<2, 5> {};
-template <> struct Dft<12> : DftComp<3, 4> {};
-template <> struct Dft<15> : DftComp<3, 5> {};
-template <> struct Dft<16> : DftComp<4, 4> {};

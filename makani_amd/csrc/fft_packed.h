@@ -10,11 +10,12 @@
 //   * real constants (radix-3 / radix-5 butterflies) multiply both halves in one instruction.
 // hipcc folds whole-vector negations and half swaps of a two-float vector into the instruction's modifiers, but not the
 // negation of ONE half, so the two products that need it are inline assembly; everything else is plain vector code.
-// The struct-of-two-floats form of the same butterflies (fft_common.h, still used by the generic kernels) reaches the
+// The struct-of-two-floats form of the same butterflies (fft_common.h: the generic kernels' radix 2-5) reaches the
 // packed instructions only through the SLP vectoriser, which pairs unrelated scalars and pays for it in register moves:
 // 1 003 packed + 400 scalar floating-point instructions + 676 v_mov in the 1440-point forward kernel.
 #pragma once
 #include "fft_common.h"
+#include "fft_consts.h"
 
 typedef float cf __attribute__((ext_vector_type(2)));       // (re, im)
 
@@ -99,7 +100,8 @@ __device__ __forceinline__ void pdft_small<5>(cf* v) {
     v[3] = sub_mi(p2, q2);
 }
 
-// ---- in-register DFTs of composite size (Cooley-Tukey on two small factors), as Dft<R> in fft_common.h ----------------
+// ---- in-register DFTs of composite size (Cooley-Tukey on two factors) ------------------------------------------------
+// PDft<R>::run(v) transforms v[0..R) in place; output bin o ends up at v[PDft<R>::loc(o)].
 template <int R>
 struct PDft {
     __device__ static __forceinline__ void run(cf* v) { pdft_small<R>(v); }
@@ -132,13 +134,6 @@ struct PDftComp {
     }
 };
 template <> struct PDft<6> : PDftComp<2, 3> {};
-template <> struct PDft<8> : PDftComp<2, 4> {};
-template <> struct PDft<9> : PDftComp<3, 3> {};
 template <> struct PDft<10> : PDftComp<2, 5> {};
-template <> struct PDft<12> : PDftComp<3, 4> {};
-template <> struct PDft<15> : PDftComp<3, 5> {};
-template <> struct PDft<16> : PDftComp<4, 4> {};
-template <> struct PDft<18> : PDftComp<2, 9> {};
-template <> struct PDft<20> : PDftComp<4, 5> {};
 template <> struct PDft<24> : PDftComp<4, 6> {};
 template <> struct PDft<30> : PDftComp<5, 6> {};
