@@ -1,4 +1,4 @@
-# round-3 call 27: final bench line + rocprofv3 kernel trace + PMC passes of the default bench command
-bash tools/profile_round.sh r03n > gpurun_out/r03n_profile.log 2>&1
-tail -3 gpurun_out/r03n_profile.log
-grep '^{' gpurun_out/r03n/bench.json | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline'], d['parity_rel_l2'])"
+# round-3 call 28: full GPU suite + smoke on the final library (two-pass 1440-point FFT, trimmed headers)
+mkdir -p gpurun_out/r03o
+timeout 1500 python -m pytest tests -q -x -m gpu --durations=5 2>&1 | tail -12 | tee gpurun_out/r03o/gpu_suite_tail.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee -a gpurun_out/r03o/gpu_suite_tail.txt
