@@ -1,4 +1,4 @@
-# round-3 call 28: full GPU suite + smoke on the final library (two-pass 1440-point FFT, trimmed headers)
-mkdir -p gpurun_out/r03o
-timeout 1500 python -m pytest tests -q -x -m gpu --durations=5 2>&1 | tail -12 | tee gpurun_out/r03o/gpu_suite_tail.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee -a gpurun_out/r03o/gpu_suite_tail.txt
+# round-3 call 29: complex split kernel with one loop per wave group (exact wait counts, two k-steps of prefetch distance)
+mkdir -p gpurun_out/r03p
+MAKANI_AMD_LIB=$PWD/makani_amd/libmakani_amd_tl.so timeout 300 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_headline.py -q -x -m gpu -k "cgemm or dhconv or contract or spectral" 2>&1 | tail -3
+timeout 300 python tools/ab.py run cur tl -- python tools/microbench.py dhconv 2>&1 | grep -v gen1 | tee gpurun_out/r03p/ab_twoloops.txt

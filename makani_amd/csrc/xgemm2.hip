@@ -446,9 +446,12 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
         // hipcc's wait-count pass then takes the loads of the masked-off path for the newest ones in flight on the same
         // staging registers and every split waits for ALL loads in flight (vmcnt(3..0)): the effective prefetch distance is
         // one k-step.  Branching on readfirstlane(grp) gives exact counts but the register allocator then spills the
-        // accumulators (384-612 bytes of scratch in every instantiation); making split and loads unconditional (main loop
-        // without the last step) removes one vmcnt(0) per step and measured 16 % SLOWER.  The kernel is bound by the bytes a
-        // CU ingests per clock: 32 KB per k-step against 3072 MFMA cycles per SIMD, tools/x2_diag.py)
+        // accumulators (384-612 bytes of scratch in every instantiation).  ONE LOOP PER GROUP (if (grp == 0) { loop of
+        // produce, compute, barrier } else { loop of compute, produce, barrier }, split and loads unconditional) gives exact
+        // counts without spilling — vmcnt(7, 7, 6, 5, 4): only the set requested one step ago may still be in flight, a true
+        // distance of two k-steps — and runs at the same speed (dhconv fwd 0.281 -> 0.275 ms, wgrad 0.237 -> 0.241,
+        // profiles/r03_ab_twoloops.txt): the wait in front of the split is not latency, the kernel is bound by the bytes a
+        // CU ingests per clock (32 KB per k-step against 3072 MFMA cycles per SIMD, tools/x2_diag.py))
         if (grp == 0) {
             produce(set, i);
             MK_X2_STAMP(0);
