@@ -53,6 +53,9 @@ constexpr int NT2 = 512;
 #ifndef MK_X2_DEPTH_R
 #define MK_X2_DEPTH_R 1
 #endif
+#ifndef MK_X2_WGRAD_NT         // interleaved-complex results (the dhconv weight gradient, read again only by the optimizer at the end
+#define MK_X2_WGRAD_NT 1      // of the step) leave with non-temporal stores: 0.227 -> 0.223 ms, and 283 MB less cache turnover per launch
+#endif
 #ifndef MK_X2_ILV             // limb products issued round-robin over the independent accumulators
 #define MK_X2_ILV 1
 #endif
@@ -488,7 +491,12 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
                     vi += *di;
                 }
                 if (p.c_col == 2) {          // interleaved complex C: one 8-byte store per entry
+#if MK_X2_WGRAD_NT
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(f32x2_t{vr, vi}, reinterpret_cast<f32x2_t*>(dr));
+#else
                     *reinterpret_cast<float2*>(dr) = make_float2(vr, vi);
+#endif
                 } else {
                     *dr = vr;
                     *di = vi;
