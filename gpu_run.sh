@@ -1,4 +1,4 @@
-# round-3 call 41: full GPU suite + smoke on the final library
-mkdir -p gpurun_out/r03r
-timeout 1500 python -m pytest tests -q -x -m gpu --durations=5 2>&1 | tail -12 | tee gpurun_out/r03r/gpu_suite_tail.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee -a gpurun_out/r03r/gpu_suite_tail.txt
+# round-3 call 42: FourCastNet3 bench line on the final library
+mkdir -p gpurun_out/r03s
+timeout 400 python bench.py --config fcn3_sc2_edim45_layers10 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r03s/bench_fcn3.json 2> gpurun_out/r03s/bench_fcn3.err
+grep '^{' gpurun_out/r03s/bench_fcn3.json | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('peak_hbm_GB'))"
