@@ -250,3 +250,22 @@ def test_precomputed_convolution_tensor_is_that_quadrature_sum():
         got = torch.zeros(9, dtype=torch.float64).index_add_(0, idx[0][sel], vals[sel] * u[idx[2][sel]]).numpy()
         ref = _discrete_convolution(fb, float(lats[t]), 46, 90, 1.001 * cutoff, "equiangular")
         assert np.abs(got - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("gi,go", [("legendre-gauss", "equiangular"), ("equiangular", "legendre-gauss")])
+def test_resample_converges_to_the_field_it_interpolates(gi, go):
+    """ResampleS2 (bilinear) of a smooth analytic field sampled on the input grid approaches the field's values on the output
+    grid with second order in the input spacing (error / 4 per refinement), poles included (the Gauss grid has no polar rows:
+    the pole extension supplies them).  FourCastNet3's decoder direction is Gauss 360 x 720 -> equiangular 721 x 1440."""
+    def field(nlat, nlon, grid):
+        lats, _ = precompute_latitudes(nlat, grid)
+        la = torch.from_numpy(lats)[:, None]
+        lo = torch.linspace(0, 2 * math.pi, nlon + 1, dtype=torch.float64)[:-1][None, :]
+        return _smooth_field(torch.sin(la) * torch.cos(lo), torch.sin(la) * torch.sin(lo), torch.cos(la).expand(-1, nlon))
+    errs = []
+    for n in (23, 45, 90):
+        nin, nout = (n, 2 * n), (2 * n + 1, 4 * n)
+        m = od.ResampleS2(*nin, *nout, grid_in=gi, grid_out=go).double()
+        got = m(field(*nin, gi).view(1, 1, *nin))[0, 0]
+        errs.append(float((got - field(*nout, go)).abs().max()))
+    assert errs[2] < 2e-3 and errs[1] < errs[0] / 3.0 and errs[2] < errs[1] / 3.0, errs
