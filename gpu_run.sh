@@ -1,4 +1,4 @@
-# round-3 call 42: FourCastNet3 bench line on the final library
+# round-3 call 43: forward 480-point bf16 FFT with two workgroups per CU, same box
 mkdir -p gpurun_out/r03s
-timeout 400 python bench.py --config fcn3_sc2_edim45_layers10 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r03s/bench_fcn3.json 2> gpurun_out/r03s/bench_fcn3.err
-grep '^{' gpurun_out/r03s/bench_fcn3.json | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('peak_hbm_GB'))"
+MAKANI_AMD_LIB=$PWD/makani_amd/libmakani_amd_occ.so timeout 300 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "fft" 2>&1 | tail -2
+timeout 300 python tools/ab.py run cur occ -- python tools/microbench.py fft cold 2>&1 | grep "rfft" | grep -v irfft | tee gpurun_out/r03s/ab_fft_occ.txt

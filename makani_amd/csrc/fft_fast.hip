@@ -23,6 +23,9 @@
 #ifndef MK_FFT_1440_2PASS
 #define MK_FFT_1440_2PASS 1
 #endif
+#ifndef MK_FFT_480_FWD_OCC     // the forward 480-point bf16 kernel limited to 128 registers = two workgroups per CU (see WGS below):
+#define MK_FFT_480_FWD_OCC 1    // 75 -> 71 us; the other 480-point instantiations spill at 128 registers and keep one workgroup
+#endif
 
 namespace {
 
@@ -230,10 +233,11 @@ struct RowVec<u16> {
 
 // WGS: the second __launch_bounds__ argument, which in HIP is the minimum number of WAVES per SIMD (not workgroups per CU).
 // For the 256-thread kernels the two coincide; the 512-thread 480-point kernel asks for 2 and therefore runs ONE workgroup per
-// CU (130 / 169 registers).  Asking for 4 (two workgroups per CU, 128 registers) was measured: forward bf16 0.076 -> 0.071 ms,
-// everything else spills (inverse bf16 0.083 -> 0.103 ms): profiles/r03_ab_fft_launch_bounds.txt
+// CU (130 / 169 registers).  Asking for 4 (two workgroups per CU, 128 registers) was measured: forward bf16 0.076 -> 0.071 ms
+// (taken for exactly that instantiation, MK_FFT_480_FWD_OCC), everything else spills (inverse bf16 0.083 -> 0.103 ms):
+// profiles/r03_ab_fft_launch_bounds.txt
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
-__global__ __launch_bounds__(NT, WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
+__global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) == 2 && !SEG) ? 4 : WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
                                                             const cf* __restrict__ tw_g, int C, int Cp,
                                                             long long rows, long long planes, int nlat, int mmax,
                                                             int ngr, long long nitems, float w_dc, float w_pos,
