@@ -489,7 +489,7 @@ def run_worker(args):
     device = torch.device("cuda", local)
     if world > 1:
         import datetime
-        to = datetime.timedelta(seconds=int(os.environ.get("MAKANI_AMD_BENCH_PG_TIMEOUT", "300")))
+        to = datetime.timedelta(seconds=int(os.environ.get("MAKANI_AMD_BENCH_PG_TIMEOUT", "150")))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device, timeout=to)
         else:
@@ -784,7 +784,7 @@ def launch(args):
     base_port = int(os.environ.get("MASTER_PORT", "0")) if under_torchrun else 0
     head = args.parallelism if args.parallelism != "auto" else default_parallelism(world, args.config)
     phases = [head] + (["dp"] if (head != "dp" and not args.no_secondary) else [])
-    timeout_s = int(os.environ.get("MAKANI_AMD_BENCH_PHASE_TIMEOUT", "600"))
+    timeout_s = int(os.environ.get("MAKANI_AMD_BENCH_PHASE_TIMEOUT", "360"))
     results, errors = {}, {}
     if under_torchrun:                         # the copies of this script agree on each phase's outcome over a host-side group
         import datetime
