@@ -1,4 +1,3 @@
-# round-3 call 43: forward 480-point bf16 FFT with two workgroups per CU, same box
+# round-3 call 45: final library: the 384-channel block tests (240x480, bf16 + fp32) and the ragged distributed split
 mkdir -p gpurun_out/r03s
-MAKANI_AMD_LIB=$PWD/makani_amd/libmakani_amd_occ.so timeout 300 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "fft" 2>&1 | tail -2
-timeout 300 python tools/ab.py run cur occ -- python tools/microbench.py fft cold 2>&1 | grep "rfft" | grep -v irfft | tee gpurun_out/r03s/ab_fft_occ.txt
+timeout 400 python -m pytest tests/test_gpu_headline.py tests/test_gpu_distributed.py -q -x -m gpu -k "block_240x480 or ragged" 2>&1 | tail -3 | tee gpurun_out/r03s/final_subset2.txt
