@@ -1,3 +1,3 @@
-# round-3 call 45: final library: the 384-channel block tests (240x480, bf16 + fp32) and the ragged distributed split
+# round-3 call 46: CRPS kernels with five instead of thirteen compiled ensemble capacities
 mkdir -p gpurun_out/r03s
-timeout 400 python -m pytest tests/test_gpu_headline.py tests/test_gpu_distributed.py -q -x -m gpu -k "block_240x480 or ragged" 2>&1 | tail -3 | tee gpurun_out/r03s/final_subset2.txt
+timeout 400 python -m pytest tests/test_crps.py tests/test_losses.py tests/test_fcn3.py -q -x -m gpu 2>&1 | tail -3 | tee gpurun_out/r03s/crps_tests.txt
