@@ -16,8 +16,7 @@
 // exactly as the reference's loop does (same branch conditions), optionally with per-member ensemble weights; its gradient
 // is the derivative of that loop with respect to the sorted members, scattered back through the ranks.
 // Ensemble sizes: every E in 2..32 — the kernels are instantiated for EM in {2, 4, 8, 16, 32} and run any E <= EM with the
-// surplus members predicated off (thirteen capacities were instantiated at first: 7.5 of the library's 8 minutes of build time
-// went into this file's fully unrolled O(EM^2) loops).
+// surplus members predicated off.
 #include "common.h"
 
 namespace {
@@ -238,27 +237,36 @@ __global__ __launch_bounds__(CNT) void crps_cplx_kernel(const float2* __restrict
         float2 o = op[p];
         const bool masked = (o.x != o.x) || (o.y != o.y);
         if (masked) o = make_float2(0.f, 0.f);
+        // Branch-free and every unordered pair once (the two ordered pairs contribute the same distance and opposite
+        // gradients): members e >= E carry the mask 0.  The first version walked the E^2 ordered pairs under `j < E && j != e`
+        // and `rr > 0` branches; fully unrolled at 32 members that was 1 024 conditional blocks, and hipcc spent five of the
+        // library's seven minutes of build time on this one kernel.
         float skill = 0.f, spread = 0.f;
         float2 g[EM];
+        float mk[EM];
 #pragma unroll
         for (int e = 0; e < EM; ++e) {
-            g[e] = make_float2(0.f, 0.f);
-            if (e < E) {
-                const float dx = v[e].x - o.x, dy = v[e].y - o.y;
-                const float r = sqrtf(dx * dx + dy * dy);
-                skill += r;
-                if (GRAD && r > 0.f) g[e] = make_float2(dx / r * inv_e, dy / r * inv_e);
+            mk[e] = (e < E) ? 1.f : 0.f;
+            const float dx = v[e].x - o.x, dy = v[e].y - o.y;
+            const float r = sqrtf(dx * dx + dy * dy);
+            skill += mk[e] * r;
+            const float ir = (GRAD && r > 0.f) ? mk[e] * inv_e / r : 0.f;
+            g[e] = make_float2(dx * ir, dy * ir);
+        }
 #pragma unroll
-                for (int j = 0; j < EM; ++j) {
-                    if (j < E && j != e) {
-                        const float ex = v[e].x - v[j].x, ey = v[e].y - v[j].y;
-                        const float rr = sqrtf(ex * ex + ey * ey);
-                        spread += rr;
-                        if (GRAD && rr > 0.f) {
-                            g[e].x -= coef * ex / rr;
-                            g[e].y -= coef * ey / rr;
-                        }
-                    }
+        for (int e = 0; e < EM; ++e) {
+#pragma unroll
+            for (int j = e + 1; j < EM; ++j) {
+                const float ex = v[e].x - v[j].x, ey = v[e].y - v[j].y;
+                const float rr = sqrtf(ex * ex + ey * ey);
+                const float m = mk[e] * mk[j];
+                spread += 2.f * m * rr;
+                if (GRAD) {
+                    const float cr = (rr > 0.f) ? coef * m / rr : 0.f;
+                    g[e].x -= cr * ex;
+                    g[e].y -= cr * ey;
+                    g[j].x += cr * ex;
+                    g[j].y += cr * ey;
                 }
             }
         }
