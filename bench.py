@@ -39,6 +39,10 @@ CONFIGS = {
     # small stand-in with the same structure (plumbing / CI on small GPUs)
     "sfno_debug": dict(inp_shape=(91, 180), out_shape=(91, 180), inp_chans=8, out_chans=8, scale_factor=3,
                        embed_dim=64, num_layers=4, mlp_ratio=2),
+    # ... on a grid whose row lengths (1440 / 480) have specialised FFT kernels, so that an h x w split of it runs the FUSED
+    # exchange schedule of makani_amd/dist_pipeline.py like the headline config does (plumbing / CI of the N > 1 line)
+    "sfno_debug_seg": dict(inp_shape=(91, 1440), out_shape=(91, 1440), inp_chans=8, out_chans=8, scale_factor=3,
+                           embed_dim=32, num_layers=2, mlp_ratio=2),
 }
 _LEVELS = [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]
 _FCN3_CHANS = ["u10m", "v10m", "u100m", "v100m", "t2m", "msl", "tcwv"] + [f"{v}{l}" for v in "uvztq" for l in _LEVELS]
@@ -68,6 +72,8 @@ for _k, _v in FCN3_CONFIGS.items():
     CONFIGS[_k] = dict(kind="fcn3", inp_shape=_v["model"]["inp_shape"], out_shape=_v["model"]["out_shape"],
                        inp_chans=len(_v["model"]["channel_names"]) + len(_v["model"]["aux_channel_names"]),
                        out_chans=len(_v["model"]["channel_names"]), **_v)
+PMC_TRAFFIC = "r04_pmc_hbm_traffic.json"              # written by tools/profile_round.sh on this round's code
+PMC_TRAFFIC_FCN3 = "r03_pmc_hbm_traffic_fcn3.json"   # the FourCastNet3 kernels have not changed since
 PEAK_F32_VALU_TF = 157.3      # packed fp32 FMA on the vector ALUs (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0    # dense
@@ -174,18 +180,15 @@ def roofline_of(family, members, prof, gemm_mode, traffic):
 
 def load_pmc_traffic(fcn3=False):
     """HBM bytes per launch of every kernel family from the committed PMC passes of THIS command (rocprofv3 counters
-    cannot be collected from inside the timed run; profiles/r02d_pmc_hbm_traffic.json (the newest of profiles/r02*_pmc_hbm_traffic.json) says how they were taken and
-    tools/pmc_traffic.py rebuilds it — to be regenerated whenever a kernel of the family changes)"""
-    names = (("r03_pmc_hbm_traffic_fcn3.json",) if fcn3 else
-             ("r03_pmc_hbm_traffic.json", "r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json",
-              "r02_pmc_hbm_traffic.json"))
-    for name in names:       # newest first
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                return {k: v["hbm_bytes"] for k, v in json.load(fh).items() if isinstance(v, dict) and "hbm_bytes" in v}
-        except (OSError, ValueError):
-            continue
-    return {}
+    cannot be collected from inside the timed run; the file says how they were taken, tools/pmc_traffic.py rebuilds it — to be
+    regenerated whenever a kernel of the family changes).  ONE file, the current round's: a missing file reports no traffic
+    (null) rather than an older round's numbers."""
+    name = PMC_TRAFFIC_FCN3 if fcn3 else PMC_TRAFFIC
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            return {k: v["hbm_bytes"] for k, v in json.load(fh).items() if isinstance(v, dict) and "hbm_bytes" in v}
+    except (OSError, ValueError):
+        return {}
 
 
 def parse_parallelism(par):
@@ -287,6 +290,30 @@ def parity_input(cfg):
     return torch.rand(1, cfg["inp_chans"], *cfg["inp_shape"], generator=gen)
 
 
+def parity_target(cfg):
+    """the target of the in-run gradient parity check (seeded like ``parity_input``)"""
+    gen = torch.Generator().manual_seed(PARITY_SEED + 1)
+    return torch.rand(1, cfg["out_chans"], *cfg["out_shape"], generator=gen)
+
+
+# gradients compared end to end (VERDICT r3 item 1): the encoder's first weight (the far end of the backward pass), the spectral
+# weights of the first and the last block (both resolution changes), the decoder's last weight, plus the loss and the norm of
+# ALL gradients
+PARITY_GRADS = ("encoder.fwd.0.weight", "blocks.0.filter.filter.weight", "blocks.7.filter.filter.weight", "decoder.fwd.2.weight")
+
+
+def _grad_record(model, loss):
+    """loss, total gradient norm (fp64 over every parameter) and the PARITY_GRADS gradients of a model after backward()"""
+    sq = 0.0
+    for p in model.parameters():
+        if p.grad is not None:
+            g = torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad
+            sq += float(g.detach().double().square().sum())
+    named = dict(model.named_parameters())
+    grads = {n: named[n].grad.detach().cpu().clone() for n in PARITY_GRADS if n in named and named[n].grad is not None}
+    return dict(loss=float(loss.detach()), grad_norm=math.sqrt(sq), grads=grads)
+
+
 def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
     """child process: the oracle (the reference's model code restated over the restated torch-harmonics SHT), fp32, on
     the host cores.  Always: forward and forward+backward of ONE internal-grid block (seconds; also picks the thread
@@ -333,7 +360,7 @@ def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
     inp, tar = torch.rand(1, cfg["inp_chans"], H, W), torch.rand(1, cfg["out_chans"], H, W)
     if state_path:
         model.load_state_dict(torch.load(state_path, map_location="cpu"), strict=True)
-        inp = parity_input(cfg)
+        inp, tar = parity_input(cfg), parity_target(cfg)
     yb = None
     if out_path:
         # the reference's own arithmetic under op-by-op bf16 autocast (CPU), same weights and input: the yardstick for the
@@ -361,6 +388,10 @@ def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
     t_aux = time.perf_counter() - t_aux
     loss = (y - tar).square().mean()
     loss.backward()
+    t_aux2 = time.perf_counter()
+    if out_path:                                               # the oracle side of the gradient parity (bookkeeping, not timed)
+        torch.save(_grad_record(model, loss), out_path + ".grads")
+    t_aux += time.perf_counter() - t_aux2
     torch.nn.utils.clip_grad_norm_(model.parameters(), 32.0)
     opt.step()
     rec.update(t_step=time.perf_counter() - t0 - t_aux, loss=float(loss.detach()))
@@ -368,10 +399,12 @@ def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
 
 
 class ParityProbe:
-    """In-run parity of the measured model against the oracle: before the first train step the GPU
-    model's forward output on ``parity_input`` is taken in fp32 and under bf16 autocast (the benchmark's precision) and its
-    initial weights are written to a scratch file; the CPU child that times the oracle's full-size forward pass loads
-    those weights, runs on the same input and keeps its output; ``finish`` reports both rel-L2 distances."""
+    """In-run parity of the measured model against the oracle: before the first train step the
+    GPU model — initial weights, ``parity_input`` / ``parity_target`` — runs forward (fp32 and bf16 autocast, the benchmark's
+    precision) and forward + backward of ``mean((y - target)^2)`` (fp32 and bf16 autocast); its initial weights go to a scratch
+    file.  The CPU child that times the oracle's full train step loads those weights, runs the same input / target / loss and
+    keeps its output and its gradients (before clipping); ``finish`` reports the rel-L2 distances of the output, of the loss,
+    of the norm of ALL gradients and of the four gradients of ``PARITY_GRADS``."""
 
     def __init__(self, model, cfg, device):
         import tempfile
@@ -380,7 +413,7 @@ class ParityProbe:
         self.state_path = os.path.join(self.dir, "state.pt")
         self.out_path = os.path.join(self.dir, "oracle_out.pt")
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, self.state_path)
-        x = parity_input(cfg).to(device)
+        x, tar = parity_input(cfg).to(device), parity_target(cfg).to(device)
         was_training = model.training
         model.eval()
         with torch.no_grad():
@@ -388,9 +421,25 @@ class ParityProbe:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 self.y16 = model(x).float().cpu()
         model.train(was_training)
-        del x
+        self.bwd = {}
+        for name, amp in (("fp32", False), ("bf16_autocast", True)):
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                y = model(x)
+            loss = (y.float() - tar).square().mean()
+            loss.backward()
+            self.bwd[name] = _grad_record(model, loss)
+            del y, loss
+        model.zero_grad(set_to_none=True)
+        del x, tar
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()                       # peak_hbm_GB is the train loop's, not the probe's
+
+    @staticmethod
+    def _rel(a, b):
+        a = torch.view_as_real(a) if a.is_complex() else a
+        b = torch.view_as_real(b) if b.is_complex() else b
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
 
     def finish(self):
         import shutil
@@ -401,11 +450,25 @@ class ParityProbe:
                 den = float(yo.norm())
                 out = dict(fp32=float((self.y32.double() - yo).norm()) / den, bf16_autocast=float((self.y16.double() - yo).norm()) / den,
                            oracle_bf16_autocast=self.oracle_bf16,
+                           bf16_gate="relative to the oracle's own bf16 autocast (oracle_bf16_autocast), not the flat 2e-2 of BASELINE.md §3",
                            what="rel-L2 of the GPU model's forward output (initial weights of this run, seeded U[0,1) input, "
                                 "721x1440x73, all 8 layers) against the fp32 CPU oracle's output of the pass timed as "
                                 "cpu_baseline; oracle_bf16_autocast = the same distance for the oracle itself under op-by-op CPU "
                                 "bf16 autocast (the reference's own bf16 arithmetic).  Gates: fp32 <= 1e-4 (BASELINE.md §3); bf16 "
-                                "autocast <= the oracle's own bf16 distance (2e-2 holds per block, not through 8 bf16 layers)")
+                                "autocast <= the oracle's own bf16 distance (2e-2 holds per block, not through 8 bf16 layers).  "
+                                "grad_*: the same run's backward pass of mean((y - target)^2) against the oracle's backward pass "
+                                "(the one timed inside cpu_baseline's train step): loss, norm of all gradients (relative "
+                                "difference) and rel-L2 of four gradients; gate fp32 <= 1e-4")
+            gpath = self.out_path + ".grads"
+            if out is not None and os.path.exists(gpath):
+                ref = torch.load(gpath, map_location="cpu")
+                for name, rec in self.bwd.items():
+                    sfx = "" if name == "fp32" else "_bf16"
+                    out[f"grad_loss{sfx}"] = abs(rec["loss"] - ref["loss"]) / abs(ref["loss"])
+                    out[f"grad_norm{sfx}"] = abs(rec["grad_norm"] - ref["grad_norm"]) / ref["grad_norm"]
+                    for n, g in rec["grads"].items():
+                        if n in ref["grads"]:
+                            out[f"grad_{n}{sfx}"] = self._rel(g, ref["grads"][n])
         finally:
             shutil.rmtree(self.dir, ignore_errors=True)
         return out
@@ -603,6 +666,7 @@ def run_worker(args):
     ops.PROFILER.reset()
     ops.PROFILER.enabled = graph is None
     ops.PROFILER.only = set(dom_members) if dom_members else None      # HIP events on the dominant kernel only (see above)
+    thd.COMM_STATS.clear()                                             # all-to-all accounting of the timed steps (N > 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -621,6 +685,8 @@ def run_worker(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.PROFILER.enabled = False
+    comm_stats = {f"group_of_{k}": dict(MB_sent=round(v["bytes_sent"] / args.steps / 1e6, 2), all_to_alls=v["all_to_alls"] / args.steps)
+                  for k, v in sorted(thd.COMM_STATS.items())}
     event_steps = args.steps
     if graph is not None:
         # launch durations of the dominant kernel: HIP events cannot bracket a node inside a replayed graph, so the same
@@ -690,6 +756,12 @@ def run_worker(args):
             "hip_kernel_ms_per_step": round(hip_ms, 2),
             "final_loss": final_loss,
         }
+        if msize > 1:
+            # what this rank (rank 0) puts on the links per step in the distributed transforms, by size of the process group the
+            # all-to-all runs over (h, w or h x w) — to be read against SURVEY.md §8(e)'s 9.4 ms/step communication budget
+            out["exchange_per_step_rank0"] = dict(comm_stats, total_MB_sent=round(sum(v["MB_sent"] for v in comm_stats.values()), 2),
+                                                  schedule=("fused (one h x w all-to-all between FFT and Legendre transform)"
+                                                            if os.environ.get("MAKANI_AMD_DIST_FUSED", "1") == "1" else "transpose by transpose"))
         if graph_note:
             out["note"] = graph_note
         if graph is not None and roofline:

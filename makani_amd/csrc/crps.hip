@@ -135,14 +135,17 @@ __device__ __forceinline__ float crps_point(float (&f)[EM], int E, float obs, in
                     last = fo;
                 }
             }
-            score = integ + fmaxf(obs - last, 0.f);
+            // a NaN observation propagates (the reference's torch.clamp(observation - forecast, min=0) does; fmaxf would
+            // drop it and report a finite, meaningless score): NaN score, zero gradients
+            const bool obs_nan = obs != obs;
+            score = obs_nan ? obs : integ + fmaxf(obs - last, 0.f);
             if (GRAD) {
 #pragma unroll
                 for (int e = 0; e < EM; ++e) {
                     float ge = 0.f;
 #pragma unroll
                     for (int n = 0; n < EM; ++n) ge = (n < E && rank[e] == n + 1) ? gs[n] : ge;
-                    g[e] = ge - ((rank[e] == E && obs > last) ? 1.f : 0.f);
+                    g[e] = obs_nan ? 0.f : ge - ((rank[e] == E && obs > last) ? 1.f : 0.f);
                 }
             }
         } else if (type == CRPS_PWM) {

@@ -86,23 +86,50 @@ class Plan:
                 off += self.slab[j][i]
         self.base, self.f_total = base, off
 
-        # latitude chunks of steps (2)+(3): the same count on every rank (each collective is entered by all of them)
+        # latitude chunks of steps (2)+(3): the same count on every rank (each collective is entered by all of them) — the
+        # count depends on an environment variable, so the ranks of the transform's groups compare it once per plan: ranks
+        # that disagree would enter different numbers of collectives and hang
         nmin = min(self.lat)
         self.nc = max(1, min(int(os.environ.get("MAKANI_AMD_DIST_CHUNKS", "2")), nmin // 32 if nmin >= 64 else 1))
+        lo, hi = agree_min_max(self.nc)
+        if lo != hi:
+            raise RuntimeError(f"MAKANI_AMD_DIST_CHUNKS differs between the ranks of the spatial group (chunk counts {lo}..{hi}): "
+                               "every rank must run the same exchange schedule")
 
     def chunks(self, n):
         """latitude chunk boundaries of a rank with n local latitudes"""
         return [(c * n) // self.nc for c in range(self.nc + 1)]
 
 
+def agree_min_max(value: int):
+    """(min, max) of an integer over the ranks of the polar and the azimuth group (both all-reduces are entered by every rank
+    of the h x w block, whatever its local value).  One tiny collective per group, at plan / eligibility time only."""
+    from . import distributed as thd
+    lo = hi = int(value)
+    for group in (thd.polar_group(), thd.azimuth_group()):
+        if group is None or dist.get_world_size(group) == 1:
+            continue
+        dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+        t = torch.tensor([-lo, hi], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        lo, hi = -int(t[0]), int(t[1])
+    return lo, hi
+
+
 def eligible(T, x_dtype) -> bool:
     """the fused schedule needs the specialised FFT kernels, equal longitude pieces of whole 16-byte vectors and at most
-    MK_FFT_SEG_MAX peers per direction; anything else runs the transpose-by-transpose schedule of distributed.py"""
+    MK_FFT_SEG_MAX peers per direction; anything else runs the transpose-by-transpose schedule of distributed.py.
+    The decision depends on environment variables and on the local group layout, so it is AGREED over the transform's groups
+    the first time it is taken: the fused schedule runs only if every rank finds it eligible — ranks that decide
+    differently would enter different collective sequences and hang instead of raising."""
     from . import distributed as thd
-    key = (x_dtype, os.environ.get("MAKANI_AMD_DIST_FUSED", "1"), id(thd._BACKEND))
+    key = (x_dtype, os.environ.get("MAKANI_AMD_DIST_FUSED", "1"), os.environ.get("MAKANI_AMD_DIST_FORCE_FUSED", "0"), id(thd._BACKEND))
     cache = T.__dict__.setdefault("_fused_ok", {})
     if key not in cache:
-        cache[key] = _eligible(T, x_dtype)
+        ok = _eligible(T, x_dtype)
+        if T.comm_size_polar * T.comm_size_azimuth > 1:
+            ok = bool(agree_min_max(1 if ok else 0)[0])
+        cache[key] = ok
     return cache[key]
 
 
@@ -114,7 +141,11 @@ def _eligible(T, x_dtype) -> bool:
     if not getattr(thd._BACKEND, "segmented", False):
         return False
     h, w = T.comm_size_polar, T.comm_size_azimuth
-    if h > _lib.MK_FFT_SEG_MAX or w > _lib.MK_FFT_SEG_MAX or h * w == 1:
+    # MAKANI_AMD_DIST_FORCE_FUSED=1: the fused pipeline also with ONE rank (h = w = 1) — every collective it issues (the list
+    # all_to_all with async_op=True on contiguous slab views, the waits that order the compute stream behind it) then runs on a
+    # process group of one rank: how the RCCL call signatures and the stream ordering are exercised on a one-GPU box
+    force = os.environ.get("MAKANI_AMD_DIST_FORCE_FUSED", "0") == "1" and dist.is_available() and dist.is_initialized()
+    if h > _lib.MK_FFT_SEG_MAX or w > _lib.MK_FFT_SEG_MAX or (h * w == 1 and not force):
         return False
     if len(set(T.lon_shapes)) != 1:
         return False
@@ -146,6 +177,8 @@ def _exchange_async(recv, send, group):
     assert all(t.is_contiguous() for t in recv)                  # (a reshape of a strided tensor would receive into a copy)
     recv = [t.reshape(-1) for t in recv]
     send = [t.reshape(-1) for t in send]
+    from .distributed import _count_exchange
+    _count_exchange(send, group)
     if dist.get_backend(group) != "gloo":
         return dist.all_to_all(recv, send, group=group, async_op=True)
     _exchange(recv, send, group)

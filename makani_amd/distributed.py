@@ -143,8 +143,23 @@ def _pad_to4(t: torch.Tensor, dim: int) -> torch.Tensor:
     return torch.cat([t, t.new_zeros(shape)], dim=dim)
 
 
-def _exchange(recv, send, group):
+# exchange accounting (bench.py reports it per step and rank at N > 1, so that the first scaling curve can be read against
+# SURVEY.md §8(e)'s communication budget): bytes this rank SENDS to other ranks and the number of all-to-alls, per group size
+COMM_STATS = {}
+
+
+def _count_exchange(send, group):
+    me = dist.get_rank(group)
+    n = sum(t.numel() * t.element_size() for i, t in enumerate(send) if i != me)
+    st = COMM_STATS.setdefault(dist.get_world_size(group), {"bytes_sent": 0, "all_to_alls": 0})
+    st["bytes_sent"] += n
+    st["all_to_alls"] += 1
+
+
+def _exchange(recv, send, group, count=False):
     """one all-to-all; RCCL ("nccl") has it natively, gloo (CPU tests) is served by paired isend/irecv"""
+    if count:
+        _count_exchange(send, group)
     if dist.get_backend(group) != "gloo":
         dist.all_to_all(recv, send, group=group)
         return
@@ -181,14 +196,14 @@ def _a2a(x, sdim, ssizes, cdim, csizes, group, me):
     if cdim == 0:                                   # arriving slabs are contiguous ranges of the result
         y = torch.empty(shape, dtype=x.dtype, device=x.device)
         recv = list(torch.split(y, csizes, dim=0))
-        _exchange(recv, send, group)
+        _exchange(recv, send, group, count=True)
         return y
     recv = []
     for src in range(P):
         sh = list(shape)
         sh[cdim] = csizes[src]
         recv.append(torch.empty(sh, dtype=x.dtype, device=x.device))
-    _exchange(recv, send, group)
+    _exchange(recv, send, group, count=True)
     return torch.cat(recv, dim=cdim)
 
 

@@ -480,8 +480,20 @@ class _ReduceFromGroupFn(torch.autograd.Function):
 
 
 def _ensemble_active(flag) -> bool:
+    """``ensemble_distributed`` is honoured when the process-group tree names a split "ensemble" group.  The tree may not have
+    been looked at yet (a loss constructed before any makani_amd network under makani's own driver): adopt makani's tree first;
+    a set flag without such a group in a multi-rank job is reported — each rank would otherwise silently score its local
+    members only."""
+    if not flag:
+        return False
     from . import comm as _comm
-    return bool(flag) and _comm.is_distributed("ensemble") and _comm.get_size("ensemble") > 1
+    _comm.autodetect()
+    active = _comm.is_distributed("ensemble") and _comm.get_size("ensemble") > 1
+    if not active and _comm.get_world_size() > 1:
+        import warnings
+        warnings.warn("ensemble_distributed=True, but the process-group tree has no split 'ensemble' group: the loss scores the "
+                      "members of this rank only (makani_amd.comm.init(h, w, ensemble=n) or makani's own tree provides the group)")
+    return active
 
 
 def _ens_w(w, E):
@@ -495,7 +507,7 @@ class CRPSLoss(nn.Module):
     (B, C, H, W), spatial_weights=None) -> (B, C)``, the quadrature-weighted ensemble CRPS.  Score and quadrature are one HIP
     kernel (``csrc/crps.hip``), the gradient with respect to the forecasts one more.  Built: ``crps_type`` "skillspread"
     (default, with the almost-fair factor ``alpha``), "naive skillspread", "probability weighted moment", "gauss" and "cdf"
-    (:55-122, with optional per-member ``ensemble_weights``, the only form in which the reference uses them); any ensemble
+    (:55-122, with optional per-member ``ensemble_weights``; the "probability weighted moment" form accepts them too and, like the reference's kernel, ignores their values); any ensemble
     size 2..32; ``ensemble_distributed=True`` with a split "ensemble" group (``makani_amd.comm.init(h, w, ensemble=n)`` or
     makani's own tree) trades the members for a share of the grid points before scoring, as the reference does."""
 
@@ -511,7 +523,9 @@ class CRPSLoss(nn.Module):
                                          crop_offset=crop_offset, normalize=True, distributed=spatial_distributed)
         self.spatial_distributed = self.quadrature.distributed
         self.ensemble_distributed = _ensemble_active(ensemble_distributed)                # crps_loss.py:305-307
-        if ensemble_weights is not None and crps_type != "cdf":      # the reference uses them in the cdf form only (:392-396)
+        # the reference hands ensemble_weights to the "cdf" kernel (:392-396) and to the "probability weighted moment" kernel
+        # (:404-409), which ignores their values: accepted for both (and ignored by the latter, as there); other forms raise
+        if ensemble_weights is not None and crps_type not in ("cdf", "probability weighted moment"):
             raise NotImplementedError("currently only constant ensemble weights are supported")
         if crps_type not in _CRPS_TYPES:
             raise ValueError(f"Unknown CRPS crps_type {crps_type}")

@@ -116,6 +116,43 @@ class FusedAdamW(torch.optim.Optimizer):
     def grad_norm(self):
         return self.clip_coef(None)[1]
 
+    @torch.no_grad()
+    def full_state_dict(self):
+        """``state_dict()`` with every ZeRO-sharded moment all-gathered to the parameter's full size (COLLECTIVE over the data
+        group: every data rank calls it; what makani's checkpointing then saves from ONE rank — ``driver.py`` writes the
+        optimizer state of data rank 0 — restores on any rank and under any data-group size: ``step()`` slices full-size moments
+        to the local shard).  Without ZeRO this is ``state_dict()``.  The moments are laid out in the parameter's own memory order
+        (as non-ZeRO ``exp_avg`` tensors are)."""
+        sd = self.state_dict()
+        index = {}
+        for gi, group in enumerate(self.param_groups):
+            for pi, p in enumerate(group["params"]):
+                index[id(p)] = sd["param_groups"][gi]["params"][pi]
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p, {})
+                z = getattr(p, "_mk_zero", None)
+                if "zero_shard" not in st or z is None:
+                    continue
+                _, zgroup, nranks, rank = z
+                out = dict(sd["state"][index[id(p)]])
+                out.pop("zero_shard", None)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    mine = st[key]
+                    if dist.get_backend(zgroup) == "gloo":
+                        h = mine.cpu() if mine.is_cuda else mine.clone()
+                        parts = [torch.empty_like(h) for _ in range(nranks)]
+                        dist.all_gather(parts, h, group=zgroup)
+                        flat = torch.cat(parts).to(mine.device)
+                    else:
+                        flat = torch.empty(mine.numel() * nranks, dtype=mine.dtype, device=mine.device)
+                        dist.all_gather_into_tensor(flat, mine, group=zgroup)
+                    full = torch.empty_like(p, memory_format=torch.preserve_format)
+                    _flat(full, p).reshape(-1).copy_(flat)
+                    out[key] = full
+                sd["state"][index[id(p)]] = out
+        return sd
+
     def _step_state(self, group, device):
         """device-side step counter + bias corrections of a parameter group (mk_adamw_advance)"""
         st = group.get("_mk_step_state")

@@ -64,6 +64,32 @@ def test_bench_launches_its_own_ranks_headline_split_and_secondary_dp():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_h4w2_line_shape():
+    """``python bench.py --gpus 8`` as the driver's SCALE run will issue it, functionally on ONE GPU (8 ranks share cuda:0,
+    gloo): the headline is the north-star split h4 x w2 over all 8 ranks running the FUSED exchange schedule (the grid's row
+    lengths have segmented FFT kernels), the line names the collectives backend, the exchange volume per step and rank, and
+    carries data parallelism over 8 ranks as ``secondary``"""
+    env = dict(os.environ, MAKANI_AMD_BENCH_BACKEND="gloo", MAKANI_AMD_BENCH_PHASE_TIMEOUT="800")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "sfno_debug_seg", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=1700, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["parallelism"] == "dp1_h4w2", d["config"]
+    assert d["config"]["collectives"] == "gloo" and d["config"]["global_batch"] == 1 and d["value"] > 0 and "note" not in d, d.get("note")
+    ex = d["exchange_per_step_rank0"]
+    assert ex["schedule"].startswith("fused") and ex["total_MB_sent"] > 0
+    assert ex["group_of_8"]["all_to_alls"] > 0            # the single h x w exchange between FFT and Legendre transform
+    assert ex["group_of_4"]["all_to_alls"] > 0 and ex["group_of_2"]["all_to_alls"] > 0
+    s = d["secondary"]
+    assert s["parallelism"] == "dp8" and s["scaling"] == "weak" and s["global_batch"] == 8 and s["value"] > 0
+    assert d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
 def test_bench_rank_launched_by_torchrun_form():
     """the driver's form: ``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`` — every rank's copy
     of the script starts its own worker per phase on a fresh rendezvous port; rank 0 prints the line"""
@@ -128,8 +154,17 @@ def test_roofline_report_on_a_synthetic_profile():
     warm = {"adamw": _rec(8, 0.39, 0.0, 1.98e9), **{k: _rec(v["launches"] // 10, v["ms_avg"], v["flops"] / v["launches"], v["bytes"] / v["launches"]) for k, v in prof.items()}}
     t = bench.kernel_table(warm, {"dhconv_dgrad": prof["dhconv_dgrad"]}, 10)
     assert t["adamw"]["launches_per_step"] == 8 and t["dhconv_dgrad"]["launches_per_step"] == 8
+    # HBM traffic comes from ONE committed file, this round's; a missing file reports nothing instead of an older round's numbers
     pm = bench.load_pmc_traffic()
-    assert pm.get("dhconv_dgrad", 0) > 0 and all(isinstance(v, (int, float)) for v in pm.values())
+    assert isinstance(pm, dict) and all(isinstance(v, (int, float)) for v in pm.values())
+    cur = bench.PMC_TRAFFIC
+    try:
+        bench.PMC_TRAFFIC = "r03_pmc_hbm_traffic.json"
+        assert bench.load_pmc_traffic().get("dhconv_dgrad", 0) > 0
+        bench.PMC_TRAFFIC = "no_such_round.json"
+        assert bench.load_pmc_traffic() == {}
+    finally:
+        bench.PMC_TRAFFIC = cur
 
 
 @pytest.mark.gpu

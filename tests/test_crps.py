@@ -26,6 +26,9 @@ def test_crps_constructor_contract():
         ma.CRPSLoss(crps_type="cdf", alpha=0.9, **kw)
     with pytest.raises(NotImplementedError):
         ma.CRPSLoss(ensemble_weights=torch.ones(4), **kw)            # skillspread: constant weights only (crps_loss.py:408-410)
+    # the reference's "probability weighted moment" branch takes ensemble_weights as well (crps_loss.py:397-407; its kernel
+    # ignores their values): a reference config with PWM + weights must construct
+    assert ma.CRPSLoss(crps_type="probability weighted moment", ensemble_weights=torch.ones(4), **kw).ensemble_weights.shape == (4,)
     with pytest.raises(ValueError):
         m(torch.zeros(2, 2, 9, 16), torch.zeros(2, 2, 9, 16))          # forecasts need the ensemble dimension
 
@@ -72,6 +75,29 @@ def test_crps_cdf_equals_fair_score_identity_and_large_ensemble_errors():
         assert rel_l2(got, ref) < 1e-5, (E, got, ref)
     with pytest.raises(NotImplementedError):
         cdf(torch.zeros(1, 33, 2, 16, 32, device="cuda:0"), torch.zeros(1, 2, 16, 32, device="cuda:0"))
+
+
+@pytest.mark.gpu
+def test_crps_cdf_nan_observation_propagates_and_pwm_ignores_weights():
+    """(i) the reference's "cdf" form does not mask NaN observations — its last term torch.clamp(obs - forecast,
+    min=0) propagates the NaN into the point's score and hence into the (B, C) loss (crps_loss.py:55-122); the kernel's fmaxf
+    would have dropped it.  (ii) "probability weighted moment" accepts ensemble_weights and ignores their values."""
+    import makani_amd as ma
+    kw = dict(img_shape=(9, 16), crop_shape=(9, 16), crop_offset=(0, 0), channel_names=["a", "b"], grid_type="equiangular")
+    torch.manual_seed(1)
+    f = torch.randn(1, 4, 2, 9, 16, device="cuda:0", requires_grad=True)
+    o = torch.randn(1, 2, 9, 16, device="cuda:0")
+    o_nan = o.clone()
+    o_nan[0, 1, 3, 5] = float("nan")
+    cdf = ma.CRPSLoss(crps_type="cdf", **kw).to("cuda:0")
+    out = cdf(f, o_nan)
+    assert torch.isfinite(out[0, 0]) and torch.isnan(out[0, 1])           # only the channel that holds the NaN
+    assert torch.equal(out[0, 0], cdf(f, o)[0, 0])
+    out[0, 0].backward()
+    assert torch.isfinite(f.grad).all()
+    pwm = ma.CRPSLoss(crps_type="probability weighted moment", **kw).to("cuda:0")
+    pwm_w = ma.CRPSLoss(crps_type="probability weighted moment", ensemble_weights=torch.tensor([0.1, 0.2, 0.3, 0.4]), **kw).to("cuda:0")
+    assert torch.equal(pwm(f, o), pwm_w(f, o))
 
 
 @pytest.mark.gpu

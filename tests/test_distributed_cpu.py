@@ -227,6 +227,43 @@ def test_fused_distributed_sht_latitude_chunks():
     mp.spawn(_worker_sht, args=(4, _free_port(), 2, 2, 130, 48, 20, 21, "equiangular", 1, 5, True, "2"), nprocs=4, join=True)
 
 
+def _worker_disagree(rank, world, port, what):
+    """ranks whose environment differs must agree on the schedule before the first collective of a transform: a differing
+    chunk count raises on EVERY rank (instead of a hang in mismatched collectives), a differing MAKANI_AMD_DIST_FUSED makes
+    every rank run the transpose-by-transpose schedule"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd.distributed as thd
+        from makani_amd import dist_pipeline as dp
+        wg = dist.new_group([0, 1])
+        thd.init(None, wg, dist.group.WORLD)
+        thd._BACKEND = OracleSegBackend
+        nlat, nlon, lmax, mmax = 130, 48, 20, 21
+        if what == "chunks":
+            os.environ["MAKANI_AMD_DIST_CHUNKS"] = "2" if rank == 0 else "1"
+        else:
+            os.environ["MAKANI_AMD_DIST_FUSED"] = "1" if rank == 0 else "0"
+        fwd = thd.DistributedRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid="equiangular")
+        x = torch.randn(1, 4, nlat, nlon // 2, dtype=torch.float64)
+        if what == "chunks":
+            with pytest.raises(RuntimeError, match="MAKANI_AMD_DIST_CHUNKS differs"):
+                fwd.analysis(x)
+        else:
+            assert dp.eligible(fwd, x.dtype) is False          # rank 0 alone would have taken the fused schedule
+            S = fwd.analysis(x)                                  # ... and both ranks complete the same (plain) schedule
+            assert S.shape[0] == lmax
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("what", ["chunks", "fused"])
+def test_ranks_agree_on_the_exchange_schedule(what):
+    mp.spawn(_worker_disagree, args=(2, _free_port(), what), nprocs=2, join=True)
+
+
 def _worker_dp(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -460,6 +497,21 @@ def _worker_zero(rank, world, port):
                 assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), (it, k, (a - b).abs().max())
         # sharded state: 1 / world of the elements
         assert opt.state[model.w]["exp_avg"].numel() == 3072 // world and opt.state[model.b]["exp_avg"].numel() == 37
+        # a checkpoint one data rank can write for all: full_state_dict() all-gathers the sharded moments; they
+        # equal the single-process optimizer's, carry no shard tag, and restore on any rank (step() re-slices them)
+        fsd = opt.full_state_dict()
+        names = [k for k, _ in model.named_parameters()]
+        for i, k in enumerate(names):
+            st = fsd["state"][i]
+            assert "zero_shard" not in st and st["exp_avg"].shape == ref[k].shape
+            for key in ("exp_avg", "exp_avg_sq"):
+                a = torch.view_as_real(st[key]) if st[key].is_complex() else st[key]
+                b = ropt.state[ref[k]][key]
+                b = torch.view_as_real(b) if b.is_complex() else b
+                assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (k, key)
+        opt2 = mo.FusedAdamW(model.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+        opt2.load_state_dict(fsd)
+        assert opt2.state[model.w]["exp_avg"].numel() == 3072 and "zero_shard" not in opt2.state[model.w]
     finally:
         dist.destroy_process_group()
 

@@ -191,6 +191,8 @@ def _perturb_affine(mod, seed):
 
 @pytest.fixture(scope="module")
 def config2_pair():
+    """the oracle side of the whole-network tests: forward (fp32 and the reference's own CPU bf16 autocast) and ONE backward
+    pass of sum(y * g) — input gradient and the gradient of every parameter (about a minute on the GPU box's host)"""
     import makani_amd as ma
     from oracle import sfno as osf
     _threads()
@@ -198,20 +200,24 @@ def config2_pair():
     omod = osf.SphericalFourierNeuralOperatorNet(**CONFIG2)
     _perturb_affine(omod, 7)
     x = torch.rand(1, 73, 721, 1440)                    # DummyLoader-shaped U[0, 1) input (data_loader_dummy.py:264-277)
-    with torch.no_grad():
-        yo = omod(x)
-        with torch.autocast("cpu", dtype=torch.bfloat16):       # the reference's own op-by-op bf16 autocast, on the CPU
-            yo_bf16 = omod(x).float()
+    g = torch.randn(1, 73, 721, 1440, generator=torch.Generator().manual_seed(99))
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):       # the reference's own op-by-op bf16 autocast, on the CPU
+        yo_bf16 = omod(x).float()
+    xo = x.clone().requires_grad_(True)
+    yo = omod(xo)
+    (yo * g).sum().backward()
+    ref = dict(gx=xo.grad.detach(), grads={n: p.grad.detach() for n, p in omod.named_parameters()})
+    yo = yo.detach()
     model = ma.SphericalFourierNeuralOperatorNet(**CONFIG2)
     model.load_state_dict(omod.state_dict(), strict=True)
-    del omod
-    return model.to(DEV).eval(), x, yo, yo_bf16
+    del omod, xo
+    return model.to(DEV).eval(), x, yo, yo_bf16, g, ref
 
 
 def test_sfno_config2_forward_721x1440_matches_oracle(config2_pair):
     """all eight layers at the benchmark's size: encoder 73 -> 384, block 0 (721x1440 -> 240x480), six internal blocks,
     block 7 (240x480 -> 721x1440, residual re-sampled through SHT -> iSHT), decoder 384 -> 73, big skip; fp32 <= 1e-4"""
-    model, x, yo, _ = config2_pair
+    model, x, yo = config2_pair[:3]
     with torch.no_grad():
         y = model(x.to(DEV))
     assert y.shape == yo.shape and y.dtype == torch.float32
@@ -227,12 +233,67 @@ def test_sfno_config2_forward_721x1440_bf16_autocast_matches_oracle(config2_pair
     their fp32 result (measured in the build container and again here).  Gate: no further from the fp32 oracle than the
     reference's own bf16 arithmetic is, and <= 6e-2 absolute; measured 4.1e-2 (fewer bf16 rounding points: norm + GELU and
     bias + GELU are fused)."""
-    model, x, yo, yo_bf16 = config2_pair
+    model, x, yo, yo_bf16 = config2_pair[:4]
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y = model(x.to(DEV))
     e, e_ref = rel_l2(y.float(), yo), rel_l2(yo_bf16, yo)
     print(f"config 2 forward 721x1440 bf16 autocast rel-L2 vs fp32 oracle: HIP {e:.2e}, the oracle's own CPU bf16 autocast {e_ref:.2e}")
     assert e < 6e-2 and e <= 1.05 * e_ref, (e, e_ref)
+
+
+def _fwd_bwd_config2(model, x, g, amp):
+    model.zero_grad(set_to_none=True)
+    xd = x.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = model(xd)
+    (y.float() * g.to(DEV)).sum().backward()
+    return y.float().detach(), xd.grad.detach()
+
+
+def test_sfno_config2_fwd_bwd_721x1440_matches_oracle(config2_pair):
+    """the backward pass END TO END at the benchmark's size — the input gradient and the gradient of
+    every one of the 108 parameters (encoder, 8 x (norms, 283 MB spectral weight, skip, MLP), decoder, big skip) of
+    sfno_sc3_layers8_edim384 at 721 x 1440 x 73 against the oracle's backward pass of the same sum(y * g): how big_skip, the
+    encoder / decoder edges and the block-7 residual resample chain their gradients together.  fp32 <= 1e-4
+    (tests/distributed/tests_distributed_layers.py:73-76); gradients that are exactly zero by construction (a per-channel
+    constant in front of an instance norm) are accepted on the absolute scale of the largest gradient entry."""
+    model, x, yo, _, g, ref = config2_pair
+    y, gx = _fwd_bwd_config2(model, x, g, amp=False)
+    errs = {"y": rel_l2(y, yo), "gx": rel_l2(gx, ref["gx"])}
+    gmax = max(float(torch.view_as_real(v).abs().max() if v.is_complex() else v.abs().max()) for v in ref["grads"].values())
+    worst = ("", 0.0)
+    for n, p in model.named_parameters():
+        r = ref["grads"][n]
+        e = rel_l2(p.grad, r)
+        a = float((torch.view_as_real(p.grad.detach().cpu()) - torch.view_as_real(r)).abs().max()) if r.is_complex() \
+            else float((p.grad.detach().cpu().float() - r).abs().max())
+        errs[n] = e
+        assert e < TOL_E2E or a < 1e-5 * gmax, (n, e, a, gmax)
+        if e > worst[1] and a >= 1e-5 * gmax:
+            worst = (n, e)
+    print(f"config 2 fwd+bwd 721x1440 fp32 rel-L2 vs oracle: y {errs['y']:.2e}  gx {errs['gx']:.2e}  worst parameter gradient "
+          f"{worst[0]} {worst[1]:.2e}  (of {len(ref['grads'])})")
+    for n in ("encoder.fwd.0.weight", "blocks.0.filter.filter.weight", "blocks.7.filter.filter.weight", "decoder.fwd.2.weight",
+              "residual_transform.weight"):
+        print(f"    {n}: {errs[n]:.2e}")
+    assert errs["y"] < TOL_E2E and errs["gx"] < TOL_E2E, errs
+
+
+def test_sfno_config2_fwd_bwd_721x1440_bf16_autocast_gradients(config2_pair):
+    """the benchmark's precision through the whole backward pass: under bf16 autocast the gradients carry the rounding of
+    eight bf16 layers twice (forward activations and backward signals), so the gate is the whole-network forward gate (6e-2,
+    see the forward test) on the input gradient and on the large parameter gradients (the eight spectral weights and the
+    channel-GEMM weights), measured against the fp32 oracle"""
+    model, x, yo, _, g, ref = config2_pair
+    y, gx = _fwd_bwd_config2(model, x, g, amp=True)
+    errs = {"gx": rel_l2(gx, ref["gx"])}
+    for n, p in model.named_parameters():
+        if n.endswith(("filter.filter.weight", "fwd.0.weight", "fwd.2.weight", "fwd.3.weight", "outer_skip.weight")):
+            errs[n] = rel_l2(p.grad, ref["grads"][n])
+    worst = max(errs, key=errs.get)
+    print(f"config 2 fwd+bwd 721x1440 bf16 autocast rel-L2 vs fp32 oracle: gx {errs['gx']:.2e}  worst weight gradient {worst} {errs[worst]:.2e}")
+    assert max(errs.values()) < 6e-2, {k: f"{v:.2e}" for k, v in errs.items()}
+    model.zero_grad(set_to_none=True)
 
 
 # --------------------------------------------------------------------------- #

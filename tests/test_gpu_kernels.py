@@ -373,7 +373,10 @@ def test_instance_norm(dtype, tol, fuse_gelu, B, C, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,C,H,W", [(2, 5, 12, 24), (1, 3, 37, 71), (1, 768, 240, 480), (3, 700, 9, 16)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 5, 12, 24), (1, 3, 37, 71), (1, 768, 240, 480), (3, 700, 9, 16),
+                                     # block 7's MLP hidden gradient at the benchmark's size: 768 planes of
+                                     # 1 038 240 points, non-zero mean, against the fp64 sum
+                                     (1, 768, 721, 1440)])
 def test_plane_sums_bias_gradient(dtype, B, C, H, W):
     from makani_amd import ops
     torch.manual_seed(B * C + H)
@@ -447,7 +450,10 @@ def test_fused_adamw_matches_torch():
                                      (1, 677, 1354, 16, 40), (1, 641, 677, 20, 36), (2, 200, 100, 10, 52), (1, 1354, 641, 8, 40),
                                      # ... and enough pixels for the weight-gradient ring kernel with both channel counts above 384
                                      # (two-dimensional tiling: slabs of P x 384-row slabs of Q, either operand as Q, batch)
-                                     (1, 677, 1354, 48, 48), (1, 1354, 641, 48, 48), (2, 450, 400, 32, 72)])
+                                     (1, 677, 1354, 48, 48), (1, 1354, 641, 48, 48), (2, 450, 400, 32, 72),
+                                     # FourCastNet3's local-block channel mix itself: 677 <- 6093 = 677 x 9 (96 k-tiles, the last
+                                     # one ragged: 13 of 64 input channels), forward / fused epilogues / weight gradient
+                                     (1, 677, 6093, 24, 48), (1, 6093, 677, 16, 24)])
 def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
     from makani_amd import ops
     torch.manual_seed(M + K)
