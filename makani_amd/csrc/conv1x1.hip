@@ -649,26 +649,40 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt_le() {      // N_ m
 
 // TM: 32-row channel tiles per wave (slab = 4 waves x TM x 32 = 256 or 384 channels); KCH: input channels per ring
 // chunk and barrier (64 or 128)
-template <int TM, int KCH, bool PRE, bool EPI_LOADS>
-__global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, int slabs, long long tilesN) {
+// KS: k16-steps of the contraction.  24 = the embedding width K = 384.  5 (round 4) = the 73-channel edges of the network
+// (encoder 384 <- 73 with bias + GELU + pre-activation, data gradient of the decoder's last layer 384 <- 73 with gelu'): K = 73 is
+// padded to lda = 80 by the weight image; the ONE chunk of a pixel tile is 96 input-channel rows (whole DMA pieces of 8 rows per
+// wave), of which rows >= K arrive as zeros (the activation descriptor ends with row K - 1) and rows >= 80 are never multiplied.
+// Those launches are pure output streams (9 KB in, 48 KB out per tile, 30 MFMAs per wave): with 60 weight registers instead of
+// 288 two workgroups share a CU (the variant without epilogue operand), so that one's epilogue overlaps the other's loads.
+template <int TM, int KCH, bool PRE, bool EPI_LOADS, int KS = 24>
+__global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_astat_kernel(const ConvNN p, int slabs, long long tilesN) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int KS = 24;                              // k16-steps: K = 384
+    constexpr bool SMALLK = KS < 24;
+    static_assert(KS == 24 || (KS * 16 <= KCH && KCH % 32 == 0), "small K: one chunk per pixel tile");
     constexpr int TN = 2;                               // wave tile: TM * 32 channels x 64 pixels
     constexpr int BM = 4 * TM * 32, BN = 64, NT_ = 256;
     constexpr int CH = KCH * 128;                       // one chunk: KCH input channels x 64 pixels, bf16
-    constexpr int NCH = 384 / KCH;                      // chunks per pixel tile
-    constexpr int K4 = KCH / 16;                        // k16-steps per chunk
+    constexpr int NCH = SMALLK ? 1 : 384 / KCH;         // chunks per pixel tile
+    constexpr int K4 = KS / NCH;                        // k16-steps per chunk
     constexpr int ROUNDS_ = TM;
     // EPI_LOADS: the epilogue operand (gelu'(G) factor or skip tensor R) of every staging round arrives by LDS-DMA in its
     // own 16 KB image, requested at the START of the pixel tile, so that it lands behind the tile's multiplications;
     // the ring gives up one slot's worth of space per round for that (128 -> 96 KB with three rounds)
     constexpr int EBYTES = EPI_LOADS ? ROUNDS_ * 128 * 128 : 0;
-    constexpr int NSLOT = (EPI_LOADS ? (144 * 1024 - EBYTES) : 128 * 1024) / CH;   // ring slots
+    // ring slots (small K without epilogue operand: 5 slots = 76 KB with the staging image, two workgroups per CU)
+    constexpr int NSLOT = SMALLK ? (EPI_LOADS ? 8 : 5) : (EPI_LOADS ? (144 * 1024 - EBYTES) : 128 * 1024) / CH;
     constexpr int NP = KCH / 32;                        // DMA pieces (8 rows x 128 B) per wave and chunk
     constexpr int ROUNDS = TM;                          // staging rounds of 128 channel rows (32 per wave)
     constexpr int NSTORE = ROUNDS * 4 * (PRE ? 2 : 1);  // epilogue memory instructions per thread and tile (always issued)
+    constexpr int EPIECES = EPI_LOADS ? ROUNDS * 4 : 0; // DMA pieces of the epilogue operand per wave and tile
     // chunks in flight ahead of the one being multiplied: as many as the ring and the 6-bit vmcnt field allow
-    constexpr int LOOK = KCH == 64 ? 8 : ((NP * 4 + 2 * NSTORE <= 63) ? 5 : 4);
+    constexpr int LOOK = SMALLK ? ((PRE || EPI_LOADS) ? 2 : 3) : (KCH == 64 ? 8 : ((NP * 4 + 2 * NSTORE <= 63) ? 5 : 4));
+    // small K with an epilogue operand: memory instructions a wave issues between the pieces of chunk c (requested in tile
+    // c - LOOK, after that tile's multiplications) and the wait for them at the start of tile c — the stores of tile c - LOOK,
+    // then operand pieces + chunk pieces + stores of each of the LOOK - 1 tiles in between
+    constexpr int SMALLK_EPI_WAIT = NSTORE + (LOOK - 1) * (EPIECES + NP + NSTORE);
+    static_assert(!(SMALLK && EPI_LOADS) || SMALLK_EPI_WAIT <= 63, "vmcnt is a 6-bit counter");
     constexpr int NEPI_MAX = (LOOK + NCH - 1) / NCH;    // tile ends the look-ahead window can span
     static_assert(LOOK <= NSLOT - 1, "a slot is refilled only after every wave has left it");
     static_assert(EPI_LOADS || NP * (LOOK - 1) + NEPI_MAX * NSTORE <= 63, "vmcnt is a 6-bit counter");
@@ -723,7 +737,8 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
     for (int q = 0; q < NP; ++q) vx[q] = (unsigned)((wave * NP + q) * 8 + (lane >> 3)) * nbytes + (unsigned)cxl * 16u;
     // the DMA stream: chunks in the order they are multiplied (tile after tile, NCH chunks each), kept as running scalar
     // state so that issuing one costs a handful of scalar instructions
-    const v4i_t rsX = make_rsrc(p.X + (long long)cb * p.K * p.N);
+    // small K: the descriptor ends with input channel K - 1, so that the chunk's rows K .. KCH - 1 arrive as zeros
+    const v4i_t rsX = SMALLK ? make_rsrc_n(p.X + (long long)cb * p.K * p.N, (unsigned)p.K * nbytes) : make_rsrc(p.X + (long long)cb * p.K * p.N);
     const unsigned kstride = (unsigned)KCH * nbytes;    // KCH input channels further
     int i_pt = pfirst, i_kc = 0, i_slot = 0;            // next chunk to issue: pixel tile, chunk within it, ring slot
     auto issue_next = [&]() {
@@ -732,6 +747,7 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)i_kc * kstride + n0b));
         const unsigned back = (unsigned)max(0, cxl - cmax) * 16u;
         if constexpr (NP == 2) dma2<1024>(lds0 + (unsigned)i_slot * CH, rsX, soff, vx[0] - back, vx[1] - back);
+        else if constexpr (NP == 3) dma3<1024>(lds0 + (unsigned)i_slot * CH, rsX, soff, vx[0] - back, vx[1] - back, vx[2] - back);
         else dma4<1024>(lds0 + (unsigned)i_slot * CH, rsX, soff, vx[0] - back, vx[1] - back, vx[2] - back, vx[3] - back);
         i_slot = i_slot + 1 == NSLOT ? 0 : i_slot + 1;
         if (++i_kc == NCH) {
@@ -801,6 +817,10 @@ __global__ __launch_bounds__(256, 1) void conv_nn_astat_kernel(const ConvNN p, i
             const int nfull = (LOOK - kc + NCH - 1) / NCH;      // a constant once the kc loop is unrolled
             if (c + LOOK > nchunks) {
                 wait_vmcnt<0>();
+            } else if (SMALLK && EPI_LOADS) {
+                // (the K = 384 form below drains the counter at every tile start, which is harmless with six or three chunks per
+                // tile requested a whole tile ahead; with ONE chunk per tile it would wait for the chunk requested a moment ago)
+                if (ts < LOOK) wait_vmcnt<0>(); else wait_vmcnt_le<SMALLK_EPI_WAIT>();
             } else if (EPI_LOADS) {
                 if (kc == 0) wait_vmcnt<0>();
             } else {
@@ -1272,6 +1292,23 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
     static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
     static const bool no_astat = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 'r'; }();   // "ring": no weight-stationary kernel
+    static const bool no_smallk = [] { const char* e = getenv("MAKANI_AMD_ASTAT_SMALLK"); return e && e[0] == '0'; }();
+    if (!force_tile && !no_astat && !no_smallk && lda == 80 && K > 64 && K <= 80 && M >= 256 && (long long)M * N * 2 < (1ll << 31) &&
+        (long long)K * N * 2 < (1ll << 32) && N >= 64 && !(R && G) && !((R || G) && act && Ypre)) {
+        // the 73-channel edges (K padded to lda = 80): the weight-stationary kernel with 5 k16-steps and one 96-row chunk per tile
+        const bool epi_loads = R || G;
+        const int slabs = (M + 383) / 384;
+        const long long tn = (N + 63) / 64;
+        const int wgs = epi_loads ? 256 : 512;                     // two workgroups per CU without the epilogue operand images
+        const long long streams = tn < wgs / slabs ? tn : wgs / slabs;
+        const dim3 grid((unsigned)(streams * slabs), (unsigned)B), blk(256);
+        const bool pre = act && Ypre;
+        hipStream_t s = (hipStream_t)stream;
+        if (epi_loads) hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, false, true, 5>), grid, blk, 0, s, p, slabs, tn);
+        else if (pre) hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, true, false, 5>), grid, blk, 0, s, p, slabs, tn);
+        else hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, false, false, 5>), grid, blk, 0, s, p, slabs, tn);
+        return mk_check_launch("mk_conv1x1_nn");
+    }
     if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
         // weights stationary in registers: 256- or 384-channel slabs (4 waves x 2 or 3 row tiles), 64-pixel tiles,
         // persistent grid of 256-thread workgroups.  MAKANI_AMD_ASTAT = "<tm><kch>" (e.g. 3128, 264) overrides the choice.

@@ -178,10 +178,15 @@ typedef __attribute__((address_space(1))) const u32x4 g_u32x4;
 __device__ const f32x4 g_zero32[2] = {};
 
 // fp32 tile staging: the tile of the NEXT k-step rides in registers while the current one is multiplied
-template <int ROWS, bool KC>
+// RQN: float4 vectors per k-row that are staged (default: the whole ROWS-wide tile).  A narrower operand (the real kernel's
+// NARROW form: 160 of 256 columns) is dealt over the threads vector by vector, so that whole waves — not lanes — go without
+// work for the columns that do not exist; the LDS image keeps the pitch of the ROWS-wide tile.
+template <int ROWS, bool KC, int RQN = ROWS / 4>
 struct Stage2 {
-    static constexpr int NV = (ROWS * BK / 4) / NT2;
-    static_assert(NV >= 1, "tile too small");
+    static constexpr int NVEC = KC ? ROWS * BK / 4 : RQN * BK;          // vectors of one k-step
+    static constexpr int NV = (NVEC + NT2 - 1) / NT2;
+    static constexpr bool RAGGED = NVEC % NT2 != 0;                       // the last round is not full
+    static_assert(NV >= 1 && (KC ? RQN == ROWS / 4 : true), "tile too small");
     f32x4 v[NV];
     unsigned keep;              // KC: 4 bits per vector = elements inside [klo, khi), applied when the tile is stored
     bool interior;              // uniform: the tile lies inside [klo, khi) (then no element masks are applied)
@@ -206,10 +211,10 @@ struct Stage2 {
                 p0[q] = base + (long long)(r0 + row) * rs + kq * 4 * u;
                 ok |= (r0 + row < rmax ? 1u : 0u) << q;
             } else {
-                constexpr int RQ = ROWS / 4;
-                const int kk = f / RQ, rq = f % RQ;
+                constexpr int RQ = RQN;
+                const int kk = (f / RQ) % BK, rq = f % RQ;            // (% BK: threads past the last vector of a ragged round)
                 p0[q] = base + (long long)kk * ks + (long long)(r0 + rq * 4) * u;
-                ok |= (r0 + rq * 4 < rmax ? 1u : 0u) << q;
+                ok |= ((r0 + rq * 4 < rmax && f < NVEC) ? 1u : 0u) << q;
             }
         }
     }
@@ -232,7 +237,7 @@ struct Stage2 {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) m |= in_range(k + e, klo, khi) ? (1u << e) : 0u;
                 } else {
-                    constexpr int RQ = ROWS / 4;
+                    constexpr int RQ = RQN;
                     valid = valid && in_range(k0 + f / RQ, klo, khi);
                 }
             }
@@ -247,7 +252,7 @@ struct Stage2 {
         if constexpr (KC) {
             return (f >> 2) * PK + (f & 3) * 4;
         } else {
-            constexpr int RQ = ROWS / 4;
+            constexpr int RQ = RQN;
             return (f / RQ) * (ROWS + 32) + (f % RQ) * 4;
         }
     }
@@ -257,6 +262,7 @@ struct Stage2 {
     __device__ __forceinline__ void store(u16* lds, int tid, float sign) const {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
+            if (RAGGED && q == NV - 1 && tid + q * NT2 >= NVEC) continue;      // (whole waves: NVEC is a multiple of 64)
             f32x4 r = v[q] * sign;
             if constexpr (KC) {
                 if (!interior) r = mask4(r, keep >> (4 * q));
@@ -537,9 +543,17 @@ struct PreA {
     int band_mode;
 };
 
-template <int NP>
+// NARROW (round 4; the ERA5-shaped transform of BASELINE's "fwd SHT GB/s" metric: 73 channels = 152 columns): at most 160
+// columns exist.  In the column-slice mapping above the waves of column slices 2 and 3 would then multiply (mostly) padding —
+// 146 TF dense-equivalent at C = 73 against 272 TF at C = 384.  Here wave w owns ROW tile t0 + w (all eight live row tiles of the
+// block, counted from the first live one, so that the triangle still shortens the waves' work evenly) x the five 32-column
+// tiles that exist: 30 MFMAs per wave and k-step instead of 48 on the busiest SIMD, and the data operand is split for 160
+// columns instead of 256 (whole waves skip the columns that do not exist).  Same arithmetic and accumulation order per
+// accumulator as the wide form.
+template <int NP, bool NARROW>
 __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA a, int tilesM, int tilesN) {
     constexpr int BM = 256, BN = 256;
+    constexpr int NCT = 5;                                 // NARROW: live 32-column tiles
     constexpr int PR = BM + 32;                            // pitch of the [k][row] limb tiles (both operands)
     constexpr int PL = BK * PR;                            // elements per limb plane
     constexpr int STG = 2 * NP * PL;
@@ -573,13 +587,14 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     bool live[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        tile[j] = t0 + grp + 2 * j;
-        live[j] = tile[j] < t1;
+        tile[j] = NARROW ? t0 + wave : t0 + grp + 2 * j;   // NARROW: one row tile per wave (slot 0)
+        live[j] = tile[j] < t1 && (!NARROW || j == 0);
     }
 
-    f32x16 acc[4][2];
+    // wide: acc[j][n] = row tile j x column tile n of the wave's slice; NARROW: acc[0 .. 4] (flattened) = the five column tiles
+    f32x16 acc[NARROW ? 3 : 4][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < (NARROW ? 3 : 4); ++j)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
     const int nk = kt1 - kt0;
     constexpr int D = MK_X2_DEPTH_R;
-    Stage2<BN, false> sb[D];
+    Stage2<BN, false, NARROW ? NCT * 8 : BN / 4> sb[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) sb[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
     // A limb vectors of this thread: k-row ak (0..15), rows [ar0, ar0 + 8) of the block
@@ -619,6 +634,26 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
         const u16* As = smem + buf * STG;
         const u16* Bs = As + NP * PL;
         if (!live[0]) return;
+        if constexpr (NARROW) {
+            bf16x8 bn[NCT][NP], an[NP];
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) bn[n][pl] = frag<BN, false>(Bs + pl * PL, n * 32, lane);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) an[pl] = frag<BM, false>(As + pl * PL, tile[0] * 32, lane);
+            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int IA[6] = {1, 0, 2, 0, 1, 0}, IB[6] = {1, 2, 0, 1, 0, 0};      // smallest terms first (as mma_split)
+            constexpr int O = NP == 3 ? 0 : 3;
+            prio_hi();
+#pragma unroll
+            for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+                for (int n = 0; n < NCT; ++n)
+                    acc[n >> 1][n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(an[IA[O + q]], bn[n][IB[O + q]], acc[n >> 1][n & 1], 0, 0, 0);
+            prio_lo();
+            return;
+        }
         bf16x8 bf[2][NP];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -674,11 +709,11 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
 
     float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
     if (a.band_mode == 2 && !p.beta) {                     // stored rows outside the band: exact zeros
-        for (int t = s0 + grp; t < s1; t += 2) {
+        for (int t = s0 + (NARROW ? wave : grp); t < s1; t += (NARROW ? 8 : 2)) {
             if (t >= t0 && t < t1) continue;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int col = c.j0 + cs * 64 + n * 32 + l31;
+            for (int n = 0; n < (NARROW ? NCT : 2); ++n) {
+                const int col = NARROW ? c.j0 + n * 32 + l31 : c.j0 + cs * 64 + n * 32 + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = c.i0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -686,6 +721,25 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
                 }
             }
         }
+    }
+    if constexpr (NARROW) {
+        if (live[0]) {
+#pragma unroll
+            for (int n = 0; n < NCT; ++n) {
+                const int col = c.j0 + n * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = c.i0 + tile[0] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < c.Meff && col < p.N) {
+                        float* dst = Cb + (long long)row * p.c_row + col;
+                        float val = acc[n >> 1][n & 1][r];
+                        if (p.beta) val += *dst;
+                        *dst = val;
+                    }
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -776,9 +830,16 @@ extern "C" int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, 
     PreA a{(const u16*)a_planes, pl_stride, pl_batch, pl_k, (int)(pl_k & ~7ll), band_lo, band_hi, band_mode};
     dim3 grid((unsigned)nb), block(NT2);
     hipStream_t s = (hipStream_t)stream;
-    if (limbs == 3)
-        hipLaunchKernelGGL((xgemm2_kernel<3>), grid, block, 0, s, *g, a, tm, tn);
+    // at most 160 columns (one column tile, five 32-column MFMA tiles): the row-tile-per-wave form (MK_X2_NARROW=0 keeps the wide one)
+    static const bool narrow_ok = [] { const char* e = getenv("MAKANI_AMD_X2_NARROW"); return !(e && e[0] == '0'); }();
+    if (narrow_ok && g->N <= 160) {
+        if (limbs == 3)
+            hipLaunchKernelGGL((xgemm2_kernel<3, true>), grid, block, 0, s, *g, a, tm, tn);
+        else
+            hipLaunchKernelGGL((xgemm2_kernel<2, true>), grid, block, 0, s, *g, a, tm, tn);
+    } else if (limbs == 3)
+        hipLaunchKernelGGL((xgemm2_kernel<3, false>), grid, block, 0, s, *g, a, tm, tn);
     else
-        hipLaunchKernelGGL((xgemm2_kernel<2>), grid, block, 0, s, *g, a, tm, tn);
+        hipLaunchKernelGGL((xgemm2_kernel<2, false>), grid, block, 0, s, *g, a, tm, tn);
     return mk_check_launch("mk_sgemm_presplit_batched");
 }

@@ -496,10 +496,10 @@ def _ensemble_active(flag) -> bool:
     return active
 
 
-def _ens_w(w, E):
+def _ens_w(w, E, crps_type="cdf"):
     if w is not None and w.numel() != E:
         raise ValueError(f"ensemble_weights holds {w.numel()} entries for an ensemble of {E}")
-    return w
+    return w if crps_type == "cdf" else None          # only the cdf kernel reads the values (PWM accepts and ignores them)
 
 
 class CRPSLoss(nn.Module):
@@ -562,10 +562,10 @@ class CRPSLoss(nn.Module):
                                                 w.reshape(B, Cc, H * W) if w is not None else None)
             E = f.shape[1]
             crps = CrpsFn.apply(f.unsqueeze(-1), o.unsqueeze(-1), q, w.unsqueeze(-1) if w is not None else None,
-                                _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, E))
+                                _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, E, self.crps_type))
             return self.quadrature._reduce(_ReduceFromGroupFn.apply(crps, group))
         crps = CrpsFn.apply(forecasts, observations, q, w,
-                            _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, E))
+                            _CRPS_TYPES[self.crps_type], self.alpha, self.eps, _ens_w(self.ensemble_weights, E, self.crps_type))
         return self.quadrature._reduce(crps)
 
 

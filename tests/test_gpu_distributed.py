@@ -295,6 +295,21 @@ def _worker_multistep(rank, world, port, h, w, checkpointed, amp):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             ys = MultiStepWrapper(serial, n_future=NF).train()(xs)
         (ys.float() * G).sum().backward()
+        e_ser = None
+        if amp:
+            # bf16: a 4-step rollout of a 16-channel random network amplifies rounding differences (the two schedules sum in
+            # different orders), so the reference is the serial FP32 rollout and the yardstick the serial bf16 rollout's own
+            # distance from it
+            def _r(t):
+                return torch.view_as_real(t) if t.is_complex() else t
+            g16 = {k: p.grad.clone() for k, p in serial.named_parameters()}
+            y16, gx16 = ys.float().detach(), xs.grad.clone()
+            serial.zero_grad(set_to_none=True)
+            xs = x.clone().requires_grad_(True)
+            ys = MultiStepWrapper(serial, n_future=NF).train()(xs)
+            (ys * G).sum().backward()
+            e_ser = (_rel(y16, ys), _rel(gx16, xs.grad),
+                     max(_rel(_r(g16[k]), _r(p.grad)) for k, p in serial.named_parameters() if not k.endswith("mlp.fwd.3.bias")))
 
         _, ih, iw = mcomm.init(h, w)                       # the tree bench.py builds; the network finds h / w / spatial in it
         model = ma.SphericalFourierNeuralOperatorNet(**cfg).to(dev)
@@ -314,13 +329,18 @@ def _worker_multistep(rank, world, port, h, w, checkpointed, amp):
             yl = net(xl)
         assert yl.shape == (B, 4 * (NF + 1), hl, wl)
         (yl.float() * G[..., lat0:lat0 + hl, lon0:lon0 + wl]).sum().backward()
-        tol_y, tol_g = (2e-2, 4e-2) if amp else (2e-4, 1e-3)            # three steps feed on each other's rounding
+        # fp32: against the serial rollout; bf16: against the serial FP32 rollout, no further from it than 2 x the serial bf16
+        # rollout is (a shard's relative error scatters around the whole field's)
+        tol_y, tol_g = (2 * e_ser[0], 2 * e_ser[1]) if amp else (2e-4, 1e-3)
         e_y = _rel(yl.float(), ys.float()[..., lat0:lat0 + hl, lon0:lon0 + wl])
         e_gx = _rel(xl.grad, xs.grad[..., lat0:lat0 + hl, lon0:lon0 + wl])
-        assert e_y < tol_y and e_gx < tol_g, (rank, e_y, e_gx)
+        assert e_y < tol_y and e_gx < tol_g, (rank, e_y, e_gx, e_ser)
         sref = dict(serial.named_parameters())
         for k, p in model.named_parameters():
-            if k.endswith("mlp.fwd.3.bias"):
+            # bf16: the parameter gradients of this 16-channel random network through a 4-step rollout are dominated by rounding
+            # (the serial bf16 rollout's own gradients sit e_ser[2] ~ 1 from the fp32 ones; measured 2.7 between the schedules on
+            # the encoder weight), so they are compared in fp32 only — outputs and input gradient above are compared in both
+            if amp or k.endswith("mlp.fwd.3.bias"):
                 continue
             ref = sref[k].grad[..., l0:l0 + ll] if k.endswith("filter.filter.weight") else sref[k].grad
             e = _rel(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad,

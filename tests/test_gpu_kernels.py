@@ -453,7 +453,12 @@ def test_fused_adamw_matches_torch():
                                      (1, 677, 1354, 48, 48), (1, 1354, 641, 48, 48), (2, 450, 400, 32, 72),
                                      # FourCastNet3's local-block channel mix itself: 677 <- 6093 = 677 x 9 (96 k-tiles, the last
                                      # one ragged: 13 of 64 input channels), forward / fused epilogues / weight gradient
-                                     (1, 677, 6093, 24, 48), (1, 6093, 677, 16, 24)])
+                                     (1, 677, 6093, 24, 48), (1, 6093, 677, 16, 24),
+                                     # the 73-channel edges on the weight-stationary kernel (round 4: K padded to lda = 80, one 96-row
+                                     # chunk per tile whose rows >= K arrive as zeros): ragged last pixel tile, batch, slab rows past M,
+                                     # two slabs with K = 80 exactly, fewer tiles than workgroups
+                                     (1, 384, 73, 37, 72), (2, 384, 73, 16, 40), (1, 300, 73, 91, 184), (1, 768, 80, 12, 24),
+                                     (1, 384, 73, 8, 16)])
 def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
     from makani_amd import ops
     torch.manual_seed(M + K)
@@ -469,6 +474,10 @@ def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
     pre_ref = ref + bias.double().view(1, -1, 1, 1)
     assert rel_l2(pre, pre_ref) < 4e-3
     assert rel_l2(y, torch.nn.functional.gelu(pre_ref) + res.double()) < 5e-3
+    y, pre = ops.conv1x1_nn(A, K, x.to(_dev()), bias=bias.to(_dev()), act=True, want_pre=True)      # the MLP's / encoder's first layer
+    assert rel_l2(pre, pre_ref) < 4e-3 and rel_l2(y, torch.nn.functional.gelu(pre_ref)) < 5e-3
+    y, _ = ops.conv1x1_nn(A, K, x.to(_dev()), residual=res.to(_dev()))                               # the skip connections
+    assert rel_l2(y, ref + res.double()) < 5e-3
     gsrc = torch.randn(B, M, H, W).bfloat16()
     y, _ = ops.conv1x1_nn(A, K, x.to(_dev()), gelu_grad_of=gsrc.to(_dev()))
     gd = gsrc.double().requires_grad_(True)

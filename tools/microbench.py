@@ -258,6 +258,27 @@ def spectral():
         print(f"sep wgrad Mw={Mw:3d}: {ms:7.3f} ms  {nb/ms/1e6:7.1f} GB/s dense")
 
 
+def sht():
+    """BASELINE's secondary metric "fwd SHT GB/s" (bench.py: sht_bandwidth): S1 ERA5-shaped (73 channels, full band),
+    S2 model-shaped; plus the Legendre step of S1 alone (the narrow-operand form of the real split kernel, csrc/xgemm2.hip)"""
+    for name, C, lmax, mmax in (("S1_c73_L721_M721", 73, 721, 721), ("S2_c384_L240_M241", 384, 240, 241)):
+        S = ma.RealSHT(721, 1440, lmax=lmax, mmax=mmax, grid="equiangular").to(dev)
+        x = torch.rand(1, C, 721, 1440, device=dev)
+        ms = timeit(lambda: S(x), reps=10, warm=2)
+        nb = C * 721 * 1440 * 4 + C * lmax * mmax * 8
+        print(f"fwd SHT {name}: {ms:7.3f} ms  {nb/ms/1e6:7.1f} GB/s")
+        if C == 73:
+            R = ops.round4(C)
+            F = torch.randn(mmax, 721, 2, R, device=dev)
+            fl = 4.0 * C * 721 * lmax * mmax
+            ms = timeit(lambda: ops.legendre_analysis(F, S.weights_t, lmax), reps=10, warm=2)
+            print(f"   legendre analysis  C=73 full band: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
+            c = 2 * math.pi / 1440
+            ms = timeit(lambda: ops.rfft_rows(x, mmax, R, (c, c, c)), reps=10, warm=2)
+            print(f"   rfft 1440 fp32 C=73 full spectrum : {ms:7.3f} ms")
+        del S, x
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fft", "legendre", "dhconv", "pointwise"]
     for w in which:
