@@ -18,6 +18,10 @@
 
 #include "common.h"
 
+#ifndef MK_ASTAT_EPI_DRAIN
+#define MK_ASTAT_EPI_DRAIN 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -811,9 +815,7 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
             // tile ends among the steps c - LOOK .. c - 1, i.e. ceil((LOOK - kc) / NCH) of them once the stream is that old,
             // fewer within the first tiles (never more than ts).  vmcnt retires in order (loads and stores alike), so "at
             // most that many outstanding" means chunk c has landed.  Near the end of the stream fewer chunks are in flight:
-            // wait for everything.  With operand loads in the epilogue (EPI_LOADS) hipcc's wait in front of their first use
-            // drains the whole counter in every round, and every chunk is issued at least one epilogue before its use
-            // (LOOK >= NCH); one explicit drain at the start of a tile makes that independent of the compiler.
+            // wait for everything.
             const int nfull = (LOOK - kc + NCH - 1) / NCH;      // a constant once the kc loop is unrolled
             if (c + LOOK > nchunks) {
                 wait_vmcnt<0>();
@@ -822,7 +824,29 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                 // tile requested a whole tile ahead; with ONE chunk per tile it would wait for the chunk requested a moment ago)
                 if (ts < LOOK) wait_vmcnt<0>(); else wait_vmcnt_le<SMALLK_EPI_WAIT>();
             } else if (EPI_LOADS) {
+                // Round 4: counted like the other variants (the drain that stood here — s_waitcnt vmcnt(0) at the start of every
+                // tile — waited for the chunk requested ONE step earlier, i.e. exposed a full memory round trip per pixel tile;
+                // tools/vmcnt_check.py reports the slack of every wait and checks this count against a model of the stream).
+                // Behind the pieces of chunk c (requested in step c - LOOK, after that step's operand images) a wave issued:
+                // the LOOK - 1 younger chunks, the stores of the nfull tile ends in between and the operand images of the tile
+                // starts strictly in between (nfull of them, one fewer when this step is itself a tile start: its images are
+                // requested behind this wait).  The first tiles have fewer epilogues behind them: drained.
+#if MK_ASTAT_EPI_DRAIN          // the round-3 behaviour, kept for the same-box A/B (tools/ab_fast.sh conv1x1 drain:-DMK_ASTAT_EPI_DRAIN=1)
                 if (kc == 0) wait_vmcnt<0>();
+                if (true) {
+                } else
+#endif
+                if (ts < NEPI_MAX) {
+                    wait_vmcnt<0>();
+                } else if (kc == 0) {
+                    if (nfull == 1) wait_vmcnt_le<NP * (LOOK - 1) + NSTORE>();
+                    else if (nfull == 2) wait_vmcnt_le<NP * (LOOK - 1) + 2 * NSTORE + EPIECES>();
+                    else wait_vmcnt_le<NP * (LOOK - 1) + 3 * NSTORE + 2 * EPIECES>();
+                } else {
+                    if (nfull == 1) wait_vmcnt_le<NP * (LOOK - 1) + NSTORE + EPIECES>();
+                    else if (nfull == 2) wait_vmcnt_le<NP * (LOOK - 1) + 2 * NSTORE + 2 * EPIECES>();
+                    else wait_vmcnt_le<NP * (LOOK - 1) + 3 * NSTORE + 3 * EPIECES>();
+                }
             } else {
                 const int nepi = min(nfull, ts);
                 if (nepi == 0) wait_vmcnt_le<NP * (LOOK - 1)>();
