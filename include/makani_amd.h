@@ -263,12 +263,19 @@ int mk_spec_diag_wgrad(const float* x, const float* gy, float* gw_c64, int L, in
  *       A: (M, lda) k-contiguous, zero padded to lda (multiple of 8).  Forward: A = W; dgrad: A = W^T.
  *       epi(v) = v + bias[m]; if act: (Ypre = v), v = gelu(v); if G: v *= gelu'(G[b][m][n]); if R: v += R[b][m][n].
  *   mk_conv1x1_wgrad: dW[m][k] (+)= sum_{b,n} G[b][m][n] X[b][k][n]; `part` = scratch of
- *       mk_conv1x1_wgrad_workspace(M, K, B, N) floats (split-pixel partial tiles, reduced deterministically). */
+ *       mk_conv1x1_wgrad_workspace(M, K, B, N) floats (split-pixel partial tiles, reduced deterministically).
+ *   mk_conv1x1_wgrad_bias: the same and, from the same pass over G, the bias gradient of the convolution
+ *       db[m] = sum_{b,n} G[b][m][n] (what torch's conv backward returns as grad_bias; fp32, M entries, overwritten) —
+ *       available where mk_conv1x1_wgrad_fuses_bias(M, K, B, N) returns 1 (the streaming "ring" kernel), else the caller
+ *       takes the plane sums with mk_plane_sums. */
 int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, const float* bias, const void* R, const void* G,
                   int M, int K, int lda, int B, long long N, int act, void* stream);
 long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N);
 int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* part, int M, int K, int B, long long N,
                      int accumulate, void* stream);
+int mk_conv1x1_wgrad_fuses_bias(int M, int K, int B, long long N);
+int mk_conv1x1_wgrad_bias(const void* G, const void* X, float* dW, float* dbias, float* part, int M, int K, int B, long long N,
+                          int accumulate, void* stream);
 
 /* ---- optimizer ------------------------------------------------------------------------
  * One fused AdamW update (torch.optim.AdamW semantics: decoupled weight decay, bias correction with

@@ -83,6 +83,8 @@ _SIGS = {
     "mk_conv1x1_nn": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
     "mk_conv1x1_wgrad_workspace": ([c_int, c_int, c_int, c_ll], c_ll),
     "mk_conv1x1_wgrad": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
+    "mk_conv1x1_wgrad_fuses_bias": ([c_int, c_int, c_int, c_ll], c_int),
+    "mk_conv1x1_wgrad_bias": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_ll, c_int, c_vp], c_int),
     "mk_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_f, c_f, c_f, c_f, c_f, c_int, c_vp, c_vp], c_int),
     "mk_adamw_advance": ([c_vp, c_f, c_f, c_vp], c_int),
     "mk_bias_gelu_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_ll, c_vp], c_int),

@@ -1141,6 +1141,7 @@ struct ConvWgR {
     int ldo;         // row length of the output (= K)
     long long N;
     long long chunk;   // pixels per split (multiple of 64)
+    float* bias_part;  // optional (S, M): per-split row sums of G (the bias gradient), see below
 };
 
 
@@ -1227,6 +1228,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Bias gradient (round 4): db[m] = sum over pixels of G[m] — the same rows this kernel streams anyway; a separate
+    // plane-sum pass re-read every gradient tensor (0.87 ms per step).  G is operand P (rows m) when not swapped, Q when
+    // swapped; the waves of ONE column (row) of the wave grid add up the fragments they read for the MFMAs with
+    // v_dot2c_f32_bf16 against (1, 1) — 4 VALU instructions per fragment on a VALU that is otherwise idle here, no extra
+    // accumulator tile — and only the workgroups of Q slab 0 (P slab 0) write their split's sums.
+    constexpr int WTG = SWAP ? WTQ : WTP;
+    const bool bias_wave = p.bias_part != nullptr && (SWAP ? (wp == 0 && slab == 0) : (wq == 0 && qs == 0));
+    float rsum[WTG];
+#pragma unroll
+    for (int i = 0; i < WTG; ++i) rsum[i] = 0.f;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    auto add8 = [](float s, bf16x8 v) {
+        const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+        s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{v[0], v[1]}, one, s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{v[2], v[3]}, one, s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{v[4], v[5]}, one, s, false);
+        return __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{v[6], v[7]}, one, s, false);
+    };
+
     auto compute = [&](int stage) {
         const unsigned char* sb = smem + stage * STAGE;
 #pragma unroll
@@ -1236,6 +1256,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
             for (int i = 0; i < WTP; ++i) pf[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(sb + pa[ks] + i * 4096));
 #pragma unroll
             for (int j = 0; j < WTQ; ++j) qf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(sb + qa[ks] + j * 4096));
+            if (bias_wave) {                            // (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < WTG; ++i) rsum[i] = add8(rsum[i], SWAP ? qf[i] : pf[i]);
+            }
 #pragma unroll
             for (int i = 0; i < WTP; ++i)
 #pragma unroll
@@ -1254,6 +1278,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my fragment reads have RETURNED (a raw s_barrier does not wait) ...
         __builtin_amdgcn_s_barrier();                                   // ... and everybody's: the stage may be overwritten
         if (kt + 2 < nk) issue(kt + 2, kt & 1);
+    }
+
+    if (bias_wave) {                                    // lane (l31, lh) holds the pixels of k-block lh of row l31: add the halves
+        const int RG = SWAP ? p.RQ : p.RP;              // rows of G = M
+#pragma unroll
+        for (int i = 0; i < WTG; ++i) {
+            const float tot = rsum[i] + __shfl_xor(rsum[i], 32);
+            const int m = SWAP ? q0 + (wq * WTQ + i) * 32 + l31 : slab * TP + (wp * WTP + i) * 32 + l31;
+            if (lh == 0 && m < RG) p.bias_part[(long long)sp * RG + m] = tot;
+        }
     }
 
     // ---- partial tile -> part[sp] in output orientation (lanes along k) ----
@@ -1466,12 +1500,37 @@ WgPlan wgrad_plan(int M, int K, int B, long long N) {
 }  // namespace
 
 extern "C" long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N) {
-    // number of fp32 elements the caller must provide as `part`
-    return wgrad_plan(M, K, B, N).S * (long long)M * K;
+    // number of fp32 elements the caller must provide as `part` (the (S, M, K) partial products, then (S, M) partial row sums
+    // of G for mk_conv1x1_wgrad_bias)
+    const WgPlan pl = wgrad_plan(M, K, B, N);
+    return pl.S * (long long)M * K + pl.S * (long long)M;
 }
+
+// 1 if mk_conv1x1_wgrad_bias computes the bias gradient inside the weight-gradient kernel for this shape (the ring kernel),
+// 0 if the caller has to take the plane sums itself (mk_plane_sums)
+extern "C" int mk_conv1x1_wgrad_fuses_bias(int M, int K, int B, long long N) {
+    return wgrad_plan(M, K, B, N).ring ? 1 : 0;
+}
+
+static int conv1x1_wgrad_impl(const void* G, const void* X, float* dW, float* dbias, float* part, int M, int K, int B, long long N,
+                              int accumulate, void* stream);
 
 extern "C" int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* part, int M, int K, int B, long long N,
                                 int accumulate, void* stream) {
+    return conv1x1_wgrad_impl(G, X, dW, nullptr, part, M, K, B, N, accumulate, stream);
+}
+
+// the weight gradient AND the bias gradient db[m] = sum_{b,n} G[b][m][n] (fp32, M entries, overwritten) from one pass over G;
+// only where mk_conv1x1_wgrad_fuses_bias says so
+extern "C" int mk_conv1x1_wgrad_bias(const void* G, const void* X, float* dW, float* dbias, float* part, int M, int K, int B,
+                                     long long N, int accumulate, void* stream) {
+    MK_REQUIRE(dbias, "conv1x1_wgrad_bias: null pointer");
+    MK_REQUIRE(wgrad_plan(M, K, B, N).ring, "conv1x1_wgrad_bias: this shape runs the tile kernel, which does not form the bias gradient");
+    return conv1x1_wgrad_impl(G, X, dW, dbias, part, M, K, B, N, accumulate, stream);
+}
+
+static int conv1x1_wgrad_impl(const void* G, const void* X, float* dW, float* dbias, float* part, int M, int K, int B, long long N,
+                              int accumulate, void* stream) {
     MK_REQUIRE(G && X && dW && part, "conv1x1_wgrad: null pointer");
     MK_REQUIRE(M > 0 && K > 0 && B > 0 && N > 0 && (N % 8) == 0, "conv1x1_wgrad: bad shape");
     const WgPlan pl = wgrad_plan(M, K, B, N);
@@ -1483,6 +1542,7 @@ extern "C" int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* 
         p.RP = pl.swap ? K : M;
         p.RQ = pl.swap ? M : K;
         p.part = part, p.B = B, p.S = (int)pl.S, p.slabs = pl.slabs, p.qslabs = pl.qslabs, p.ldo = K, p.N = N, p.chunk = pl.chunk;
+        p.bias_part = dbias ? part + pl.S * (long long)M * K : nullptr;
         const dim3 grid((unsigned)(pl.slabs * pl.qslabs * pl.S)), blk(512);
         if (pl.tp == 256) {
             if (pl.swap) hipLaunchKernelGGL((conv_wgrad_ring_kernel<2, 4, 4, 3, true>), grid, blk, 0, s, p);
@@ -1504,5 +1564,7 @@ extern "C" int mk_conv1x1_wgrad(const void* G, const void* X, float* dW, float* 
                            n / 4, (int)pl.S, accumulate);
     else
         hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dW, n, (int)pl.S, accumulate);
+    if (dbias)
+        hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, part + pl.S * n, dbias, (long long)M, (int)pl.S, 0);
     return mk_check_launch("mk_conv1x1_wgrad");
 }

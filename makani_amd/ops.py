@@ -942,8 +942,10 @@ def conv1x1_nn(A: torch.Tensor, K: int, x: torch.Tensor, bias=None, act=False, w
     return y, ypre
 
 
-def conv1x1_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW[m][k] = sum_{b,n} g[b][m][n] x[b][k][n]  -> (M, K) fp32."""
+def conv1x1_wgrad(g: torch.Tensor, x: torch.Tensor, want_bias: bool = False):
+    """dW[m][k] = sum_{b,n} g[b][m][n] x[b][k][n]  -> (M, K) fp32.  ``want_bias``: returns (dW, db) with the bias gradient
+    db[m] = sum_{b,n} g[b][m][n] — formed inside the weight-gradient kernel from the rows it streams anyway where the library
+    can (the ring kernel: every shape of the train step), by a separate plane-sum pass elsewhere."""
     B, M, H, W = g.shape
     K = x.shape[1]
     N = H * W
@@ -951,9 +953,16 @@ def conv1x1_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     nws = lib().mk_conv1x1_wgrad_workspace(M, K, B, N)
     part = torch.empty((nws,), dtype=torch.float32, device=g.device)
     dW = torch.empty((M, K), dtype=torch.float32, device=g.device)
+    fused = want_bias and bool(lib().mk_conv1x1_wgrad_fuses_bias(M, K, B, N)) and os.environ.get("MAKANI_AMD_WGRAD_BIAS", "1") != "0"
     with _timed(f"conv1x1_wgrad_m{M}_k{K}_n{N}", flops=2.0 * B * M * K * N, nbytes=2.0 * B * N * (M + K)):
-        check(lib().mk_conv1x1_wgrad(ptr(g), ptr(x), ptr(dW), ptr(part), M, K, B, N, 0, stream()), "mk_conv1x1_wgrad")
-    return dW
+        if fused:
+            db = torch.empty((M,), dtype=torch.float32, device=g.device)
+            check(lib().mk_conv1x1_wgrad_bias(ptr(g), ptr(x), ptr(dW), ptr(db), ptr(part), M, K, B, N, 0, stream()), "mk_conv1x1_wgrad_bias")
+        else:
+            check(lib().mk_conv1x1_wgrad(ptr(g), ptr(x), ptr(dW), ptr(part), M, K, B, N, 0, stream()), "mk_conv1x1_wgrad")
+    if not want_bias:
+        return dW
+    return dW, (db if fused else _sum_planes(g))
 
 
 def _sum_planes(t: torch.Tensor) -> torch.Tensor:
@@ -989,9 +998,14 @@ class Conv1x1Fn(torch.autograd.Function):
         gx = gw = gb = gr = None
         if ctx.needs_input_grad[0]:
             gx, _ = conv1x1_nn(At, M, gy)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = conv1x1_wgrad(gy, x).view_as(weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_b:                                  # the bias gradient rides on the weight gradient's pass over gy
+                gw, gb = conv1x1_wgrad(gy, x, want_bias=True)
+                gw = gw.view_as(weight)
+            else:
+                gw = conv1x1_wgrad(gy, x).view_as(weight)
+        elif want_b:
             gb = _sum_planes(gy)
         if ctx.has_res and ctx.needs_input_grad[3]:
             gr = gy
@@ -1023,10 +1037,21 @@ class ConvGeluConvFn(torch.autograd.Function):
         gy = gy.contiguous()
         # ga1 = (W2^T gy) * gelu'(a1)
         ga1, _ = conv1x1_nn(A2t, M, gy, gelu_grad_of=a1)
-        gw2 = conv1x1_wgrad(gy, h).view_as(w2) if ctx.needs_input_grad[3] else None
-        gb2 = _sum_planes(gy) if (ctx.has_b[1] and ctx.needs_input_grad[4]) else None
-        gw1 = conv1x1_wgrad(ga1, x).view_as(w1) if ctx.needs_input_grad[1] else None
-        gb1 = _sum_planes(ga1) if (ctx.has_b[0] and ctx.needs_input_grad[2]) else None
+        # (the bias gradients ride on the weight gradients' passes over gy / ga1 where both are wanted)
+        gw2 = gb2 = gw1 = gb1 = None
+        want_b2, want_b1 = ctx.has_b[1] and ctx.needs_input_grad[4], ctx.has_b[0] and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[3] and want_b2:
+            gw2, gb2 = conv1x1_wgrad(gy, h, want_bias=True)
+            gw2 = gw2.view_as(w2)
+        else:
+            gw2 = conv1x1_wgrad(gy, h).view_as(w2) if ctx.needs_input_grad[3] else None
+            gb2 = _sum_planes(gy) if want_b2 else None
+        if ctx.needs_input_grad[1] and want_b1:
+            gw1, gb1 = conv1x1_wgrad(ga1, x, want_bias=True)
+            gw1 = gw1.view_as(w1)
+        else:
+            gw1 = conv1x1_wgrad(ga1, x).view_as(w1) if ctx.needs_input_grad[1] else None
+            gb1 = _sum_planes(ga1) if want_b1 else None
         gx = None
         if ctx.needs_input_grad[0]:
             gx, _ = conv1x1_nn(A1t, H1, ga1)

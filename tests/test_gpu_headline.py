@@ -117,11 +117,13 @@ def test_conv1x1_wgrad_fullres(Mm, K):
     torch.manual_seed(Mm * 7 + K)
     g = (torch.randn(1, Mm, 721, 1440) * 0.5).bfloat16()
     x = (torch.rand(1, K, 721, 1440) - 0.3).bfloat16()          # non-zero mean: the partial sums do not cancel
-    dW = ops.conv1x1_wgrad(g.to(DEV), x.to(DEV))
+    dW, db = ops.conv1x1_wgrad(g.to(DEV), x.to(DEV), want_bias=True)       # the bias gradient rides on the same pass over g
     ref = _wgrad_ref(g, x)
     assert dW.shape == (Mm, K) and dW.dtype == torch.float32
     e = rel_l2(dW, ref)
     assert e < TOL_OP, e
+    bref = g.reshape(Mm, -1).double().sum(dim=1)
+    assert db.shape == (Mm,) and float((db.cpu().double() - bref).abs().max()) < 2e-6 * float(g.reshape(Mm, -1).double().abs().sum(dim=1).max())
 
 
 @pytest.mark.parametrize("Mm,K", [(768, 384), (384, 768), (384, 384), (73, 384), (384, 73)])

@@ -488,6 +488,13 @@ def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
     dW = ops.conv1x1_wgrad(g.to(_dev()), x.to(_dev()))
     dref = torch.einsum("bmhw,bkhw->mk", g.double(), x.double())
     assert dW.dtype == torch.float32 and rel_l2(dW, dref) < 1e-5
+    # ... with the bias gradient from the same pass over g (round 4: row sums inside the ring kernel; plane sums elsewhere)
+    gm = (g.float() + 0.25).bfloat16()                               # non-zero mean: the sums do not cancel
+    dW2, db = ops.conv1x1_wgrad(gm.to(_dev()), x.to(_dev()), want_bias=True)
+    assert db.shape == (M,) and db.dtype == torch.float32
+    bref = gm.double().sum(dim=(0, 2, 3))
+    assert float((db.cpu().double() - bref).abs().max()) < 2e-6 * float(gm.double().abs().sum(dim=(0, 2, 3)).max())
+    assert rel_l2(dW2, torch.einsum("bmhw,bkhw->mk", gm.double(), x.double())) < 1e-5
 
 
 def test_conv_gelu_conv_autograd():
