@@ -1230,11 +1230,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
 
     // Bias gradient (round 4): db[m] = sum over pixels of G[m] — the same rows this kernel streams anyway; a separate
     // plane-sum pass re-read every gradient tensor (0.87 ms per step).  G is operand P (rows m) when not swapped, Q when
-    // swapped; the waves of ONE column (row) of the wave grid add up the fragments they read for the MFMAs with
-    // v_dot2c_f32_bf16 against (1, 1) — 4 VALU instructions per fragment on a VALU that is otherwise idle here, no extra
-    // accumulator tile — and only the workgroups of Q slab 0 (P slab 0) write their split's sums.
+    // swapped.  The waves add up the fragments they read for the MFMAs with v_dot2c_f32_bf16 against (1, 1); the NSH waves that
+    // read the same G rows (the WQ waves of a row of the wave grid, or the WP waves of a column) share the work by k16-step —
+    // a first version that left it to one wave of each row made those waves 40 % longer than their neighbours (wgrad +0.4 ms
+    // per step); a v_dot2c costs about ten cycles beside MFMAs — and write their shares as separate partial rows:
+    // bias_part is (S x NSH, M).  Only the workgroups of Q slab 0 (P slab 0 when swapped) write.
     constexpr int WTG = SWAP ? WTQ : WTP;
-    const bool bias_wave = p.bias_part != nullptr && (SWAP ? (wp == 0 && slab == 0) : (wq == 0 && qs == 0));
+    constexpr int NSH = SWAP ? WP : WQ;                 // waves sharing one set of G rows
+    static_assert(NSH == 2 || NSH == 4, "k16-steps are dealt over 2 or 4 waves");
+    const int bshare = SWAP ? wp : wq;
+    const bool bias_wave = p.bias_part != nullptr && (SWAP ? slab == 0 : qs == 0);
     float rsum[WTG];
 #pragma unroll
     for (int i = 0; i < WTG; ++i) rsum[i] = 0.f;
@@ -1256,7 +1261,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
             for (int i = 0; i < WTP; ++i) pf[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(sb + pa[ks] + i * 4096));
 #pragma unroll
             for (int j = 0; j < WTQ; ++j) qf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(sb + qa[ks] + j * 4096));
-            if (bias_wave) {                            // (wave-uniform)
+            if (bias_wave && (ks & (NSH - 1)) == bshare) {      // (wave-uniform)
 #pragma unroll
                 for (int i = 0; i < WTG; ++i) rsum[i] = add8(rsum[i], SWAP ? qf[i] : pf[i]);
             }
@@ -1286,7 +1291,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
         for (int i = 0; i < WTG; ++i) {
             const float tot = rsum[i] + __shfl_xor(rsum[i], 32);
             const int m = SWAP ? q0 + (wq * WTQ + i) * 32 + l31 : slab * TP + (wp * WTP + i) * 32 + l31;
-            if (lh == 0 && m < RG) p.bias_part[(long long)sp * RG + m] = tot;
+            if (lh == 0 && m < RG) p.bias_part[((long long)sp * NSH + bshare) * RG + m] = tot;
         }
     }
 
@@ -1503,7 +1508,7 @@ extern "C" long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N
     // number of fp32 elements the caller must provide as `part` (the (S, M, K) partial products, then (S, M) partial row sums
     // of G for mk_conv1x1_wgrad_bias)
     const WgPlan pl = wgrad_plan(M, K, B, N);
-    return pl.S * (long long)M * K + pl.S * (long long)M;
+    return pl.S * (long long)M * K + 4 * pl.S * (long long)M;
 }
 
 // 1 if mk_conv1x1_wgrad_bias computes the bias gradient inside the weight-gradient kernel for this shape (the ring kernel),
@@ -1564,7 +1569,8 @@ static int conv1x1_wgrad_impl(const void* G, const void* X, float* dW, float* db
                            n / 4, (int)pl.S, accumulate);
     else
         hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dW, n, (int)pl.S, accumulate);
-    if (dbias)
-        hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, part + pl.S * n, dbias, (long long)M, (int)pl.S, 0);
+    if (dbias)      // (S x NSH, M) partial rows: NSH = 4 waves share a set of G rows when G is the slab operand, 2 when it is not
+        hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, part + pl.S * n, dbias, (long long)M,
+                           (int)pl.S * (pl.swap ? 2 : 4), 0);
     return mk_check_launch("mk_conv1x1_wgrad");
 }
