@@ -1228,18 +1228,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Bias gradient (round 4): db[m] = sum over pixels of G[m] — the same rows this kernel streams anyway; a separate
-    // plane-sum pass re-read every gradient tensor (0.87 ms per step).  G is operand P (rows m) when not swapped, Q when
-    // swapped.  The waves add up the fragments they read for the MFMAs with v_dot2c_f32_bf16 against (1, 1); the NSH waves that
-    // read the same G rows (the WQ waves of a row of the wave grid, or the WP waves of a column) share the work by k16-step —
-    // a first version that left it to one wave of each row made those waves 40 % longer than their neighbours (wgrad +0.4 ms
-    // per step); a v_dot2c costs about ten cycles beside MFMAs — and write their shares as separate partial rows:
-    // bias_part is (S x NSH, M).  Only the workgroups of Q slab 0 (P slab 0 when swapped) write.
+    // Bias gradient (round 4): db[m] = sum over pixels of G[m] — the same rows this kernel streams anyway; the separate
+    // plane-sum pass re-reads every gradient tensor (0.87 ms per step, at 5 TB/s).  G is operand P (rows m) when not swapped, Q
+    // when swapped.  The waves of ONE column (row) of the wave grid add up the fragments they read for the MFMAs with
+    // v_dot2c_f32_bf16 against (1, 1); only the workgroups of Q slab 0 (P slab 0 when swapped) write their split's sums.
+    // Measured, same box (profiles/r04_step_ab_waits_bias_v1.txt, r04_step_ab_bias_v2.txt): the dot products are NOT free beside
+    // the MFMAs (about ten cycles each, dependent chains of four): weight-gradient time per step 5.04 -> 5.44 ms with one wave per
+    // row doing them (this form: net -0.45 ms of kernel time, -0.15 ms of step time; FourCastNet3 539.6 -> 534.7 ms), 5.05 -> 6.0 ms
+    // when the four waves of a row share them by k16-step (every wave then carries a dependent VALU chain: net zero) — so the
+    // work stays on one wave per row.
     constexpr int WTG = SWAP ? WTQ : WTP;
-    constexpr int NSH = SWAP ? WP : WQ;                 // waves sharing one set of G rows
-    static_assert(NSH == 2 || NSH == 4, "k16-steps are dealt over 2 or 4 waves");
-    const int bshare = SWAP ? wp : wq;
-    const bool bias_wave = p.bias_part != nullptr && (SWAP ? slab == 0 : qs == 0);
+    constexpr int NSH = 1;                              // waves sharing the row sums of one set of G rows (see above)
+    const int bshare = 0;
+    const bool bias_wave = p.bias_part != nullptr && (SWAP ? (wp == 0 && slab == 0) : (wq == 0 && qs == 0));
     float rsum[WTG];
 #pragma unroll
     for (int i = 0; i < WTG; ++i) rsum[i] = 0.f;
@@ -1508,7 +1509,7 @@ extern "C" long long mk_conv1x1_wgrad_workspace(int M, int K, int B, long long N
     // number of fp32 elements the caller must provide as `part` (the (S, M, K) partial products, then (S, M) partial row sums
     // of G for mk_conv1x1_wgrad_bias)
     const WgPlan pl = wgrad_plan(M, K, B, N);
-    return pl.S * (long long)M * K + 4 * pl.S * (long long)M;
+    return pl.S * (long long)M * K + pl.S * (long long)M;
 }
 
 // 1 if mk_conv1x1_wgrad_bias computes the bias gradient inside the weight-gradient kernel for this shape (the ring kernel),
@@ -1569,8 +1570,8 @@ static int conv1x1_wgrad_impl(const void* G, const void* X, float* dW, float* db
                            n / 4, (int)pl.S, accumulate);
     else
         hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, dW, n, (int)pl.S, accumulate);
-    if (dbias)      // (S x NSH, M) partial rows: NSH = 4 waves share a set of G rows when G is the slab operand, 2 when it is not
+    if (dbias)      // (S, M) partial row sums
         hipLaunchKernelGGL(reduce_splits, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, part + pl.S * n, dbias, (long long)M,
-                           (int)pl.S * (pl.swap ? 2 : 4), 0);
+                           (int)pl.S, 0);
     return mk_check_launch("mk_conv1x1_wgrad");
 }
