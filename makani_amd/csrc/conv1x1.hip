@@ -21,6 +21,24 @@
 #ifndef MK_ASTAT_EPI_DRAIN
 #define MK_ASTAT_EPI_DRAIN 0
 #endif
+// timing diagnostic of the weight-stationary kernel (tools/astat_diag.py; build with -DMK_ASTAT_DIAG=1): s_memtime stamps at the
+// segment boundaries of every pixel tile, summed per wave into g_astat_diag:
+// [0 wait for the chunk + barrier, 1 fragment reads + MFMAs, 2 next chunk's DMA issue, 3 epilogue: convert + stage, 4 barrier,
+//  5 epilogue: read back + epilogue math + stores, 6 barrier, 7 prologue (weights), 8 whole kernel, 9 waves, 10 tiles]
+#ifndef MK_ASTAT_DIAG
+#define MK_ASTAT_DIAG 0
+#endif
+#if MK_ASTAT_DIAG
+__device__ unsigned long long g_astat_diag[16];
+#define MK_AS_STAMP(k)                                              \
+    do {                                                            \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        dg[k] += t_ - tprev;                                        \
+        tprev = t_;                                                 \
+    } while (0)
+#else
+#define MK_AS_STAMP(k)
+#endif
 
 namespace {
 
@@ -697,6 +715,11 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int s15 = lane & 15, g1 = (lane >> 4) & 1;
+#if MK_ASTAT_DIAG
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+    const unsigned long long tstart = tprev;
+#endif
 
     // ---- work: blockIdx.y = batch entry; slab = id % slabs keeps the weights; pixel tiles id / slabs, + gridDim.x / slabs, ... ----
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
@@ -790,6 +813,7 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
     }
 
     const int nchunks = my_tiles * NCH;
+    MK_AS_STAMP(7);
     for (int c = 0; c < LOOK && c < nchunks; ++c) issue_next();
     int c_slot = 0;                                     // ring slot of the chunk being multiplied
 
@@ -855,6 +879,7 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                 else wait_vmcnt_le<NP * (LOOK - 1) + 3 * NSTORE>();
             }
             __builtin_amdgcn_s_barrier();
+            MK_AS_STAMP(0);
             if (EPI_LOADS && kc == 0) issue_epi(cn0);      // the previous tile's last round left the operand images behind this barrier
             const unsigned char* sb = smem + c_slot * CH;
             c_slot = c_slot + 1 == NSLOT ? 0 : c_slot + 1;
@@ -877,7 +902,12 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
             }
             // chunk c + LOOK goes to slot (c + LOOK) % NSLOT, last multiplied at step c + LOOK - NSLOT <= c - 1: every wave
             // finished that step before it reached the barrier of the step after it, which lies behind us
+#if MK_ASTAT_DIAG
+            asm volatile("s_nop 0" : "+v"(acc[TM - 1][TN - 1]));      // (the stamp must not move in front of the last MFMA)
+#endif
+            MK_AS_STAMP(1);
             if (c + LOOK < nchunks) issue_next();
+            MK_AS_STAMP(2);
         }
 
         // ---- epilogue: TM rounds of 128 channel rows (32 per wave) x 64 pixels through the staging image ----
@@ -912,7 +942,9 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                     *reinterpret_cast<uint2*>(stg + lrow * 128 + (((px >> 3) ^ ((lrow >> 1) & 7)) * 16) + ((px >> 2) & 1) * 8) = u;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MK_AS_STAMP(3);
             __builtin_amdgcn_s_barrier();
+            MK_AS_STAMP(4);
 #pragma unroll
             for (int u4 = 0; u4 < 4; ++u4) {
                 const int idx = tid + NT_ * u4;
@@ -959,9 +991,20 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff[u4], 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MK_AS_STAMP(5);
             __builtin_amdgcn_s_barrier();
+            MK_AS_STAMP(6);
         }
     }
+#if MK_ASTAT_DIAG
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_astat_diag[k], dg[k]);
+        atomicAdd(&g_astat_diag[8], tprev - tstart);
+        atomicAdd(&g_astat_diag[9], 1ull);
+        atomicAdd(&g_astat_diag[10], (unsigned long long)my_tiles);
+    }
+#endif
 #endif
 }
 
@@ -1345,6 +1388,17 @@ __global__ void reduce_splits4(const float4* __restrict__ part, float4* __restri
 }
 
 }  // namespace
+
+#if MK_ASTAT_DIAG
+extern "C" int mk_astat_diag_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_astat_diag), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_astat_diag), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, const float* bias, const void* R,
                              const void* G, int M, int K, int lda, int B, long long N, int act, void* stream) {
