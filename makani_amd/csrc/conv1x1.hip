@@ -15,6 +15,7 @@
 // Tiles: 256 threads = 4 waves (2 x 2); v_mfma_f32_32x32x16_bf16, fp32 accumulate; BK = 32;
 // double-buffered LDS with register-staged prefetch, one barrier per k-tile.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -1009,6 +1010,321 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
 }
 
 // ------------------------------------------------------------------------------------------
+// Weight-stationary channel GEMM, second form (round 4): TWO wave groups, one multiplying while the other runs its epilogue.
+//
+// s_memtime stamps of the kernel above (profiles/r04_astat_diag.txt): a wave spends 46 % of its cycles in the MFMA segment and
+// 35 % (plain) to 55 % (bias + GELU + pre-activation, gelu') in the epilogue — convert, stage, read back, epilogue math, stores —
+// and only 7 % waiting for memory: with ONE wave per SIMD the matrix pipe idles through every epilogue and the vector ALU through
+// every multiplication.  Here the 384-row slab is held by EIGHT waves (48 rows each = three 16-row tiles of
+// v_mfma_f32_16x16x32_bf16, 36 weight fragments = 144 registers, so that two waves fit a SIMD's register file); waves 0-3
+// (group 0) and 4-7 (group 1) run the SAME seven phases per 64-pixel tile — three chunk multiplications, one staging phase
+// (all 48 rows of a wave; the accumulators are dead from then on, which is what lets the epilogue math fit beside 144 weight
+// registers), three rounds of {read back 16 rows per wave, epilogue math, stores} — with group 1 THREE phases behind group 0.
+// Every phase boundary is a workgroup barrier that all eight waves execute ("tick"), but on every SIMD one wave is in the matrix
+// pipe while its partner is in the vector ALU / LDS / store path:
+//
+//   tick mod 7      0    1    2    3    4    5    6
+//   group 0         M0   M1   M2   S    R0   R1   R2         M = multiply chunk kc, S = stage, R = read back + math + store
+//   group 1         R0'  R1'  R2'  M0   M1   M2   S          (' = previous tile)
+//
+// Activations: chunks of 128 input channels x 64 pixels (16 KB) in a ring of four slots (six spilled registers in the variants
+// without epilogue operand: the modulo-6 slot arithmetic); chunk c + 4 is requested by all eight waves (two 1 KB pieces each) one
+// tick after group 1 multiplied chunk c, i.e. at ticks 4, 5, 6 of the period, at least four ticks before group 0 needs it.  The instructions a wave issues between a
+// chunk's request and the wait for it are a fixed multiset per (group, chunk position) once the stream is two tiles old —
+// a1 NP + b1 NS3 + e1 EPIECES with the small tables below, derived from the schedule and checked by tools/vmcnt_check.py against
+// an in-order retirement model of both groups (first tiles and end of stream: drained).
+// LDS: ring 64 KB + 24 KB staging image per group + (epilogue operand) 24 KB per group = 112 / 160 KB.
+// Fragment reads: ds_read_b64_tr_b16 on [k][pixel] rows of 128 B; the 16-byte chunk index of a row is XOR-swizzled with
+// ((k >> 1) & 1) << 2 (as above) and (k >> 3 & 1) << 1 (the two 16-lane groups of a half-wave read k-blocks 8 rows apart).
+template <bool PRE, bool EPI_LOADS>
+__global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int slabs, long long tilesN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int KS = 12;                              // k32-steps: K = 384
+    constexpr int KCH = 128, NCH = 3, K4 = 4;           // chunk: 128 input channels = 4 k32-steps; 3 chunks per pixel tile
+    constexpr int CH = KCH * 128;                       // 16 KB
+    constexpr int NSLOT = 4, NP = 2;                    // ring slots; DMA pieces per wave and chunk
+    constexpr int PT = 4, CT = 3;                       // 16-pixel tiles per pixel tile; 16-row channel tiles per wave
+    constexpr int PER = 7, OFF = 3;                     // ticks per tile; ticks group 1 runs behind group 0
+    constexpr int NS3 = 2 * (PRE ? 2 : 1);              // stores per thread and read-back round (always issued)
+    constexpr int EPIECES = EPI_LOADS ? 6 : 0;          // DMA pieces of the epilogue operand per wave and tile (192 rows / 4 waves / 8)
+    // steady-state count of memory instructions between a chunk's request and the wait for it, per (group, chunk position)
+    constexpr int WA[2][3] = {{3, 2, 1}, {3, 2, 1}};    // [group][kc]: chunk requests
+    constexpr int WB[2][3] = {{4, 3, 2}, {3, 1, 2}};    //              read-back rounds (stores)
+    constexpr int WE[2][3] = {{1, 1, 1}, {1, 0, 0}};    //              operand requests
+#define MK_A2_WAIT(G, K) (WA[G][K] * NP + WB[G][K] * NS3 + WE[G][K] * EPIECES)
+    static_assert(MK_A2_WAIT(0, 0) <= 63 && MK_A2_WAIT(1, 2) <= 63, "vmcnt is a 6-bit counter");
+    constexpr int EBYTES = EPI_LOADS ? 2 * 192 * 128 : 0;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * CH + 2 * 192 * 128 + EBYTES];
+    unsigned char* const stg = smem + NSLOT * CH;       // [group][192 rows][128 B]: row = 64 ct + 16 (wave in group) + channel in tile
+    unsigned char* const ebuf = stg + 2 * 192 * 128;    // [group][192 rows][128 B], linear (as the DMA writes it)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wg = wave & 3;
+    const int c16 = lane & 15, q4 = lane >> 4;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int slab = vid % slabs;
+    const int pstride = gridDim.x / slabs;
+    const int pfirst = vid / slabs;
+    const int tilesN32 = (int)tilesN;
+    const int T = pfirst < tilesN32 ? (tilesN32 - pfirst + pstride - 1) / pstride : 0;
+    const int nchunks = NCH * T;
+    const int cb = blockIdx.y;
+    const int m_base = slab * 384 + wave * 48;          // first output channel of this wave
+    const unsigned nbytes = (unsigned)(p.N * 2);
+
+    // ---- the stationary operand: W[m_base + 16 ct + c16][32 ks + 8 q4 .. + 7] ----
+    bf16x8 wf[CT][KS];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int row = min(m_base + ct * 16 + c16, p.M - 1);
+        const u16* src = p.A + (long long)row * p.lda + q4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[ct][ks] = __builtin_bit_cast(bf16x8, ld16(src + ks * 32));
+    }
+    float bvr[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int mrow = m_base + ct * 16 + c16;
+        bvr[ct] = (p.bias && mrow < p.M) ? p.bias[mrow] : 0.f;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {                   // wait for the weights here, before any DMA piece is in flight
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ct][ks]));
+        asm volatile("" : "+v"(bvr[ct]));
+    }
+
+    // ---- DMA of the activation chunks: wave w issues pieces 2 w, 2 w + 1 (rows 16 w .. 16 w + 15 of the chunk) ----
+    const unsigned lds0 = lds_addr(smem) + (unsigned)wave * (NP * 1024);
+    const v4i_t rsX = make_rsrc(p.X + (long long)cb * p.K * p.N);
+    const unsigned kstride = (unsigned)KCH * nbytes;
+    auto issue_chunk = [&](int c) __attribute__((always_inline)) {                     // chunk c = 3 ts + kc of this workgroup's stream -> slot c % NSLOT
+        const int ts = c / NCH, kc = c - ts * NCH;
+        const unsigned n0b = (unsigned)(pfirst + ts * pstride) * 128u;              // first pixel of the tile, in bytes
+        const int cmax = min(7, (int)((nbytes - n0b) / 16) - 1);                    // pixels past N: re-read the last valid chunk
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kc * kstride + n0b));
+        // (per-lane addressing recomputed per request: the kernel has no registers to spare)
+        // row = 8 (2 w + q) + (lane >> 3): (row >> 1) & 1 = (lane >> 4) & 1, (row >> 3) & 1 = q
+        const int c0 = (lane & 7) ^ ((((lane >> 3) >> 1) & 1) << 2), c1 = c0 ^ 2;
+        const unsigned r0 = (unsigned)(wave * 16 + (lane >> 3)) * nbytes;
+        dma2<1024>((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(c % NSLOT) * CH)), rsX, soff,
+                   r0 + (unsigned)min(c0, cmax) * 16u, r0 + 8u * nbytes + (unsigned)min(c1, cmax) * 16u);
+    };
+
+    // ---- epilogue operand by DMA (G if present, else R): the 192 channel rows of this GROUP, 6 pieces of 8 rows per wave ----
+    const u16* const eop = p.G ? p.G : p.R;
+    const v4i_t rsE = make_rsrc(EPI_LOADS ? (const void*)(eop + (long long)cb * p.M * p.N) : (const void*)p.X);
+    const unsigned ldsE = lds_addr(ebuf) + (unsigned)grp * (192 * 128) + (unsigned)wg * (6 * 1024);
+    auto issue_epi = [&](int ts) __attribute__((always_inline)) {
+        const unsigned n0b = (unsigned)(pfirst + ts * pstride) * 128u;
+        const int cmax = min(7, (int)((nbytes - n0b) / 16) - 1);
+        const unsigned col = (unsigned)min(lane & 7, cmax) * 16u;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)n0b);
+        const unsigned le = (unsigned)__builtin_amdgcn_readfirstlane((int)ldsE);      // (wave-uniform: the DMA base goes through M0)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                   // image row r = 48 wg + 8 q + (lane >> 3) <-> channel slab * 384 + 192 grp + r
+            unsigned v[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int r = 48 * wg + 8 * (3 * h + q) + (lane >> 3);
+                v[q] = (unsigned)min(slab * 384 + 192 * grp + r, p.M - 1) * nbytes + col;
+            }
+            dma3<1024>(le + (unsigned)h * 3072u, rsE, soff, v[0], v[1], v[2]);
+            __builtin_amdgcn_sched_barrier(0);          // (three offsets at a time: registers)
+        }
+    };
+
+    // ---- fragment addressing inside a chunk: transpose read of rows 32 k4 + 8 q4 + (c16 >> 2) [+ 4], pixels 16 pt + 4 (c16 & 3) .. ----
+    int xoff[PT];
+    {
+        const int kk = q4 * 8 + (c16 >> 2);
+        const int swz = ((((kk >> 1) & 1) << 2) ^ ((q4 & 1) << 1));
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xoff[pt] = kk * 128 + (((2 * pt + ((c16 & 3) >> 1)) ^ swz) * 16) + (c16 & 1) * 8;
+    }
+
+    f32x4_t acc[PT][CT];
+    const long long plane0 = (long long)cb * p.M * p.N;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Y + plane0), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)((PRE ? p.Ypre : p.Y) + plane0), 0, 0x80000000u, 0x00020000);
+    unsigned char* const stgG = stg + grp * (192 * 128);
+    const unsigned char* const ebufG = ebuf + grp * (192 * 128);
+
+    auto mult = [&](int ts, auto kc_) __attribute__((always_inline)) {                 // multiply chunk kc of tile ts
+        constexpr int kc = decltype(kc_)::value;
+        if constexpr (kc == 0) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned char* sb = smem + ((NCH * ts + kc) % NSLOT) * CH;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) {
+#pragma unroll
+            for (int hp = 0; hp < PT / 2; ++hp) {       // two 16-pixel tiles at a time: 8 fragment registers instead of 16
+                bf16x8 xf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned char* q0 = sb + xoff[2 * hp + j] + k4 * 32 * 128;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 128));
+                    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    xf[j] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[2 * hp + j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], wf[ct][kc * K4 + k4], acc[2 * hp + j][ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // (the kernel sits at 256 registers: no fragment prefetch across steps)
+            }
+        }
+    };
+    auto stage = [&]() __attribute__((always_inline)) {                                // 48 rows of this wave x 64 pixels -> the group's staging image (bf16)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float bv = bvr[ct];
+            const int lrow = ct * 64 + wg * 16 + c16;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                uint2 u;
+                u.x = (uint32_t)f32_to_bf16(acc[pt][ct][0] + bv) | ((uint32_t)f32_to_bf16(acc[pt][ct][1] + bv) << 16);
+                u.y = (uint32_t)f32_to_bf16(acc[pt][ct][2] + bv) | ((uint32_t)f32_to_bf16(acc[pt][ct][3] + bv) << 16);
+                const int chunk = 2 * pt + (q4 >> 1);   // pixels 16 pt + 4 q4 .. + 3
+                *reinterpret_cast<uint2*>(stgG + lrow * 128 + ((chunk ^ ((lrow >> 1) & 7)) * 16) + (q4 & 1) * 8) = u;
+            }
+        }
+    };
+    auto readback_store = [&](int ts, int ct) __attribute__((always_inline)) {         // 64 staged rows of round ct as whole 128-byte rows: epilogue math + stores
+        const unsigned cn0b = (unsigned)(pfirst + ts * pstride) * 128u;           // first pixel of the tile, in bytes (32-bit: M N 2 < 2^31)
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const int tg = tid & 255;                       // thread inside the group
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+            const int idx = tg + 256 * u2;
+            const int row = idx >> 3, ch = idx & 7;     // row of the round = 16 (wave in group) + channel in tile
+            const int srow = ct * 64 + row;             // row of the staging image
+            const int grow = (row >> 4) * 48 + ct * 16 + (row & 15);                 // row inside the group's 192 channels
+            const int m = slab * 384 + grp * 192 + grow;
+            const unsigned nb = cn0b + (unsigned)ch * 16u;
+            const bool live = m < p.M && nb < nbytes;
+            const unsigned voff = live ? (unsigned)m * nbytes + nb : 0xC0000000u;   // out of range: the store is dropped
+            const uint4 raw = *reinterpret_cast<const uint4*>(stgG + srow * 128 + ((ch ^ ((srow >> 1) & 7)) * 16));
+            if (PRE) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{raw.x, raw.y, raw.z, raw.w}, rsP, voff, 0, 0);
+            uint4 ev = make_uint4(0, 0, 0, 0);
+            if constexpr (EPI_LOADS) ev = *reinterpret_cast<const uint4*>(ebufG + grow * 128 + ch * 16);
+            uint4 out = raw;
+            if (p.act || EPI_LOADS) {
+                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = __uint_as_float(w[e] << 16);
+                    v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+                }
+                if (p.act) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+                }
+                if (EPI_LOADS && p.G) {
+                    const uint32_t gw[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] *= gelu_grad_fast_f(__uint_as_float(gw[e] << 16));
+                        v[2 * e + 1] *= gelu_grad_fast_f(__uint_as_float(gw[e] & 0xffff0000u));
+                    }
+                }
+                if (EPI_LOADS && !p.G) {
+                    const uint32_t rw[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(rw[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                    }
+                }
+                out.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                out.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                out.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                out.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // (the two rows of a thread one after the other: registers)
+        }
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    for (int c = 0; c < NSLOT && c < nchunks; ++c) issue_chunk(c);
+
+    // One tick: (1) wait for this wave's pieces of the chunk that group 0 multiplies first in this tick, (2) barrier, (3) request
+    // the chunk whose slot group 1 freed in the previous tick.  gph / gts: position of the tick in the workgroup's stream
+    // (tick = 7 gts + gph).  The first two tiles and the last one have fewer instructions behind the chunk (group 1 idles through
+    // its first OFF ticks, no request follows the last chunks): drained.
+    auto tick = [&](int gts, auto gph_, auto grp_) __attribute__((always_inline)) {
+        constexpr int gph = decltype(gph_)::value, g = decltype(grp_)::value;
+        if constexpr (gph < NCH) {
+            if (gts < T) {
+                if (gts <= 1 || gts >= T - 1) wait_vmcnt<0>(); else wait_vmcnt<MK_A2_WAIT(g, gph)>();
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS reads of the last phase have returned (slots / images are re-used)
+        __builtin_amdgcn_s_barrier();
+        if constexpr (gph > OFF) {                              // group 1 multiplied chunk 3 gts + (gph - 4) in the previous tick
+            const int c = NCH * gts + (gph - OFF - 1) + NSLOT;
+            if (c < nchunks) issue_chunk(c);
+        }
+    };
+    // the seven phases of one tile of this group (lts), each behind its tick; grp_: the group as a compile-time constant
+    auto tile = [&](int lts, auto grp_) __attribute__((always_inline)) {
+        constexpr int g = decltype(grp_)::value;
+        // phase p of group g is tick (p + 3 g) mod 7 of global tile lts + (p + 3 g) / 7
+#define MK_A2_TICK(P) tick(lts + ((P) + OFF * g) / PER, std::integral_constant<int, ((P) + OFF * g) % PER>{}, grp_)
+        MK_A2_TICK(0);
+        if constexpr (EPI_LOADS) issue_epi(lts);                // (the previous tile's last round left the images a barrier ago)
+        mult(lts, I0{});
+        MK_A2_TICK(1);
+        mult(lts, I1{});
+        MK_A2_TICK(2);
+        mult(lts, I2{});
+        MK_A2_TICK(3);
+        stage();
+        MK_A2_TICK(4);
+        if constexpr (EPI_LOADS) {
+            // behind the operand pieces (requested in this group's phase 0): group 0 the chunk request of this very tick, group 1
+            // the three chunk requests of ticks 4 - 6; near the end of the stream fewer: drained
+            if (lts >= T - 2) wait_vmcnt<0>(); else wait_vmcnt<(g == 0 ? NP : 3 * NP)>();
+        }
+        readback_store(lts, 0);
+        MK_A2_TICK(5);
+        readback_store(lts, 1);
+        MK_A2_TICK(6);
+        readback_store(lts, 2);
+#undef MK_A2_TICK
+    };
+    if (T > 0) {
+        if (grp == 0) {
+            for (int lts = 0; lts < T; ++lts) tile(lts, I0{});
+            tick(T, I0{}, I0{});                                // group 1 is three ticks behind: its last phases' barriers
+            tick(T, I1{}, I0{});
+            tick(T, I2{}, I0{});
+        } else {
+            tick(0, I0{}, I1{});                                // group 0's first three ticks (tile 0's chunks: drained waits)
+            tick(0, I1{}, I1{});
+            tick(0, I2{}, I1{});
+            for (int lts = 0; lts < T; ++lts) tile(lts, I1{});
+        }
+    }
+#undef MK_A2_WAIT
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad: part[s][m][k] = sum_{n in split s} G[b][m][n] X[b][k][n];   tile 128 (m) x 128 (k-channel)
 struct ConvWg {
     const u16* G;   // (B, M, N)
@@ -1425,6 +1741,22 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
         if (epi_loads) hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, false, true, 5>), grid, blk, 0, s, p, slabs, tn);
         else if (pre) hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, true, false, 5>), grid, blk, 0, s, p, slabs, tn);
         else hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, false, false, 5>), grid, blk, 0, s, p, slabs, tn);
+        return mk_check_launch("mk_conv1x1_nn");
+    }
+    static const int astat2 = [] { const char* e = getenv("MAKANI_AMD_ASTAT2"); return e ? atoi(e) : 0; }();
+    if (astat2 && !force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
+        // two wave groups, one multiplying while the other runs its epilogue (conv_nn_astat2_kernel): 384-channel slabs
+        const bool epi_loads = R || G;
+        const int slabs = (M + 383) / 384;
+        const long long tn = (N + 63) / 64;
+        const long long streams = tn < 256 / slabs ? tn : 256 / slabs;
+        const dim3 grid((unsigned)(streams * slabs), (unsigned)B), blk(512);
+        const bool pre = act && Ypre;
+        hipStream_t s = (hipStream_t)stream;
+        if (epi_loads && pre) hipLaunchKernelGGL((conv_nn_astat2_kernel<true, true>), grid, blk, 0, s, p, slabs, tn);
+        else if (epi_loads) hipLaunchKernelGGL((conv_nn_astat2_kernel<false, true>), grid, blk, 0, s, p, slabs, tn);
+        else if (pre) hipLaunchKernelGGL((conv_nn_astat2_kernel<true, false>), grid, blk, 0, s, p, slabs, tn);
+        else hipLaunchKernelGGL((conv_nn_astat2_kernel<false, false>), grid, blk, 0, s, p, slabs, tn);
         return mk_check_launch("mk_conv1x1_nn");
     }
     if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {

@@ -241,6 +241,145 @@ def check_isa(path=None, verbose=True):
             print(f"isa ok    {v.name:58s} DMA runs {sorted(set(runs))}, {nstores} stores, vmcnt {sorted(imm)}")
 
 
+# --------------------------------------------------------------------------- #
+# the two-group form (conv_nn_astat2_kernel): both groups' instruction streams against the same retirement model
+# --------------------------------------------------------------------------- #
+class Variant2:
+    """compile-time constants of conv_nn_astat2_kernel<PRE, EPI_LOADS>"""
+    NP, NCH, PER, OFF = 2, 3, 7, 3
+    WA = ((3, 2, 1), (3, 2, 1))        # [group][kc]: chunk requests / read-back rounds / operand requests behind a chunk
+    WB = ((4, 3, 2), (3, 1, 2))
+    WE = ((1, 1, 1), (1, 0, 0))
+
+    def __init__(self, PRE, EPI):
+        self.PRE, self.EPI = PRE, EPI
+        self.NSLOT = 4
+        self.NS3 = 2 * (2 if PRE else 1)
+        self.EPIECES = 6 if EPI else 0
+
+    @property
+    def name(self):
+        return f"astat2<PRE={int(self.PRE)}, EPI_LOADS={int(self.EPI)}>"
+
+    def mangled(self):
+        return f"21conv_nn_astat2_kernelILb{int(self.PRE)}ELb{int(self.EPI)}EE"
+
+    def wait_const(self, g, kc):
+        return self.WA[g][kc] * self.NP + self.WB[g][kc] * self.NS3 + self.WE[g][kc] * self.EPIECES
+
+    def chunk_wait(self, g, gts, gph, T):
+        return 0 if (gts <= 1 or gts >= T - 1) else self.wait_const(g, gph)
+
+    def epi_wait(self, g, lts, T):
+        return 0 if lts >= T - 2 else (self.NP if g == 0 else 3 * self.NP)
+
+    def expected_vmcnt(self):
+        return {0} | {self.wait_const(g, k) for g in (0, 1) for k in range(3)} | ({self.NP, 3 * self.NP} if self.EPI else set())
+
+
+VARIANTS2 = [Variant2(pre, epi) for pre in (False, True) for epi in (False, True)]
+
+
+def simulate2(v: Variant2, T: int):
+    """the streams of one wave of each group over T pixel tiles (ticks = workgroup barriers; group 1 runs OFF ticks behind).
+    Checks at every chunk wait that the chunk's pieces of THIS wave have retired (every wave waits before the barrier behind
+    which group 0 starts reading), at every operand wait that the images have, that a slot is only re-requested after group 1 read
+    it, and returns the largest steady-state slack."""
+    PER, OFF, NCH, NP = v.PER, v.OFF, v.NCH, v.NP
+    nchunks = NCH * T
+    steady = 0
+    for grp in (0, 1):
+        ops, retired = [], 0
+
+        def issue(tag, n):
+            ops.extend([tag] * n)
+
+        def last(tag):
+            idx = [i for i, t in enumerate(ops) if t == tag]
+            assert idx, f"{v.name}: {tag} never requested"
+            return idx[-1]
+
+        requested = set()
+        for c in range(min(v.NSLOT, nchunks)):
+            issue(("X", c), NP)
+            requested.add(c)
+        for t in range(PER * T + OFF if T else 0):
+            gph, gts = t % PER, t // PER
+            if gph < NCH and gts < T:                      # (1) every wave: the chunk group 0 multiplies in this tick
+                c = NCH * gts + gph
+                assert c in requested, f"{v.name}: chunk {c} waited for before it was requested (T={T})"
+                need = len(ops) - 1 - last(("X", c))
+                w = v.chunk_wait(grp, gts, gph, T)
+                assert w <= need, f"{v.name}: group {grp} tile {gts} chunk {gph} of {T} tiles: vmcnt({w}) but only {need} instructions follow the chunk"
+                retired = max(retired, len(ops) - w)
+                assert last(("X", c)) < retired
+                if 2 <= gts < T - 2:
+                    steady = max(steady, need - w)
+            if gph > OFF:                                  # (2) the slot group 1 read in the previous tick
+                c = NCH * gts + (gph - OFF - 1) + v.NSLOT
+                if c < nchunks:
+                    # chunk c - NSLOT was multiplied by group 1 in tick t - 1 and by group 0 three ticks before that
+                    assert (c - v.NSLOT) == NCH * ((t - 1 - OFF) // PER) + ((t - 1 - OFF) % PER) and (t - 1 - OFF) % PER < NCH
+                    issue(("X", c), NP)
+                    requested.add(c)
+            lt = t - grp * OFF                              # (3) this group's phase
+            if 0 <= lt < PER * T:
+                lts, lph = lt // PER, lt % PER
+                if lph < NCH:
+                    c = NCH * lts + lph                     # multiplied now: requested, and waited for (by every wave) at or before this tick
+                    assert c in requested and PER * lts + lph <= t
+                if lph == 0 and v.EPI:
+                    issue(("E", lts), v.EPIECES)
+                if lph == 4 and v.EPI:
+                    need = len(ops) - 1 - last(("E", lts))
+                    w = v.epi_wait(grp, lts, T)
+                    assert w <= need, f"{v.name}: group {grp} operand wait of tile {lts} of {T}: vmcnt({w}), {need} instructions follow"
+                    retired = max(retired, len(ops) - w)
+                    assert last(("E", lts)) < retired
+                if lph >= 4:
+                    issue(("S", lts, lph), v.NS3)
+    return steady
+
+
+def check_model2(verbose=True):
+    for v in VARIANTS2:
+        assert max(v.expected_vmcnt()) <= 63
+        lds = v.NSLOT * 16384 + 2 * 192 * 128 + (2 * 192 * 128 if v.EPI else 0)
+        assert lds <= 160 * 1024, (v.name, lds)
+        steady = max(simulate2(v, T) for T in list(range(0, 12)) + [31, 64])
+        assert steady == 0, f"{v.name}: a steady-state wait fires {steady} instructions early"
+        if verbose:
+            print(f"model ok  {v.name:40s} slots={v.NSLOT} waits " +
+                  " ".join(f"g{g}k{k}={v.wait_const(g, k)}" for g in (0, 1) for k in range(3)) + f"  LDS {lds // 1024} KB")
+
+
+def check_isa2(path=None, verbose=True):
+    path = assembly(path)
+    for v in VARIANTS2:
+        body = kernel_body(path, v.mangled())
+        assert body, f"{v.name}: kernel not found in {path}"
+        ops = [m.group(1) + " " + l.strip() for l in body for m in [re.match(r"^\t([a-z_0-9]+)", l)] if m]
+        first_dma = next(i for i, o in enumerate(ops) if o.startswith("buffer_load") and " lds" in o)
+        stray = [o for o in ops[first_dma:] if re.match(r"^(global_|flat_|scratch_)", o) or
+                 (o.startswith("buffer_load") and " lds" not in o) or o.startswith("buffer_atomic")]
+        assert not stray, f"{v.name}: {len(stray)} vector memory instructions inside the stream (register spills?): {stray[:3]}"
+        imm = set()
+        for o in ops[first_dma:]:
+            if o.startswith("s_waitcnt"):
+                m = re.search(r"vmcnt\((\d+)\)", o)
+                if m:
+                    imm.add(int(m.group(1)))
+        exp = v.expected_vmcnt()
+        assert imm <= exp, f"{v.name}: vmcnt immediates {sorted(imm - exp)} are not part of the schedule {sorted(exp)}"
+        nstores = sum(1 for o in ops if o.startswith("buffer_store_dwordx4"))
+        assert nstores and nstores % v.NS3 == 0
+        if verbose:
+            print(f"isa ok    {v.name:40s} {nstores} stores, vmcnt {sorted(imm)}")
+
+
 if __name__ == "__main__":
     check_model()
-    check_isa(sys.argv[1] if len(sys.argv) > 1 else None)
+    check_model2()
+    path = assembly(sys.argv[1] if len(sys.argv) > 1 else None)
+    check_isa(path)
+    check_isa2(path)
