@@ -1027,13 +1027,13 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
 //   group 0         M0   M1   M2   S    R0   R1   R2         M = multiply chunk kc, S = stage, R = read back + math + store
 //   group 1         R0'  R1'  R2'  M0   M1   M2   S          (' = previous tile)
 //
-// Activations: chunks of 128 input channels x 64 pixels (16 KB) in a ring of four slots (six spilled registers in the variants
-// without epilogue operand: the modulo-6 slot arithmetic); chunk c + 4 is requested by all eight waves (two 1 KB pieces each) one
-// tick after group 1 multiplied chunk c, i.e. at ticks 4, 5, 6 of the period, at least four ticks before group 0 needs it.  The instructions a wave issues between a
+// Activations: chunks of 128 input channels x 64 pixels (16 KB) in a ring of NSLOT slots (6; 4 beside the epilogue operand
+// images); chunk c + NSLOT is requested by all eight waves (two 1 KB pieces each) one tick after group 1 multiplied chunk c,
+// i.e. at ticks 4, 5, 6 of the period, at least four (eight with 6 slots) ticks before group 0 needs it.  The instructions a wave issues between a
 // chunk's request and the wait for it are a fixed multiset per (group, chunk position) once the stream is two tiles old —
 // a1 NP + b1 NS3 + e1 EPIECES with the small tables below, derived from the schedule and checked by tools/vmcnt_check.py against
 // an in-order retirement model of both groups (first tiles and end of stream: drained).
-// LDS: ring 64 KB + 24 KB staging image per group + (epilogue operand) 24 KB per group = 112 / 160 KB.
+// LDS: ring 96 / 64 KB + 24 KB staging image per group + (epilogue operand) 24 KB per group = 144 / 160 KB.
 // Fragment reads: ds_read_b64_tr_b16 on [k][pixel] rows of 128 B; the 16-byte chunk index of a row is XOR-swizzled with
 // ((k >> 1) & 1) << 2 (as above) and (k >> 3 & 1) << 1 (the two 16-lane groups of a half-wave read k-blocks 8 rows apart).
 template <bool PRE, bool EPI_LOADS>
@@ -1043,16 +1043,16 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     constexpr int KS = 12;                              // k32-steps: K = 384
     constexpr int KCH = 128, NCH = 3, K4 = 4;           // chunk: 128 input channels = 4 k32-steps; 3 chunks per pixel tile
     constexpr int CH = KCH * 128;                       // 16 KB
-    constexpr int NSLOT = 4, NP = 2;                    // ring slots; DMA pieces per wave and chunk
+    constexpr int NSLOT = EPI_LOADS ? 4 : 6, NP = 2;    // ring slots; DMA pieces per wave and chunk
     constexpr int PT = 4, CT = 3;                       // 16-pixel tiles per pixel tile; 16-row channel tiles per wave
     constexpr int PER = 7, OFF = 3;                     // ticks per tile; ticks group 1 runs behind group 0
     constexpr int NS3 = 2 * (PRE ? 2 : 1);              // stores per thread and read-back round (always issued)
     constexpr int EPIECES = EPI_LOADS ? 6 : 0;          // DMA pieces of the epilogue operand per wave and tile (192 rows / 4 waves / 8)
     // steady-state count of memory instructions between a chunk's request and the wait for it, per (group, chunk position)
-    constexpr int WA[2][3] = {{3, 2, 1}, {3, 2, 1}};    // [group][kc]: chunk requests
-    constexpr int WB[2][3] = {{4, 3, 2}, {3, 1, 2}};    //              read-back rounds (stores)
-    constexpr int WE[2][3] = {{1, 1, 1}, {1, 0, 0}};    //              operand requests
-#define MK_A2_WAIT(G, K) (WA[G][K] * NP + WB[G][K] * NS3 + WE[G][K] * EPIECES)
+    constexpr int WA[2][2][3] = {{{5, 4, 3}, {5, 4, 3}}, {{3, 2, 1}, {3, 2, 1}}};      // [4 slots][group][kc]: chunk requests
+    constexpr int WB[2][2][3] = {{{6, 5, 4}, {3, 4, 5}}, {{4, 3, 2}, {3, 1, 2}}};      //                       read-back rounds (stores)
+    constexpr int WE[2][2][3] = {{{0, 0, 0}, {0, 0, 0}}, {{1, 1, 1}, {1, 0, 0}}};      //                       operand requests
+#define MK_A2_WAIT(G, K) (WA[NSLOT == 4][G][K] * NP + WB[NSLOT == 4][G][K] * NS3 + WE[NSLOT == 4][G][K] * EPIECES)
     static_assert(MK_A2_WAIT(0, 0) <= 63 && MK_A2_WAIT(1, 2) <= 63, "vmcnt is a 6-bit counter");
     constexpr int EBYTES = EPI_LOADS ? 2 * 192 * 128 : 0;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * CH + 2 * 192 * 128 + EBYTES];
@@ -1063,6 +1063,14 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wg = wave & 3;
     const int c16 = lane & 15, q4 = lane >> 4;
+    // The per-lane addressing of every phase is a handful of integer instructions on the lane id.  hipcc hoists all of it out of
+    // the tile loop, and the kernel — 144 weight + 48 accumulator registers per lane of 256 — then spills those values; an opaque
+    // copy of the lane id per phase keeps the arithmetic inside the phase (where the vector ALU has slots to spare).
+    auto lane_here = [&]() __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
 
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int slab = vid % slabs;
@@ -1108,8 +1116,9 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kc * kstride + n0b));
         // (per-lane addressing recomputed per request: the kernel has no registers to spare)
         // row = 8 (2 w + q) + (lane >> 3): (row >> 1) & 1 = (lane >> 4) & 1, (row >> 3) & 1 = q
-        const int c0 = (lane & 7) ^ ((((lane >> 3) >> 1) & 1) << 2), c1 = c0 ^ 2;
-        const unsigned r0 = (unsigned)(wave * 16 + (lane >> 3)) * nbytes;
+        const int ln = lane_here();
+        const int c0 = (ln & 7) ^ ((((ln >> 3) >> 1) & 1) << 2), c1 = c0 ^ 2;
+        const unsigned r0 = (unsigned)(wave * 16 + (ln >> 3)) * nbytes;
         dma2<1024>((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(c % NSLOT) * CH)), rsX, soff,
                    r0 + (unsigned)min(c0, cmax) * 16u, r0 + 8u * nbytes + (unsigned)min(c1, cmax) * 16u);
     };
@@ -1121,7 +1130,8 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     auto issue_epi = [&](int ts) __attribute__((always_inline)) {
         const unsigned n0b = (unsigned)(pfirst + ts * pstride) * 128u;
         const int cmax = min(7, (int)((nbytes - n0b) / 16) - 1);
-        const unsigned col = (unsigned)min(lane & 7, cmax) * 16u;
+        const int ln = lane_here();
+        const unsigned col = (unsigned)min(ln & 7, cmax) * 16u;
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)n0b);
         const unsigned le = (unsigned)__builtin_amdgcn_readfirstlane((int)ldsE);      // (wave-uniform: the DMA base goes through M0)
 #pragma unroll
@@ -1129,7 +1139,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
             unsigned v[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int r = 48 * wg + 8 * (3 * h + q) + (lane >> 3);
+                const int r = 48 * wg + 8 * (3 * h + q) + (ln >> 3);
                 v[q] = (unsigned)min(slab * 384 + 192 * grp + r, p.M - 1) * nbytes + col;
             }
             dma3<1024>(le + (unsigned)h * 3072u, rsE, soff, v[0], v[1], v[2]);
@@ -1162,29 +1172,36 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
                 for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         const unsigned char* sb = smem + ((NCH * ts + kc) % NSLOT) * CH;
+        // eight sub-steps (k32-step x pixel half): the fragments of sub-step s + 1 are requested before the six MFMAs of sub-step
+        // s are issued (two fragment sets = 16 registers; no deeper: the kernel sits at 256 registers)
+        auto frags = [&](bf16x8* xf, int sub) __attribute__((always_inline)) {
+            const int k4 = sub >> 1, hp = sub & 1;
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) {
-#pragma unroll
-            for (int hp = 0; hp < PT / 2; ++hp) {       // two 16-pixel tiles at a time: 8 fragment registers instead of 16
-                bf16x8 xf[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const unsigned char* q0 = sb + xoff[2 * hp + j] + k4 * 32 * 128;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 128));
-                    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    xf[j] = __builtin_bit_cast(bf16x8, v);
-                }
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[2 * hp + j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], wf[ct][kc * K4 + k4], acc[2 * hp + j][ct], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);      // (the kernel sits at 256 registers: no fragment prefetch across steps)
+            for (int j = 0; j < 2; ++j) {
+                const unsigned char* q0 = sb + xoff[2 * hp + j] + k4 * 32 * 128;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 128));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                xf[j] = __builtin_bit_cast(bf16x8, v);
             }
+        };
+        bf16x8 xf[2][2];
+        frags(xf[0], 0);
+#pragma unroll
+        for (int sub = 0; sub < 2 * K4; ++sub) {
+            if (sub + 1 < 2 * K4) frags(xf[(sub + 1) & 1], sub + 1);
+            const int k4 = sub >> 1, hp = sub & 1;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[2 * hp + j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[sub & 1][j], wf[ct][kc * K4 + k4], acc[2 * hp + j][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto stage = [&]() __attribute__((always_inline)) {                                // 48 rows of this wave x 64 pixels -> the group's staging image (bf16)
+        const int ln = lane_here();
+        const int c16 = ln & 15, q4 = ln >> 4;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const float bv = bvr[ct];
@@ -1202,7 +1219,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     auto readback_store = [&](int ts, int ct) __attribute__((always_inline)) {         // 64 staged rows of round ct as whole 128-byte rows: epilogue math + stores
         const unsigned cn0b = (unsigned)(pfirst + ts * pstride) * 128u;           // first pixel of the tile, in bytes (32-bit: M N 2 < 2^31)
         typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-        const int tg = tid & 255;                       // thread inside the group
+        const int tg = (wg << 6) | lane_here();         // thread inside the group
 #pragma unroll
         for (int u2 = 0; u2 < 2; ++u2) {
             const int idx = tg + 256 * u2;

@@ -247,13 +247,14 @@ def check_isa(path=None, verbose=True):
 class Variant2:
     """compile-time constants of conv_nn_astat2_kernel<PRE, EPI_LOADS>"""
     NP, NCH, PER, OFF = 2, 3, 7, 3
-    WA = ((3, 2, 1), (3, 2, 1))        # [group][kc]: chunk requests / read-back rounds / operand requests behind a chunk
-    WB = ((4, 3, 2), (3, 1, 2))
-    WE = ((1, 1, 1), (1, 0, 0))
+    # [4 slots][group][kc]: chunk requests / read-back rounds / operand requests behind a chunk
+    WA = (((5, 4, 3), (5, 4, 3)), ((3, 2, 1), (3, 2, 1)))
+    WB = (((6, 5, 4), (3, 4, 5)), ((4, 3, 2), (3, 1, 2)))
+    WE = (((0, 0, 0), (0, 0, 0)), ((1, 1, 1), (1, 0, 0)))
 
     def __init__(self, PRE, EPI):
         self.PRE, self.EPI = PRE, EPI
-        self.NSLOT = 4
+        self.NSLOT = 4 if EPI else 6
         self.NS3 = 2 * (2 if PRE else 1)
         self.EPIECES = 6 if EPI else 0
 
@@ -265,7 +266,8 @@ class Variant2:
         return f"21conv_nn_astat2_kernelILb{int(self.PRE)}ELb{int(self.EPI)}EE"
 
     def wait_const(self, g, kc):
-        return self.WA[g][kc] * self.NP + self.WB[g][kc] * self.NS3 + self.WE[g][kc] * self.EPIECES
+        e = int(self.NSLOT == 4)
+        return self.WA[e][g][kc] * self.NP + self.WB[e][g][kc] * self.NS3 + self.WE[e][g][kc] * self.EPIECES
 
     def chunk_wait(self, g, gts, gph, T):
         return 0 if (gts <= 1 or gts >= T - 1) else self.wait_const(g, gph)
