@@ -22,6 +22,9 @@
 #ifndef MK_ASTAT_EPI_DRAIN
 #define MK_ASTAT_EPI_DRAIN 0
 #endif
+#ifndef MK_A2_SLOTS6            // conv_nn_astat2_kernel without epilogue operand: six ring slots instead of four (A/B knob)
+#define MK_A2_SLOTS6 0
+#endif
 // timing diagnostic of the weight-stationary kernel (tools/astat_diag.py; build with -DMK_ASTAT_DIAG=1): s_memtime stamps at the
 // segment boundaries of every pixel tile, summed per wave into g_astat_diag:
 // [0 wait for the chunk + barrier, 1 fragment reads + MFMAs, 2 next chunk's DMA issue, 3 epilogue: convert + stage, 4 barrier,
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     constexpr int KS = 12;                              // k32-steps: K = 384
     constexpr int KCH = 128, NCH = 3, K4 = 4;           // chunk: 128 input channels = 4 k32-steps; 3 chunks per pixel tile
     constexpr int CH = KCH * 128;                       // 16 KB
-    constexpr int NSLOT = EPI_LOADS ? 4 : 6, NP = 2;    // ring slots; DMA pieces per wave and chunk
+    constexpr int NSLOT = (EPI_LOADS || !MK_A2_SLOTS6) ? 4 : 6, NP = 2;      // ring slots; DMA pieces per wave and chunk
     constexpr int PT = 4, CT = 3;                       // 16-pixel tiles per pixel tile; 16-row channel tiles per wave
     constexpr int PER = 7, OFF = 3;                     // ticks per tile; ticks group 1 runs behind group 0
     constexpr int NS3 = 2 * (PRE ? 2 : 1);              // stores per thread and read-back round (always issued)
