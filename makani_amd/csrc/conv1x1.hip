@@ -1066,6 +1066,11 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wg = wave & 3;
     const int c16 = lane & 15, q4 = lane >> 4;
+#if MK_ASTAT_DIAG          // [0 chunk wait + barrier, 1 multiply, 2 chunk / operand requests, 3 stage, 4 (operand wait), 5 read back + math + stores, 7 prologue]
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+    const unsigned long long tstart = tprev;
+#endif
     // The per-lane addressing of every phase is a handful of integer instructions on the lane id.  hipcc hoists all of it out of
     // the tile loop, and the kernel — 144 weight + 48 accumulator registers per lane of 256 — then spills those values; an opaque
     // copy of the lane id per phase keeps the arithmetic inside the phase (where the vector ALU has slots to spare).
@@ -1280,6 +1285,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
 
+    MK_AS_STAMP(7);
     for (int c = 0; c < NSLOT && c < nchunks; ++c) issue_chunk(c);
 
     // One tick: (1) wait for this wave's pieces of the chunk that group 0 multiplies first in this tick, (2) barrier, (3) request
@@ -1295,36 +1301,53 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS reads of the last phase have returned (slots / images are re-used)
         __builtin_amdgcn_s_barrier();
+        MK_AS_STAMP(0);
         if constexpr (gph > OFF) {                              // group 1 multiplied chunk 3 gts + (gph - 4) in the previous tick
             const int c = NCH * gts + (gph - OFF - 1) + NSLOT;
             if (c < nchunks) issue_chunk(c);
         }
+        MK_AS_STAMP(2);
     };
     // the seven phases of one tile of this group (lts), each behind its tick; grp_: the group as a compile-time constant
     auto tile = [&](int lts, auto grp_) __attribute__((always_inline)) {
         constexpr int g = decltype(grp_)::value;
         // phase p of group g is tick (p + 3 g) mod 7 of global tile lts + (p + 3 g) / 7
 #define MK_A2_TICK(P) tick(lts + ((P) + OFF * g) / PER, std::integral_constant<int, ((P) + OFF * g) % PER>{}, grp_)
+#if MK_ASTAT_DIAG
+#define MK_A2_SEG(K) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm volatile("s_nop 0" : "+v"(acc[PT - 1][CT - 1])); MK_AS_STAMP(K); } while (0)
+#else
+#define MK_A2_SEG(K)
+#endif
         MK_A2_TICK(0);
         if constexpr (EPI_LOADS) issue_epi(lts);                // (the previous tile's last round left the images a barrier ago)
+        MK_AS_STAMP(2);
         mult(lts, I0{});
+        MK_A2_SEG(1);
         MK_A2_TICK(1);
         mult(lts, I1{});
+        MK_A2_SEG(1);
         MK_A2_TICK(2);
         mult(lts, I2{});
+        MK_A2_SEG(1);
         MK_A2_TICK(3);
         stage();
+        MK_A2_SEG(3);
         MK_A2_TICK(4);
         if constexpr (EPI_LOADS) {
             // behind the operand pieces (requested in this group's phase 0): group 0 the chunk request of this very tick, group 1
             // the three chunk requests of ticks 4 - 6; near the end of the stream fewer: drained
             if (lts >= T - 2) wait_vmcnt<0>(); else wait_vmcnt<(g == 0 ? NP : 3 * NP)>();
         }
+        MK_AS_STAMP(4);
         readback_store(lts, 0);
+        MK_A2_SEG(5);
         MK_A2_TICK(5);
         readback_store(lts, 1);
+        MK_A2_SEG(5);
         MK_A2_TICK(6);
         readback_store(lts, 2);
+        MK_A2_SEG(5);
+#undef MK_A2_SEG
 #undef MK_A2_TICK
     };
     if (T > 0) {
@@ -1340,6 +1363,15 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
             for (int lts = 0; lts < T; ++lts) tile(lts, I1{});
         }
     }
+#if MK_ASTAT_DIAG
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_astat_diag[q], dg[q]);
+        atomicAdd(&g_astat_diag[8], tprev - tstart);
+        atomicAdd(&g_astat_diag[9], 1ull);
+        atomicAdd(&g_astat_diag[10], (unsigned long long)T);
+    }
+#endif
 #undef MK_A2_WAIT
 #endif
 }

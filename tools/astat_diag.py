@@ -16,7 +16,10 @@ lib.mk_astat_diag_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_
 buf = (ctypes.c_ulonglong * 16)()
 NAMES = ["wait for chunk + barrier", "fragment reads + MFMAs", "DMA issue", "epilogue: convert + stage", "epilogue: barrier",
          "epilogue: read back + math + stores", "epilogue: end barrier", "prologue (weights)"]
-for (M, K, H, W) in ((384, 384, 721, 1440), (768, 384, 721, 1440), (768, 384, 240, 480), (384, 384, 240, 480), (384, 73, 721, 1440)):
+shapes = ((384, 384, 721, 1440), (768, 384, 721, 1440), (768, 384, 240, 480), (384, 384, 240, 480), (384, 73, 721, 1440))
+if os.environ.get("MAKANI_AMD_ASTAT2", "0") != "0":      # the two-group kernel: segments 0 wait + barrier, 1 multiply, 2 requests, 3 stage, 5 read back
+    shapes = shapes[:3]
+for (M, K, H, W) in shapes:
     torch.manual_seed(M + K)
     x = (torch.rand(1, K, H, W, device=dev) - 0.5).bfloat16()
     w = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
