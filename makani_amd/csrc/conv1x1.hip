@@ -1046,16 +1046,16 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     constexpr int KS = 12;                              // k32-steps: K = 384
     constexpr int KCH = 128, NCH = 3, K4 = 4;           // chunk: 128 input channels = 4 k32-steps; 3 chunks per pixel tile
     constexpr int CH = KCH * 128;                       // 16 KB
-    constexpr int NSLOT = (EPI_LOADS || !MK_A2_SLOTS6) ? 4 : 6, NP = 2;      // ring slots; DMA pieces per wave and chunk
+    constexpr int NSLOT = 4, NP = 2;                    // ring slots (six measured slower); DMA pieces per wave and chunk
     constexpr int PT = 4, CT = 3;                       // 16-pixel tiles per pixel tile; 16-row channel tiles per wave
     constexpr int PER = 7, OFF = 3;                     // ticks per tile; ticks group 1 runs behind group 0
     constexpr int NS3 = 2 * (PRE ? 2 : 1);              // stores per thread and read-back round (always issued)
     constexpr int EPIECES = EPI_LOADS ? 6 : 0;          // DMA pieces of the epilogue operand per wave and tile (192 rows / 4 waves / 8)
     // steady-state count of memory instructions between a chunk's request and the wait for it, per (group, chunk position)
-    constexpr int WA[2][2][3] = {{{5, 4, 3}, {5, 4, 3}}, {{3, 2, 1}, {3, 2, 1}}};      // [4 slots][group][kc]: chunk requests
-    constexpr int WB[2][2][3] = {{{6, 5, 4}, {3, 4, 5}}, {{4, 3, 2}, {3, 1, 2}}};      //                       read-back rounds (stores)
-    constexpr int WE[2][2][3] = {{{0, 0, 0}, {0, 0, 0}}, {{1, 1, 1}, {1, 0, 0}}};      //                       operand requests
-#define MK_A2_WAIT(G, K) (WA[NSLOT == 4][G][K] * NP + WB[NSLOT == 4][G][K] * NS3 + WE[NSLOT == 4][G][K] * EPIECES)
+    constexpr int WA[2][3] = {{3, 2, 1}, {3, 2, 1}};    // [group][kc]: chunk requests
+    constexpr int WB[2][3] = {{3, 2, 1}, {3, 1, 2}};    //              read-back rounds (stores)
+    constexpr int WE[2][3] = {{1, 1, 1}, {1, 0, 0}};    //              operand requests
+#define MK_A2_WAIT(G, K) (WA[G][K] * NP + WB[G][K] * NS3 + WE[G][K] * EPIECES)
     static_assert(MK_A2_WAIT(0, 0) <= 63 && MK_A2_WAIT(1, 2) <= 63, "vmcnt is a 6-bit counter");
     constexpr int EBYTES = EPI_LOADS ? 2 * 192 * 128 : 0;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * CH + 2 * 192 * 128 + EBYTES];
@@ -1117,8 +1117,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     const unsigned lds0 = lds_addr(smem) + (unsigned)wave * (NP * 1024);
     const v4i_t rsX = make_rsrc(p.X + (long long)cb * p.K * p.N);
     const unsigned kstride = (unsigned)KCH * nbytes;
-    auto issue_chunk = [&](int c) __attribute__((always_inline)) {                     // chunk c = 3 ts + kc of this workgroup's stream -> slot c % NSLOT
-        const int ts = c / NCH, kc = c - ts * NCH;
+    auto issue_chunk = [&](int ts, int kc, int slot) __attribute__((always_inline)) {  // chunk 3 ts + kc of this workgroup's stream -> slot (3 ts + kc) % 4
         const unsigned n0b = (unsigned)(pfirst + ts * pstride) * 128u;              // first pixel of the tile, in bytes
         const int cmax = min(7, (int)((nbytes - n0b) / 16) - 1);                    // pixels past N: re-read the last valid chunk
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kc * kstride + n0b));
@@ -1127,7 +1126,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         const int ln = lane_here();
         const int c0 = (ln & 7) ^ ((((ln >> 3) >> 1) & 1) << 2), c1 = c0 ^ 2;
         const unsigned r0 = (unsigned)(wave * 16 + (ln >> 3)) * nbytes;
-        dma2<1024>((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(c % NSLOT) * CH)), rsX, soff,
+        dma2<1024>((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)slot * CH)), rsX, soff,
                    r0 + (unsigned)min(c0, cmax) * 16u, r0 + 8u * nbytes + (unsigned)min(c1, cmax) * 16u);
     };
 
@@ -1179,7 +1178,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-        const unsigned char* sb = smem + ((NCH * ts + kc) % NSLOT) * CH;
+        const unsigned char* sb = smem + ((NCH * ts + kc) & (NSLOT - 1)) * CH;
         // eight sub-steps (k32-step x pixel half): the fragments of sub-step s + 1 are requested before the six MFMAs of sub-step
         // s are issued (two fragment sets = 16 registers; no deeper: the kernel sits at 256 registers)
         auto frags = [&](bf16x8* xf, int sub) __attribute__((always_inline)) {
@@ -1277,7 +1276,6 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
                 out.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
             }
             __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);          // (the two rows of a thread one after the other: registers)
         }
     };
 
@@ -1286,7 +1284,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     using I2 = std::integral_constant<int, 2>;
 
     MK_AS_STAMP(7);
-    for (int c = 0; c < NSLOT && c < nchunks; ++c) issue_chunk(c);
+    for (int c = 0; c < NSLOT && c < nchunks; ++c) issue_chunk(c / NCH, c % NCH, c);
 
     // One tick: (1) wait for this wave's pieces of the chunk that group 0 multiplies first in this tick, (2) barrier, (3) request
     // the chunk whose slot group 1 freed in the previous tick.  gph / gts: position of the tick in the workgroup's stream
@@ -1302,9 +1300,17 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS reads of the last phase have returned (slots / images are re-used)
         __builtin_amdgcn_s_barrier();
         MK_AS_STAMP(0);
-        if constexpr (gph > OFF) {                              // group 1 multiplied chunk 3 gts + (gph - 4) in the previous tick
-            const int c = NCH * gts + (gph - OFF - 1) + NSLOT;
-            if (c < nchunks) issue_chunk(c);
+    };
+    // ... and at the END of the phase work of ticks 4, 5, 6: group 1 multiplied chunk 3 gts + (gph - 4) in the previous tick, every
+    // wave has passed this tick's barrier: the slot is free.  Requested behind the phase work, so that the group that finishes its
+    // phase first issues while the other one is still busy (all eight waves issuing right behind the barrier cost 540 cycles per
+    // chunk, 13 % of a wave's time: profiles/r04_astat2_diag.txt)
+    auto tick_end = [&](int gts, auto gph_) __attribute__((always_inline)) {
+        constexpr int gph = decltype(gph_)::value;
+        if constexpr (gph > OFF) {
+            // chunk 3 gts + gph = tile gts + 1, chunks 1, 2 (ticks 4, 5) and tile gts + 2, chunk 0 (tick 6); slot = chunk & 3
+            const int ts = gts + (gph == 6 ? 2 : 1);
+            if (ts < T) issue_chunk(ts, gph == 6 ? 0 : gph - 3, (NCH * gts + gph) & (NSLOT - 1));
         }
         MK_AS_STAMP(2);
     };
@@ -1313,6 +1319,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         constexpr int g = decltype(grp_)::value;
         // phase p of group g is tick (p + 3 g) mod 7 of global tile lts + (p + 3 g) / 7
 #define MK_A2_TICK(P) tick(lts + ((P) + OFF * g) / PER, std::integral_constant<int, ((P) + OFF * g) % PER>{}, grp_)
+#define MK_A2_END(P) tick_end(lts + ((P) + OFF * g) / PER, std::integral_constant<int, ((P) + OFF * g) % PER>{})
 #if MK_ASTAT_DIAG
 #define MK_A2_SEG(K) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm volatile("s_nop 0" : "+v"(acc[PT - 1][CT - 1])); MK_AS_STAMP(K); } while (0)
 #else
@@ -1323,32 +1330,40 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         MK_AS_STAMP(2);
         mult(lts, I0{});
         MK_A2_SEG(1);
+        MK_A2_END(0);
         MK_A2_TICK(1);
         mult(lts, I1{});
         MK_A2_SEG(1);
+        MK_A2_END(1);
         MK_A2_TICK(2);
         mult(lts, I2{});
         MK_A2_SEG(1);
+        MK_A2_END(2);
         MK_A2_TICK(3);
         stage();
         MK_A2_SEG(3);
+        MK_A2_END(3);
         MK_A2_TICK(4);
         if constexpr (EPI_LOADS) {
-            // behind the operand pieces (requested in this group's phase 0): group 0 the chunk request of this very tick, group 1
-            // the three chunk requests of ticks 4 - 6; near the end of the stream fewer: drained
-            if (lts >= T - 2) wait_vmcnt<0>(); else wait_vmcnt<(g == 0 ? NP : 3 * NP)>();
+            // behind the operand pieces (requested in this group's phase 0): group 0 nothing (the chunk requests of ticks 4 - 6 sit
+            // behind its read-back phases), group 1 those three chunk requests; near the end of the stream fewer: drained
+            if (g == 0 || lts >= T - 2) wait_vmcnt<0>(); else wait_vmcnt<3 * NP>();
         }
         MK_AS_STAMP(4);
         readback_store(lts, 0);
         MK_A2_SEG(5);
+        MK_A2_END(4);
         MK_A2_TICK(5);
         readback_store(lts, 1);
         MK_A2_SEG(5);
+        MK_A2_END(5);
         MK_A2_TICK(6);
         readback_store(lts, 2);
         MK_A2_SEG(5);
+        MK_A2_END(6);
 #undef MK_A2_SEG
 #undef MK_A2_TICK
+#undef MK_A2_END
     };
     if (T > 0) {
         if (grp == 0) {

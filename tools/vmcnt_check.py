@@ -247,14 +247,14 @@ def check_isa(path=None, verbose=True):
 class Variant2:
     """compile-time constants of conv_nn_astat2_kernel<PRE, EPI_LOADS>"""
     NP, NCH, PER, OFF = 2, 3, 7, 3
-    # [4 slots][group][kc]: chunk requests / read-back rounds / operand requests behind a chunk
-    WA = (((5, 4, 3), (5, 4, 3)), ((3, 2, 1), (3, 2, 1)))
-    WB = (((6, 5, 4), (3, 4, 5)), ((4, 3, 2), (3, 1, 2)))
-    WE = (((0, 0, 0), (0, 0, 0)), ((1, 1, 1), (1, 0, 0)))
+    # [group][kc]: chunk requests / read-back rounds / operand requests behind a chunk
+    WA = ((3, 2, 1), (3, 2, 1))
+    WB = ((3, 2, 1), (3, 1, 2))
+    WE = ((1, 1, 1), (1, 0, 0))
 
     def __init__(self, PRE, EPI):
         self.PRE, self.EPI = PRE, EPI
-        self.NSLOT = 4 if EPI else 6
+        self.NSLOT = 4
         self.NS3 = 2 * (2 if PRE else 1)
         self.EPIECES = 6 if EPI else 0
 
@@ -266,17 +266,16 @@ class Variant2:
         return f"21conv_nn_astat2_kernelILb{int(self.PRE)}ELb{int(self.EPI)}EE"
 
     def wait_const(self, g, kc):
-        e = int(self.NSLOT == 4)
-        return self.WA[e][g][kc] * self.NP + self.WB[e][g][kc] * self.NS3 + self.WE[e][g][kc] * self.EPIECES
+        return self.WA[g][kc] * self.NP + self.WB[g][kc] * self.NS3 + self.WE[g][kc] * self.EPIECES
 
     def chunk_wait(self, g, gts, gph, T):
         return 0 if (gts <= 1 or gts >= T - 1) else self.wait_const(g, gph)
 
     def epi_wait(self, g, lts, T):
-        return 0 if lts >= T - 2 else (self.NP if g == 0 else 3 * self.NP)
+        return 0 if (g == 0 or lts >= T - 2) else 3 * self.NP
 
     def expected_vmcnt(self):
-        return {0} | {self.wait_const(g, k) for g in (0, 1) for k in range(3)} | ({self.NP, 3 * self.NP} if self.EPI else set())
+        return {0} | {self.wait_const(g, k) for g in (0, 1) for k in range(3)} | ({3 * self.NP} if self.EPI else set())
 
 
 VARIANTS2 = [Variant2(pre, epi) for pre in (False, True) for epi in (False, True)]
@@ -317,14 +316,7 @@ def simulate2(v: Variant2, T: int):
                 assert last(("X", c)) < retired
                 if 2 <= gts < T - 2:
                     steady = max(steady, need - w)
-            if gph > OFF:                                  # (2) the slot group 1 read in the previous tick
-                c = NCH * gts + (gph - OFF - 1) + v.NSLOT
-                if c < nchunks:
-                    # chunk c - NSLOT was multiplied by group 1 in tick t - 1 and by group 0 three ticks before that
-                    assert (c - v.NSLOT) == NCH * ((t - 1 - OFF) // PER) + ((t - 1 - OFF) % PER) and (t - 1 - OFF) % PER < NCH
-                    issue(("X", c), NP)
-                    requested.add(c)
-            lt = t - grp * OFF                              # (3) this group's phase
+            lt = t - grp * OFF                              # (2) this group's phase
             if 0 <= lt < PER * T:
                 lts, lph = lt // PER, lt % PER
                 if lph < NCH:
@@ -340,6 +332,13 @@ def simulate2(v: Variant2, T: int):
                     assert last(("E", lts)) < retired
                 if lph >= 4:
                     issue(("S", lts, lph), v.NS3)
+            if gph > OFF:                                  # (3) END of the tick: the slot group 1 read in the previous tick
+                c = NCH * gts + (gph - OFF - 1) + v.NSLOT
+                if c < nchunks:
+                    # chunk c - NSLOT was multiplied by group 1 in tick t - 1 and by group 0 three ticks before that
+                    assert (c - v.NSLOT) == NCH * ((t - 1 - OFF) // PER) + ((t - 1 - OFF) % PER) and (t - 1 - OFF) % PER < NCH
+                    issue(("X", c), NP)
+                    requested.add(c)
     return steady
 
 
