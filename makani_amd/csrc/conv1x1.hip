@@ -1810,8 +1810,12 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
         else hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, false, false, 5>), grid, blk, 0, s, p, slabs, tn);
         return mk_check_launch("mk_conv1x1_nn");
     }
-    static const int astat2 = [] { const char* e = getenv("MAKANI_AMD_ASTAT2"); return e ? atoi(e) : 0; }();
-    if (astat2 && !force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
+    // MAKANI_AMD_ASTAT2: 0 = never, 1 = every K = 384 launch, unset = where it measured faster (profiles/r04_ab_astat2.txt: plain
+    // -7 %, gelu' -14 ... -22 %, skip operand -10 ... -21 %; bias + GELU + pre-activation — two output streams, bound by the
+    // stores — +0 ... 2 %: that variant stays on the one-group kernel)
+    static const int astat2 = [] { const char* e = getenv("MAKANI_AMD_ASTAT2"); return e ? atoi(e) : 2; }();
+    if (astat2 && (astat2 == 1 || !(act && Ypre && !(R || G))) && !force_tile && !no_astat && K == 384 && M >= 256 &&
+        (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
         // two wave groups, one multiplying while the other runs its epilogue (conv_nn_astat2_kernel): 384-channel slabs
         const bool epi_loads = R || G;
         const int slabs = (M + 383) / 384;
