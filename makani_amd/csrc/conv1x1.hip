@@ -22,8 +22,8 @@
 #ifndef MK_ASTAT_EPI_DRAIN
 #define MK_ASTAT_EPI_DRAIN 0
 #endif
-#ifndef MK_A2_SLOTS6            // conv_nn_astat2_kernel without epilogue operand: six ring slots instead of four (A/B knob)
-#define MK_A2_SLOTS6 0
+#ifndef MK_A2_PRIO              // conv_nn_astat2_kernel: s_setprio 1 around the multiplication phases (A/B knob)
+#define MK_A2_PRIO 0
 #endif
 // timing diagnostic of the weight-stationary kernel (tools/astat_diag.py; build with -DMK_ASTAT_DIAG=1): s_memtime stamps at the
 // segment boundaries of every pixel tile, summed per wave into g_astat_diag:
@@ -1194,6 +1194,9 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         };
         bf16x8 xf[2][2];
         frags(xf[0], 0);
+#if MK_A2_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int sub = 0; sub < 2 * K4; ++sub) {
             if (sub + 1 < 2 * K4) frags(xf[(sub + 1) & 1], sub + 1);
@@ -1205,6 +1208,9 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
                     acc[2 * hp + j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[sub & 1][j], wf[ct][kc * K4 + k4], acc[2 * hp + j][ct], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if MK_A2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto stage = [&]() __attribute__((always_inline)) {                                // 48 rows of this wave x 64 pixels -> the group's staging image (bf16)
         const int ln = lane_here();
