@@ -23,7 +23,7 @@
 #define MK_ASTAT_EPI_DRAIN 0
 #endif
 #ifndef MK_A2_PRIO              // conv_nn_astat2_kernel: s_setprio 1 around the multiplication phases (A/B knob)
-#define MK_A2_PRIO 0
+#define MK_A2_PRIO 1
 #endif
 // timing diagnostic of the weight-stationary kernel (tools/astat_diag.py; build with -DMK_ASTAT_DIAG=1): s_memtime stamps at the
 // segment boundaries of every pixel tile, summed per wave into g_astat_diag:
