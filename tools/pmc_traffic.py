@@ -9,7 +9,7 @@ import re
 import sys
 
 FAMILIES = [          # (family, regex on the kernel symbol, fetch correction)
-    ("conv1x1_nn", r"^conv_nn_(astat|ring)?_?kernel", 2),
+    ("conv1x1_nn", r"^conv_nn_(astat2?|ring)?_?kernel", 2),
     ("conv1x1_wgrad", r"^conv_wgrad_(ring_)?kernel", 2),
     ("dhconv_fwd", r"^xcgemm2?_kernel<true, false", 2),
     ("dhconv_dgrad", r"^xcgemm2?_kernel<true, true", 2),
@@ -26,7 +26,7 @@ FAMILIES = [          # (family, regex on the kernel symbol, fetch correction)
 FAMILIES_FCN3 = [     # bench.py --config fcn3_sc2_edim45_layers10
     ("disco_fwd", r"^disco_(fused_fwd|runs_fwd|fwd)_kernel", 2),
     ("disco_bwd", r"^disco_(runs_bwd|bwd_same|bwd)_kernel", 2),
-    ("conv1x1_nn", r"^conv_nn_(astat|ring)?_?kernel", 2),
+    ("conv1x1_nn", r"^conv_nn_(astat2?|ring)?_?kernel", 2),
     ("conv1x1_wgrad", r"^conv_wgrad_(ring_)?kernel", 2),
     ("resample_bwd", r"^resample_bwd", 2),
     ("resample_fwd", r"^resample_fwd", 2),
