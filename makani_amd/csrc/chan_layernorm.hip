@@ -52,8 +52,8 @@ __device__ __forceinline__ void stpx<float, 1>(float* p, const float (&v)[1]) { 
 template <>
 __device__ __forceinline__ void stpx<u16, 4>(u16* p, const float (&v)[4]) {
     uint2 r;
-    r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    r.x = pack_bf16x2(v[0], v[1]);
+    r.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = r;
 }
 template <>

@@ -44,6 +44,16 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
     return __builtin_bit_cast(u16, h);
 }
 
+// two fp32 values -> one dword of two bf16 (a in the low half), ONE v_cvt_pk_bf16_f32 (the element-at-a-time form
+// (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16) compiles to two conversions with an unused source each plus a
+// v_or_b32_sdwa: the epilogues of the channel GEMMs pack 48-96 pairs per lane and tile); same rounding, same bits
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef float mk_f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 mk_bf16x2_t __attribute__((ext_vector_type(2)));
+    const mk_f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mk_bf16x2_t));
+}
+
 // XCD-aware remap of a 1-D block id: consecutive ids handed to one XCD (blocks b, b+8, b+16 ...
 // run on XCD b%8 — speed only, never correctness).  Bijective for any n (guide §5 "XCD swizzle").
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -342,10 +342,10 @@ __global__ __launch_bounds__(NT, WGS) void conv_nn_kernel(const ConvNN p, int ti
             auto put = [&](u16* dst, const float* x) {
                 if (full) {
                     uint4 u;
-                    u.x = (uint32_t)f32_to_bf16(x[0]) | ((uint32_t)f32_to_bf16(x[1]) << 16);
-                    u.y = (uint32_t)f32_to_bf16(x[2]) | ((uint32_t)f32_to_bf16(x[3]) << 16);
-                    u.z = (uint32_t)f32_to_bf16(x[4]) | ((uint32_t)f32_to_bf16(x[5]) << 16);
-                    u.w = (uint32_t)f32_to_bf16(x[6]) | ((uint32_t)f32_to_bf16(x[7]) << 16);
+                    u.x = pack_bf16x2(x[0], x[1]);
+                    u.y = pack_bf16x2(x[2], x[3]);
+                    u.z = pack_bf16x2(x[4], x[5]);
+                    u.w = pack_bf16x2(x[6], x[7]);
                     *reinterpret_cast<uint4*>(dst + o) = u;
                 } else {
                     for (int e = 0; e < 8 && n + e < p.N; ++e) dst[o + e] = f32_to_bf16(x[e]);
@@ -582,8 +582,8 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
                 for (int q = 0; q < 4; ++q) {
                     const int px = (wn * TN + j) * 32 + 8 * q + 4 * lh;           // 4 consecutive pixels of this lane's channel
                     uint2 u;
-                    u.x = (uint32_t)f32_to_bf16(acc[i][j][4 * q] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 1] + bv) << 16);
-                    u.y = (uint32_t)f32_to_bf16(acc[i][j][4 * q + 2] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 3] + bv) << 16);
+                    u.x = pack_bf16x2(acc[i][j][4 * q] + bv, acc[i][j][4 * q + 1] + bv);
+                    u.y = pack_bf16x2(acc[i][j][4 * q + 2] + bv, acc[i][j][4 * q + 3] + bv);
                     *reinterpret_cast<uint2*>(stg + lrow * 512 + (((px >> 3) ^ (lrow & 15)) * 16) + ((px >> 2) & 1) * 8) = u;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -639,10 +639,10 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
                             }
                         }
                         uint4 out;
-                        out.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        out.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        out.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-                        out.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                        out.x = pack_bf16x2(v[0], v[1]);
+                        out.y = pack_bf16x2(v[2], v[3]);
+                        out.z = pack_bf16x2(v[4], v[5]);
+                        out.w = pack_bf16x2(v[6], v[7]);
                         *reinterpret_cast<uint4*>(p.Y + o) = out;
                     }
                 }
@@ -941,8 +941,8 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                 for (int q = 0; q < 4; ++q) {
                     const int px = j * 32 + 8 * q + 4 * lh;
                     uint2 u;
-                    u.x = (uint32_t)f32_to_bf16(acc[i][j][4 * q] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 1] + bv) << 16);
-                    u.y = (uint32_t)f32_to_bf16(acc[i][j][4 * q + 2] + bv) | ((uint32_t)f32_to_bf16(acc[i][j][4 * q + 3] + bv) << 16);
+                    u.x = pack_bf16x2(acc[i][j][4 * q] + bv, acc[i][j][4 * q + 1] + bv);
+                    u.y = pack_bf16x2(acc[i][j][4 * q + 2] + bv, acc[i][j][4 * q + 3] + bv);
                     *reinterpret_cast<uint2*>(stg + lrow * 128 + (((px >> 3) ^ ((lrow >> 1) & 7)) * 16) + ((px >> 2) & 1) * 8) = u;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -987,10 +987,10 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                             v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
                         }
                     }
-                    out.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    out.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    out.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-                    out.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                    out.x = pack_bf16x2(v[0], v[1]);
+                    out.y = pack_bf16x2(v[2], v[3]);
+                    out.z = pack_bf16x2(v[4], v[5]);
+                    out.w = pack_bf16x2(v[6], v[7]);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff[u4], 0, 0);
             }
@@ -1222,8 +1222,8 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 uint2 u;
-                u.x = (uint32_t)f32_to_bf16(acc[pt][ct][0] + bv) | ((uint32_t)f32_to_bf16(acc[pt][ct][1] + bv) << 16);
-                u.y = (uint32_t)f32_to_bf16(acc[pt][ct][2] + bv) | ((uint32_t)f32_to_bf16(acc[pt][ct][3] + bv) << 16);
+                u.x = pack_bf16x2(acc[pt][ct][0] + bv, acc[pt][ct][1] + bv);
+                u.y = pack_bf16x2(acc[pt][ct][2] + bv, acc[pt][ct][3] + bv);
                 const int chunk = 2 * pt + (q4 >> 1);   // pixels 16 pt + 4 q4 .. + 3
                 *reinterpret_cast<uint2*>(stgG + lrow * 128 + ((chunk ^ ((lrow >> 1) & 7)) * 16) + (q4 & 1) * 8) = u;
             }
@@ -1276,10 +1276,10 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
                         v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
                     }
                 }
-                out.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                out.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                out.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-                out.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                out.x = pack_bf16x2(v[0], v[1]);
+                out.y = pack_bf16x2(v[2], v[3]);
+                out.z = pack_bf16x2(v[4], v[5]);
+                out.w = pack_bf16x2(v[6], v[7]);
             }
             __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff, 0, 0);
         }

@@ -225,8 +225,8 @@ __device__ __forceinline__ void store_outputs(T* dst, const typename FV<PB>::typ
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += 4) {
             u32x2 v;
-            v[0] = (uint32_t)f32_to_bf16(acc[r0][b]) | ((uint32_t)f32_to_bf16(acc[r0 + 1][b]) << 16);
-            v[1] = (uint32_t)f32_to_bf16(acc[r0 + 2][b]) | ((uint32_t)f32_to_bf16(acc[r0 + 3][b]) << 16);
+            v[0] = pack_bf16x2(acc[r0][b], acc[r0 + 1][b]);
+            v[1] = pack_bf16x2(acc[r0 + 2][b], acc[r0 + 3][b]);
             *reinterpret_cast<u32x2*>(dst + r0) = v;
         }
     }

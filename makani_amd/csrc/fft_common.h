@@ -74,5 +74,5 @@ __device__ __forceinline__ void store_pair<float>(float* p, float a, float b) {
 }
 template <>
 __device__ __forceinline__ void store_pair<u16>(u16* p, float a, float b) {
-    *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b);
 }

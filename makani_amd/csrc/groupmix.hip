@@ -42,7 +42,7 @@ struct GVec<u16> {
     __device__ static __forceinline__ Raw pack(const float* v) {
         Raw r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         return r;
     }
 };

@@ -59,7 +59,7 @@ struct VecIO<u16> {
     __device__ static __forceinline__ void store(u16* p, const float* v) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     __device__ static __forceinline__ float load1(const u16* p) { return bf16_to_f32(*p); }
@@ -512,8 +512,8 @@ __device__ __forceinline__ void store4(float* p, const float* v) {
     *reinterpret_cast<f32x4*>(p) = r;
 }
 __device__ __forceinline__ void store4(u16* p, const float* v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
-                                              (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]),
+                                              pack_bf16x2(v[2], v[3]));
 }
 __device__ __forceinline__ float lp_pow(float d, float p) {
     const float ad = fabsf(d);

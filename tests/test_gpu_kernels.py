@@ -497,6 +497,21 @@ def test_conv1x1_nn_and_wgrad(B, M, K, H, W):
     assert rel_l2(dW2, torch.einsum("bmhw,bkhw->mk", gm.double(), x.double())) < 1e-5
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_weight_stationary_kernel_forms(form):
+    """the K = 384 launches pick the one-group or the two-group weight-stationary kernel per epilogue variant (csrc/conv1x1.hip:
+    MAKANI_AMD_ASTAT2 unset); the switch is read once per process, so both forms of EVERY variant are run here in child
+    processes: "0" = one wave group everywhere, "1" = two wave groups everywhere (incl. bias + GELU + pre-activation)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-k",
+                          "test_conv1x1_nn_and_wgrad and 384 and not 73"], env=dict(os.environ, MAKANI_AMD_ASTAT2=form),
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
 def test_conv_gelu_conv_autograd():
     from makani_amd import ops
     torch.manual_seed(4)
