@@ -501,10 +501,11 @@ def test_c_abi_host_side_planning_functions():
     assert L.mk_disco_fused_shape(720, 4, 13, 677, C.byref(LG), C.byref(PB)) == 0                    # K != 9: one stream per basis function
     assert [L.mk_group_mix_supported(c, r) for c, r in ((9, 9), (9, 8), (8, 9), (8, 8), (9, 10), (3, 9))] == [1, 1, 1, 1, 0, 0]
     assert L.mk_group_mix_blocks(1038240, MK_F32, 65) == 32 and L.mk_group_mix_blocks(64, MK_BF16, 4) == 1
-    # weight gradient workspace = splits x M x K: FourCastNet3's 677 x 6093 at 259 200 pixels is tiled 3 x 16 with 5 pixel splits
+    # weight gradient workspace = splits x (M x K partial products + M partial row sums for the fused bias gradient):
+    # FourCastNet3's 677 x 6093 at 259 200 pixels is tiled 3 x 16 with 5 pixel splits
     L.mk_conv1x1_wgrad_workspace.restype = C.c_longlong
-    assert L.mk_conv1x1_wgrad_workspace(677, 6093, 1, 259200) == 5 * 677 * 6093
-    assert L.mk_conv1x1_wgrad_workspace(384, 384, 1, 1038240) % (384 * 384) == 0
+    assert L.mk_conv1x1_wgrad_workspace(677, 6093, 1, 259200) == 5 * 677 * (6093 + 1)
+    assert L.mk_conv1x1_wgrad_workspace(384, 384, 1, 1038240) % (384 * (384 + 1)) == 0
 
 
 def test_fused_schedule_plan_invariants():
