@@ -28,6 +28,7 @@ using gemm::BlockCoord;
 using gemm::decode_block;
 using gemm::validate;
 using namespace xsplit;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NT2 = 512;
 // timing diagnostics (tools/ab.py variants; results are WRONG with any of them), a bit mask: 1 = no limb split / LDS stores in
@@ -165,7 +166,6 @@ __device__ __forceinline__ void rmma_split2(const bf16x8* a, const bf16x8* b0, c
     c1 = mma_split<NP>(a, b1, c1);
 #endif
 }
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // explicit global address space on the staging loads: a pointer that may be either an operand address or the zero
 // block is otherwise treated as generic and loaded with flat_load (which also ties up the LDS counter)
 typedef __attribute__((address_space(1))) const f32x4 g_f32x4;
@@ -181,7 +181,11 @@ __device__ const f32x4 g_zero32[2] = {};
 // RQN: float4 vectors per k-row that are staged (default: the whole ROWS-wide tile).  A narrower operand (the real kernel's
 // NARROW form: 160 of 256 columns) is dealt over the threads vector by vector, so that whole waves — not lanes — go without
 // work for the columns that do not exist; the LDS image keeps the pitch of the ROWS-wide tile.
-template <int ROWS, bool KC, int RQN = ROWS / 4>
+// SW (KC only): the [row][k] limb image has NO padding (pitch 16 elements = 32 B); the two 16-byte halves of a row are
+// exchanged in rows whose bit 3 is set, which keeps the ds_read_b128 fragment reads (16 lanes = 16 rows per pass, 32 B apart)
+// and the ds_write_b64 split stores conflict-free.  A third less LDS per [row][k] plane: what lets the 256-row complex tile
+// keep two stages.
+template <int ROWS, bool KC, int RQN = ROWS / 4, bool SW = false>
 struct Stage2 {
     static constexpr int NVEC = KC ? ROWS * BK / 4 : RQN * BK;          // vectors of one k-step
     static constexpr int NV = (NVEC + NT2 - 1) / NT2;
@@ -190,9 +194,10 @@ struct Stage2 {
     f32x4 v[NV];
     unsigned keep;              // KC: 4 bits per vector = elements inside [klo, khi), applied when the tile is stored
     bool interior;              // uniform: the tile lies inside [klo, khi) (then no element masks are applied)
-    const float* p0[NV];        // address of every vector at k = 0
+    const float* p0[KC ? 1 : NV];   // address of every vector at k = 0 (KC: of vector 0; vector q lies q * qstep floats further)
     unsigned ok;                // bit q: the row(s) of vector q exist
     long long kstride;          // floats per unit of k
+    long long qstep;            // KC: floats between the rows of consecutive vectors of a thread (uniform)
 
     // ilv: the operand is an interleaved complex tensor; this stage then loads 8 consecutive floats per vector
     // (v = first four, v2 = last four) and store_ilv() separates real and imaginary parts
@@ -203,12 +208,13 @@ struct Stage2 {
         ok = 0u;
         const int u = ilv ? 2 : 1;
         kstride = KC ? u : ks;
+        qstep = (long long)(NT2 / 4) * rs;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int f = tid + q * NT2;
             if constexpr (KC) {
                 const int row = f >> 2, kq = f & 3;
-                p0[q] = base + (long long)(r0 + row) * rs + kq * 4 * u;
+                if (q == 0) p0[0] = base + (long long)(r0 + row) * rs + kq * 4 * u;
                 ok |= (r0 + row < rmax ? 1u : 0u) << q;
             } else {
                 constexpr int RQ = RQN;
@@ -219,15 +225,27 @@ struct Stage2 {
         }
     }
 
+    // load_at: the addresses of another stage (passed by value) plus a uniform offset: the imaginary part of a planar operand
+    // lies `im` floats behind the real part, its stage then carries no pointers of its own
     template <bool ILV>
     __device__ __forceinline__ void load(int k0, int klo, int khi, int tid) {
-        const long long koff = (long long)k0 * kstride;
+        load_at<ILV>(k0, klo, khi, tid, p0[0], ok, kstride, qstep, 0);
+    }
+    template <bool ILV>
+    __device__ __forceinline__ void load_from(const Stage2& ad, long long off, int k0, int klo, int khi, int tid) {
+        static_assert(KC || NV == 1, "only vector 0 takes its address from the other stage");
+        load_at<ILV>(k0, klo, khi, tid, ad.p0[0], ad.ok, ad.kstride, ad.qstep, off);
+    }
+    template <bool ILV>
+    __device__ __forceinline__ void load_at(int k0, int klo, int khi, int tid, const float* a0, unsigned aok,
+                                            long long akstride, long long aqstep, long long off) {
+        const long long koff = (long long)k0 * akstride + off;
         interior = k0 >= klo && k0 + BK <= khi;                 // uniform
         keep = 0u;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int f = tid + q * NT2;
-            bool valid = (ok >> q) & 1u;
+            bool valid = (aok >> q) & 1u;
             unsigned m = 0xfu;
             if (!interior) {
                 if constexpr (KC) {
@@ -242,14 +260,18 @@ struct Stage2 {
                 }
             }
             keep |= (valid ? m : 0u) << (4 * q);
-            const g_f32x4* src = valid ? (const g_f32x4*)(p0[q] + koff) : (const g_f32x4*)g_zero32;
+            const float* pq = KC ? a0 + q * aqstep : (q == 0 ? a0 : p0[KC ? 0 : q]);
+            const g_f32x4* src = valid ? (const g_f32x4*)(pq + koff) : (const g_f32x4*)g_zero32;
             v[q] = src[0];
             if constexpr (ILV) v2[q] = src[1];
         }
     }
 
     __device__ static __forceinline__ int lds_off(int f) {
-        if constexpr (KC) {
+        if constexpr (KC && SW) {
+            const int row = f >> 2, kq = f & 3;
+            return row * BK + ((((kq >> 1) ^ (row >> 3)) & 1) << 3) + (kq & 1) * 4;
+        } else if constexpr (KC) {
             return (f >> 2) * PK + (f & 3) * 4;
         } else {
             constexpr int RQ = RQN;
@@ -291,14 +313,69 @@ struct Stage2 {
     }
 };
 
+template <int ROWS, bool KC, bool SW>
+constexpr int plane_elems2() {
+    return (KC && SW) ? ROWS * BK : plane_elems<ROWS, KC>();
+}
+template <int ROWS, bool KC, bool SW>
+__device__ __forceinline__ bf16x8 frag2(const u16* plane, int r0, int lane) {
+    if constexpr (KC && SW) {
+        const int row = r0 + (lane & 31);
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(plane + row * BK + ((((lane >> 5) ^ (row >> 3)) & 1) << 3)));
+    } else {
+        return frag<ROWS, KC>(plane, r0, lane);
+    }
+}
+// the limbs of -x are the negated limbs of x (round to nearest even is symmetric): flip the sign bits of a fragment
+__device__ __forceinline__ bf16x8 neg_frag(bf16x8 v) {
+    u32x4 u = __builtin_bit_cast(u32x4, v);
+    u ^= 0x80008000u;
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// 32 x 32 x 16 complex tile update on TWO accumulators: im += ai br, re += ar br; then the sign bits of the ai fragments are
+// flipped in place (no registers for a negated copy) and re += (-ai) bi, im += ar bi.  Both halves alternate between the two
+// accumulators.
+template <int NP>
+__device__ __forceinline__ void cmma_split2acc(const bf16x8* ar, bf16x8* ai, const bf16x8* br, const bf16x8* bi, f32x16& cre,
+                                               f32x16& cim) {
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int IA[6] = {1, 0, 2, 0, 1, 0}, IB[6] = {1, 2, 0, 1, 0, 0};
+    constexpr int O = NP == 3 ? 0 : 3;
+#pragma unroll
+    for (int q = 0; q < NPROD; ++q) {
+        const int a = IA[O + q], b = IB[O + q];
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[a], br[b], cim, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[a], br[b], cre, 0, 0, 0);
+    }
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) ai[pl] = neg_frag(ai[pl]);
+#pragma unroll
+    for (int q = 0; q < NPROD; ++q) {
+        const int a = IA[O + q], b = IB[O + q];
+        cre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[a], bi[b], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[a], bi[b], cim, 0, 0, 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // complex kernel: tile 128 x 128, wave (g = wave >> 2, cs = wave & 3) owns columns [32 cs, 32 cs + 32) of row tiles g, g + 2
 // ---------------------------------------------------------------------------------------------------------------
-template <bool A_KC, bool B_KC, int NP, bool B_ILV>
+// RT = 4 ("tall"): tile 256 x 128, wave (g, cs) owns columns [32 cs, 32 cs + 32) of row tiles g, g + 2, g + 4, g + 6.  One k-step
+// then ingests 48 KB of fp32 for 6 144 matrix-pipe cycles per SIMD (7.8 B/clk) where the 128 x 128 tile ingests 32 KB for 3 072
+// (10.7 B/clk, more than a CU's memory path delivers: DESIGN.md section 4), the weight tile is read by half as many workgroups
+// and its fragments are read from LDS once per four row tiles.  What makes it fit: the [row][k] limb images are unpadded and
+// swizzled (two stages of a 256-row A and a 128-column B = 144-156 KB), and the complex product runs on TWO accumulators per
+// tile (re += ar br + ai (-bi) with the sign bits of the bi fragment flipped once per k-step: 128 accumulator registers
+// instead of 192), with one staging register set.
+template <bool A_KC, bool B_KC, int NP, bool B_ILV, int RT = 2>
 __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM, int tilesN) {
-    constexpr int BM = 128, BN = 128;
-    constexpr int PLA = plane_elems<BM, A_KC>(), PLB = plane_elems<BN, B_KC>();
+    constexpr int BM = 64 * RT, BN = 128;
+    constexpr bool TALL = RT == 4;
+    static_assert(RT == 2 || (RT == 4 && A_KC), "row tiles per wave: 2, or 4 with a k-contiguous A");
+    constexpr int PLA = plane_elems2<BM, A_KC, TALL>(), PLB = plane_elems2<BN, B_KC, TALL>();
     constexpr int STG = 2 * NP * (PLA + PLB);             // elements per stage: (re, im) x limbs x (A, B)
+    static_assert(2 * STG * 2 <= 160 * 1024, "two stages must fit the LDS of a CU");
     __shared__ __attribute__((aligned(16))) u16 smem[2 * STG];
 
     const BlockCoord c = decode_block2<BM, BN>(p, tilesM, tilesN);
@@ -316,49 +393,56 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
     const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
     const float sgn_a = p.conj_a ? -1.f : 1.f;
     const float sgn_b = p.conj_b ? -1.f : 1.f;
-    bool live[2];
+    bool live[RT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) live[j] = c.i0 + 32 * (grp + 2 * j) < c.Meff;
+    for (int j = 0; j < RT; ++j) live[j] = c.i0 + 32 * (grp + 2 * j) < c.Meff;
 
-    f32x16 cre[2], cim[2], cng[2];
+    constexpr int NNG = TALL ? 1 : RT;                      // (the tall form has no separate accumulator for - ai bi)
+    f32x16 cre[RT], cim[RT], cng[NNG];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < RT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             cre[j][r] = 0.f;
             cim[j][r] = 0.f;
-            cng[j][r] = 0.f;
+            if (j < NNG) cng[j][r] = 0.f;
         }
 
     const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
     const int nk = kt1 - kt0;
     const int a_rmax = A_KC ? c.Meff : p.M;
-    constexpr int D = MK_X2_DEPTH;                          // staging register sets: tile t rides in set t % D
-    Stage2<BM, A_KC> sar[D], sai[D];
-    Stage2<BN, B_KC> sbr[D], sbi[D];                        // B_ILV: sbr carries both parts, sbi is unused
+    constexpr int D = TALL ? 1 : MK_X2_DEPTH;               // staging register sets: tile t rides in set t % D
+    Stage2<BM, A_KC, BM / 4, TALL> sar[D], sai[D];
+    Stage2<BN, B_KC, BN / 4, TALL> sbr[D], sbi[D];          // B_ILV: sbr carries both parts, sbi is unused
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         sar[d].init(Ab, p.a_row, p.a_k, c.i0, a_rmax, tid);
-        sai[d].init(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, tid);
+        if constexpr (!TALL) sai[d].init(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, tid);
         if constexpr (B_ILV) {
             sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid, true);
         } else {
             sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
-            sbi[d].init(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, tid);
+            if constexpr (!TALL) sbi[d].init(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, tid);
         }
     }
-    auto ld = [&](auto set, int kt) {
+    auto ld = [&](auto set, int kt) __attribute__((always_inline)) {
         constexpr int d = decltype(set)::value;
         sar[d].template load<false>(kt * BK, c.klo, c.khi, tid);
-        sai[d].template load<false>(kt * BK, c.klo, c.khi, tid);
+        if constexpr (TALL)
+            sai[d].template load_from<false>(sar[d], p.a_im, kt * BK, c.klo, c.khi, tid);
+        else
+            sai[d].template load<false>(kt * BK, c.klo, c.khi, tid);
         if constexpr (B_ILV) {
             sbr[d].template load<true>(kt * BK, c.klo, c.khi, tid);
         } else {
             sbr[d].template load<false>(kt * BK, c.klo, c.khi, tid);
-            sbi[d].template load<false>(kt * BK, c.klo, c.khi, tid);
+            if constexpr (TALL)
+                sbi[d].template load_from<false>(sbr[d], p.b_im, kt * BK, c.klo, c.khi, tid);
+            else
+                sbi[d].template load<false>(kt * BK, c.klo, c.khi, tid);
         }
     };
-    auto st = [&](auto set, int buf) {
+    auto st = [&](auto set, int buf) __attribute__((always_inline)) {
         constexpr int d = decltype(set)::value;
         u16* Are = smem + buf * STG;
         u16* Aim = Are + NP * PLA;
@@ -374,10 +458,10 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
         }
     };
 #if MK_X2_DIAG & 8
-    bf16x8 d_br[NP], d_bim[NP], d_ar[2][NP], d_ai[2][NP];
+    bf16x8 d_br[NP], d_bim[NP], d_ar[RT][NP], d_ai[RT][NP];
     bool d_have = false;
 #endif
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const u16* Are = smem + buf * STG;
         const u16* Aim = Are + NP * PLA;
         const u16* Bre = Aim + NP * PLA;
@@ -387,49 +471,52 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
         if (!d_have) {
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
-                d_br[pl] = frag<BN, B_KC>(Bre + pl * PLB, cs * 32, lane);
-                d_bim[pl] = frag<BN, B_KC>(Bim + pl * PLB, cs * 32, lane);
+                d_br[pl] = frag2<BN, B_KC, TALL>(Bre + pl * PLB, cs * 32, lane);
+                d_bim[pl] = frag2<BN, B_KC, TALL>(Bim + pl * PLB, cs * 32, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    d_ar[j][pl] = frag<BM, A_KC>(Are + pl * PLA, (grp + 2 * j) * 32, lane);
-                    d_ai[j][pl] = frag<BM, A_KC>(Aim + pl * PLA, (grp + 2 * j) * 32, lane);
+                for (int j = 0; j < RT; ++j) {
+                    d_ar[j][pl] = frag2<BM, A_KC, TALL>(Are + pl * PLA, (grp + 2 * j) * 32, lane);
+                    d_ai[j][pl] = frag2<BM, A_KC, TALL>(Aim + pl * PLA, (grp + 2 * j) * 32, lane);
                 }
             }
             d_have = true;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < RT; ++j) {
             if (!live[j]) continue;
             prio_hi();
-            cmma_split<NP>(d_ar[j], d_ai[j], d_br, d_bim, cre[j], cng[j], cim[j]);
+            cmma_split<NP>(d_ar[j], d_ai[j], d_br, d_bim, cre[j], cng[TALL ? 0 : j], cim[j]);
             prio_lo();
         }
 #else
         bf16x8 br[NP], bim[NP];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            br[pl] = frag<BN, B_KC>(Bre + pl * PLB, cs * 32, lane);
-            bim[pl] = frag<BN, B_KC>(Bim + pl * PLB, cs * 32, lane);
+            br[pl] = frag2<BN, B_KC, TALL>(Bre + pl * PLB, cs * 32, lane);
+            bim[pl] = frag2<BN, B_KC, TALL>(Bim + pl * PLB, cs * 32, lane);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < RT; ++j) {
             if (!live[j]) continue;
             bf16x8 ar[NP], ai[NP];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
-                ar[pl] = frag<BM, A_KC>(Are + pl * PLA, (grp + 2 * j) * 32, lane);
-                ai[pl] = frag<BM, A_KC>(Aim + pl * PLA, (grp + 2 * j) * 32, lane);
+                ar[pl] = frag2<BM, A_KC, TALL>(Are + pl * PLA, (grp + 2 * j) * 32, lane);
+                ai[pl] = frag2<BM, A_KC, TALL>(Aim + pl * PLA, (grp + 2 * j) * 32, lane);
             }
             // (ar + i ai)(br + i bi): re = ar br - ai bi (second part accumulated apart), im = ar bi + ai br
             MK_X2_STAMP(1);
             prio_hi();
-            cmma_split<NP>(ar, ai, br, bim, cre[j], cng[j], cim[j]);
+            if constexpr (TALL)
+                cmma_split2acc<NP>(ar, ai, br, bim, cre[j], cim[j]);
+            else
+                cmma_split<NP>(ar, ai, br, bim, cre[j], cng[j], cim[j]);
             prio_lo();
             MK_X2_STAMP(2);
         }
 #endif
     };
-    auto produce = [&](auto set, int i) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
+    auto produce = [&](auto set, int i) __attribute__((always_inline)) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
         if (!(MK_X2_DIAG & 1) && i + 1 < nk) st(set, (i + 1) & 1);
         if (!(MK_X2_DIAG & 4) && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
     };
@@ -443,7 +530,7 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
         if (D == 2 && nk > 2) ld(S0{}, kt0 + 2);
     }
     __syncthreads();
-    auto step = [&](auto set, int i) {
+    auto step = [&](auto set, int i) __attribute__((always_inline)) {
 #if MK_X2_MIDBAR
         if (grp == 0) { if (!(MK_X2_DIAG & 2)) compute(i & 1); } else produce(set, i);
         __syncthreads();
@@ -483,7 +570,7 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
     float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
     const int col = c.j0 + cs * 32 + l31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < RT; ++j) {
         if (!live[j]) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -491,7 +578,7 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
             if (row < c.Meff && col < p.N && (!(MK_X2_DIAG & 16) || p.K == -12345)) {
                 float* dr = Cb + (long long)row * p.c_row + (long long)col * p.c_col;
                 float* di = dr + p.c_im;
-                float vr = cre[j][r] - cng[j][r], vi = cim[j][r];
+                float vr = TALL ? cre[j][r] : cre[j][r] - cng[TALL ? 0 : j][r], vi = cim[j][r];
                 if (p.beta) {
                     vr += *dr;
                     vi += *di;
@@ -611,7 +698,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     const bool a_ok = c.i0 + ar0 < a.rows_valid && ar0 < 32 * t1 && ar0 + 8 > 32 * t0;
     const u16* ap = Ab + (long long)ak * a.pl_k + c.i0 + ar0;
     u32x4 av[D][NP];
-    auto ld = [&](auto set, int kt) {
+    auto ld = [&](auto set, int kt) __attribute__((always_inline)) {
         constexpr int d = decltype(set)::value;
         sb[d].template load<false>(kt * BK, c.klo, c.khi, tid);
         const int k = kt * BK + ak;
@@ -622,7 +709,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
             av[d][q] = src[0];
         }
     };
-    auto st = [&](auto set, int buf) {
+    auto st = [&](auto set, int buf) __attribute__((always_inline)) {
         constexpr int d = decltype(set)::value;
         u16* As = smem + buf * STG;
         u16* Bs = As + NP * PL;
@@ -630,7 +717,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(As + q * PL + ak * PR + ar0) = av[d][q];
     };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const u16* As = smem + buf * STG;
         const u16* Bs = As + NP * PL;
         if (!live[0]) return;
@@ -670,7 +757,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
             prio_lo();
         }
     };
-    auto produce = [&](auto set, int i) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
+    auto produce = [&](auto set, int i) __attribute__((always_inline)) {                  // tile kt0 + i + 1 sits in staging set `set` = (i + 1) % D
         if (!(MK_X2_DIAG & 1) && i + 1 < nk) st(set, (i + 1) & 1);
         if (!(MK_X2_DIAG & 4) && i + 1 + D < nk) ld(set, kt0 + i + 1 + D);
     };
@@ -684,7 +771,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
         if (D == 2 && nk > 2) ld(S0{}, kt0 + 2);
     }
     __syncthreads();
-    auto step = [&](auto set, int i) {
+    auto step = [&](auto set, int i) __attribute__((always_inline)) {
 #if MK_X2_MIDBAR
         if (grp == 0) { if (!(MK_X2_DIAG & 2)) compute(i & 1); } else produce(set, i);
         __syncthreads();
@@ -763,18 +850,33 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
 
 template <int NP>
 int launch_cplx2(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t s) {
-    constexpr int BM = 128, BN = 128;
+    // more than 128 rows and a k-contiguous A (the dhconv forward / data gradient: A = the coefficients of one degree, rows = orders):
+    // the 256 x 128 form.  MAKANI_AMD_X2_TALL=0 keeps the 128 x 128 tile everywhere
+    static const bool tall_ok = [] { const char* e = getenv("MAKANI_AMD_X2_TALL"); return !(e && e[0] == '0'); }();
+    const bool tall = tall_ok && a_kc && g->M > 128;
+    const int BM = tall ? 256 : 128, BN = 128;
     const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
     const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
     MK_REQUIRE(nb < (1ll << 31), "xcgemm2: grid too large");
     dim3 grid((unsigned)nb), block(NT2);
 #define MK_XC2(AK, BK_, IL) hipLaunchKernelGGL((xcgemm2_kernel<AK, BK_, NP, IL>), grid, block, 0, s, *g, tm, tn)
+#define MK_XC2T(BK_, IL) hipLaunchKernelGGL((xcgemm2_kernel<true, BK_, NP, IL, 4>), grid, block, 0, s, *g, tm, tn)
     if (b_ilv) {
         MK_REQUIRE(a_kc, "xcgemm2: an interleaved B operand needs a k-contiguous A");
-        if (b_kc)
+        if (tall) {
+            if (b_kc)
+                MK_XC2T(true, true);
+            else
+                MK_XC2T(false, true);
+        } else if (b_kc)
             MK_XC2(true, true, true);
         else
             MK_XC2(true, false, true);
+    } else if (tall) {
+        if (b_kc)
+            MK_XC2T(true, false);
+        else
+            MK_XC2T(false, false);
     } else if (a_kc && b_kc)
         MK_XC2(true, true, false);
     else if (a_kc && !b_kc)
@@ -784,6 +886,7 @@ int launch_cplx2(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t 
     else
         MK_XC2(false, false, false);
 #undef MK_XC2
+#undef MK_XC2T
     return mk_check_launch("mk_cgemm_split2_batched");
 }
 
