@@ -512,6 +512,45 @@ def test_weight_stationary_kernel_forms(form):
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
+@pytest.mark.parametrize("engine", ["x6", "x3"])
+@pytest.mark.parametrize("native", [True, False])
+def test_dhconv_high_degrees_all_row_tiles(engine, native, monkeypatch):
+    """degrees 217 ... 240 of the 241-order contraction (tri_off: the degree of the first batch entry): all eight 32-row tiles
+    of the complex split kernel's 256 x 128 form are live, the last one with 17 of its 32 rows; forward and data gradient, native
+    (interleaved B operand) and planar weights, against a complex128 einsum"""
+    from makani_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", engine)
+    torch.manual_seed(3)
+    B, C, L, M, off = 1, 384, 24, 241, 217
+    w = torch.randn(1, C, C, L, dtype=torch.complex64, device=_dev())
+    W = ops.native_w_empty(C, C, L, _dev()).copy_(w) if native else ops.weight_to_wlayout(w)
+    live = (torch.arange(L, device=_dev())[:, None] + off >= torch.arange(M, device=_dev())[None, :])[:, :, None]
+    S = torch.randn(L, M, 2, C, device=_dev()) * live[..., None]           # the contraction's own layout [l][m][re / im][channel]
+    x = torch.complex(S[:, :, 0].double(), S[:, :, 1].double())
+    cplx = lambda T: torch.where(live, torch.complex(T[:, :, 0], T[:, :, 1]), torch.zeros((), dtype=torch.complex64, device=_dev()))
+    y = cplx(ops.dhconv_fwd(S, W, B, C, tri_off=off))                      # (orders above the degree are not written)
+    gx = cplx(ops.dhconv_dgrad(S, W, B, C, C, tri_off=off))
+    ref = torch.einsum("lmi,iol->lmo", x, w[0].to(torch.complex128))
+    refg = torch.einsum("lmo,iol->lmi", x, w[0].conj().to(torch.complex128))
+    tol = 1e-5 if engine == "x6" else 1e-4
+    assert rel_l2(y, ref) < tol and rel_l2(gx, refg) < tol
+
+
+def test_complex_split_kernel_square_tile_form():
+    """the dhconv forward / data gradient with more than 128 orders run on the 256 x 128 tile of the complex split kernel
+    (csrc/xgemm2.hip, RT = 4); MAKANI_AMD_X2_TALL=0 (read once per process) keeps the 128 x 128 tile: the 241-order cases of the
+    dhconv tests in a child process on that form"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-k",
+                          "(test_dhconv_native_weight_order_matches_planar and 241) or test_dhconv_high_degrees"],
+                         env=dict(os.environ, MAKANI_AMD_X2_TALL="0"),
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
 def test_conv_gelu_conv_autograd():
     from makani_amd import ops
     torch.manual_seed(4)
