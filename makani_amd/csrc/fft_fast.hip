@@ -107,64 +107,96 @@ __device__ __forceinline__ long long seg_f_offset(const SegTab* t, int nw, int n
     return t->base[jw * MK_FFT_SEG_MAX + ih] + ((klat * Mj + (m - t->m_off[jw])) * 2) * Pi + (pr - t->r_off[ih]);
 }
 
+// LDS address map of one "generation" of the work buffer (the rows as one pass leaves them and the next one reads them):
+// position p of row r lives at r * LS + p + (p / BS) * D (complex values).  All loads of a pass happen before the barrier and
+// all its stores after it, so every generation may have its own row stride and padding: what matters is that the 16 / 32 lanes
+// the LDS serves in one cycle (MI355X_MICROARCH.md, LDS: ds_read_b64 = 2 x 32 lanes over 64 banks, ds_write_b64 = 4 x 16 lanes
+// over 32 banks) touch different banks.  The first pass stores with a stride of R1 values between lanes — an even stride puts
+// lanes l and l + 8 on one bank — so the generation it writes is padded to blocks of R1 + 1 (BS = R1, D = 1), which the next
+// pass then reads as consecutive values; see LdsPlan below and tools/fft_lds_model.py (bank-conflict model of every phase).
+template <int LS_, int BS_, int D_>
+struct Gen {
+    static constexpr int LS = LS_, BS = BS_, D = D_;
+    __device__ static __forceinline__ int pad(int pos) {
+        if constexpr (D_ == 0) return pos; else return pos + (pos / BS_) * D_;
+    }
+    template <int STEP>
+    static constexpr int step() {                       // address step of a position step that is a multiple of the block
+        if constexpr (D_ == 0) return STEP; else { static_assert(STEP % BS_ == 0, "step must cover whole blocks"); return STEP + (STEP / BS_) * D_; }
+    }
+};
+
 // One in-place Stockham pass of radix R (Ns = product of earlier radices) over RB rows, split into
 // its load half and its twiddle + butterfly + store half so that the loads of the NEXT work item can
 // be issued early (software prefetch) and so that load and store may alias the same LDS buffer
 // (all loads of a thread happen before the barrier, all stores after it).
-template <int N2, int R, int RB, int NT>
+// LPR: lanes per row.  0 = the N2 / R butterflies of the rows are dealt over consecutive threads; 32 / 64 = every row starts
+// on a lane group of its own (lanes past N2 / R idle), so that no group of lanes the LDS serves together spans two rows.
+template <int N2, int R, int RB, int NT, int LPR = 0>
 struct PassShape {
     static constexpr int NB = N2 / R;
-    static constexpr int ITEMS = RB * NB;
+    static constexpr int LANES = LPR ? LPR : NB;
+    static_assert(LANES >= NB, "lanes per row");
+    static constexpr int ITEMS = RB * LANES;
     static constexpr int NR = Rounds<ITEMS, NT>::value;
 };
 
-template <int N2, int R, int RB, int NT>
-using PassRegs = cf[PassShape<N2, R, RB, NT>::NR][R];
+template <int N2, int R, int RB, int NT, int LPR = 0>
+using PassRegs = cf[PassShape<N2, R, RB, NT, LPR>::NR][R];
 
-template <int N2, int R, int RB, int NT, typename LoadFn>
-__device__ __forceinline__ void pass_load(PassRegs<N2, R, RB, NT>& v, LoadFn load, int tid) {
-    using S = PassShape<N2, R, RB, NT>;
+// load(row, position, LDS address)
+template <int N2, int R, int RB, int NT, int LPR, typename GIN, typename LoadFn>
+__device__ __forceinline__ void pass_load(PassRegs<N2, R, RB, NT, LPR>& v, LoadFn load, int tid) {
+    using S = PassShape<N2, R, RB, NT, LPR>;
 #pragma unroll
     for (int q = 0; q < S::NR; ++q) {
         const int idx = tid + q * NT;
         if (idx < S::ITEMS) {
-            const int row = idx / S::NB, j = idx % S::NB;
+            const int row = idx / S::LANES, j = idx % S::LANES;
+            if (LPR == 0 || j < S::NB) {
+                const int base = row * GIN::LS + GIN::pad(j);
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[q][r] = load(row, j + r * S::NB);
+                for (int r = 0; r < R; ++r) v[q][r] = load(row, j + r * S::NB, base + r * GIN::template step<S::NB>());
+            }
         }
     }
 }
 
 // tp: this pass's twiddles, tp[(r-1)*NS + k] = exp(-2 pi i k r / (NS R)): consecutive lanes (k) read
-// consecutive LDS words
-template <int N2, int R, int NS, int RB, int NT, typename StoreFn>
-__device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB, NT>& v, const cf* __restrict__ tp,
+// consecutive LDS words.  store(row, position, LDS address, value)
+template <int N2, int R, int NS, int RB, int NT, int LPR, typename GOUT, typename StoreFn>
+__device__ __forceinline__ void pass_compute_store(PassRegs<N2, R, RB, NT, LPR>& v, const cf* __restrict__ tp,
                                                    StoreFn store, int tid) {
-    using S = PassShape<N2, R, RB, NT>;
+    using S = PassShape<N2, R, RB, NT, LPR>;
+    static_assert(GOUT::D == 0 || GOUT::BS == NS * R, "a padded generation is padded per output block of the pass that writes it");
 #pragma unroll
     for (int q = 0; q < S::NR; ++q) {
         const int idx = tid + q * NT;
         if (idx < S::ITEMS) {
-            const int row = idx / S::NB, j = idx % S::NB;
-            const int k = j % NS;
-            if (NS > 1) {
+            const int row = idx / S::LANES, j = idx % S::LANES;
+            if (LPR == 0 || j < S::NB) {
+                const int k = j % NS;
+                if (NS > 1) {
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[q][r] = cmul(v[q][r], tp[(r - 1) * NS + k]);
+                    for (int r = 1; r < R; ++r) v[q][r] = cmul(v[q][r], tp[(r - 1) * NS + k]);
+                }
+                PDft<R>::run(v[q]);
+                const int j0 = (j - k) * R + k;
+                const int base = row * GOUT::LS + (j / NS) * (NS * R + GOUT::D) + k;      // = row * LS + pad(j0)
+#pragma unroll
+                for (int o = 0; o < R; ++o) store(row, j0 + o * NS, base + o * NS, v[q][PDft<R>::loc(o)]);
             }
-            PDft<R>::run(v[q]);
-            const int j0 = (j - k) * R + k;
-#pragma unroll
-            for (int o = 0; o < R; ++o) store(row, j0 + o * NS, v[q][PDft<R>::loc(o)]);
         }
     }
 }
 
-template <int N2, int R, int NS, int RB, int NT, bool SYNC_BETWEEN, typename LoadFn, typename StoreFn>
+template <int N2, int R, int NS, int RB, int NT, bool SYNC_BETWEEN, int LPR, typename GIN, typename GOUT, typename LoadFn,
+          typename StoreFn>
 __device__ __forceinline__ void fft_pass(const cf* __restrict__ tp, LoadFn load, StoreFn store, int tid) {
-    cf v[PassShape<N2, R, RB, NT>::NR][R];
-    pass_load<N2, R, RB, NT>(v, load, tid);
+    cf v[PassShape<N2, R, RB, NT, LPR>::NR][R];
+    pass_load<N2, R, RB, NT, LPR, GIN>(v, load, tid);
     if (SYNC_BETWEEN) __syncthreads();
-    pass_compute_store<N2, R, NS, RB, NT>(v, tp, store, tid);
+    pass_compute_store<N2, R, NS, RB, NT, LPR, GOUT>(v, tp, store, tid);
 }
 
 struct ItemRange {
@@ -193,6 +225,51 @@ __host__ __device__ constexpr int row_stride(int n2, int rb, bool inverse) {
         if (rb <= 8) { while (ls % 4 != 2) ++ls; } else { while (ls % 2 != 1) ++ls; }
     }
     return ls;
+}
+
+// Row strides, padding and lanes per row of the generations of one kernel (g0 = what the first pass reads, g1 / g2 = what
+// passes 1 / 2 leave, the last generation of the forward kernel = what the untangle step reads).  Default: one layout for all
+// (row_stride above, chosen for the [row][m] <-> [m][row] steps).  The plans of the benchmark's kernels come out of the bank
+// model (tools/fft_lds_model.py; LDS cycles of one item, current -> plan, conflict-free = 1.00x):
+//   forward 1440 (16 rows, 512 threads)   5 608 -> 3 216 (1.79x -> 1.00x)      inverse 1440   2 900 -> 2 084 (1.59x -> 1.13x)
+//   forward 480 (2 x 16 rows, 2 x 256)    2 568 -> 1 808 (1.64x -> 1.15x)      inverse 480    4 788 -> 3 901 (1.66x -> 1.34x)
+// MK_FFT_LDSPLAN=0: the default layout everywhere (the A/B build).
+#ifndef MK_FFT_LDSPLAN
+#define MK_FFT_LDSPLAN 1
+#endif
+template <int N2, int R1, int R2, int R3, int RBH, int NTH, bool INV, bool ON = (MK_FFT_LDSPLAN != 0)>
+struct LdsPlan {
+    static constexpr int LS0 = row_stride(N2, RBH, INV), LS1 = LS0, LS2 = LS0, LS3 = LS0;
+    static constexpr int D1 = 0, D2 = 0, LPR1 = 0, LPR2 = 0, LPR3 = 0;
+    static constexpr bool SWAP = false;     // forward, bf16 rows: the two 16-byte halves of a vector stored in lane-dependent order
+};
+template <>
+struct LdsPlan<720, 30, 24, 1, 16, 512, false, true> {
+    static constexpr int LS0 = 728, LS1 = 744, LS2 = 722, LS3 = 722, D1 = 1, D2 = 0, LPR1 = 0, LPR2 = 32, LPR3 = 0;
+    static constexpr bool SWAP = true;
+};
+template <>
+struct LdsPlan<720, 30, 24, 1, 16, 512, true, true> {
+    static constexpr int LS0 = 721, LS1 = 744, LS2 = 721, LS3 = 721, D1 = 1, D2 = 0, LPR1 = 0, LPR2 = 32, LPR3 = 0;
+    static constexpr bool SWAP = false;
+};
+template <>
+struct LdsPlan<240, 10, 6, 4, 16, 256, false, true> {      // (128 registers: 64 lanes per row in pass 3 would spill; 1 728 with it)
+    static constexpr int LS0 = 248, LS1 = 264, LS2 = 296, LS3 = 242, D1 = 1, D2 = 14, LPR1 = 0, LPR2 = 0, LPR3 = 0;
+    static constexpr bool SWAP = true;
+};
+template <>
+struct LdsPlan<240, 10, 6, 4, 32, 512, true, true> {
+    static constexpr int LS0 = 249, LS1 = 264, LS2 = 296, LS3 = 249, D1 = 1, D2 = 14, LPR1 = 0, LPR2 = 0, LPR3 = 64;
+    static constexpr bool SWAP = false;
+};
+template <typename PL>
+constexpr int plan_max_stride() {
+    int m = PL::LS0;
+    if (PL::LS1 > m) m = PL::LS1;
+    if (PL::LS2 > m) m = PL::LS2;
+    if (PL::LS3 > m) m = PL::LS3;
+    return m;
 }
 
 // twiddle tables in LDS: per-pass tables (see pass_compute_store) + U[m] = exp(-2 pi i m / N), m < UN
@@ -278,17 +355,24 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
     static_assert(R1 * R2 * R3 == N2, "radix product");
     // HV halves of NTH threads, RBH rows each (see MK_FFT_HV above); below, RBH / NTH / tid are the half's
     constexpr int NTH = NT / HV, RBH = RB / HV;
-    constexpr int N = 2 * N2, LS = row_stride(N2, RBH, false);
+    using PL = LdsPlan<N2, R1, R2, R3, RBH, NTH, false>;
+    using G0 = Gen<PL::LS0, 0, 0>;                                        // the committed rows
+    using G1 = Gen<PL::LS1, R1, PL::D1>;                                  // after pass 1
+    using G2 = Gen<PL::LS2, R1 * R2, (R3 > 1) ? PL::D2 : 0>;              // after pass 2 (two-pass plans: the last generation)
+    using G3 = Gen<PL::LS3, 0, 0>;                                        // after pass 3
+    constexpr int LS0 = PL::LS0, LS = (R3 > 1) ? PL::LS3 : PL::LS2;       // LS: the generation the untangle step reads
+    constexpr int LSM = plan_max_stride<PL>();
+    constexpr int N = 2 * N2;
     constexpr int VP = RowVec<T>::PAIRS, VROW = N2 / VP;        // vectors per row
-    static_assert(N2 % VP == 0 && LS % 2 == 0 && RBH % 4 == 0 && NT % HV == 0 && RB % HV == 0 && NTH % 64 == 0, "vector layout");
+    static_assert(N2 % VP == 0 && LS0 % 2 == 0 && RBH % 4 == 0 && NT % HV == 0 && RB % HV == 0 && NTH % 64 == 0, "vector layout");
     using Tb = Tables<N2, R1, R2, R3, MCAP>;        // mmax <= MCAP
-    __shared__ __attribute__((aligned(16))) cf smem[RB * LS + Tb::SIZE];
+    __shared__ __attribute__((aligned(16))) cf smem[RB * LSM + Tb::SIZE];
     __shared__ SegTab segtab_s;
     SegTab* segtab = &segtab_s;
     const int half = HV > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTH) : 0;
     const int rofs = half * RBH;                    // first row of this half inside the item
-    cf* buf = smem + half * (RBH * LS);
-    cf* tw2 = smem + RB * LS;
+    cf* buf = smem + half * (RBH * LSM);
+    cf* tw2 = smem + RB * LSM;
     cf* tw3 = tw2 + Tb::T2;
     cf* twu = tw3 + Tb::T3;
     const int tid = (int)threadIdx.x % NTH;
@@ -296,8 +380,8 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
     if constexpr (SEG) seg_fill<NT>(segtab, sg, (int)threadIdx.x);
 
     const ItemRange it = my_items(nitems);
-    auto st_lds = [&](int row, int pos, cf val) { buf[row * LS + pos] = val; };
-    auto ld_lds = [&](int row, int pos) -> cf { return buf[row * LS + pos]; };
+    auto st_lds = [&](int, int, int addr, cf val) { buf[addr] = val; };
+    auto ld_lds = [&](int, int, int addr) -> cf { return buf[addr]; };
     // work item = one latitude x RB consecutive (batch, channel) planes (k-major F layout, see fft.hip)
     // SEG: the row of a plane is cut into sg.xseg equal pieces in separate buffers (see SegTab): per (lane, q) the piece and
     // the offset inside it are fixed, only the (plane, latitude) part moves with the item
@@ -327,16 +411,26 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
         for (int q = 0; q < NV; ++q) {
             const int idx = tid + q * NTH;
             const int row = idx / VROW, c = idx % VROW;
-            float4* d = reinterpret_cast<float4*>(buf + row * LS + c * VP);
+            float4* d = reinterpret_cast<float4*>(buf + row * LS0 + c * VP);
             const uint4 u = rawv[q];
             if (idx < RBH * VROW) {
                 if constexpr (sizeof(T) == 4) {
                     d[0] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
                 } else {
-                    d[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-                    d[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
-                                       __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+                    const float4 lo = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                                  __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                    const float4 hi = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                                  __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+                    if constexpr (PL::SWAP) {
+                        // a lane's vector is 32 bytes of LDS: eight lanes storing their FIRST halves cover 256 bytes = every bank
+                        // twice.  Every second group of four lanes stores its second half first: 128 bytes per instruction
+                        const bool sw = (c >> 2) & 1;
+                        d[sw ? 1 : 0] = make_float4(sw ? hi.x : lo.x, sw ? hi.y : lo.y, sw ? hi.z : lo.z, sw ? hi.w : lo.w);
+                        d[sw ? 0 : 1] = make_float4(sw ? lo.x : hi.x, sw ? lo.y : hi.y, sw ? lo.z : hi.z, sw ? lo.w : hi.w);
+                    } else {
+                        d[0] = lo;
+                        d[1] = hi;
+                    }
                 }
             }
         }
@@ -355,12 +449,12 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
         const int nr = (int)max(0ll, min((long long)RBH, planes - p0));
 
         if (item + 1 < it.end) prefetch(item + 1);       // in flight during the passes and the untangle step
-        fft_pass<N2, R1, 1, RBH, NTH, true>(tw2, ld_lds, st_lds, tid);
+        fft_pass<N2, R1, 1, RBH, NTH, true, PL::LPR1, G0, G1>(tw2, ld_lds, st_lds, tid);
         __syncthreads();
-        fft_pass<N2, R2, R1, RBH, NTH, true>(tw2, ld_lds, st_lds, tid);
+        fft_pass<N2, R2, R1, RBH, NTH, true, PL::LPR2, G1, G2>(tw2, ld_lds, st_lds, tid);
         __syncthreads();
         if constexpr (R3 > 1) {
-            fft_pass<N2, R3, R1 * R2, RBH, NTH, true>(tw3, ld_lds, st_lds, tid);
+            fft_pass<N2, R3, R1 * R2, RBH, NTH, true, PL::LPR3, G2, G3>(tw3, ld_lds, st_lds, tid);
             __syncthreads();
         }
 
@@ -422,18 +516,22 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     static_assert(N2 <= 1024, "the piece index of the SEG stores is a multiply-shift valid for rows of at most 2048 points");
     constexpr int NTH = NT / HV, RBH = RB / HV;      // HV halves of NTH threads, RBH rows each (see MK_FFT_HV above)
     static_assert(NT % HV == 0 && RB % HV == 0 && RBH % 4 == 0 && NTH % 64 == 0, "halves");
-    constexpr int N = 2 * N2, LS = row_stride(N2, RBH, true);
+    using PL = LdsPlan<N2, R1, R2, R3, RBH, NTH, true>;
+    using G0 = Gen<PL::LS0, 0, 0>;                                        // the (pre-twiddled) spectrum rows
+    using G1 = Gen<PL::LS1, R1, PL::D1>;                                  // after pass 1
+    using G2 = Gen<PL::LS2, R1 * R2, (R3 > 1) ? PL::D2 : 0>;              // after pass 2 (three-pass plans)
+    constexpr int N = 2 * N2, LS = PL::LS0, LSM = plan_max_stride<PL>();
     // PRUNED (mmax <= N2/2): the spectrum is zero for mmax <= m <= N2 - mmax ... N2, which the kernel never
     // touches: no zero fill, the pre-twiddle runs on the loaded registers, the first pass substitutes zeros
     constexpr bool PRUNED = MCAP <= N2 / 2;
     using Tb = Tables<N2, R1, R2, R3, PRUNED ? MCAP : N2 + 1>;
-    __shared__ __attribute__((aligned(16))) cf smem[RB * LS + Tb::SIZE];
+    __shared__ __attribute__((aligned(16))) cf smem[RB * LSM + Tb::SIZE];
     __shared__ SegTab segtab_s;
     SegTab* segtab = &segtab_s;
     const int half = HV > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTH) : 0;
     const int rofs = half * RBH;
-    cf* buf = smem + half * (RBH * LS);
-    cf* tw2 = smem + RB * LS;
+    cf* buf = smem + half * (RBH * LSM);
+    cf* tw2 = smem + RB * LSM;
     cf* tw3 = tw2 + Tb::T2;
     cf* twu = tw3 + Tb::T3;
     const int tid = (int)threadIdx.x % NTH;
@@ -570,11 +668,11 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
             __syncthreads();
         }
 
-        auto ld_lds = [&](int row, int pos) -> cf { return buf[row * LS + pos]; };
-        auto st_lds = [&](int row, int pos, cf val) { buf[row * LS + pos] = val; };
+        auto ld_lds = [&](int, int, int addr) -> cf { return buf[addr]; };
+        auto st_lds = [&](int, int, int addr, cf val) { buf[addr] = val; };
         // the last pass writes its rows straight to global memory (staging them through LDS for 16-byte
         // stores measured 10 % slower: the extra round trip costs more than the narrower stores)
-        auto st_global = [&](int row, int pos, cf val) {
+        auto st_global = [&](int row, int pos, int, cf val) {
             long long e = 2 * pos;
             if constexpr (SEG) {
                 // piece j = e / wl by a multiply-shift that is exact for e < 2 N2 <= 2^11 and wl >= 8 (e * wl < 2^24)
@@ -585,19 +683,20 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
         };
         if constexpr (PRUNED) {
             const int z0 = mmax, z1 = N2 - mmax;               // never-written (zero) positions, inclusive
-            fft_pass<N2, R1, 1, RBH, NTH, true>(tw2, [&](int row, int pos) -> cf {
-                return (pos >= z0 && pos <= z1) ? cf_make(0.f, 0.f) : buf[row * LS + pos];
+            fft_pass<N2, R1, 1, RBH, NTH, true, PL::LPR1, G0, G1>(tw2, [&](int, int pos, int addr) -> cf {
+                return (pos >= z0 && pos <= z1) ? cf_make(0.f, 0.f) : buf[addr];
             }, st_lds, tid);
         } else {
-            fft_pass<N2, R1, 1, RBH, NTH, true>(tw2, ld_lds, st_lds, tid);
+            fft_pass<N2, R1, 1, RBH, NTH, true, PL::LPR1, G0, G1>(tw2, ld_lds, st_lds, tid);
         }
         __syncthreads();
+        using GX = Gen<1, 0, 0>;                               // (the last pass stores to global memory: no LDS map)
         if constexpr (R3 > 1) {
-            fft_pass<N2, R2, R1, RBH, NTH, true>(tw2, ld_lds, st_lds, tid);
+            fft_pass<N2, R2, R1, RBH, NTH, true, PL::LPR2, G1, G2>(tw2, ld_lds, st_lds, tid);
             __syncthreads();
-            fft_pass<N2, R3, R1 * R2, RBH, NTH, false>(tw3, ld_lds, st_global, tid);
+            fft_pass<N2, R3, R1 * R2, RBH, NTH, false, PL::LPR3, G2, GX>(tw3, ld_lds, st_global, tid);
         } else {
-            fft_pass<N2, R2, R1, RBH, NTH, false>(tw2, ld_lds, st_global, tid);
+            fft_pass<N2, R2, R1, RBH, NTH, false, PL::LPR2, G1, GX>(tw2, ld_lds, st_global, tid);
         }
         __syncthreads();
     }

@@ -72,3 +72,67 @@ def test_two_stages_of_the_tall_tile_fit_the_lds():
     for plb in (b_kc, b_kr):
         assert 2 * (2 * 3 * (a_kc + plb)) * 2 <= 160 * 1024
     assert 2 * (2 * 3 * (256 * PK + 128 * PK)) * 2 > 160 * 1024        # the padded pitch would not
+
+
+# ---- the FFT kernels' work-buffer layouts (csrc/fft_fast.hip LdsPlan, tools/fft_lds_model.py) -------------------------------
+def _fft_model():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fft_lds_model
+    return fft_lds_model
+
+
+def test_fft_lds_plans_against_the_bank_model():
+    """LDS cycles of one work item under the bank model: the one-layout default against the plans the kernels ship with"""
+    fm = _fft_model()
+    want = {"rfft 1440": (5608, 3216), "irfft 1440": (2900, 2084), "rfft 480": (2568, 1808), "irfft 480": (4788, 3901)}
+    for name, (fn, default, plan) in fm.KERNELS.items():
+        key = " ".join(name.split()[:2])
+        assert (fn(*default).total()[0], fn(*plan).total()[0]) == want[key], name
+    # the forward 1440-point plan is conflict-free in the passes and the untangle step (the commit keeps 16 cycles of 736)
+    t = fm.KERNELS["rfft 1440 bf16 (16 rows, 512 threads)"][0](*fm.KERNELS["rfft 1440 bf16 (16 rows, 512 threads)"][2])
+    assert all(t.c[k] == t.i[k] for k in t.c if k != "commit") and t.c["commit"] <= 1.03 * t.i["commit"]
+
+
+def test_fft_lds_plans_of_the_source_are_the_modelled_ones_and_consistent():
+    """the LdsPlan specialisations in csrc/fft_fast.hip carry the constants the model was run with; every generation's map is a
+    bijection of a row into its stride, and what a pass stores at the padded address is what the next pass loads there"""
+    import os
+    import re
+    fm = _fft_model()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "makani_amd", "csrc", "fft_fast.hip")).read()
+    found = {}
+    for m in re.finditer(r"struct LdsPlan<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), true> \{[^\n]*\n\s*static constexpr int "
+                         r"LS0 = (\d+), LS1 = (\d+), LS2 = (\d+), LS3 = (\d+), D1 = (\d+), D2 = (\d+), LPR1 = (\d+), LPR2 = (\d+), LPR3 = (\d+);\n"
+                         r"\s*static constexpr bool SWAP = (true|false);", src):
+        g = m.groups()
+        found[(int(g[0]), int(g[4]), g[6] == "true")] = ([int(x) for x in g[7:11]], [0, int(g[11]), int(g[12])], [int(x) for x in g[13:16]], g[16] == "true")
+    shipped = {(720, 16, False): fm.KERNELS["rfft 1440 bf16 (16 rows, 512 threads)"][2], (720, 16, True): fm.KERNELS["irfft 1440 pruned (16 rows, 512 threads)"][2],
+               (240, 16, False): fm.KERNELS["rfft 480 bf16 (one half: 16 rows, 256 threads)"][2], (240, 32, True): fm.KERNELS["irfft 480 (32 rows, 512 threads)"][2]}
+    assert set(found) == set(shipped)
+    for key, (LS, D, LPR, swap) in shipped.items():
+        sLS, sD, sLPR, sswap = found[key]
+        n = len(LS)
+        assert sLS[:n] == LS and sD[:len(D)] == D[:3] and sLPR[:len(LPR)] == LPR and sswap == swap, key
+    for N2, rad, LS, D in ((720, (30, 24), [728, 744, 722], [0, 1, 0]), (720, (30, 24), [721, 744, 721], [0, 1, 0]),
+                           (240, (10, 6, 4), [248, 264, 296, 242], [0, 1, 14, 0]), (240, (10, 6, 4), [249, 264, 296, 249], [0, 1, 14, 0])):
+        NS = [1]
+        for r in rad:
+            NS.append(NS[-1] * r)
+        for p, R in enumerate(rad):
+            BS, Dg, NB = NS[p] * R, D[p + 1], N2 // R
+            pad = lambda pos: pos + (pos // BS) * Dg
+            seen = set()
+            for j in range(NB):
+                k = j % NS[p]
+                for o in range(R):
+                    addr = (j // NS[p]) * (BS + Dg) + k + o * NS[p]                      # pass_compute_store
+                    assert addr == pad((j - k) * R + k + o * NS[p]) and addr < LS[p + 1] and addr not in seen
+                    seen.add(addr)
+            assert len(seen) == N2
+            if p + 1 < len(rad):
+                NB2 = N2 // rad[p + 1]
+                assert NB2 % BS == 0
+                step = NB2 + (NB2 // BS) * Dg
+                assert all(pad(j) + r * step == pad(j + r * NB2) for j in range(NB2) for r in range(rad[p + 1]))     # pass_load
