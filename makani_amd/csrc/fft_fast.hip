@@ -811,6 +811,8 @@ int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, con
         // forcing 3 workgroups/CU on the 8-row forward 1440 kernel spills (2.6x slower)
         // 16 rows / 512 threads, one workgroup per CU: the F side is touched in 64-byte runs (8 rows / 256 threads,
         // two workgroups per CU: 14-16 % slower)
+        // 12 rows / 512 threads at 128 registers = TWO workgroups per CU (77 KB of LDS each; launch<720, 30, 24, 1, 12, 512, 4>):
+        // 12-18 spilled registers and 48-byte runs on the F side, rfft bf16 0.49 -> 0.64 ms, irfft 0.41 -> 0.64 (round 4, rejected)
 #if MK_FFT_1440_2PASS
         case 1440: return launch<720, 30, 24, 1, 16, 512, 1>(MK_FFT_ARGS);
 #else
