@@ -50,7 +50,28 @@
 #define MK_FFT_SKEW 3
 #endif
 
+// MK_FFT_DIAG=1 (tools/ab_fast.sh fft_fast diag:-DMK_FFT_DIAG=1, tools/fft_diag.py): s_memtime stamps at the phase boundaries of the
+// forward kernel, summed over all waves of a launch: where a wave's cycles go (every stamp waits for the wave's own LDS traffic first)
+#ifndef MK_FFT_DIAG
+#define MK_FFT_DIAG 0
+#endif
+
 namespace {
+
+#if MK_FFT_DIAG
+// 0 prefetch issue, 1 pass loads (LDS reads landed), 2 barriers, 3 twiddle + butterflies + LDS stores, 4 untangle (LDS reads, arithmetic,
+// global store issue), 5 commit (wait for the prefetched row vectors, convert, LDS stores), 6 whole kernel, 7 waves
+__device__ unsigned long long g_fft_diag[8];
+#define MK_FFT_STAMP(k)                                             \
+    do {                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        dg[k] += t_ - tprev;                                        \
+        tprev = t_;                                                 \
+    } while (0)
+#else
+#define MK_FFT_STAMP(k)
+#endif
 
 template <int HV>
 __device__ __forceinline__ void skew_barriers(bool mine) {
@@ -198,6 +219,20 @@ __device__ __forceinline__ void fft_pass(const cf* __restrict__ tp, LoadFn load,
     if (SYNC_BETWEEN) __syncthreads();
     pass_compute_store<N2, R, NS, RB, NT, LPR, GOUT>(v, tp, store, tid);
 }
+#if MK_FFT_DIAG
+// the same pass with the diagnostic stamps of the forward kernel
+template <int N2, int R, int NS, int RB, int NT, int LPR, typename GIN, typename GOUT, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void fft_pass_diag(const cf* __restrict__ tp, LoadFn load, StoreFn store, int tid, unsigned long long* dg,
+                                              unsigned long long& tprev) {
+    cf v[PassShape<N2, R, RB, NT, LPR>::NR][R];
+    pass_load<N2, R, RB, NT, LPR, GIN>(v, load, tid);
+    MK_FFT_STAMP(1);
+    __syncthreads();
+    MK_FFT_STAMP(2);
+    pass_compute_store<N2, R, NS, RB, NT, LPR, GOUT>(v, tp, store, tid);
+    MK_FFT_STAMP(3);
+}
+#endif
 
 struct ItemRange {
     long long begin, end;
@@ -443,11 +478,31 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
     }
     __syncthreads();
     skew_barriers<HV>(half == 1);                         // half 1 runs MK_FFT_SKEW barrier intervals behind half 0
+#if MK_FFT_DIAG
+    unsigned long long dg[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+    const unsigned long long tstart = tprev;
+#endif
     for (long long item = it.begin; item < it.end; ++item) {
         const long long klat = (unsigned)item / (unsigned)ngr;
         const long long p0 = (item - klat * ngr) * RB + rofs;
         const int nr = (int)max(0ll, min((long long)RBH, planes - p0));
 
+#if MK_FFT_DIAG
+        if (item + 1 < it.end) prefetch(item + 1);
+        MK_FFT_STAMP(0);
+        fft_pass_diag<N2, R1, 1, RBH, NTH, PL::LPR1, G0, G1>(tw2, ld_lds, st_lds, tid, dg, tprev);
+        __syncthreads();
+        MK_FFT_STAMP(2);
+        fft_pass_diag<N2, R2, R1, RBH, NTH, PL::LPR2, G1, G2>(tw2, ld_lds, st_lds, tid, dg, tprev);
+        __syncthreads();
+        MK_FFT_STAMP(2);
+        if constexpr (R3 > 1) {
+            fft_pass_diag<N2, R3, R1 * R2, RBH, NTH, PL::LPR3, G2, G3>(tw3, ld_lds, st_lds, tid, dg, tprev);
+            __syncthreads();
+            MK_FFT_STAMP(2);
+        }
+#else
         if (item + 1 < it.end) prefetch(item + 1);       // in flight during the passes and the untangle step
         fft_pass<N2, R1, 1, RBH, NTH, true, PL::LPR1, G0, G1>(tw2, ld_lds, st_lds, tid);
         __syncthreads();
@@ -457,6 +512,8 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
             fft_pass<N2, R3, R1 * R2, RBH, NTH, true, PL::LPR3, G2, G3>(tw3, ld_lds, st_lds, tid);
             __syncthreads();
         }
+
+#endif
 
         // Hermitian untangle + truncation + weights
         if (vec) {
@@ -495,13 +552,25 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
                 o[rows] = X.y;
             }
         }
+        MK_FFT_STAMP(4);
         __syncthreads();
+        MK_FFT_STAMP(2);
         if (item + 1 < it.end) {
             commit();
+            MK_FFT_STAMP(5);
             __syncthreads();
+            MK_FFT_STAMP(2);
         }
     }
     skew_barriers<HV>(half == 0);
+#if MK_FFT_DIAG
+    dg[6] = tprev - tstart;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_fft_diag[k], dg[k]);
+        atomicAdd(&g_fft_diag[7], 1ull);
+    }
+#endif
 }
 
 // MCAP: compile-time bound on mmax (N2/3+1 for the 3x-truncated spectra of the scale-3 model, else N2+1);
@@ -828,3 +897,14 @@ int mk_fft_fast_dispatch(bool inverse, const void* in, void* out, int dtype, con
         default: return -1000;
     }
 }
+
+#if MK_FFT_DIAG
+extern "C" int mk_fft_diag_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft_diag), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fft_diag), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
