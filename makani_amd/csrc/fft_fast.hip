@@ -266,8 +266,8 @@ __host__ __device__ constexpr int row_stride(int n2, int rb, bool inverse) {
 // passes 1 / 2 leave, the last generation of the forward kernel = what the untangle step reads).  Default: one layout for all
 // (row_stride above, chosen for the [row][m] <-> [m][row] steps).  The plans of the benchmark's kernels come out of the bank
 // model (tools/fft_lds_model.py; LDS cycles of one item, current -> plan, conflict-free = 1.00x):
-//   forward 1440 (16 rows, 512 threads)   5 608 -> 3 216 (1.79x -> 1.00x)      inverse 1440   2 900 -> 2 084 (1.59x -> 1.13x)
-//   forward 480 (2 x 16 rows, 2 x 256)    2 568 -> 1 808 (1.64x -> 1.15x)      inverse 480    4 788 -> 3 901 (1.66x -> 1.34x)
+//   forward 1440 (16 rows, 512 threads)   5 608 -> 3 920 (1.79x -> 1.23x)      inverse 1440   2 900 -> 2 084 (1.59x -> 1.13x)
+//   forward 480 (2 x 16 rows, 2 x 256)    2 568 -> 2 032 (1.64x -> 1.30x)      inverse 480    4 788 -> 3 901 (1.66x -> 1.34x)
 // MK_FFT_LDSPLAN=0: the default layout everywhere (the A/B build).
 #ifndef MK_FFT_LDSPLAN
 #define MK_FFT_LDSPLAN 1
@@ -278,10 +278,17 @@ struct LdsPlan {
     static constexpr int D1 = 0, D2 = 0, LPR1 = 0, LPR2 = 0, LPR3 = 0;
     static constexpr bool SWAP = false;     // forward, bf16 rows: the two 16-byte halves of a vector stored in lane-dependent order
 };
+// SWAP (the two 16-byte halves of a bf16 vector stored in lane-dependent order by the commit: removes its 2-way conflict, 1 424 ->
+// 736 LDS cycles per item at 1440 points) is OFF: its selects are 152 of the forward kernel's 1 255 vector instructions per
+// item, and the kernel is bound by those, not by LDS cycles (rfft 1440 bf16 0.507 / 0.512 ms with it, 0.491 / 0.484 without:
+// profiles/r04_ab_fft_swap_hoist.txt).  MK_FFT_SWAP=1 is the A/B build.
+#ifndef MK_FFT_SWAP
+#define MK_FFT_SWAP 0
+#endif
 template <>
 struct LdsPlan<720, 30, 24, 1, 16, 512, false, true> {
     static constexpr int LS0 = 728, LS1 = 744, LS2 = 722, LS3 = 722, D1 = 1, D2 = 0, LPR1 = 0, LPR2 = 32, LPR3 = 0;
-    static constexpr bool SWAP = true;
+    static constexpr bool SWAP = MK_FFT_SWAP != 0;
 };
 template <>
 struct LdsPlan<720, 30, 24, 1, 16, 512, true, true> {
@@ -291,7 +298,7 @@ struct LdsPlan<720, 30, 24, 1, 16, 512, true, true> {
 template <>
 struct LdsPlan<240, 10, 6, 4, 16, 256, false, true> {      // (128 registers: 64 lanes per row in pass 3 would spill; 1 728 with it)
     static constexpr int LS0 = 248, LS1 = 264, LS2 = 296, LS3 = 242, D1 = 1, D2 = 14, LPR1 = 0, LPR2 = 0, LPR3 = 0;
-    static constexpr bool SWAP = true;
+    static constexpr bool SWAP = MK_FFT_SWAP != 0;
 };
 template <>
 struct LdsPlan<240, 10, 6, 4, 32, 512, true, true> {

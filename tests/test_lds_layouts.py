@@ -86,13 +86,16 @@ def _fft_model():
 def test_fft_lds_plans_against_the_bank_model():
     """LDS cycles of one work item under the bank model: the one-layout default against the plans the kernels ship with"""
     fm = _fft_model()
-    want = {"rfft 1440": (5608, 3216), "irfft 1440": (2900, 2084), "rfft 480": (2568, 1808), "irfft 480": (4788, 3901)}
+    want = {"rfft 1440": (5608, 3920), "irfft 1440": (2900, 2084), "rfft 480": (2568, 2032), "irfft 480": (4788, 3901)}
     for name, (fn, default, plan) in fm.KERNELS.items():
         key = " ".join(name.split()[:2])
         assert (fn(*default).total()[0], fn(*plan).total()[0]) == want[key], name
-    # the forward 1440-point plan is conflict-free in the passes and the untangle step (the commit keeps 16 cycles of 736)
-    t = fm.KERNELS["rfft 1440 bf16 (16 rows, 512 threads)"][0](*fm.KERNELS["rfft 1440 bf16 (16 rows, 512 threads)"][2])
-    assert all(t.c[k] == t.i[k] for k in t.c if k != "commit") and t.c["commit"] <= 1.03 * t.i["commit"]
+    # the forward 1440-point plan is conflict-free in the passes and the untangle step; the commit keeps its 2-way conflict (the
+    # lane-dependent store order that removes it costs more vector instructions than the conflict costs time: LdsPlan::SWAP off)
+    fn, _, (LS, D, LPR, _sw) = fm.KERNELS["rfft 1440 bf16 (16 rows, 512 threads)"]
+    t = fn(LS, D, LPR, False)
+    assert all(t.c[k] == t.i[k] for k in t.c if k != "commit")
+    assert fn(LS, D, LPR, True).total()[0] == 3216
 
 
 def test_fft_lds_plans_of_the_source_are_the_modelled_ones_and_consistent():
@@ -105,9 +108,9 @@ def test_fft_lds_plans_of_the_source_are_the_modelled_ones_and_consistent():
     found = {}
     for m in re.finditer(r"struct LdsPlan<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), true> \{[^\n]*\n\s*static constexpr int "
                          r"LS0 = (\d+), LS1 = (\d+), LS2 = (\d+), LS3 = (\d+), D1 = (\d+), D2 = (\d+), LPR1 = (\d+), LPR2 = (\d+), LPR3 = (\d+);\n"
-                         r"\s*static constexpr bool SWAP = (true|false);", src):
+                         r"\s*static constexpr bool SWAP = (true|false|MK_FFT_SWAP != 0);", src):
         g = m.groups()
-        found[(int(g[0]), int(g[4]), g[6] == "true")] = ([int(x) for x in g[7:11]], [0, int(g[11]), int(g[12])], [int(x) for x in g[13:16]], g[16] == "true")
+        found[(int(g[0]), int(g[4]), g[6] == "true")] = ([int(x) for x in g[7:11]], [0, int(g[11]), int(g[12])], [int(x) for x in g[13:16]], g[16] == "true")      # (MK_FFT_SWAP defaults to 0)
     shipped = {(720, 16, False): fm.KERNELS["rfft 1440 bf16 (16 rows, 512 threads)"][2], (720, 16, True): fm.KERNELS["irfft 1440 pruned (16 rows, 512 threads)"][2],
                (240, 16, False): fm.KERNELS["rfft 480 bf16 (one half: 16 rows, 256 threads)"][2], (240, 32, True): fm.KERNELS["irfft 480 (32 rows, 512 threads)"][2]}
     assert set(found) == set(shipped)

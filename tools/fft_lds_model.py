@@ -207,11 +207,11 @@ def inverse(N2, rad, RBH, NTH, mmax, LS, D, LPR, pruned):
 # (kernel, default plan, shipped plan = the LdsPlan specialisations of csrc/fft_fast.hip)
 KERNELS = {
     "rfft 1440 bf16 (16 rows, 512 threads)": (lambda LS, D, LPR, sw: forward(720, (30, 24), 16, 512, 4, 241, LS, D, LPR, sw),
-                                              ([722] * 3, [0, 0, 0], [0, 0], False), ([728, 744, 722], [0, 1, 0], [0, 32], True)),
+                                              ([722] * 3, [0, 0, 0], [0, 0], False), ([728, 744, 722], [0, 1, 0], [0, 32], False)),
     "irfft 1440 pruned (16 rows, 512 threads)": (lambda LS, D, LPR, sw: inverse(720, (30, 24), 16, 512, 241, LS, D, LPR, True),
                                                  ([721] * 2, [0, 0], [0, 0], False), ([721, 744], [0, 1], [0, 32], False)),
     "rfft 480 bf16 (one half: 16 rows, 256 threads)": (lambda LS, D, LPR, sw: forward(240, (10, 6, 4), 16, 256, 4, 241, LS, D, LPR, sw),
-                                                       ([242] * 4, [0] * 4, [0, 0, 0], False), ([248, 264, 296, 242], [0, 1, 14, 0], [0, 0, 0], True)),
+                                                       ([242] * 4, [0] * 4, [0, 0, 0], False), ([248, 264, 296, 242], [0, 1, 14, 0], [0, 0, 0], False)),
     "irfft 480 (32 rows, 512 threads)": (lambda LS, D, LPR, sw: inverse(240, (10, 6, 4), 32, 512, 241, LS, D, LPR, False),
                                          ([241] * 3, [0] * 3, [0, 0, 0], False), ([249, 264, 296], [0, 1, 14], [0, 0, 64], False)),
 }
