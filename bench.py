@@ -685,7 +685,7 @@ def run_worker(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.PROFILER.enabled = False
-    comm_stats = {f"group_of_{k}": dict(MB_sent=round(v["bytes_sent"] / args.steps / 1e6, 2), all_to_alls=v["all_to_alls"] / args.steps)
+    comm_stats = {f"{k[0]}_group_of_{k[1]}": dict(MB_sent=round(v["bytes_sent"] / args.steps / 1e6, 2), all_to_alls=v["all_to_alls"] / args.steps)
                   for k, v in sorted(thd.COMM_STATS.items())}
     event_steps = args.steps
     if graph is not None:

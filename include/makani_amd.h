@@ -263,7 +263,10 @@ int mk_spec_diag_wgrad(const float* x, const float* gy, float* gw_c64, int L, in
  *       A: (M, lda) k-contiguous, zero padded to lda (multiple of 8).  Forward: A = W; dgrad: A = W^T.
  *       epi(v) = v + bias[m]; if act: (Ypre = v), v = gelu(v); if G: v *= gelu'(G[b][m][n]); if R: v += R[b][m][n].
  *   mk_conv1x1_wgrad: dW[m][k] (+)= sum_{b,n} G[b][m][n] X[b][k][n]; `part` = scratch of
- *       mk_conv1x1_wgrad_workspace(M, K, B, N) floats (split-pixel partial tiles, reduced deterministically).
+ *       mk_conv1x1_wgrad_workspace(M, K, B, N) floats, laid out as (S, M, K) split-pixel partial tiles FOLLOWED BY (S, M)
+ *       partial row sums of G (S = the kernel's pixel splits; both reduced deterministically).  The query returns
+ *       S*M*K + S*M; mk_conv1x1_wgrad_bias REQUIRES a scratch of the size this version of the query returns (a caller that
+ *       sized it as S*M*K, the layout before the bias sums existed, would be overrun by S*M floats).
  *   mk_conv1x1_wgrad_bias: the same and, from the same pass over G, the bias gradient of the convolution
  *       db[m] = sum_{b,n} G[b][m][n] (what torch's conv backward returns as grad_bias; fp32, M entries, overwritten) —
  *       available where mk_conv1x1_wgrad_fuses_bias(M, K, B, N) returns 1 (the streaming "ring" kernel), else the caller

@@ -1349,12 +1349,15 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
         stage();
         MK_A2_SEG(3);
         MK_A2_END(3);
-        MK_A2_TICK(4);
         if constexpr (EPI_LOADS) {
             // behind the operand pieces (requested in this group's phase 0): group 0 nothing (the chunk requests of ticks 4 - 6 sit
-            // behind its read-back phases), group 1 those three chunk requests; near the end of the stream fewer: drained
+            // behind its read-back phases), group 1 those three chunk requests; near the end of the stream fewer: drained.
+            // IN FRONT of the phase-4 barrier: vmcnt covers this wave's own LDS-DMA pieces only, and read-back round 0 reads
+            // image rows that sibling waves of the group requested (wave wg reads rows 8 wg.. and 32 + 8 wg..) — every wave's
+            // pieces must have landed before any wave passes the barrier
             if (g == 0 || lts >= T - 2) wait_vmcnt<0>(); else wait_vmcnt<3 * NP>();
         }
+        MK_A2_TICK(4);
         MK_AS_STAMP(4);
         readback_store(lts, 0);
         MK_A2_SEG(5);

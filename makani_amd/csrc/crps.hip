@@ -136,7 +136,10 @@ __device__ __forceinline__ float crps_point(float (&f)[EM], int E, float obs, in
                 }
             }
             // a NaN observation propagates (the reference's torch.clamp(observation - forecast, min=0) does; fmaxf would
-            // drop it and report a finite, meaningless score): NaN score, zero gradients
+            // drop it and report a finite, meaningless score): NaN score, zero gradients.  The zero gradients DEPART from the
+            // reference's backward on purpose: there only the clamp term's gradient vanishes and the piecewise-integral terms still
+            // hand finite, non-zero gradients to the members of a point whose score is NaN; a training step that masks NaN
+            // scores would then still be pulled by those points.  Here a point without an observation moves nothing.
             const bool obs_nan = obs != obs;
             score = obs_nan ? obs : integ + fmaxf(obs - last, 0.f);
             if (GRAD) {

@@ -116,50 +116,76 @@ def agree_min_max(value: int):
     return lo, hi
 
 
+FALLBACKS = []            # (transform class, grid, dtype, reason) of every transform that left the fused schedule
+
+
 def eligible(T, x_dtype) -> bool:
     """the fused schedule needs the specialised FFT kernels, equal longitude pieces of whole 16-byte vectors and at most
     MK_FFT_SEG_MAX peers per direction; anything else runs the transpose-by-transpose schedule of distributed.py.
     The decision depends on environment variables and on the local group layout, so it is AGREED over the transform's groups
     the first time it is taken: the fused schedule runs only if every rank finds it eligible — ranks that decide
-    differently would enter different collective sequences and hang instead of raising."""
+    differently would enter different collective sequences and hang instead of raising.
+    A transform of a split group that does NOT run the fused schedule says so once (``logging`` warning + ``FALLBACKS``):
+    the transpose-by-transpose schedule is correct but moves every coefficient twice, and a scaling run should not fall
+    into it unnoticed."""
     from . import distributed as thd
     key = (x_dtype, os.environ.get("MAKANI_AMD_DIST_FUSED", "1"), os.environ.get("MAKANI_AMD_DIST_FORCE_FUSED", "0"), id(thd._BACKEND))
     cache = T.__dict__.setdefault("_fused_ok", {})
     if key not in cache:
-        ok = _eligible(T, x_dtype)
+        why = _ineligible(T, x_dtype)
+        ok = why is None
         if T.comm_size_polar * T.comm_size_azimuth > 1:
-            ok = bool(agree_min_max(1 if ok else 0)[0])
+            agreed = bool(agree_min_max(1 if ok else 0)[0])
+            if ok and not agreed:
+                why = "another rank of the transform's groups found the fused schedule ineligible"
+            ok = agreed
+            if not ok:
+                rec = (type(T).__name__, f"{T.nlat}x{T.nlon}", str(x_dtype), why)
+                FALLBACKS.append(rec)
+                import logging
+                logging.getLogger("makani_amd.dist").warning(
+                    "%s %s (%s, h%d w%d) runs the transpose-by-transpose schedule, not the fused one: %s",
+                    rec[0], rec[1], rec[2], T.comm_size_polar, T.comm_size_azimuth, why)
         cache[key] = ok
     return cache[key]
 
 
-def _eligible(T, x_dtype) -> bool:
+def _ineligible(T, x_dtype):
+    """None when this rank can run the fused schedule for ``T``, else the reason it cannot"""
     from . import _lib
     from . import distributed as thd
     if os.environ.get("MAKANI_AMD_DIST_FUSED", "1") != "1":
-        return False
+        return "MAKANI_AMD_DIST_FUSED=0"
     if not getattr(thd._BACKEND, "segmented", False):
-        return False
+        return "the compute backend has no segmented FFT kernels"
     h, w = T.comm_size_polar, T.comm_size_azimuth
     # MAKANI_AMD_DIST_FORCE_FUSED=1: the fused pipeline also with ONE rank (h = w = 1) — every collective it issues (the list
     # all_to_all with async_op=True on contiguous slab views, the waits that order the compute stream behind it) then runs on a
     # process group of one rank: how the RCCL call signatures and the stream ordering are exercised on a one-GPU box
     force = os.environ.get("MAKANI_AMD_DIST_FORCE_FUSED", "0") == "1" and dist.is_available() and dist.is_initialized()
-    if h > _lib.MK_FFT_SEG_MAX or w > _lib.MK_FFT_SEG_MAX or (h * w == 1 and not force):
-        return False
+    if h > _lib.MK_FFT_SEG_MAX or w > _lib.MK_FFT_SEG_MAX:
+        return f"more than MK_FFT_SEG_MAX = {_lib.MK_FFT_SEG_MAX} peers in one direction"
+    if h * w == 1 and not force:
+        return "one rank"
     if len(set(T.lon_shapes)) != 1:
-        return False
+        return f"unequal longitude pieces {T.lon_shapes}"
     ev = 8 if x_dtype == torch.bfloat16 else 4
-    if T.lon_shapes[0] % ev or not thd._BACKEND.seg_supported(T.nlon):
-        return False
+    if T.lon_shapes[0] % ev:
+        return f"longitude pieces of {T.lon_shapes[0]} points are not whole 16-byte vectors of {x_dtype}"
+    if not thd._BACKEND.seg_supported(T.nlon):
+        return f"no segmented FFT kernel for {T.nlon} longitudes"
     if h > 1 and w > 1:
         try:
             sp = thd.spatial_group()
         except ValueError:
-            return False
+            return "h and w are split but no spatial (h x w) group was given to init()"
         if sp is None or dist.get_world_size(sp) != h * w or dist.get_rank(sp) != T.comm_rank_polar * w + T.comm_rank_azimuth:
-            return False
-    return True
+            return "the spatial group is not the h-major h x w block of the polar and azimuth groups"
+    return None
+
+
+def _eligible(T, x_dtype) -> bool:
+    return _ineligible(T, x_dtype) is None
 
 
 # --------------------------------------------------------------------------- #

@@ -144,14 +144,26 @@ def _pad_to4(t: torch.Tensor, dim: int) -> torch.Tensor:
 
 
 # exchange accounting (bench.py reports it per step and rank at N > 1, so that the first scaling curve can be read against
-# SURVEY.md §8(e)'s communication budget): bytes this rank SENDS to other ranks and the number of all-to-alls, per group size
+# SURVEY.md §8(e)'s communication budget): bytes this rank SENDS to other ranks and the number of all-to-alls, per
+# (direction, group size): "polar" (h), "azimuth" (w), "spatial" (the fused schedule's one h x w exchange)
 COMM_STATS = {}
+
+
+def _group_label(group) -> str:
+    """which direction of the h x w block an exchange runs over (with h == w the sizes alone cannot tell)"""
+    if group is _SPATIAL and not (group is _POLAR or group is _AZIMUTH):
+        return "spatial"
+    if group is _POLAR:
+        return "polar"
+    if group is _AZIMUTH:
+        return "azimuth"
+    return "other"
 
 
 def _count_exchange(send, group):
     me = dist.get_rank(group)
     n = sum(t.numel() * t.element_size() for i, t in enumerate(send) if i != me)
-    st = COMM_STATS.setdefault(dist.get_world_size(group), {"bytes_sent": 0, "all_to_alls": 0})
+    st = COMM_STATS.setdefault((_group_label(group), dist.get_world_size(group)), {"bytes_sent": 0, "all_to_alls": 0})
     st["bytes_sent"] += n
     st["all_to_alls"] += 1
 
@@ -523,6 +535,7 @@ class GradReducer:
         self.comm = comm or _comm
         self.big_bytes = big_bytes
         self.zero = bool(zero)
+        self.enabled = True        # False inside GradReduceWrapper.no_sync()
         self.pending = []          # (work, real-view gradient, remaining stages)
         self.small = {}            # signature -> (stages, [params])
         self._armed = False
@@ -603,6 +616,8 @@ class GradReducer:
         return self._issue(g, stages[0])
 
     def _hook(self, p, stages):
+        if not self.enabled:           # GradReduceWrapper.no_sync(): the gradient keeps accumulating locally
+            return
         self._arm()
         g = _real(p.grad)
         dense = g if g.is_contiguous() else _dense(g)
@@ -671,6 +686,24 @@ class GradReduceWrapper(nn.Module):
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        """``DistributedDataParallel.no_sync()`` as makani's trainer uses it under gradient accumulation
+        (``makani/utils/training/deterministic_trainer.py:531-546``: every micro-batch but the last runs inside it): backward
+        passes inside the context issue NO collective — the hooks return at once and ``p.grad`` accumulates this rank's
+        contributions —, the first backward pass outside it reduces the accumulated gradients (the post-accumulate hooks see
+        the sums).  As with DDP, forward AND backward of a micro-batch belong inside the context."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = self.reducer.enabled
+            self.reducer.enabled = False
+            try:
+                yield
+            finally:
+                self.reducer.enabled = old
+        return ctx()
 
 
 def init_gradient_reduction_hooks(model, device=None, reduction_buffer_count=1, broadcast_buffers=True,

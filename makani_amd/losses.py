@@ -496,6 +496,14 @@ def _ensemble_active(flag) -> bool:
     return active
 
 
+def _check_finite_weights(w):
+    """Non-finite ``ensemble_weights`` are rejected at construction.  Deviation from the reference, stated: its kernels fold
+    ``isnan(weights)`` into their NaN mask (``crps_loss.py:66-73,176-177``), so a NaN weight — one entry per member, broadcast
+    over every grid point — silently zeroes the whole score (PWM) or drops the member everywhere (cdf); here that is an error."""
+    if w is not None and not bool(torch.isfinite(w).all()):
+        raise ValueError("ensemble_weights must be finite (the reference would mask every grid point of a member with a NaN weight)")
+
+
 def _ens_w(w, E, crps_type="cdf"):
     if w is not None and w.numel() != E:
         raise ValueError(f"ensemble_weights holds {w.numel()} entries for an ensemble of {E}")
@@ -507,7 +515,7 @@ class CRPSLoss(nn.Module):
     (B, C, H, W), spatial_weights=None) -> (B, C)``, the quadrature-weighted ensemble CRPS.  Score and quadrature are one HIP
     kernel (``csrc/crps.hip``), the gradient with respect to the forecasts one more.  Built: ``crps_type`` "skillspread"
     (default, with the almost-fair factor ``alpha``), "naive skillspread", "probability weighted moment", "gauss" and "cdf"
-    (:55-122, with optional per-member ``ensemble_weights``; the "probability weighted moment" form accepts them too and, like the reference's kernel, ignores their values); any ensemble
+    (:55-122, with optional per-member ``ensemble_weights``; the "probability weighted moment" form accepts them too and, like the reference's kernel, ignores their values — finite values: non-finite weights raise, see ``_check_finite_weights``); any ensemble
     size 2..32; ``ensemble_distributed=True`` with a split "ensemble" group (``makani_amd.comm.init(h, w, ensemble=n)`` or
     makani's own tree) trades the members for a share of the grid points before scoring, as the reference does."""
 
@@ -527,6 +535,7 @@ class CRPSLoss(nn.Module):
         # (:404-409), which ignores their values: accepted for both (and ignored by the latter, as there); other forms raise
         if ensemble_weights is not None and crps_type not in ("cdf", "probability weighted moment"):
             raise NotImplementedError("currently only constant ensemble weights are supported")
+        _check_finite_weights(ensemble_weights)
         if crps_type not in _CRPS_TYPES:
             raise ValueError(f"Unknown CRPS crps_type {crps_type}")
         if crps_type not in ("skillspread", "naive skillspread") and alpha < 1.0:
@@ -588,6 +597,7 @@ class SpectralCRPSLoss(SpectralLpLoss):
         self.ensemble_distributed = _ensemble_active(ensemble_distributed)
         if ensemble_weights is not None and crps_type != "cdf":
             raise NotImplementedError("currently only constant ensemble weights are supported")
+        _check_finite_weights(ensemble_weights)
         if crps_type not in ("cdf", "skillspread", "probability weighted moment", "gauss"):     # what the reference's forward knows
             raise ValueError(f"Unknown CRPS crps_type {crps_type}")
         if crps_type not in ("skillspread", "naive skillspread") and alpha < 1.0:

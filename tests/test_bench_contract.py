@@ -82,8 +82,8 @@ def test_bench_eight_ranks_h4w2_line_shape():
     assert d["config"]["collectives"] == "gloo" and d["config"]["global_batch"] == 1 and d["value"] > 0 and "note" not in d, d.get("note")
     ex = d["exchange_per_step_rank0"]
     assert ex["schedule"].startswith("fused") and ex["total_MB_sent"] > 0
-    assert ex["group_of_8"]["all_to_alls"] > 0            # the single h x w exchange between FFT and Legendre transform
-    assert ex["group_of_4"]["all_to_alls"] > 0 and ex["group_of_2"]["all_to_alls"] > 0
+    assert ex["spatial_group_of_8"]["all_to_alls"] > 0            # the single h x w exchange between FFT and Legendre transform
+    assert ex["polar_group_of_4"]["all_to_alls"] > 0 and ex["azimuth_group_of_2"]["all_to_alls"] > 0
     s = d["secondary"]
     assert s["parallelism"] == "dp8" and s["scaling"] == "weak" and s["global_batch"] == 8 and s["value"] > 0
     assert d["cpu_baseline"] is None

@@ -298,6 +298,60 @@ def test_data_parallel_grad_reducer_world2():
     mp.spawn(_worker_dp, args=(2, _free_port()), nprocs=2, join=True)
 
 
+def _worker_no_sync(rank, world, port):
+    """gradient accumulation over two micro-batches with ``no_sync()`` around the first (deterministic_trainer.py:531-546)
+    against the reduction of the summed gradients: identical results, and NO collective inside the context"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import makani_amd.comm as mcomm
+        import makani_amd.distributed as thd
+        mcomm.init(1, 1)
+        torch.manual_seed(0)
+        model = torch.nn.Module()
+        model.a = torch.nn.Parameter(torch.randn(5, 3))
+        model.c = torch.nn.Parameter(torch.randn(4, 2, dtype=torch.complex64))
+        model.big = torch.nn.Parameter(torch.randn(3 * 1024 * 1024))          # > 8 MB: async path
+        xs = [torch.randn(5, 3, generator=torch.Generator().manual_seed(10 * rank + i)) for i in range(2)]
+
+        def fwd(i):
+            return (model.a * xs[i]).sum() + (torch.view_as_real(model.c).sum() * (rank + 2 + i)) + (model.big * (rank + i)).sum()
+        model.forward = fwd
+        net = thd.init_gradient_reduction_hooks(model, torch.device("cpu"))
+        assert hasattr(net, "no_sync")
+        calls = []
+        real = thd.GradReducer._issue
+        thd.GradReducer._issue = staticmethod(lambda t, st: (calls.append(1), real(t, st))[1])
+        with net.no_sync():
+            net(0).backward()
+        assert not calls and not net.reducer.pending and not net.reducer.small      # nothing was issued or queued
+        local_a = model.a.grad.clone()
+        assert torch.equal(local_a, xs[0])                                          # this rank's contribution only
+        net(1).backward()                                                            # reduces the ACCUMULATED gradients
+        assert calls and not net.reducer.pending and not net.reducer.small
+        # expected: mean over ranks of the per-rank sums over the two micro-batches
+        ga = sum(torch.randn(5, 3, generator=torch.Generator().manual_seed(10 * r + i)) for r in range(world) for i in range(2)) / world
+        assert torch.allclose(model.a.grad, ga, atol=1e-6)
+        gc = sum((r + 2 + i) for r in range(world) for i in range(2)) / world
+        assert torch.allclose(torch.view_as_real(model.c.grad), torch.full((4, 2, 2), float(gc)))
+        gb = sum((r + i) for r in range(world) for i in range(2)) / world
+        assert torch.allclose(model.big.grad, torch.full_like(model.big, float(gb)))
+        # the context restores the state it found, also on an exception
+        try:
+            with net.no_sync():
+                raise KeyError("x")
+        except KeyError:
+            pass
+        assert net.reducer.enabled
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reduce_wrapper_no_sync_gradient_accumulation_world2():
+    mp.spawn(_worker_no_sync, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def _worker_tree(rank, world, port, ph, pw):
     """makani_amd.comm.init (makani/utils/comm.py:114-201) + the gradient reductions of makani/mpu/mappings.py:460-523
     driven by the is_shared_mp annotations: dhconv weights (["matmul", "w"], l-sharded over h) are summed over "w" only,

@@ -175,54 +175,27 @@ def test_dhconv_c384_l240_m241_matches_contract_lwise():
 # (iv) the whole network of BASELINE config 2 (sfno_sc3_layers8_edim384, 721 x 1440 x 73, B = 1): forward against the oracle
 #      (makani/models/networks/sfnonet.py:866-934; tolerances tests/distributed/tests_distributed_layers.py:71-76,539)
 # --------------------------------------------------------------------------- #
-CONFIG2 = dict(inp_shape=(721, 1440), out_shape=(721, 1440), inp_chans=73, out_chans=73, scale_factor=3, embed_dim=384,
-               num_layers=8, mlp_ratio=2, operator_type="dhconv", normalization_layer="instance_norm",
-               activation_function="gelu", big_skip=True, model_grid_type="equiangular", sht_grid_type="legendre-gauss")
+from _fullsize import CONFIG2, config2_oracle  # noqa: E402  (the oracle side is computed once per box and shared with
+#                                                     tests/test_gpu_dist_fullsize.py through a file: tests/_fullsize.py)
 
 
 def _perturb_affine(mod, seed):
-    """non-trivial norm weights and biases (the initial ones are 1 / 0, which hides a wrong bias or affine path)"""
-    gen = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for n, p in mod.named_parameters():
-            if n.endswith("bias"):
-                p.copy_(torch.randn(p.shape, generator=gen) * 0.1)
-            elif ".norm" in n or n.startswith("norm"):
-                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+    from _fullsize import perturb_affine
+    perturb_affine(mod, seed)
 
 
 @pytest.fixture(scope="module")
 def config2_pair():
     """the oracle side of the whole-network tests: forward (fp32 and the reference's own CPU bf16 autocast) and ONE backward
-    pass of sum(y * g) — input gradient and the gradient of every parameter (about a minute on the GPU box's host)"""
+    pass of sum(y * g) in each precision — input gradient and the gradient of every parameter (tests/_fullsize.py: about
+    three minutes on the GPU box's host the first time a test session asks, then a memory-mapped file)"""
     import makani_amd as ma
-    from oracle import sfno as osf
     _threads()
-    torch.manual_seed(333)
-    omod = osf.SphericalFourierNeuralOperatorNet(**CONFIG2)
-    _perturb_affine(omod, 7)
-    x = torch.rand(1, 73, 721, 1440)                    # DummyLoader-shaped U[0, 1) input (data_loader_dummy.py:264-277)
-    g = torch.randn(1, 73, 721, 1440, generator=torch.Generator().manual_seed(99))
-    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):       # the reference's own op-by-op bf16 autocast, on the CPU
-        yo_bf16 = omod(x).float()
-    xo = x.clone().requires_grad_(True)
-    yo = omod(xo)
-    (yo * g).sum().backward()
-    ref = dict(gx=xo.grad.detach(), grads={n: p.grad.detach() for n, p in omod.named_parameters()})
-    yo = yo.detach()
-    # ... and the reference's own bf16 arithmetic through the BACKWARD pass (op-by-op CPU bf16 autocast): the yardstick of the
-    # bf16 gradient gate, as yo_bf16 is of the forward gate
-    omod.zero_grad(set_to_none=True)
-    xb = x.clone().requires_grad_(True)
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        yb = omod(xb)
-    (yb.float() * g).sum().backward()
-    ref["bf16"] = dict(gx=xb.grad.detach(), grads={n: p.grad.detach() for n, p in omod.named_parameters()})
-    del yb, xb
+    d = config2_oracle()
+    ref = dict(gx=d["gx"], grads=d["grads"], bf16=dict(gx=d["bf16_gx"], grads=d["bf16_grads"]))
     model = ma.SphericalFourierNeuralOperatorNet(**CONFIG2)
-    model.load_state_dict(omod.state_dict(), strict=True)
-    del omod, xo
-    return model.to(DEV).eval(), x, yo, yo_bf16, g, ref
+    model.load_state_dict(d["state"], strict=True)
+    return model.to(DEV).eval(), d["x"], d["y"], d["y_bf16"], d["g"], ref
 
 
 def test_sfno_config2_forward_721x1440_matches_oracle(config2_pair):

@@ -306,6 +306,17 @@ def simulate2(v: Variant2, T: int):
             requested.add(c)
         for t in range(PER * T + OFF if T else 0):
             gph, gts = t % PER, t // PER
+            lt = t - grp * OFF
+            if v.EPI and 0 <= lt < PER * T and lt % PER == 4:
+                # (0) IN FRONT of the tick's barrier: the epilogue-operand images of this group's tile.  vmcnt retires this wave's
+                # own pieces only, and read-back round 0 (right behind the barrier) reads rows requested by sibling waves: every
+                # wave waits here, the barrier then makes the landing group-wide (the wait used to sit behind the barrier)
+                lts = lt // PER
+                need = len(ops) - 1 - last(("E", lts))
+                w = v.epi_wait(grp, lts, T)
+                assert w <= need, f"{v.name}: group {grp} operand wait of tile {lts} of {T}: vmcnt({w}), {need} instructions follow"
+                retired = max(retired, len(ops) - w)
+                assert last(("E", lts)) < retired
             if gph < NCH and gts < T:                      # (1) every wave: the chunk group 0 multiplies in this tick
                 c = NCH * gts + gph
                 assert c in requested, f"{v.name}: chunk {c} waited for before it was requested (T={T})"
@@ -316,7 +327,7 @@ def simulate2(v: Variant2, T: int):
                 assert last(("X", c)) < retired
                 if 2 <= gts < T - 2:
                     steady = max(steady, need - w)
-            lt = t - grp * OFF                              # (2) this group's phase
+            # (2) this group's phase
             if 0 <= lt < PER * T:
                 lts, lph = lt // PER, lt % PER
                 if lph < NCH:
@@ -324,12 +335,6 @@ def simulate2(v: Variant2, T: int):
                     assert c in requested and PER * lts + lph <= t
                 if lph == 0 and v.EPI:
                     issue(("E", lts), v.EPIECES)
-                if lph == 4 and v.EPI:
-                    need = len(ops) - 1 - last(("E", lts))
-                    w = v.epi_wait(grp, lts, T)
-                    assert w <= need, f"{v.name}: group {grp} operand wait of tile {lts} of {T}: vmcnt({w}), {need} instructions follow"
-                    retired = max(retired, len(ops) - w)
-                    assert last(("E", lts)) < retired
                 if lph >= 4:
                     issue(("S", lts, lph), v.NS3)
             if gph > OFF:                                  # (3) END of the tick: the slot group 1 read in the previous tick
