@@ -1,14 +1,6 @@
-# round-5 call 1: full-size distributed tests (configs 3 / 5 on N ranks sharing the GPU) + shard-shape tables (shadow ranks)
-mkdir -p gpurun_out/r05a
-export MAKANI_AMD_DIST_LOG=$PWD/gpurun_out/r05a/dist_fullsize.txt
-date +%T > gpurun_out/r05a/times.txt
-( timeout 1300 python -m pytest tests/test_gpu_dist_fullsize.py -x -q -s --durations=10 > gpurun_out/r05a/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r05a/times.txt; date +%T >> gpurun_out/r05a/times.txt ) &
-PT=$!
-for cfg in "1 1" "4 2" "4 1" "2 1"; do
-  set -- $cfg
-  timeout 300 python tools/shadow_rank.py --h $1 --w $2 --steps 3 --json gpurun_out/r05a/shadow_h$1w$2.json > gpurun_out/r05a/shadow_h$1w$2.log 2>&1
-  echo "shadow h$1w$2 rc $? $(date +%T)" >> gpurun_out/r05a/times.txt
+# round-5 call 6: which operation class, run by OTHER processes, makes the norm kernels of process 0 irreproducible
+mkdir -p gpurun_out/r05f
+for hog in conv1x1_nn conv1x1_wgrad rfft irfft legendre dhconv chan_gemm_f32 chan_wgrad_f32 bias_gelu; do
+  RACE_HUNT_TAG=$hog RACE_HUNT_HOG_FILTER=$hog timeout 200 python tools/race_hunt.py --procs 4 --reps 120 --only instnorm > gpurun_out/r05f/hog_$hog.log 2>&1
+  echo "== hog $hog rc $?"; grep "RACE\|done\|hog '" gpurun_out/r05f/hog_$hog.log | sort | cut -c1-220
 done
-wait $PT
-tail -5 gpurun_out/r05a/pytest.log
-cat gpurun_out/r05a/times.txt

@@ -87,8 +87,11 @@ int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream);
  *   bf16 limb planes — the Legendre matrices of th.RealSHT / th.InverseRealSHT [un-vendored; precomputed in
  *   makani_amd/legendre.py].  g->A is ignored; plane q of batch b holds A[b][k][row] at
  *   a_planes + q*pl_stride + b*pl_batch + k*pl_k + row (bf16 elements; row contiguous, pl_k % 8 == 0, rows beyond M
- *   inside pl_k are zero).  B must be [k][col] with the column index contiguous (b_col == 1), inner == 1.
- *   band_lo / band_hi (device int[batch], optional): outside [lo[b], hi[b]) every entry of A[b] is numerically zero by the
+ *   inside pl_k are zero).  B must be [k][col] with the column index contiguous (b_col == 1).  With inner > 1 the constant
+ *   matrix, its band and the triangle belong to the OUTER index bo = b / inner (planes at + bo*pl_batch, band_lo[bo]); the
+ *   inner index only moves B and C (b_inner / c_inner): several column blocks that live in separate buffers (the plane blocks
+ *   of the h x w distributed transform, makani_amd/dist_pipeline.py) then share ONE launch and one pass over the matrix.
+ *   band_lo / band_hi (device int[batch / inner], optional): outside [lo[b], hi[b]) every entry of A[b] is numerically zero by the
  *   caller's threshold (the Legendre functions of order m vanish towards the poles like sin^m theta).  band_mode 1: a range
  *   of k (analysis: the latitude sum is clipped); 2: a range of rows (synthesis: output latitudes outside the band are
  *   written as exact zeros); 0: no band.  Neither A nor B is read outside the band. */
@@ -177,6 +180,12 @@ int mk_plane_sums(const void* x, int dtype, float* sums, float* ws, long long pl
  * with count = quad_sum — what DistributedGeometricInstanceNormS2 merges (makani/mpu/layer_norm.py:207-222). */
 int mk_instnorm_stats(const void* x, int dtype, float* stats, float* ws, long long planes, long long hw, float eps,
                       const float* quad, float quad_sum, void* stream);
+/* merged statistics of planes sharded over `nranks` ranks: all_stats (nranks, planes, 2) = every rank's local {mean, rstd}
+ * (the all-gathered outputs of mk_instnorm_stats), counts (nranks) = every rank's pixel count (or sum of quadrature weights);
+ * stats (planes, 2) = {mean, rstd} of the whole plane — the pairwise moment merge of DistributedInstanceNorm2d
+ * (makani/mpu/layer_norm.py:31-81,140-152), fp64 inside, no host round trip. */
+int mk_instnorm_merge(const float* all_stats, const float* counts, float* stats, long long planes, int nranks, float eps,
+                      void* stream);
 int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma, const float* beta,
                       long long planes, int channels, long long hw, int fuse_gelu, void* stream);
 /* stats + apply in two launches (the apply kernel finishes the statistics reduction itself and writes `stats` for the

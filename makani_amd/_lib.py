@@ -73,6 +73,7 @@ _SIGS = {
     "mk_pointwise_chunks": ([c_ll, c_int, c_ll], c_int),
     "mk_plane_sums": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_vp], c_int),
     "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp, c_f, c_vp], c_int),
+    "mk_instnorm_merge": ([c_vp, c_vp, c_vp, c_ll, c_int, c_f, c_vp], c_int),
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
     "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_int, c_ll, c_ll, c_int, c_int, c_vp], c_int),
     "mk_chan_layernorm_chunks": ([c_int, c_ll], c_int),

@@ -682,6 +682,37 @@ static int instnorm_apply_impl(const void* x, void* y, int dtype, float* stats, 
                                const float* ws, float eps, long long planes, int channels, long long hw, int fuse_gelu,
                                const float* pre_bias, float qsum, hipStream_t s);
 
+// merged (mean, rstd) of planes sharded over P ranks from the ranks' local (mean, rstd) and pixel counts: the pairwise update
+// of makani/mpu/layer_norm.py:31-81 (Chan et al.) carried in fp64, one thread per plane
+__global__ void in_merge_stats(const float* __restrict__ all, const float* __restrict__ counts, float* __restrict__ out,
+                               long long planes, int P, float eps) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= planes) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int r = 0; r < P; ++r) {
+        const double c = (double)counts[r];
+        if (!(c > 0.0)) continue;
+        const double mu = (double)all[((long long)r * planes + p) * 2];
+        const double rs = (double)all[((long long)r * planes + p) * 2 + 1];
+        double var = 1.0 / (rs * rs) - (double)eps;
+        if (var < 0.0) var = 0.0;
+        const double nn = n + c, delta = mu - mean;
+        mean += delta * (c / nn);
+        m2 += var * c + delta * delta * (n * c / nn);
+        n = nn;
+    }
+    out[2 * p] = (float)mean;
+    out[2 * p + 1] = (float)(1.0 / sqrt((n > 0.0 ? m2 / n : 0.0) + (double)eps));
+}
+
+extern "C" int mk_instnorm_merge(const float* all_stats, const float* counts, float* stats, long long planes, int nranks,
+                                 float eps, void* stream) {
+    MK_REQUIRE(all_stats && counts && stats && planes > 0 && nranks > 0, "instnorm_merge: bad args");
+    hipLaunchKernelGGL(in_merge_stats, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, all_stats, counts,
+                       stats, planes, nranks, eps);
+    return mk_check_launch("mk_instnorm_merge");
+}
+
 extern "C" int mk_instnorm_apply(const void* x, void* y, int dtype, const float* stats, const float* gamma,
                                  const float* beta, long long planes, int channels, long long hw, int fuse_gelu,
                                  void* stream) {

@@ -653,7 +653,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     const int l31 = lane & 31, lh = lane >> 5;
     const long long bo = c.b / p.inner, bi = c.b % p.inner;
     const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
-    const u16* Ab = a.planes + (long long)c.b * a.pl_batch;
+    const u16* Ab = a.planes + bo * a.pl_batch;        // the constant matrix (and its band) belong to the OUTER batch index
 
     // rows of this block that are stored: 32-row tiles [s0, s1); rows that are computed: tiles [t0, t1) inside them
     const int rows_end = min(c.Meff, p.M) - c.i0;          // rows of this block that exist
@@ -662,12 +662,12 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
     const int s1 = min(BM / 32, (rows_end + 31) / 32);
     int t0 = s0, t1 = s1;
     if (a.band_mode == 1) {
-        c.klo = max(c.klo, a.band_lo[c.b]);
-        c.khi = min(c.khi, a.band_hi[c.b]);
+        c.klo = max(c.klo, a.band_lo[bo]);
+        c.khi = min(c.khi, a.band_hi[bo]);
         if (c.khi < c.klo) c.khi = c.klo;
     } else if (a.band_mode == 2) {
-        t0 = max(s0, (a.band_lo[c.b] - c.i0) >> 5);                    // floor (arithmetic shift of a possibly negative value)
-        t1 = min(s1, (a.band_hi[c.b] - c.i0 + 31) >> 5);
+        t0 = max(s0, (a.band_lo[bo] - c.i0) >> 5);                     // floor (arithmetic shift of a possibly negative value)
+        t1 = min(s1, (a.band_hi[bo] - c.i0 + 31) >> 5);
         if (t1 < t0) t1 = t0;
     }
     int tile[4];
@@ -918,7 +918,7 @@ extern "C" int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, 
     MK_REQUIRE(g && a_planes && g->B && g->C, "presplit gemm: null pointer");
     MK_REQUIRE(g->M > 0 && g->N > 0 && g->K >= 0 && g->batch > 0, "presplit gemm: bad extents");
     MK_REQUIRE(limbs == 2 || limbs == 3, "presplit gemm: limbs must be 2 or 3");
-    MK_REQUIRE(g->inner == 1, "presplit gemm: inner must be 1");
+    MK_REQUIRE(g->inner >= 1 && g->batch % g->inner == 0 && (g->b_inner & 3) == 0, "presplit gemm: inner must divide batch, b_inner % 4 == 0");
     MK_REQUIRE(g->b_col == 1 && (g->b_k & 3) == 0 && g->b_k >= ((g->N + 3) & ~3), "presplit gemm: B must be [k][col], col contiguous");
     MK_REQUIRE((g->b_batch & 3) == 0 && ((uintptr_t)g->B & 15) == 0, "presplit gemm: B alignment");
     MK_REQUIRE(g->c_col == 1, "presplit gemm: c_col must be 1");

@@ -85,6 +85,9 @@ class Plan:
                 base[j][i] = off
                 off += self.slab[j][i]
         self.base, self.f_total = base, off
+        # every azimuth rank's plane block splits alike over the polar group (always, unless the plane count is ragged over w):
+        # the w plane blocks of the Legendre phase then run as ONE batched GEMM and leave / arrive in ONE polar exchange
+        self.uniform = all(sj == self.sub[0] for sj in self.sub) and os.environ.get("MAKANI_AMD_DIST_BLOCKS", "1") == "1"
 
         # latitude chunks of steps (2)+(3): the same count on every rank (each collective is entered by all of them) — the
         # count depends on an environment variable, so the ranks of the transform's groups compare it once per plan: ranks
@@ -239,7 +242,12 @@ def analysis_shaped(x, p: Plan, matT, wts, m_off):
         xbuf = x.reshape(1, Pw, p.hl, p.wl)
     # (2) + (3) in latitude chunks: transform chunk c + 1 while chunk c travels
     fs = torch.empty((p.f_total,), dtype=fdt, device=dev)
-    G = [torch.empty((p.nlat, p.Ml, 2, p.sub[j][ih]), dtype=fdt, device=dev) for j in range(w)]
+    blocks = p.uniform and hasattr(be, "analysis_lm_blocks")          # (the same decision on every rank: it shapes the exchanges)
+    if blocks:        # one buffer for the w plane blocks: the Legendre phase is ONE launch over all of them
+        Gall = torch.empty((w, p.nlat, p.Ml, 2, p.sub[0][ih]), dtype=fdt, device=dev)
+        G = [Gall[j] for j in range(w)]
+    else:
+        G = [torch.empty((p.nlat, p.Ml, 2, p.sub[j][ih]), dtype=fdt, device=dev) for j in range(w)]
     lat_off = _offsets(p.lat)
     mine = p.chunks(p.hl)
     theirs = [p.chunks(n) for n in p.lat]
@@ -257,8 +265,23 @@ def analysis_shaped(x, p: Plan, matT, wts, m_off):
         works.append(_exchange_async(recv, send, group))
     for wk in works:
         wk.wait()
-    # (4) + (5) per plane block: Legendre of block j + 1 while the l <-> planes exchange of block j travels
     l_off = _offsets(p.l_shapes)
+    pad = (-p.P) % 4
+    if blocks:
+        # (4) + (5), all plane blocks at once: one GEMM (L, w, M_loc, 2, sub) — degree outermost —, one polar exchange whose
+        # l slabs are contiguous views over all blocks; the arriving [l][j][m][2][sub] pieces are joined into the
+        # channel-contiguous S layout (the one copy on this side)
+        Sall = be.analysis_lm_blocks(Gall, matT, p.L, m_off) if p.sub[0][ih] > 0 else torch.empty((p.L, w, p.Ml, 2, 0), dtype=fdt, device=dev)
+        if h > 1:
+            rec = [torch.empty((p.Ll, w, p.Ml, 2, p.sub[0][i]), dtype=fdt, device=dev) for i in range(h)]
+            _exchange_async(rec, [Sall[l_off[i]:l_off[i + 1]] for i in range(h)], thd.polar_group()).wait()
+        else:
+            rec = [Sall]
+        parts = [rec[i][:, j, :, :, :p.valid[j][i]] for j in range(w) for i in range(h) if p.valid[j][i] > 0]
+        if pad:
+            parts.append(torch.zeros((p.Ll, p.Ml, 2, pad), dtype=fdt, device=dev))
+        return torch.cat(parts, dim=3) if len(parts) > 1 else parts[0].contiguous()
+    # (4) + (5) per plane block: Legendre of block j + 1 while the l <-> planes exchange of block j travels
     pieces, works = [], []
     for j in range(w):
         if p.sub[j][ih] == 0:
@@ -274,7 +297,6 @@ def analysis_shaped(x, p: Plan, matT, wts, m_off):
     for wk in works:
         wk.wait()
     parts = [pieces[j][i][..., :p.valid[j][i]] for j in range(w) for i in range(h) if p.valid[j][i] > 0]
-    pad = (-p.P) % 4
     if pad:
         parts.append(torch.zeros((p.Ll, p.Ml, 2, pad), dtype=fdt, device=dev))
     return torch.cat(parts, dim=3) if len(parts) > 1 else parts[0].contiguous()
@@ -293,28 +315,53 @@ def synthesis_shaped(S, p: Plan, mat, wts, m_off, out_dtype):
     mine = p.chunks(p.hl)
     theirs = [p.chunks(n) for n in p.lat]
     fr = torch.empty((p.f_total,), dtype=fdt, device=dev)
-    # (5') planes <-> l per plane block (the one pack on this side), (4') Legendre synthesis into latitude-major F
-    Ts, works = [], []
-    for j in range(w):
-        Tj = torch.empty((p.L, p.Ml, 2, p.sub[j][ih]), dtype=fdt, device=dev)
+    blocks = p.uniform and hasattr(be, "synthesis_lm_blocks")
+    if blocks:
+        # (5') + (4'), all plane blocks at once: the plane sub-blocks are packed out of the S layout into per-peer pieces
+        # [l][j][m][2][sub] (the one pack on this side), ONE polar exchange delivers them as l slabs of T (L, w, M_loc, 2, sub),
+        # ONE GEMM writes the latitude-major F of every block
         send = []
         for i in range(h):
-            r0 = p.poff[j] + p.suboff[j][i]
-            blk = S[..., r0:r0 + p.valid[j][i]]
-            if p.valid[j][i] != p.sub[j][i]:
-                blk = torch.nn.functional.pad(blk, (0, p.sub[j][i] - p.valid[j][i]))
-            send.append(blk.contiguous())
+            sb = p.sub[0][i]
+            buf = torch.empty((p.Ll, w, p.Ml, 2, sb), dtype=fdt, device=dev)
+            for j in range(w):
+                r0, v = p.poff[j] + p.suboff[j][i], p.valid[j][i]
+                if v > 0:
+                    buf[:, j, :, :, :v].copy_(S[..., r0:r0 + v])
+                if v < sb:
+                    buf[:, j, :, :, v:].zero_()
+            send.append(buf)
         if h > 1:
-            works.append(_exchange_async([Tj[l_off[i]:l_off[i + 1]] for i in range(h)], send, thd.polar_group()))
+            Tall = torch.empty((p.L, w, p.Ml, 2, p.sub[0][ih]), dtype=fdt, device=dev)
+            _exchange_async([Tall[l_off[i]:l_off[i + 1]] for i in range(h)], send, thd.polar_group()).wait()
         else:
-            Tj = send[0]
-        Ts.append(Tj)
-    G = []
-    for j in range(w):
-        if h > 1:
-            works[j].wait()
-        G.append(be.synthesis_lm(Ts[j], mat, p.nlat, m_off) if p.sub[j][ih] > 0
-                 else torch.empty((p.nlat, p.Ml, 2, 0), dtype=fdt, device=dev))
+            Tall = send[0]
+        Gall = be.synthesis_lm_blocks(Tall, mat, p.nlat, m_off) if p.sub[0][ih] > 0 \
+            else torch.empty((w, p.nlat, p.Ml, 2, 0), dtype=fdt, device=dev)        # (w, nlat, M_loc, 2, sub)
+        G = [Gall[j] for j in range(w)]
+    else:
+        # (5') planes <-> l per plane block (the one pack on this side), (4') Legendre synthesis into latitude-major F
+        Ts, works = [], []
+        for j in range(w):
+            Tj = torch.empty((p.L, p.Ml, 2, p.sub[j][ih]), dtype=fdt, device=dev)
+            send = []
+            for i in range(h):
+                r0 = p.poff[j] + p.suboff[j][i]
+                blk = S[..., r0:r0 + p.valid[j][i]]
+                if p.valid[j][i] != p.sub[j][i]:
+                    blk = torch.nn.functional.pad(blk, (0, p.sub[j][i] - p.valid[j][i]))
+                send.append(blk.contiguous())
+            if h > 1:
+                works.append(_exchange_async([Tj[l_off[i]:l_off[i + 1]] for i in range(h)], send, thd.polar_group()))
+            else:
+                Tj = send[0]
+            Ts.append(Tj)
+        G = []
+        for j in range(w):
+            if h > 1:
+                works[j].wait()
+            G.append(be.synthesis_lm(Ts[j], mat, p.nlat, m_off) if p.sub[j][ih] > 0
+                     else torch.empty((p.nlat, p.Ml, 2, 0), dtype=fdt, device=dev))
     # (3') + (2') in latitude chunks of the DESTINATION: inverse FFT of chunk c while chunk c + 1 travels
     xbuf = torch.empty((w, Pw, p.hl, p.wl), dtype=out_dtype, device=dev)
     works = []

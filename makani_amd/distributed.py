@@ -315,6 +315,16 @@ class HipBackend:
         return ops.legendre_synthesis(T, mat, nlat, m_off, lat_major=True)
 
     @staticmethod
+    def analysis_lm_blocks(G, matT, L, m_off):
+        """G (w, nlat, M_loc, 2, sub): all plane blocks of the Legendre phase in ONE launch -> (L, w, M_loc, 2, sub)"""
+        return ops.legendre_analysis(G, matT, L, m_off, lat_major=True, blocks=True)
+
+    @staticmethod
+    def synthesis_lm_blocks(T, mat, nlat, m_off):
+        """T (L, w, M_loc, 2, sub) -> (w, nlat, M_loc, 2, sub)"""
+        return ops.legendre_synthesis(T, mat, nlat, m_off, lat_major=True, blocks=True)
+
+    @staticmethod
     def rfft(x4, mmax, w):
         return ops.RfftFn.apply(x4, mmax, ops.round4(x4.shape[1]), w)
 

@@ -337,49 +337,68 @@ def _presplit_ok() -> bool:
     return GEMM_GEN == "2" and GEMM_MODE != "fp32"
 
 
-def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 0, lat_major: bool = False) -> torch.Tensor:
+def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 0, lat_major: bool = False,
+                      blocks: bool = False) -> torch.Tensor:
     """S[l][m][ri][row] = sum_k matT[m][k][l] F[m][k][ri][row]      (rows l >= m only).
     ``lat_major``: F is (nlat, M, 2, R) — latitude outermost, the layout in which the slabs the ranks of a polar group send
-    concatenate by landing next to each other (makani_amd/dist_pipeline.py); only the operand strides change."""
-    if lat_major:
+    concatenate by landing next to each other (makani_amd/dist_pipeline.py); only the operand strides change.
+    ``blocks`` (with ``lat_major``): F is (nb, nlat, M, 2, R) — nb column blocks in separate buffers (the plane blocks of the
+    h x w distributed transform) — transformed by ONE launch (the block index is the GEMM's inner batch index: same matrix,
+    band and triangle per order m) into S (L, nb, M, 2, R), degree outermost: the l-slabs the polar exchange sends are
+    contiguous over all blocks."""
+    if blocks:
+        assert lat_major
+        nb, nlat, M, _, R = F.shape
+    elif lat_major:
         nlat, M, _, R = F.shape
+        nb = 1
     else:
         M, nlat, _, R = F.shape
+        nb = 1
     Mm, nk, Lp = matT.shape
     assert Mm == M and nk == nlat and Lp >= L and F.is_contiguous() and matT.is_contiguous()
-    S = torch.empty((L, M, 2, R), dtype=torch.float32, device=F.device)
+    S = torch.empty((L, nb, M, 2, R) if blocks else (L, M, 2, R), dtype=torch.float32, device=F.device)
     g = _gemm(A=matT.data_ptr(), B=F.data_ptr(), C=S.data_ptr(),
               a_batch=nlat * Lp, a_row=1, a_k=Lp,
-              b_batch=2 * R if lat_major else nlat * 2 * R, b_col=1, b_k=M * 2 * R if lat_major else 2 * R,
-              c_batch=2 * R, c_row=M * 2 * R,
-              M=L, N=2 * R, K=nlat, batch=M, tri_mode=_lib.TRI_ROW_GE, tri_off=m_off)
+              b_batch=2 * R if lat_major else nlat * 2 * R, b_inner=nlat * M * 2 * R, b_col=1, b_k=M * 2 * R if lat_major else 2 * R,
+              c_batch=2 * R, c_inner=M * 2 * R, c_row=nb * M * 2 * R,
+              M=L, N=2 * R, K=nlat, batch=M * nb, inner=nb, tri_mode=_lib.TRI_ROW_GE, tri_off=m_off)
     # dense-formulation work (SURVEY.md §8d): 2 * (2R) * nlat * L * M flops
     pre = _presplit_ok()
     b = polar_band(matT, 1) if pre else None                     # matT = (m, latitude, l): the band clips the k-loop
-    with _timed(f"legendre_analysis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
-                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat),
-                mfma_flops=lambda: 2.0 * _limb_products() * _up(2 * R, 32) * _exec_band(L, M, m_off, nlat, b, 16, rows_tri=True)):
+    with _timed(f"legendre_analysis_k{nlat}", flops=2.0 * nb * 2 * R * nlat * L * M,
+                nbytes=4.0 * (nb * 2 * R * nlat * M + nb * 2 * R * L * M + M * L * nlat),
+                mfma_flops=lambda: 2.0 * nb * _limb_products() * _up(2 * R, 32) * _exec_band(L, M, m_off, nlat, b, 16, rows_tri=True)):
         _run_gemm(g, False, "legendre_analysis", a_limbs=limb_planes(matT) if pre else None,
                   band=(b[0], b[1], 1) if b is not None else None)
     return S
 
 
-def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int = 0, lat_major: bool = False) -> torch.Tensor:
-    """F[m][k][ri][row] = sum_{l >= m} mat[m][l][k] S[l][m][ri][row].  ``lat_major``: F is written as (nlat, M, 2, R)."""
-    L, M, _, R = S.shape
+def legendre_synthesis(S: torch.Tensor, mat: torch.Tensor, nlat: int, m_off: int = 0, lat_major: bool = False,
+                       blocks: bool = False) -> torch.Tensor:
+    """F[m][k][ri][row] = sum_{l >= m} mat[m][l][k] S[l][m][ri][row].  ``lat_major``: F is written as (nlat, M, 2, R).
+    ``blocks`` (with ``lat_major``): S is (L, nb, M, 2, R), F is written as (nb, nlat, M, 2, R) by one launch (see
+    ``legendre_analysis``)."""
+    if blocks:
+        assert lat_major
+        L, nb, M, _, R = S.shape
+    else:
+        L, M, _, R = S.shape
+        nb = 1
     Mm, Lm, kp = mat.shape
     assert Mm == M and Lm == L and kp >= nlat and S.is_contiguous() and mat.is_contiguous()
-    F = torch.empty((nlat, M, 2, R) if lat_major else (M, nlat, 2, R), dtype=torch.float32, device=S.device)
+    F = torch.empty((nb, nlat, M, 2, R) if blocks else ((nlat, M, 2, R) if lat_major else (M, nlat, 2, R)),
+                    dtype=torch.float32, device=S.device)
     g = _gemm(A=mat.data_ptr(), B=S.data_ptr(), C=F.data_ptr(),
               a_batch=L * kp, a_row=1, a_k=kp,
-              b_batch=2 * R, b_col=1, b_k=M * 2 * R,
-              c_batch=2 * R if lat_major else nlat * 2 * R, c_row=M * 2 * R if lat_major else 2 * R,
-              M=nlat, N=2 * R, K=L, batch=M, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
+              b_batch=2 * R, b_inner=M * 2 * R, b_col=1, b_k=nb * M * 2 * R,
+              c_batch=2 * R if lat_major else nlat * 2 * R, c_inner=nlat * M * 2 * R, c_row=M * 2 * R if lat_major else 2 * R,
+              M=nlat, N=2 * R, K=L, batch=M * nb, inner=nb, tri_mode=_lib.TRI_K_GE, tri_off=m_off)
     pre = _presplit_ok()
     b = polar_band(mat, 2) if pre else None                      # mat = (m, l, latitude): the band clips the output rows
-    with _timed(f"legendre_synthesis_k{nlat}", flops=2.0 * 2 * R * nlat * L * M,
-                nbytes=4.0 * (2 * R * nlat * M + 2 * R * L * M + M * L * nlat),
-                mfma_flops=lambda: 2.0 * _limb_products() * _up(2 * R, 32) * _exec_band(L, M, m_off, nlat, b, 32, rows_tri=False)):
+    with _timed(f"legendre_synthesis_k{nlat}", flops=2.0 * nb * 2 * R * nlat * L * M,
+                nbytes=4.0 * (nb * 2 * R * nlat * M + nb * 2 * R * L * M + M * L * nlat),
+                mfma_flops=lambda: 2.0 * nb * _limb_products() * _up(2 * R, 32) * _exec_band(L, M, m_off, nlat, b, 32, rows_tri=False)):
         _run_gemm(g, False, "legendre_synthesis", a_limbs=limb_planes(mat) if pre else None,
                   band=(b[0], b[1], 2) if b is not None else None)
     return F
@@ -1279,13 +1298,30 @@ def _all_reduce_sum(t, group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
+_SHARD_COUNTS = {}      # (group, local count) -> (counts of all ranks as a device vector, their sum as a Python float)
+
+
+def _shard_counts(group, count: float, device):
+    """pixel counts (or quadrature-weight sums) of a plane's shards on the ranks of ``group``: constants of the grid split, so
+    they are gathered ONCE per (group, local count) — the only host read of the distributed norm, at the first call; the step
+    itself then contains no device -> host synchronisation (what a hipGraph capture of the h x w step requires)"""
+    key = (id(group), float(count), str(device))
+    hit = _SHARD_COUNTS.get(key)
+    if hit is None:
+        mine = torch.tensor([float(count)], dtype=torch.float32, device=device)
+        allc = _all_gather_stack(mine, group).reshape(-1).contiguous()
+        hit = _SHARD_COUNTS[key] = (allc, float(allc.double().sum()))
+    return hit
+
+
 class DistInstanceNormFn(torch.autograd.Function):
     """Instance norm over a plane that is sharded across the ``spatial`` process group
     (``DistributedInstanceNorm2d``, makani/mpu/layer_norm.py:108-170): local fp32 statistics (HIP) ->
-    all-gather of (mean, var, count) -> merge -> normalise (+GELU) with the merged statistics (HIP).
-    Backward all-reduces the two per-plane sums between the HIP reduce and apply phases.
+    all-gather of the ranks' (mean, rstd) -> merge with the ranks' counts (HIP, ``mk_instnorm_merge``) -> normalise (+GELU)
+    with the merged statistics (HIP).  Backward all-reduces the two per-plane sums between the HIP reduce and apply phases.
     With ``quad`` (this shard's quadrature weights, ``quad_sum`` their sum) the moments are area-weighted and the counts are
-    the weight sums: ``DistributedGeometricInstanceNormS2`` (makani/mpu/layer_norm.py:173-253)."""
+    the weight sums: ``DistributedGeometricInstanceNormS2`` (makani/mpu/layer_norm.py:173-253).
+    No host synchronisation after the first call (the shard counts are cached), no torch arithmetic between the kernels."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, fuse_gelu, group, quad=None, quad_sum=0.0):
@@ -1297,24 +1333,23 @@ class DistInstanceNormFn(torch.autograd.Function):
         stats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
         check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, ptr(quad), float(quad_sum), stream()), "instnorm_stats")
-        count = float(quad_sum) if quad is not None else float(hw)
-        local = torch.stack([stats[:, 0], 1.0 / stats[:, 1] ** 2 - eps, torch.full_like(stats[:, 0], count)], dim=0)
-        allm = _all_gather_stack(local.contiguous(), group)      # (P, 3, planes)
-        mean, var, n = merge_moments(allm[:, 0], allm[:, 1].clamp_min(0.0), allm[:, 2])
-        mstats = torch.stack([mean, torch.rsqrt(var + eps)], dim=1).contiguous()
+        counts, total = _shard_counts(group, float(quad_sum) if quad is not None else float(hw), x.device)
+        allst = _all_gather_stack(stats, group)                  # (P, planes, 2): every rank's local {mean, rstd}
+        mstats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        check(lib().mk_instnorm_merge(ptr(allst), ptr(counts), ptr(mstats), planes, allst.shape[0], eps, stream()), "instnorm_merge")
         g = gamma.float().contiguous() if gamma is not None else None
         b = beta.float().contiguous() if beta is not None else None
         y = torch.empty_like(x)
         check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(mstats), ptr(g), ptr(b), planes, Cc, hw,
                                       1 if fuse_gelu else 0, stream()), "instnorm_apply")
-        ctx.save_for_backward(x, mstats, g, b, quad, n)
-        ctx.meta = (fuse_gelu, group, dist.get_world_size(group) * hw if quad is None else None)
+        ctx.save_for_backward(x, mstats, g, b, quad)
+        ctx.meta = (fuse_gelu, group, total)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, mstats, g, b, quad, n = ctx.saved_tensors
-        fuse_gelu, group, hw_total = ctx.meta
+        x, mstats, g, b, quad = ctx.saved_tensors
+        fuse_gelu, group, total = ctx.meta
         B, Cc, H, W = x.shape
         planes, hw = B * Cc, H * W
         gy = gy.contiguous()
@@ -1324,11 +1359,9 @@ class DistInstanceNormFn(torch.autograd.Function):
         sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
         fg = 1 if fuse_gelu else 0
-        # unweighted: every shard of a plane has hw pixels except along ragged splits; the true total is the merged count
-        if quad is None:
-            hw_tot = int(round(float(n[0])))          # counts are exact small integers in fp32; one host read per backward
-        else:
-            hw_tot = hw
+        # unweighted: every shard of a plane has hw pixels except along ragged splits; the true total is the sum of the ranks'
+        # counts (exact small integers in fp32, summed in fp64 on the host once: _shard_counts)
+        hw_tot = int(round(total)) if quad is None else hw
         check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
                                     ptr(ws), planes, Cc, hw, hw_tot, 1, fg, stream()), "instnorm_bwd(reduce)")
         local = _batch_sum(sums, B, Cc).clone()                   # this rank's share of dgamma / dbeta
@@ -1336,7 +1369,7 @@ class DistInstanceNormFn(torch.autograd.Function):
         if quad is not None:
             # normalised weights p_i = q_i / Q (Q = merged count): gx = k (ga - p_i (S1 + n_i S2)); the kernel multiplies the
             # sums by q_i per element, so they are divided by Q here and the kernel's crop term is switched off (sum = 1)
-            sums = (sums / n.unsqueeze(0)).contiguous()
+            sums = (sums / total).contiguous()
         check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(quad),
                                     1.0 if quad is not None else 0.0, ptr(sums), ptr(ws), planes, Cc, hw, hw_tot, 2, fg, stream()),
               "instnorm_bwd(apply)")

@@ -116,6 +116,15 @@ class OracleSegBackend(OracleBackend):
     def synthesis_lm(T, mat, nlat, m_off):
         return torch.einsum("lmir,mlk->kmir", T, mat[:, :, :nlat].to(T.dtype)).contiguous()
 
+    @staticmethod
+    def analysis_lm_blocks(G, matT, L, m_off):
+        """(w, nlat, M_loc, 2, sub) -> (L, w, M_loc, 2, sub): all plane blocks in one call (HipBackend: one batched GEMM)"""
+        return torch.einsum("mkl,jkmir->ljmir", matT[:, :, :L].to(G.dtype), G).contiguous()
+
+    @staticmethod
+    def synthesis_lm_blocks(T, mat, nlat, m_off):
+        return torch.einsum("ljmir,mlk->jkmir", T, mat[:, :, :nlat].to(T.dtype)).contiguous()
+
 
 def _s_planes(B, C):
     """S layout: plane b * Cp + c with Cp = round4(C) when B > 1 (every sample's channels padded), round4(C) planes for B == 1"""
