@@ -640,9 +640,17 @@ def run_worker(args):
 
     # ---- hipGraph: the whole step (forward, backward, clip, AdamW: ~380 dependent launches) captured once, replayed
     # per step.  Nothing in the step depends on host state (the optimizer's step counter lives in device memory,
-    # inputs are static tensors), so a replay IS the step.  One GPU only: with more ranks the collectives stay eager.
+    # inputs are static tensors, the distributed norm reads its shard counts on the host only once), so a replay IS the step.
+    # N > 1 over RCCL: the collectives are captured WITH the step (RCCL's kernels are ordinary stream work; torch's process
+    # group records them on the capturing streams).  It is what makes the h x w step scale at all: eager, one rank of h4 w2
+    # launches for 34 ms per step while its kernels run for 11 (tools/shadow_rank.py, profiles/r05_shard_shapes.md).  Every
+    # rank must take the same path — a rank replaying a graph and a rank launching eagerly would still match collective by
+    # collective, but a rank whose capture failed half-way would not —, so the ranks agree on the outcome before the first
+    # replay; MAKANI_AMD_BENCH_GRAPH=off (set by the launcher's retry) forces the eager step.  gloo (N ranks on one GPU) is
+    # host-staged and cannot be captured.
     graph, graph_note = None, None
-    want_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    graph_mode = os.environ.get("MAKANI_AMD_BENCH_GRAPH", args.graph)
+    want_graph = graph_mode == "on" or (graph_mode == "auto" and (world == 1 or backend == "nccl"))
     if want_graph:
         try:
             side = torch.cuda.Stream()
@@ -653,14 +661,21 @@ def run_worker(args):
             torch.cuda.synchronize()
             opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # N > 1: "thread_local" — the process group's watchdog thread polls events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="global" if world == 1 else "thread_local"):
                 graph_loss = train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
-            torch.cuda.synchronize()
-            graph.replay()                                    # first replay outside the timed region
             torch.cuda.synchronize()
         except Exception as e:                                # capture is an optimisation: never lose the measurement to it
             graph, graph_note = None, f"graph capture failed ({type(e).__name__}: {str(e)[:200]}); eager launches"
             print(f"[bench] {graph_note}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+        if world > 1:                                         # all ranks replay, or none does
+            flag = torch.tensor([1 if graph is not None else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and graph is not None:
+                graph, graph_note = None, "another rank's graph capture failed; eager launches on every rank"
+        if graph is not None:
+            graph.replay()                                    # first replay outside the timed region
             torch.cuda.synchronize()
 
     ops.PROFILER.reset()
@@ -694,10 +709,13 @@ def run_worker(args):
         event_steps = 3
         ops.PROFILER.reset()
         ops.PROFILER.enabled = True
+        thd.COMM_STATS.clear()                  # (a replayed graph does not pass through the Python accounting of the exchanges)
         for _ in range(event_steps):
             train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
         torch.cuda.synchronize()
         ops.PROFILER.enabled = False
+        comm_stats = {f"{k[0]}_group_of_{k[1]}": dict(MB_sent=round(v["bytes_sent"] / event_steps / 1e6, 2), all_to_alls=v["all_to_alls"] / event_steps)
+                      for k, v in sorted(thd.COMM_STATS.items())}
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -821,6 +839,11 @@ def _run_phase(args, parallelism, ranks, world, port, timeout_s):
         env.setdefault("LOCAL_RANK", str(r))
         if len(ranks) > 1:
             env["LOCAL_RANK"] = str(r)
+        if os.environ.get("MAKANI_AMD_BENCH_BACKEND", "nccl") != "nccl" and world > 1 and torch.cuda.device_count() == 1:
+            # the functional mode "N ranks on ONE GPU over gloo": disjoint compute units per rank (makani_amd/comm.py: share_gpu
+            # says why); the variable must be in the worker's environment before its HIP runtime starts
+            per = max(1, 256 // world)
+            env["HSA_CU_MASK"] = f"0:{r * per}-{(r + 1) * per - 1}"
         keep_out = (r == 0)
         procs.append((r, subprocess.Popen(_worker_cmd(args, parallelism), env=env, stdout=subprocess.PIPE if keep_out else subprocess.DEVNULL,
                                           stderr=None, text=True)))
@@ -866,17 +889,22 @@ def launch(args):
         # the spatial split runs the fused exchange schedule (makani_amd/dist_pipeline.py); should that phase fail — its RCCL
         # branches with more than one rank cannot be exercised in the development environment — it is repeated once with the
         # transpose-by-transpose schedule before the data-parallel measurement is reported instead
-        attempts = [None] if par == "dp" else [None, "0"]
-        for fused in attempts:
+        # ... and before that once with eager launches instead of the captured step (hipGraph capture of RCCL collectives has
+        # only ever run with ONE rank here: tests/test_gpu_distributed.py::test_hipgraph_capture_of_the_distributed_blocks_with_rccl_world1)
+        gloo = os.environ.get("MAKANI_AMD_BENCH_BACKEND", "nccl") != "nccl"
+        eager = [] if (gloo or args.graph == "off") else [dict(MAKANI_AMD_BENCH_GRAPH="off")]
+        attempts = [dict()] + eager + ([] if par == "dp" else [dict(MAKANI_AMD_BENCH_GRAPH="off", MAKANI_AMD_DIST_FUSED="0")])
+        for env_over in attempts:
+            fused = env_over.get("MAKANI_AMD_DIST_FUSED")
             nport += 1
             port = (base_port + nport) if under_torchrun else _free_port()
-            if fused is not None:
-                os.environ["MAKANI_AMD_DIST_FUSED"] = fused
+            os.environ.update(env_over)
             res, err = _run_phase(args, par, ranks, world, port, timeout_s)
-            if fused is not None:
-                os.environ.pop("MAKANI_AMD_DIST_FUSED", None)
-                if res is not None and not err:
-                    res["note"] = "the fused exchange schedule failed; this line ran the transpose-by-transpose schedule (MAKANI_AMD_DIST_FUSED=0)"
+            for k in env_over:
+                os.environ.pop(k, None)
+            if env_over and res is not None and not err:
+                res["note"] = ("the first attempt of this phase failed; this line ran with " + ", ".join(f"{k}={v}" for k, v in env_over.items())
+                               + " (eager launches instead of the captured step" + ("; transpose-by-transpose exchange schedule)" if fused else ")"))
             results[par], errors[par] = res, err
             ok = err is None and (rank != 0 or res is not None)
             if under_torchrun:                 # every rank's copy of this script must take the same decision about a retry
@@ -886,7 +914,7 @@ def launch(args):
                 if not ok and errors[par] is None:
                     errors[par] = "another rank's worker failed"
             if rank == 0:
-                tag = par + (" (MAKANI_AMD_DIST_FUSED=0)" if fused is not None else "")
+                tag = par + (" (" + ", ".join(f"{k}={v}" for k, v in env_over.items()) + ")" if env_over else "")
                 print(f"[bench] phase {tag}: {'ok' if ok else 'FAILED: ' + str(errors[par])}", file=sys.stderr, flush=True)
             if ok:
                 break

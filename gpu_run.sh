@@ -1,6 +1,12 @@
-# round-5 call 6: which operation class, run by OTHER processes, makes the norm kernels of process 0 irreproducible
-mkdir -p gpurun_out/r05f
-for hog in conv1x1_nn conv1x1_wgrad rfft irfft legendre dhconv chan_gemm_f32 chan_wgrad_f32 bias_gelu; do
-  RACE_HUNT_TAG=$hog RACE_HUNT_HOG_FILTER=$hog timeout 200 python tools/race_hunt.py --procs 4 --reps 120 --only instnorm > gpurun_out/r05f/hog_$hog.log 2>&1
-  echo "== hog $hog rc $?"; grep "RACE\|done\|hog '" gpurun_out/r05f/hog_$hog.log | sort | cut -c1-220
-done
+# round-5 call 10: with disjoint compute units per rank: distributed-vs-serial diagnostic, shadow rank (merged plane blocks), full-size tests
+mkdir -p gpurun_out/r05j
+export MAKANI_AMD_DIST_LOG=$PWD/gpurun_out/r05j/dist_fullsize.txt
+timeout 300 python tools/shadow_rank.py --h 4 --w 2 --steps 3 --json gpurun_out/r05j/shadow_h4w2.json > gpurun_out/r05j/shadow_h4w2.log 2>&1; echo "shadow rc $?"
+tail -1 gpurun_out/r05j/shadow_h4w2.log | cut -c1-900
+timeout 300 python tools/dist_diag.py --h 4 --w 1 --variants base > gpurun_out/r05j/diag_h4w1.log 2>&1; echo "diag h4w1 rc $?"
+grep "^\[base\]\|encoder.fwd.2\|blocks.0.filter\|blocks.7.filter\|outer_skip" gpurun_out/r05j/diag_h4w1.log | head -30
+timeout 300 python tools/dist_diag.py --h 4 --w 2 --variants base > gpurun_out/r05j/diag_h4w2.log 2>&1; echo "diag h4w2 rc $?"
+grep "^\[base\]\|encoder.fwd.2\|blocks.0.filter\|blocks.7.filter" gpurun_out/r05j/diag_h4w2.log | head -30
+timeout 1500 python -m pytest tests/test_gpu_dist_fullsize.py -x -q -s --durations=10 > gpurun_out/r05j/pytest.log 2>&1; echo "pytest rc $?"
+tail -15 gpurun_out/r05j/pytest.log
+cat gpurun_out/r05j/dist_fullsize.txt | cut -c1-400

@@ -24,6 +24,25 @@ _SOURCE = None          # "init", "adopt" or None
 MODEL_COMM_NAMES = ("h", "w", "spatial", "matmul", "fin", "fout", "model")
 
 
+def share_gpu(rank_on_gpu: int, ranks_on_gpu: int, ncu: int = 256) -> str:
+    """Functional runs that put SEVERAL ranks on ONE GPU (the one-GPU tests of the h x w path, ``bench.py`` with
+    ``MAKANI_AMD_BENCH_BACKEND=gloo``): give every rank its own range of compute units (``HSA_CU_MASK``, read by the ROCm
+    runtime when the process creates its queues — call this BEFORE the first GPU call of the process).
+
+    Why: on the MI355X boxes of this pool, kernels of DIFFERENT processes that share a compute unit disturb each other's
+    results — a process running reduction / FFT kernels next to another process's matrix-core kernels reads a few wrong
+    values per launch (transient, input tensors untouched, 1e-4 .. 1e-2 relative on per-plane sums; measured with
+    ``tools/race_hunt.py``: 0 of ~10 000 launches differ with one process per GPU or with disjoint compute units, every
+    launch differs with shared ones; docs/LAB_NOTEBOOK.md, round 5).  One process per GPU — the deployment model of this
+    package — is not affected; ranks sharing a GPU must not share compute units if their results are to be compared at
+    fp32 tolerances.  Returns the mask it set."""
+    import os
+    per = max(1, ncu // max(1, ranks_on_gpu))
+    mask = f"0:{rank_on_gpu * per}-{(rank_on_gpu + 1) * per - 1}"
+    os.environ["HSA_CU_MASK"] = mask
+    return mask
+
+
 def reset():
     global _SOURCE
     _GROUPS.clear()

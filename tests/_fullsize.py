@@ -22,6 +22,15 @@ CONFIG2 = dict(inp_shape=(721, 1440), out_shape=(721, 1440), inp_chans=73, out_c
                activation_function="gelu", big_skip=True, model_grid_type="equiangular", sht_grid_type="legendre-gauss")
 
 
+def share_gpu(rank, world, ncu=256):
+    """disjoint compute units for the ranks that share ONE GPU in a test (``HSA_CU_MASK``; must be in the environment before the
+    process's first GPU call): kernels of different processes on one compute unit disturb each other's results on these boxes
+    (makani_amd/comm.py: share_gpu; tools/race_hunt.py; docs/LAB_NOTEBOOK.md round 5) — with one process per GPU, the
+    deployment model, nothing of the kind exists"""
+    per = max(1, ncu // max(1, world))
+    os.environ["HSA_CU_MASK"] = f"0:{rank * per}-{(rank + 1) * per - 1}"
+
+
 def host_threads(cap=64):
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(n, cap)))

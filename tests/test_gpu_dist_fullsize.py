@@ -93,6 +93,8 @@ def _setup_rank(rank, world, port, h, w):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
     torch.set_num_threads(8)
+    from _fullsize import share_gpu
+    share_gpu(rank, world)                  # disjoint compute units per rank, set before the first GPU call (tests/_fullsize.py)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import makani_amd.comm as mcomm
     return mcomm.init(h, w)

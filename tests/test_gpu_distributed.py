@@ -30,6 +30,9 @@ def _worker(rank, world, port, h, w, norm="instance_norm"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _fullsize import share_gpu
+    share_gpu(rank, world)              # ranks sharing ONE GPU get disjoint compute units, set before the first GPU call
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import makani_amd as ma
@@ -196,6 +199,9 @@ def _worker_ragged_gpu(rank, world, port, h, w, C, fused=True):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(4)
     os.environ["MAKANI_AMD_DIST_FUSED"] = "1" if fused else "0"
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _fullsize import share_gpu
+    share_gpu(rank, world)              # ranks sharing ONE GPU get disjoint compute units, set before the first GPU call
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import makani_amd as ma
@@ -277,6 +283,9 @@ def _worker_multistep(rank, world, port, h, w, checkpointed, amp):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _fullsize import share_gpu
+    share_gpu(rank, world)              # ranks sharing ONE GPU get disjoint compute units, set before the first GPU call
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import makani_amd as ma
@@ -415,3 +424,80 @@ def _worker_rccl_fused(rank, world, port):
 
 def test_fused_schedule_collectives_on_rccl_world1():
     mp.spawn(_worker_rccl_fused, args=(1, _free_port()), nprocs=1, join=True)
+
+
+# --------------------------------------------------------------------------- #
+# hipGraph capture of the distributed step's building blocks WITH their RCCL collectives (one rank): what bench.py does for the
+# h x w step at N > 1 (the eager h4 w2 step is bound by the host: tools/shadow_rank.py, profiles/r05_shard_shapes.md)
+# --------------------------------------------------------------------------- #
+def _worker_rccl_graph(rank, world, port):
+    """one captured "step" on the RCCL backend with a process group of one rank: forward + backward of the FUSED distributed
+    SHT pair (segmented FFT kernels, the list all_to_all(async_op=True) per latitude chunk, its waits), of the distributed
+    instance norm (all_gather of the statistics, all_reduce of the backward sums, no host read after the first call) and the
+    gradient reduction hooks (async all_reduce issued from post-accumulate hooks, finished by the autograd engine's
+    callback) — captured once with torch.cuda.graph, replayed twice on fresh inputs, against the eager results"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MAKANI_AMD_DIST_FORCE_FUSED"] = "1"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import makani_amd.distributed as thd
+        from makani_amd import dist_pipeline as dp
+        from makani_amd import ops
+        thd.init(None, None)
+        nlat, nlon, lmax, mmax, C = 91, 360, 30, 31, 8
+        kw = dict(lmax=lmax, mmax=mmax, grid="equiangular")
+        fwd, inv = thd.DistributedRealSHT(nlat, nlon, **kw).to(dev), thd.DistributedInverseRealSHT(nlat, nlon, **kw).to(dev)
+        assert dp.eligible(fwd, torch.float32) and dp.eligible(inv, torch.float32)
+        model = torch.nn.Module()
+        model.gamma = torch.nn.Parameter(torch.rand(C, device=dev) + 0.5)
+        model.beta = torch.nn.Parameter(torch.randn(C, device=dev) * 0.1)
+        model.big = torch.nn.Parameter(torch.randn(C, 1200, 300, device=dev) * 0.01)          # 11.5 MB: the async path of the reducer
+        for p in model.parameters():
+            p.is_shared_mp = ["spatial"]
+        red = thd.GradReducer(model, comm=_OneRankTree)
+        assert red.active
+        torch.manual_seed(5)
+        xs = torch.randn(1, C, nlat, nlon, device=dev)             # static input / cotangent buffers of the graph
+        gs = torch.randn(1, C, nlat, nlon, device=dev)
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            x = xs.clone().requires_grad_(True)
+            h = ops.DistInstanceNormFn.apply(x, model.gamma, model.beta, 1e-6, True, dist.group.WORLD)
+            y = inv(fwd(h)) + (model.big.sum() * 1e-3)
+            (y * gs).sum().backward()
+            return y.detach(), x.grad, model.gamma.grad, model.beta.grad, model.big.grad
+
+        for _ in range(2):                                          # warm-up: plans, shard counts, RCCL communicator
+            ref = [t.clone() for t in step()]
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            outs = step()
+        torch.cuda.synchronize()
+        for it in range(2):
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(outs, ref):
+                assert torch.equal(a, b), (it, (a - b).abs().max())
+            # new data in the static buffers: the replay must follow it
+            xs.copy_(torch.randn(1, C, nlat, nlon, device=dev))
+            gs.copy_(torch.randn(1, C, nlat, nlon, device=dev))
+            ref = [t.clone() for t in step()]
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hipgraph_capture_of_the_distributed_blocks_with_rccl_world1():
+    mp.spawn(_worker_rccl_graph, args=(1, _free_port()), nprocs=1, join=True)

@@ -31,6 +31,9 @@ def _setup(rank, world, port, h, w):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _fullsize import share_gpu
+    share_gpu(rank, world)              # ranks sharing ONE GPU get disjoint compute units, set before the first GPU call
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ih, iw = rank // w, rank % w
     hg = wg = None

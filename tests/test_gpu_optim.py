@@ -28,6 +28,9 @@ def _r(t):
 def _worker_zero_gpu(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _fullsize import share_gpu
+    share_gpu(rank, world)              # ranks sharing ONE GPU get disjoint compute units, set before the first GPU call
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import makani_amd.comm as mcomm

@@ -46,6 +46,9 @@ def _rel(a, b):
 def worker(rank, world, port, h, w, names, amp):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(8)
+    if os.environ.get("DIST_DIAG_SHARE_CUS", "0") != "1":
+        from _fullsize import share_gpu
+        share_gpu(rank, world)                # disjoint compute units per rank (before the first GPU call)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import makani_amd as ma
     import makani_amd.comm as mcomm

@@ -208,7 +208,16 @@ def model_cases(dev):
     return [("model 4 layers fp32", lambda: run(False)), ("model 4 layers bf16", lambda: run(True))]
 
 
+def cu_mask_env(rank, world, ncu=256):
+    """disjoint compute-unit ranges per process (HSA_CU_MASK, read by the ROCm runtime when it creates the process's queues):
+    kernels of different processes then never share a compute unit"""
+    per = ncu // world
+    return f"0:{rank * per}-{(rank + 1) * per - 1}"
+
+
 def worker(rank, world, ports, reps, only, with_model):
+    if os.environ.get("RACE_HUNT_CU_MASK", "0") == "1":
+        os.environ["HSA_CU_MASK"] = cu_mask_env(rank, world)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(ports[rank])
     dist.init_process_group("gloo", rank=0, world_size=1)                 # a world of one per process: the distributed kernels' group
     torch.set_num_threads(4)
@@ -242,10 +251,24 @@ def worker(rank, world, ports, reps, only, with_model):
             return
     bad = 0
     t0 = time.time()
+
+    def captured(fn):
+        out = []
+        for v in (fn.__defaults__ or ()):
+            if isinstance(v, torch.Tensor):
+                out.append(v)
+            elif callable(v) and getattr(v, "__defaults__", None):
+                out += [u for u in v.__defaults__ if isinstance(u, torch.Tensor)]
+        return out
+
+    def digest(ts):
+        return [float(torch.view_as_real(t).double().sum()) if t.is_complex() else float(t.double().sum()) for t in ts]
     for name, fn in todo:
         if only and only not in name:
             continue
         names = None
+        ins = captured(fn)
+        d0 = digest(ins)
         ref = fn()
         if isinstance(ref, tuple) and len(ref) == 2 and isinstance(ref[0], list) and isinstance(ref[0][0], str):
             names, ref = ref
@@ -253,6 +276,8 @@ def worker(rank, world, ports, reps, only, with_model):
         torch.cuda.synchronize()
         worst = (0, 0.0, -1, "")
         nrep_bad = 0
+        per_out = {}
+        prev, changes = ref, []          # repetitions whose result differs from the PREVIOUS one (transient vs persistent)
         for r in range(reps):
             # shift the caching allocator's choices: otherwise a stale read of a scratch buffer finds the previous repetition's
             # (identical) values at the same address and goes unnoticed
@@ -266,13 +291,26 @@ def worker(rank, world, ports, reps, only, with_model):
             for k, (a, b) in enumerate(zip(o, ref)):
                 n, e = _same(a, b)
                 rep_bad = rep_bad or n > 0
+                if n:
+                    d = per_out.setdefault(names[k] if names else f"out{k}", [0, 0, 0.0])
+                    d[0] += 1
+                    d[1] = max(d[1], n)
+                    d[2] = max(d[2], e)
                 if n and e >= worst[1]:
                     worst = (n, e, r, names[k] if names else f"out{k}")
             nrep_bad += int(rep_bad)
+            if any(_same(a, b)[0] for a, b in zip(o, prev)):
+                changes.append(r)
+            prev = [t.clone() for t in o]
+        d1 = digest(ins)
+        if d0 != d1:
+            print(f"[proc {rank}] INPUT CHANGED  {name}: checksums of the operation's fixed input tensors {d0} -> {d1}", flush=True)
         if worst[0]:
             bad += 1
             print(f"[proc {rank}] RACE  {name}: {nrep_bad} of {reps} repetitions differ from the first; worst: {worst[0]} elements "
-                  f"(rel-L2 {worst[1]:.2e}) in rep {worst[2]}, {worst[3]}", flush=True)
+                  f"(rel-L2 {worst[1]:.2e}) in rep {worst[2]}, {worst[3]}; per output (reps, max elements, max rel-L2): "
+                  + ", ".join(f"{k}: {v[0]}/{v[1]}/{v[2]:.1e}" for k, v in list(per_out.items())[:8])
+                  + f"; changed against the previous repetition in reps {changes[:40]}", flush=True)
         elif rank == 0:
             print(f"[proc {rank}] ok    {name}", flush=True)
     print(f"[proc {rank}] done: {bad} operation(s) not reproducible, {time.time() - t0:.0f} s", flush=True)
