@@ -396,6 +396,18 @@ def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
     opt.step()
     rec.update(t_step=time.perf_counter() - t0 - t_aux, loss=float(loss.detach()))
     print(json.dumps(rec), flush=True)
+    if out_path and state_path:
+        # after the measurement (a time-out from here on loses nothing of it): the yardstick of the bf16 gradient figures — the
+        # oracle's OWN backward pass under op-by-op CPU bf16 autocast on the initial weights, same input / target / loss, as
+        # oracle_bf16_rel_l2 is the yardstick of the bf16 forward figure
+        del y, loss
+        model.load_state_dict(torch.load(state_path, map_location="cpu"), strict=True)
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y16 = model(inp)
+        l16 = (y16.float() - tar).square().mean()
+        l16.backward()
+        torch.save(_grad_record(model, l16), out_path + ".grads_bf16")
 
 
 class ParityProbe:
@@ -458,8 +470,19 @@ class ParityProbe:
                                 "autocast <= the oracle's own bf16 distance (2e-2 holds per block, not through 8 bf16 layers).  "
                                 "grad_*: the same run's backward pass of mean((y - target)^2) against the oracle's backward pass "
                                 "(the one timed inside cpu_baseline's train step): loss, norm of all gradients (relative "
-                                "difference) and rel-L2 of four gradients; gate fp32 <= 1e-4")
+                                "difference) and rel-L2 of four gradients; gate fp32 <= 1e-4; every *_bf16 figure sits beside oracle_bf16_grad_* = "
+                                "the same distance for the oracle's own backward pass under CPU bf16 autocast (gate: <= 1.25 x that, "
+                                "tests/test_gpu_headline.py)")
             gpath = self.out_path + ".grads"
+            if out is not None and os.path.exists(gpath + "_bf16") and os.path.exists(gpath):
+                # oracle_bf16_grad_*: how far the reference's own bf16 arithmetic (CPU autocast) moves each of these quantities
+                # from its fp32 value — the yardstick every grad_*_bf16 figure below sits beside
+                ref, r16 = torch.load(gpath, map_location="cpu"), torch.load(gpath + "_bf16", map_location="cpu")
+                out["oracle_bf16_grad_loss"] = abs(r16["loss"] - ref["loss"]) / abs(ref["loss"])
+                out["oracle_bf16_grad_norm"] = abs(r16["grad_norm"] - ref["grad_norm"]) / ref["grad_norm"]
+                for n, g in r16["grads"].items():
+                    if n in ref["grads"]:
+                        out[f"oracle_bf16_grad_{n}"] = self._rel(g, ref["grads"][n])
             if out is not None and os.path.exists(gpath):
                 ref = torch.load(gpath, map_location="cpu")
                 for name, rec in self.bwd.items():
@@ -474,7 +497,7 @@ class ParityProbe:
         return out
 
 
-def cpu_baseline(cfg_name, timeout_s=300, parity=None):
+def cpu_baseline(cfg_name, timeout_s=420, parity=None):
     """Reference-equivalent CPU path, timed in a child process on this host's cores, fp32 (kind "port": the oracle — the
     reference's own modules cannot be imported on the benchmark host, /root/reference exists in the build container only; the
     oracle restates them and is pinned by fixtures generated from them).  Bounded sample: ONE full train step (forward +
@@ -798,6 +821,15 @@ def run_worker(args):
             out["cpu_baseline"] = None
     if world > 1:
         dist.barrier()
+        if graph is not None:
+            # the captured step holds RCCL's send / recv kernels: tearing the communicator down under the live graph hangs
+            # (tools/probes/rccl_graph_probe.py) — the rank prints its result and leaves without the teardown
+            torch.cuda.synchronize()
+            if out is not None:
+                print(json.dumps(out), flush=True)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
     return out
 

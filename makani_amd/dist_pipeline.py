@@ -209,6 +209,14 @@ def _exchange_async(recv, send, group):
     from .distributed import _count_exchange
     _count_exchange(send, group)
     if dist.get_backend(group) != "gloo":
+        if recv[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture (bench.py captures the whole h x w step): the SYNCHRONOUS form.  With RCCL 2.26 / torch 2.10
+            # the send/recv-based collectives are captured and replayed correctly when issued synchronously, while their
+            # async_op=True handles crash at the end of the capture (tools/probes/rccl_graph_probe.py, gpurun_out/r05l); the graph
+            # then orders the collective between its neighbours on the capturing stream (no chunk overlap inside a replayed graph
+            # until that is fixed upstream — the launch path it removes is worth far more: profiles/r05_shard_shapes.md)
+            dist.all_to_all(recv, send, group=group)
+            return _Done()
         return dist.all_to_all(recv, send, group=group, async_op=True)
     _exchange(recv, send, group)
     return _Done()

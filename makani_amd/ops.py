@@ -1332,7 +1332,10 @@ class DistInstanceNormFn(torch.autograd.Function):
         dt = dtype_code(x)
         stats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
-        check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, ptr(quad), float(quad_sum), stream()), "instnorm_stats")
+        nb = float(x.numel() * x.element_size())
+        tag = f"{'_gelu' if fuse_gelu else ''}_n{hw}"
+        with _timed(f"instnorm_dist_stats{tag}", nbytes=nb):
+            check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, ptr(quad), float(quad_sum), stream()), "instnorm_stats")
         counts, total = _shard_counts(group, float(quad_sum) if quad is not None else float(hw), x.device)
         allst = _all_gather_stack(stats, group)                  # (P, planes, 2): every rank's local {mean, rstd}
         mstats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
@@ -1340,8 +1343,9 @@ class DistInstanceNormFn(torch.autograd.Function):
         g = gamma.float().contiguous() if gamma is not None else None
         b = beta.float().contiguous() if beta is not None else None
         y = torch.empty_like(x)
-        check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(mstats), ptr(g), ptr(b), planes, Cc, hw,
-                                      1 if fuse_gelu else 0, stream()), "instnorm_apply")
+        with _timed(f"instnorm_dist_apply{tag}", nbytes=2.0 * nb):
+            check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(mstats), ptr(g), ptr(b), planes, Cc, hw,
+                                          1 if fuse_gelu else 0, stream()), "instnorm_apply")
         ctx.save_for_backward(x, mstats, g, b, quad)
         ctx.meta = (fuse_gelu, group, total)
         return y
@@ -1362,17 +1366,21 @@ class DistInstanceNormFn(torch.autograd.Function):
         # unweighted: every shard of a plane has hw pixels except along ragged splits; the true total is the sum of the ranks'
         # counts (exact small integers in fp32, summed in fp64 on the host once: _shard_counts)
         hw_tot = int(round(total)) if quad is None else hw
-        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
-                                    ptr(ws), planes, Cc, hw, hw_tot, 1, fg, stream()), "instnorm_bwd(reduce)")
+        nb = float(x.numel() * x.element_size())
+        tag = f"{'_gelu' if fuse_gelu else ''}_n{hw}"
+        with _timed(f"instnorm_dist_bwd_reduce{tag}", nbytes=2.0 * nb):
+            check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
+                                        ptr(ws), planes, Cc, hw, hw_tot, 1, fg, stream()), "instnorm_bwd(reduce)")
         local = _batch_sum(sums, B, Cc).clone()                   # this rank's share of dgamma / dbeta
         _all_reduce_sum(sums, group)
         if quad is not None:
             # normalised weights p_i = q_i / Q (Q = merged count): gx = k (ga - p_i (S1 + n_i S2)); the kernel multiplies the
             # sums by q_i per element, so they are divided by Q here and the kernel's crop term is switched off (sum = 1)
             sums = (sums / total).contiguous()
-        check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(quad),
-                                    1.0 if quad is not None else 0.0, ptr(sums), ptr(ws), planes, Cc, hw, hw_tot, 2, fg, stream()),
-              "instnorm_bwd(apply)")
+        with _timed(f"instnorm_dist_bwd_apply{tag}", nbytes=3.0 * nb):
+            check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(quad),
+                                        1.0 if quad is not None else 0.0, ptr(sums), ptr(ws), planes, Cc, hw, hw_tot, 2, fg, stream()),
+                  "instnorm_bwd(apply)")
         dgamma = local[1] if g is not None else None
         dbeta = local[0] if b is not None else None
         return gx, dgamma, dbeta, None, None, None, None, None

@@ -23,8 +23,10 @@ def _k_advance(sdev, b1, b2):
 
 
 def _k_adamw(pr, gr, m, v, scale, lr, b1, b2, eps, wd, sdev):
-    check(lib().mk_adamw_step(ptr(pr), ptr(gr), ptr(m), ptr(v), pr.numel(), ptr(scale), lr, b1, b2, eps, wd, 0, ptr(sdev),
-                              stream()), "mk_adamw_step")
+    from .ops import _timed                      # (28 B per parameter: p, g, m, v read, p, m, v written)
+    with _timed("adamw", nbytes=28.0 * pr.numel()):
+        check(lib().mk_adamw_step(ptr(pr), ptr(gr), ptr(m), ptr(v), pr.numel(), ptr(scale), lr, b1, b2, eps, wd, 0, ptr(sdev),
+                                  stream()), "mk_adamw_step")
 
 
 def _k_sumsq_clip(grads, max_grad_norm):
@@ -33,8 +35,10 @@ def _k_sumsq_clip(grads, max_grad_norm):
     nws = lib().mk_grad_norm_workspace(C.cast(arr, C.c_void_p), len(grads))
     ws = torch.empty((nws,), dtype=torch.float32, device=grads[0].device)
     out = torch.empty((2,), dtype=torch.float32, device=grads[0].device)
-    check(lib().mk_grad_clip_coef(C.cast(arr, C.c_void_p), len(grads), float(max_grad_norm or 0.0), ptr(ws), ptr(out), stream()),
-          "mk_grad_clip_coef")
+    from .ops import _timed
+    with _timed("adamw_grad_norm", nbytes=4.0 * sum(g.numel() for g in grads)):
+        check(lib().mk_grad_clip_coef(C.cast(arr, C.c_void_p), len(grads), float(max_grad_norm or 0.0), ptr(ws), ptr(out), stream()),
+              "mk_grad_clip_coef")
     return out
 
 
@@ -264,8 +268,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 torch.autograd.graph.increment_version(p)
             if descs:
                 arr = (MkAdamTensor * len(descs))(*descs)
-                check(lib().mk_adamw_multi(C.cast(arr, C.c_void_p), len(descs), ptr(scale), group["lr"], b1, b2, group["eps"],
-                                           group["weight_decay"], 0, ptr(sdev), stream()), "mk_adamw_multi")
+                from .ops import _timed
+                with _timed("adamw_multi", nbytes=28.0 * sum(d.n for d in descs)):
+                    check(lib().mk_adamw_multi(C.cast(arr, C.c_void_p), len(descs), ptr(scale), group["lr"], b1, b2, group["eps"],
+                                               group["weight_decay"], 0, ptr(sdev), stream()), "mk_adamw_multi")
             for p in shadowed:               # valid for exactly this version (and storage) of the parameter
                 p._mk_shadow_version = p._version
                 p._mk_shadow_ptr = p.data_ptr()

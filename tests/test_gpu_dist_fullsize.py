@@ -268,7 +268,7 @@ def serial_rollout(oracle):
         pass
 
 
-def _worker_rollout(rank, world, port, h, w, ref_path):
+def _worker_rollout(rank, world, port, h, w, amp, ref_path):
     _, ih, iw = _setup_rank(rank, world, port, h, w)
     try:
         import makani_amd.distributed as thd
@@ -287,7 +287,7 @@ def _worker_rollout(rank, world, port, h, w, ref_path):
         xl = oracle["x"][sl].to(dev).requires_grad_(True)
         torch.cuda.synchronize()
         t1 = time.time()
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             yl = net(xl)
         assert yl.shape == (1, 73 * (NF + 1), hl, wl)
         (yl.float() * ref["G"][sl].to(dev)).sum().backward()
@@ -303,25 +303,38 @@ def _worker_rollout(rank, world, port, h, w, ref_path):
             r = ref["grads"][n]
             r = r[..., l0:l0 + ll, :] if n.endswith("filter.filter.weight") else r
             e, yd = _rel(_r(p.grad), r), float(ref["yard_grads"][n])
-            if e > 2.0 * yd:
-                bad[n] = (e, yd)
-            if e / yd > worst[1]:
-                worst = (n, e / yd)
-        log_line(f"config2 multistep 4 (checkpointed, bf16 autocast) h{h}w{w} rank {rank}: vs the serial HIP fp32 rollout "
-                 f"(distributed bf16 / serial bf16):  y {e_y:.2e} / {y_y:.2e}  gx {e_gx:.2e} / {y_gx:.2e}  worst gradient ratio "
-                 f"{worst[0]} {worst[1]:.2f}  peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, "
-                 f"rollout fwd+bwd over gloo {t2 - t1:.1f} s")
-        # a shard's relative error scatters around the whole field's, and the two schedules sum in different orders: no further
-        # from the fp32 rollout than 2 x the serial bf16 rollout is (the gate of the toy-grid test, tests/test_gpu_distributed.py)
-        assert e_y <= 2.0 * y_y and e_gx <= 2.0 * y_gx, (rank, e_y, y_y, e_gx, y_gx)
+            tol = 2.0 * yd if amp else TOL_ROLLOUT
+            if e > tol:
+                bad[n] = (e, tol)
+            if e / tol > worst[1]:
+                worst = (n, e / tol)
+        if amp:
+            what = (f"bf16 autocast, vs the serial HIP fp32 rollout (distributed bf16 / serial bf16):  y {e_y:.2e} / {y_y:.2e}  "
+                    f"gx {e_gx:.2e} / {y_gx:.2e}")
+        else:
+            what = f"fp32, vs the serial HIP fp32 rollout:  y {e_y:.2e}  gx {e_gx:.2e}  (gate {TOL_ROLLOUT:.0e})"
+        log_line(f"config2 multistep 4 (checkpointed) h{h}w{w} rank {rank}: {what}  worst weight gradient / its gate {worst[0]} "
+                 f"{worst[1]:.2f}  peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, rollout fwd+bwd over gloo {t2 - t1:.1f} s")
+        if amp:
+            # the 4-step rollout of this random-weight network is chaotic under bf16 (the SERIAL bf16 rollout sits 0.35 / 1.06 from
+            # the fp32 one): bf16 is gated only against that yardstick; the composition itself is pinned by the fp32 run
+            assert e_y <= 2.0 * y_y and e_gx <= 2.0 * y_gx, (rank, e_y, y_y, e_gx, y_gx)
+        else:
+            assert e_y < TOL_ROLLOUT and e_gx < TOL_ROLLOUT, (rank, e_y, e_gx)
         assert not bad, (rank, bad)
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_config5_fullsize_multistep4_h4w2_bf16_checkpointed(oracle, serial_rollout):
-    """BASELINE configs[4]: SFNO 721 x 1440 x 73, multistep_count = 4, h = 4, w = 2, bf16 AMP — 8 ranks on one GPU, all four
-    outputs, the input gradient through the rollout and the reduced gradients of the spectral and channel-GEMM weights"""
-    log_line("--- test_config5_fullsize_multistep4_h4w2_bf16_checkpointed ---")
-    spawn(_worker_rollout, (8, _free_port(), 4, 2, serial_rollout), 8, timeout_s=1200)
+TOL_ROLLOUT = 1e-3      # four chained steps: the fp32 differences of one step (3e-6 / 6e-6) grow with every re-entry
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_config5_fullsize_multistep4_h4w2_checkpointed(amp, oracle, serial_rollout):
+    """BASELINE configs[4]: SFNO 721 x 1440 x 73, multistep_count = 4, h = 4, w = 2 — 8 ranks on one GPU, all four outputs, the
+    input gradient through the rollout and the reduced gradients of the spectral and channel-GEMM weights; fp32 (pins the
+    composition: rollout, checkpoint recomputation through the distributed transforms, gradient hooks) and bf16 AMP (the
+    configuration's precision, against the serial bf16 rollout's own distance from fp32)"""
+    log_line(f"--- test_config5_fullsize_multistep4_h4w2_checkpointed {'bf16 autocast' if amp else 'fp32'} ---")
+    spawn(_worker_rollout, (8, _free_port(), 4, 2, amp, serial_rollout), 8, timeout_s=1200)

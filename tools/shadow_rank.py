@@ -173,6 +173,32 @@ def main():
     wall = (time.perf_counter() - t0) / a.steps
     comm = {f"{k[0]}_group_of_{k[1]}": dict(MB_sent=round(v["bytes_sent"] / a.steps / 1e6, 2), all_to_alls=v["all_to_alls"] / a.steps)
             for k, v in sorted(thd.COMM_STATS.items())}
+    # (1b) the same step captured as a hipGraph (the phantom collectives are plain copies): the GPU's time for the step with
+    # no launch path at all = what a captured step with FREE links would take on this rank
+    graph_ms = None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            bench.train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            bench.train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / a.steps * 1e3
+        del graph
+    except Exception as e:
+        print(f"[shadow] graph capture failed: {type(e).__name__}: {str(e)[:300]}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     # (2) per-kernel durations
     ops.PROFILER.reset()
     ops.PROFILER.enabled = True
@@ -194,6 +220,7 @@ def main():
     out = dict(parallelism=f"h{h}w{w}", rank=dict(ih=ih, iw=iw), local_grid=f"{hl}x{wl}", dtype="fp32" if a.fp32 else "bf16 autocast",
                multistep_count=a.multistep_count, steps=a.steps,
                wall_ms_per_step_eager_phantom=round(wall * 1e3, 2), host_launch_ms_per_step=round(t_host / a.steps * 1e3, 2),
+               graph_ms_per_step_phantom=(round(graph_ms, 2) if graph_ms is not None else None),
                hip_kernel_ms_per_step=round(hip_ms, 3), launches_per_step=sum(k["launches_per_step"] for k in kernels.values()),
                exchange_per_step=comm, link_ms_per_step_at_153GBs=round(link_ms, 3),
                fused_fallbacks=dp.FALLBACKS, peak_hbm_GB=round(torch.cuda.max_memory_allocated() / 1e9, 2),
