@@ -576,6 +576,13 @@ def run_worker(args):
     if world > 1:
         import datetime
         to = datetime.timedelta(seconds=int(os.environ.get("MAKANI_AMD_BENCH_PG_TIMEOUT", "150")))
+        if backend == "nccl" and os.environ.get("MAKANI_AMD_BENCH_GRAPH", args.graph) != "off":
+            # the captured step (below) contains RCCL send / recv collectives; torch 2.10's process group hands their work to its
+            # watchdog thread, whose event query then fails ("operation not permitted on an event last recorded in a capturing
+            # stream") and would take the process down.  With these settings the watchdog thread just ends at that point
+            # (tests/test_gpu_distributed.py::test_hipgraph_capture_of_the_distributed_blocks_with_rccl_world1)
+            os.environ.setdefault("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")
+            os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device, timeout=to)
         else:

@@ -1,4 +1,2 @@
-# round-5 call 12: which RCCL collectives can be captured in a hipGraph here (one rank)
-mkdir -p gpurun_out/r05l
-timeout 900 python tools/probes/rccl_graph_probe.py > gpurun_out/r05l/rccl_graph_probe.log 2>&1
-cat gpurun_out/r05l/rccl_graph_probe.log
+mkdir -p gpurun_out/r05o
+timeout 200 python -m pytest tests/test_gpu_distributed.py -x -q -s -k "hipgraph or rccl" > gpurun_out/r05o/pytest_final.log 2>&1; echo "rc $?"; grep "replay \|passed\|failed" gpurun_out/r05o/pytest_final.log | cut -c1-300

@@ -439,6 +439,11 @@ def _worker_rccl_graph(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["MAKANI_AMD_DIST_FORCE_FUSED"] = "1"
+    # torch 2.10's process group hands the work of a CAPTURED send / recv collective to its watchdog thread, whose event query
+    # then fails ("operation not permitted on an event last recorded in a capturing stream") and, by default, takes the process
+    # down; with these two settings the watchdog thread just ends (bench.py sets them for its captured N > 1 step)
+    os.environ["TORCH_NCCL_RETHROW_CUDA_ERRORS"] = "0"
+    os.environ["TORCH_NCCL_ENABLE_MONITORING"] = "0"
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -468,12 +473,20 @@ def _worker_rccl_graph(rank, world, port):
                 p.grad = None
             x = xs.clone().requires_grad_(True)
             h = ops.DistInstanceNormFn.apply(x, model.gamma, model.beta, 1e-6, True, dist.group.WORLD)
-            y = inv(fwd(h)) + (model.big.sum() * 1e-3)
+            y = inv(fwd(h)) + model.big[0, 0, :8].sum() * 1e-3
             (y * gs).sum().backward()
             return y.detach(), x.grad, model.gamma.grad, model.beta.grad, model.big.grad
 
-        for _ in range(2):                                          # warm-up: plans, shard counts, RCCL communicator
-            ref = [t.clone() for t in step()]
+        # two data sets, their eager results computed BEFORE the capture: no eager step runs between replays (an eager torch
+        # reduction between two replays of a graph that contains the same reduction disturbed the replayed one here — torch's
+        # two-stage sum, nothing of this package; the benchmark never interleaves the two either)
+        data = [(torch.randn(1, C, nlat, nlon, device=dev), torch.randn(1, C, nlat, nlon, device=dev)) for _ in range(2)]
+        refs = []
+        for xa, ga in data:                                         # (also the warm-up: plans, shard counts, RCCL communicator)
+            xs.copy_(xa)
+            gs.copy_(ga)
+            step()
+            refs.append([t.clone() for t in step()])
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -485,15 +498,14 @@ def _worker_rccl_graph(rank, world, port):
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             outs = step()
         torch.cuda.synchronize()
-        for it in range(2):
+        for it in (1, 0, 1):                                        # the replay follows the static buffers
+            xs.copy_(data[it][0])
+            gs.copy_(data[it][1])
             graph.replay()
             torch.cuda.synchronize()
-            for a, b in zip(outs, ref):
-                assert torch.equal(a, b), (it, (a - b).abs().max())
-            # new data in the static buffers: the replay must follow it
-            xs.copy_(torch.randn(1, C, nlat, nlon, device=dev))
-            gs.copy_(torch.randn(1, C, nlat, nlon, device=dev))
-            ref = [t.clone() for t in step()]
+            diffs = [float((a - b).abs().max()) for a, b in zip(outs, refs[it])]
+            print(f"replay on data set {it}: max |graph - eager| of (y, gx, dgamma, dbeta, dbig) = {diffs}", flush=True)
+            assert all(d == 0.0 for d in diffs), (it, diffs)
         torch.cuda.synchronize()
     except BaseException:
         import traceback
