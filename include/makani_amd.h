@@ -81,7 +81,8 @@ int mk_sgemm_split_batched(const MkGemm* g, int limbs, void* stream);
 int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream);
 /* Second-generation kernels of the same arithmetic for the hot shapes (csrc/xgemm2.hip: 512-thread workgroups whose two
  * wave groups alternate between the matrix pipe and the limb split, double-buffered LDS images).
- * mk_cgemm_split2_batched: any descriptor mk_cgemm_split_batched accepts (the dhconv forward / data-gradient /
+ * mk_cgemm_split2_batched: the complex split engine (mk_cgemm_split_batched is an alias of it since round 5, when the
+ *   first-generation complex kernel was retired): any complex descriptor (the dhconv forward / data-gradient /
  *   weight-gradient GEMMs of _contract_lwise, makani/models/common/contractions.py:23-24).
  * mk_sgemm_presplit_batched: real GEMM whose A operand is a CONSTANT matrix handed over already split into `limbs`
  *   bf16 limb planes — the Legendre matrices of th.RealSHT / th.InverseRealSHT [un-vendored; precomputed in

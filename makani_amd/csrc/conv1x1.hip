@@ -1802,8 +1802,7 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
     static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
     static const bool no_astat = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 'r'; }();   // "ring": no weight-stationary kernel
-    static const bool no_smallk = [] { const char* e = getenv("MAKANI_AMD_ASTAT_SMALLK"); return e && e[0] == '0'; }();
-    if (!force_tile && !no_astat && !no_smallk && lda == 80 && K > 64 && K <= 80 && M >= 256 && (long long)M * N * 2 < (1ll << 31) &&
+    if (!force_tile && !no_astat && lda == 80 && K > 64 && K <= 80 && M >= 256 && (long long)M * N * 2 < (1ll << 31) &&
         (long long)K * N * 2 < (1ll << 32) && N >= 64 && !(R && G) && !((R || G) && act && Ypre)) {
         // the 73-channel edges (K padded to lda = 80): the weight-stationary kernel with 5 k16-steps and one 96-row chunk per tile
         const bool epi_loads = R || G;
@@ -1840,15 +1839,11 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
         return mk_check_launch("mk_conv1x1_nn");
     }
     if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
-        // weights stationary in registers: 256- or 384-channel slabs (4 waves x 2 or 3 row tiles), 64-pixel tiles,
-        // persistent grid of 256-thread workgroups.  MAKANI_AMD_ASTAT = "<tm><kch>" (e.g. 3128, 264) overrides the choice.
-        static const int forced_tm = [] { const char* e = getenv("MAKANI_AMD_ASTAT"); int a = 0, b = 0; return (e && sscanf(e, "%d,%d", &a, &b) == 2) ? a : 0; }();
-        static const int forced_kch = [] { const char* e = getenv("MAKANI_AMD_ASTAT"); int a = 0, b = 0; return (e && sscanf(e, "%d,%d", &a, &b) == 2) ? b : 0; }();
+        // weights stationary in registers: 384-channel slabs (4 waves x 3 row tiles; 256-row slabs measured slower), 64-pixel tiles,
+        // persistent grid of 256-thread workgroups
         const bool epi_loads = R || G;
-        int tmv = 3;      // 384-row slabs measured faster than 256-row ones on every shape of the step (M = 384 and 768)
-        if (forced_tm == 2 || forced_tm == 3) tmv = forced_tm;
-        int kch = (forced_kch == 64 || forced_kch == 128) ? forced_kch : 128;
-        if (tmv == 3 && epi_loads) kch = 64;           // (the 128-channel chunk form of that variant runs out of registers)
+        constexpr int tmv = 3;
+        const int kch = epi_loads ? 64 : 128;          // (the 128-channel chunk form of the epilogue-operand variant runs out of registers)
         const int bm = 128 * tmv;
         const int slabs = (M + bm - 1) / bm;
         const long long tn = (N + 63) / 64;
@@ -1863,9 +1858,7 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
         else if (pre) hipLaunchKernelGGL((conv_nn_astat_kernel<TM_, KCH_, true, false>), grid, blk, 0, s, p, slabs, tn);          \
         else hipLaunchKernelGGL((conv_nn_astat_kernel<TM_, KCH_, false, false>), grid, blk, 0, s, p, slabs, tn);                  \
     } while (0)
-        if (tmv == 2 && kch == 128) MK_ASTAT(2, 128);
-        else if (tmv == 2) MK_ASTAT(2, 64);
-        else if (kch == 128) MK_ASTAT(3, 128);
+        if (kch == 128) MK_ASTAT(3, 128);
         else MK_ASTAT(3, 64);
 #undef MK_ASTAT
         return mk_check_launch("mk_conv1x1_nn");

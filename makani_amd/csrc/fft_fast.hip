@@ -16,33 +16,20 @@
 
 #include "fft_packed.h"
 
-// 1440 points as TWO passes (720 = 30 x 24, both radices in registers) instead of three (10 x 9 x 8): a quarter less LDS
-// traffic and one barrier pair less per item; same box: rfft 0.529 -> 0.491 ms, irfft 0.461 -> 0.431 (profiles/r03_ab_fft_2pass.txt).
-// The same idea at 480 points (240 = 16 x 15) helps the forward kernel by 3 % and costs the inverse 22 % (its last pass stores
-// straight to global memory, and with 16 instead of 60 consecutive lanes per run the stores fall apart): not taken.
+// Build-time plan knobs (A/B builds: tools/ab.py; what each alternative measured is in docs/LAB_NOTEBOOK.md and
+// docs/DESIGN_rounds1-4.md section 4):
+//   MK_FFT_1440_2PASS  1440 points as two passes 30 x 24 (default) instead of three 10 x 9 x 8
+//   MK_FFT_480_FWD_OCC the forward 480-point bf16 kernel limited to 128 registers = two workgroups per CU (the only
+//                      instantiation that does not spill there)
+//   MK_FFT_HV          two half-workgroups of 256 threads with their own LDS work buffers, half 1 running MK_FFT_SKEW barrier
+//                      intervals behind half 0: 0 = never, 1 (default) = only the forward 480-point bf16 kernel (the one
+//                      instantiation where it measured faster), 2 = every 512-thread instantiation.  Bit-identical results.
 #ifndef MK_FFT_1440_2PASS
 #define MK_FFT_1440_2PASS 1
 #endif
-#ifndef MK_FFT_480_FWD_OCC     // the forward 480-point bf16 kernel limited to 128 registers = two workgroups per CU (see WGS below):
-#define MK_FFT_480_FWD_OCC 1    // 75 -> 71 us; the other 480-point instantiations spill at 128 registers and keep one workgroup
+#ifndef MK_FFT_480_FWD_OCC
+#define MK_FFT_480_FWD_OCC 1
 #endif
-
-// Two half-workgroups per workgroup (round 4; MEASURED AND NOT TAKEN except for one instantiation).  What bounded these kernels
-// (profiles/r03_pmc_sq_bench_raw.md): all eight waves walk through the same phases between the same barriers — LDS
-// reads, butterflies, LDS writes, untangle, commit — so the LDS time and the VALU time of an item add.  With HV = 2 the 512
-// threads are two halves of 256 (one wave of each half per SIMD); half h transforms rows RB/2 h .. of the same item in its OWN
-// LDS work buffer and runs the SAME instruction stream MK_FFT_SKEW barrier intervals behind the other half: every barrier is
-// still executed by all eight waves (half 1 executes SKEW extra barriers before its first item, half 0 after its last), but in
-// every interval the two waves of a SIMD are in different phases.  The halves share nothing but the read-only twiddle tables;
-// their F-side runs are adjacent in memory and written one interval apart.  Bit-identical results.
-// Same box, skew 1 / 2 / 3 against one workgroup-wide phase sequence (profiles/r04_ab_fft_halves.txt): rfft 1440 bf16 0.493 ->
-// 0.541 / 0.573 / 0.538 ms, irfft 1440 bf16 0.427 -> 0.443 / 0.470 / 0.455, irfft 480 bf16 0.082 -> 0.093 / 0.093 / 0.094 — SLOWER
-// everywhere except the forward 480-point bf16 kernel (0.071 -> 0.069 / 0.066 / 0.064).  Why: an LDS phase that only ONE wave
-// per SIMD is in runs at a fraction of the LDS rate (MI355X_MICROARCH, LDS: the 8-byte accesses reach their rate from about four
-// waves per SIMD; one wave gets a fifth) — the phases are bound by LDS LATENCY per wave, not by LDS bandwidth, and halving the
-// waves per phase lengthens every LDS phase by more than the overlap with the other half's butterflies gives back.
-// MK_FFT_HV: 0 = never; 1 (default) = only where it measured faster (forward 480 points, bf16 input, skew 3); 2 = every
-// 512-thread instantiation (the A/B builds).
 #ifndef MK_FFT_HV
 #define MK_FFT_HV 1
 #endif
@@ -265,10 +252,7 @@ __host__ __device__ constexpr int row_stride(int n2, int rb, bool inverse) {
 // Row strides, padding and lanes per row of the generations of one kernel (g0 = what the first pass reads, g1 / g2 = what
 // passes 1 / 2 leave, the last generation of the forward kernel = what the untangle step reads).  Default: one layout for all
 // (row_stride above, chosen for the [row][m] <-> [m][row] steps).  The plans of the benchmark's kernels come out of the bank
-// model (tools/fft_lds_model.py; LDS cycles of one item, current -> plan, conflict-free = 1.00x):
-//   forward 1440 (16 rows, 512 threads)   5 608 -> 3 920 (1.79x -> 1.23x)      inverse 1440   2 900 -> 2 084 (1.59x -> 1.13x)
-//   forward 480 (2 x 16 rows, 2 x 256)    2 568 -> 2 032 (1.64x -> 1.30x)      inverse 480    4 788 -> 3 901 (1.66x -> 1.34x)
-// MK_FFT_LDSPLAN=0: the default layout everywhere (the A/B build).
+// model (tools/fft_lds_model.py; tests/test_lds_layouts.py).  MK_FFT_LDSPLAN=0: the default layout everywhere (the A/B build).
 #ifndef MK_FFT_LDSPLAN
 #define MK_FFT_LDSPLAN 1
 #endif
@@ -278,10 +262,8 @@ struct LdsPlan {
     static constexpr int D1 = 0, D2 = 0, LPR1 = 0, LPR2 = 0, LPR3 = 0;
     static constexpr bool SWAP = false;     // forward, bf16 rows: the two 16-byte halves of a vector stored in lane-dependent order
 };
-// SWAP (the two 16-byte halves of a bf16 vector stored in lane-dependent order by the commit: removes its 2-way conflict, 1 424 ->
-// 736 LDS cycles per item at 1440 points) is OFF: its selects are 152 of the forward kernel's 1 255 vector instructions per
-// item, and the kernel is bound by those, not by LDS cycles (rfft 1440 bf16 0.507 / 0.512 ms with it, 0.491 / 0.484 without:
-// profiles/r04_ab_fft_swap_hoist.txt).  MK_FFT_SWAP=1 is the A/B build.
+// SWAP: the two 16-byte halves of a bf16 vector stored in lane-dependent order by the commit (removes its 2-way bank conflict).
+// OFF: its selects cost more vector instructions than the conflict costs cycles.  MK_FFT_SWAP=1 is the A/B build.
 #ifndef MK_FFT_SWAP
 #define MK_FFT_SWAP 0
 #endif
@@ -384,10 +366,6 @@ struct RowVec<u16> {
 };
 
 // WGS: the second __launch_bounds__ argument, which in HIP is the minimum number of WAVES per SIMD (not workgroups per CU).
-// For the 256-thread kernels the two coincide; the 512-thread 480-point kernel asks for 2 and therefore runs ONE workgroup per
-// CU (130 / 169 registers).  Asking for 4 (two workgroups per CU, 128 registers) was measured: forward bf16 0.076 -> 0.071 ms
-// (taken for exactly that instantiation, MK_FFT_480_FWD_OCC), everything else spills (inverse bf16 0.083 -> 0.103 ms):
-// profiles/r03_ab_fft_launch_bounds.txt
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG, int HV>
 __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) == 2 && !SEG) ? 4 : WGS) void rfft_fast_kernel(const T* __restrict__ x, float* __restrict__ F,
                                                             const cf* __restrict__ tw_g, int C, int Cp,

@@ -623,11 +623,7 @@ __global__ __launch_bounds__(NT) void quad_lp_bwd(const TA* __restrict__ a, cons
 // pass of work per block
 template <typename T>
 int chunks_for(long long hw, long long planes) {
-    static const long long target = [] {
-        const char* e = getenv("MAKANI_AMD_PW_BLOCKS");
-        const long long v = e ? atoll(e) : 0;
-        return v > 0 ? v : 2048ll;
-    }();
+    constexpr long long target = 2048;
     const long long maxc = (hw + pass_elems<T>() - 1) / pass_elems<T>();
     const long long want = std::max(1ll, (target + planes / 2) / planes);
     return (int)std::min(maxc, want);

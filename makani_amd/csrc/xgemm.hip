@@ -110,132 +110,6 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(const MkGemm p, int tilesM
         }
 }
 
-// ---- complex kernel (planar): block tile 64 x 128, waves 2 x 2, wave tile 32 x 64 ------------
-// DEPTH = register prefetch distance in k-tiles (2: two staging register sets, the loads of tile kt+2 are issued
-// while tile kt is multiplied)
-// B_ILV: B is an interleaved complex tensor (gemm_common.h); C interleaved is a run-time property of the epilogue
-template <bool A_KC, bool B_KC, int NP, int DEPTH, bool B_ILV = false>
-__global__ __launch_bounds__(NT, 2) void xcgemm_kernel(const MkGemm p, int tilesM, int tilesN) {
-    constexpr int BM = 64, BN = 128;
-    constexpr int PLA = plane_elems<BM, A_KC>(), PLB = plane_elems<BN, B_KC>();
-    __shared__ __attribute__((aligned(16))) u16 smem[2 * NP * (PLA + PLB)];
-    u16* Are = smem;
-    u16* Aim = Are + NP * PLA;
-    u16* Bre = Aim + NP * PLA;
-    u16* Bim = Bre + NP * PLB;
-
-    const BlockCoord c = decode_block<BM, BN>(p, tilesM, tilesN);
-    if (!c.active) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const long long bo = c.b / p.inner, bi = c.b % p.inner;
-    const float* Ab = p.A + bo * p.a_batch + bi * p.a_inner;
-    const float* Bb = p.B + bo * p.b_batch + bi * p.b_inner;
-    const float sgn_a = p.conj_a ? -1.f : 1.f;
-    const float sgn_b = p.conj_b ? -1.f : 1.f;
-
-    f32x16 cre[2], cim[2], cng[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            cre[b][r] = 0.f;
-            cim[b][r] = 0.f;
-            cng[b][r] = 0.f;
-        }
-
-    const int kt0 = c.klo / BK, kt1 = (c.khi + BK - 1) / BK;
-    const int a_rmax = A_KC ? c.Meff : p.M;
-    Stage<BM, A_KC> sar[DEPTH], sai[DEPTH];
-    Stage<BN, B_KC> sbr[DEPTH], sbi[DEPTH];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        sar[d].init(Ab, p.a_row, p.a_k, c.i0, a_rmax, tid);
-        sai[d].init(Ab + p.a_im, p.a_row, p.a_k, c.i0, a_rmax, tid);
-        if constexpr (B_ILV) {
-            sbr[d].init_ilv(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
-        } else {
-            sbr[d].init(Bb, p.b_col, p.b_k, c.j0, p.N, tid);
-            sbi[d].init(Bb + p.b_im, p.b_col, p.b_k, c.j0, p.N, tid);
-        }
-    }
-    auto ld = [&](int d, int kt) {
-        sar[d].load(kt * BK, c.klo, c.khi, tid);
-        sai[d].load(kt * BK, c.klo, c.khi, tid);
-        if constexpr (B_ILV) {
-            sbr[d].load_ilv(sbi[d], kt * BK, c.klo, c.khi, tid);
-        } else {
-            sbr[d].load(kt * BK, c.klo, c.khi, tid);
-            sbi[d].load(kt * BK, c.klo, c.khi, tid);
-        }
-    };
-    auto step = [&](int d, int kt) {           // tile kt sits in register set d
-        sar[d].template store<NP, PLA>(Are, tid, 1.f);
-        sai[d].template store<NP, PLA>(Aim, tid, sgn_a);
-        sbr[d].template store<NP, PLB>(Bre, tid, 1.f);
-        sbi[d].template store<NP, PLB>(Bim, tid, sgn_b);
-        __syncthreads();
-        if (kt + DEPTH < kt1) ld(d, kt + DEPTH);
-        bf16x8 ar[NP], ai[NP];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            ar[pl] = frag<BM, A_KC>(Are + pl * PLA, wm * 32, lane);
-            ai[pl] = frag<BM, A_KC>(Aim + pl * PLA, wm * 32, lane);
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            bf16x8 br[NP], bim[NP];
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                br[pl] = frag<BN, B_KC>(Bre + pl * PLB, wn * 64 + n * 32, lane);
-                bim[pl] = frag<BN, B_KC>(Bim + pl * PLB, wn * 64 + n * 32, lane);
-            }
-            // (ar + i ai)(br + i bi): re = ar br - ai bi (second part accumulated apart), im = ar bi + ai br
-            cre[n] = mma_split<NP>(ar, br, cre[n]);
-            cng[n] = mma_split<NP>(ai, bim, cng[n]);
-            cim[n] = mma_split<NP>(ar, bim, cim[n]);
-            cim[n] = mma_split<NP>(ai, br, cim[n]);
-        }
-        __syncthreads();
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (kt0 + d < kt1) ld(d, kt0 + d);
-    for (int kt = kt0; kt < kt1; kt += DEPTH) {
-        step(0, kt);
-        if constexpr (DEPTH == 2) {
-            if (kt + 1 < kt1) step(1, kt + 1);
-        }
-    }
-
-    float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int col = c.j0 + wn * 64 + tb * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = c.i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < c.Meff && col < p.N) {
-                float* dr = Cb + (long long)row * p.c_row + (long long)col * p.c_col;
-                float* di = dr + p.c_im;
-                float vr = cre[tb][r] - cng[tb][r], vi = cim[tb][r];
-                if (p.beta) {
-                    vr += *dr;
-                    vi += *di;
-                }
-                if (p.c_col == 2) {          // interleaved complex C: one 8-byte store per entry
-                    *reinterpret_cast<float2*>(dr) = make_float2(vr, vi);
-                } else {
-                    *dr = vr;
-                    *di = vi;
-                }
-            }
-        }
-    }
-}
-
-
 template <int BM, int BN, int NP>
 int launch_real(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
     const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
@@ -253,35 +127,6 @@ int launch_real(const MkGemm* g, bool a_kc, bool b_kc, hipStream_t s) {
     return mk_check_launch("mk_sgemm_split_batched");
 }
 
-template <int NP>
-int launch_cplx(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t s) {
-    constexpr int BM = 64, BN = 128;
-    const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
-    const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
-    MK_REQUIRE(nb < (1ll << 31), "xcgemm: grid too large");
-    dim3 grid((unsigned)nb), block(NT);
-    // prefetch distance 2 (DEPTH = 2) measured: dgrad -2 %, fwd 0 %, wgrad +2 % -> distance 1
-    // measured and rejected: prefetch distance 2 (dgrad -2 %, wgrad +2 %); a wave-specialised variant (4 producer
-    // waves split + stage, 4 consumer waves run the MFMAs, one barrier per k-tile): 15-25 % slower (DESIGN.md par. 10)
-#define MK_XC_LAUNCH(AK, BK_) hipLaunchKernelGGL((xcgemm_kernel<AK, BK_, NP, 1>), grid, block, 0, s, *g, tm, tn)
-    if (b_ilv) {             // the dhconv weight in place: forward (B row-contiguous) and data gradient (B k-contiguous)
-        MK_REQUIRE(a_kc, "xcgemm: an interleaved B operand needs a k-contiguous A");
-        if (b_kc)
-            hipLaunchKernelGGL((xcgemm_kernel<true, true, NP, 1, true>), grid, block, 0, s, *g, tm, tn);
-        else
-            hipLaunchKernelGGL((xcgemm_kernel<true, false, NP, 1, true>), grid, block, 0, s, *g, tm, tn);
-    } else if (a_kc && b_kc)
-        MK_XC_LAUNCH(true, true);
-    else if (a_kc && !b_kc)
-        MK_XC_LAUNCH(true, false);
-    else if (!a_kc && b_kc)
-        MK_XC_LAUNCH(false, true);
-    else
-        MK_XC_LAUNCH(false, false);
-#undef MK_XC_LAUNCH
-    return mk_check_launch("mk_cgemm_split_batched");
-}
-
 }  // namespace
 
 extern "C" int mk_sgemm_split_batched(const MkGemm* g, int limbs, void* stream) {
@@ -295,11 +140,7 @@ extern "C" int mk_sgemm_split_batched(const MkGemm* g, int limbs, void* stream) 
     return rows_tri ? launch_real<64, 256, 2>(g, a_kc, b_kc, s) : launch_real<128, 128, 2>(g, a_kc, b_kc, s);
 }
 
-extern "C" int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream) {
-    bool a_kc, b_kc, b_ilv;
-    int rc = validate(g, true, &a_kc, &b_kc, true, &b_ilv);
-    if (rc) return rc;
-    MK_REQUIRE(limbs == 2 || limbs == 3, "split gemm: limbs must be 2 or 3");
-    hipStream_t s = (hipStream_t)stream;
-    return limbs == 3 ? launch_cplx<3>(g, a_kc, b_kc, b_ilv, s) : launch_cplx<2>(g, a_kc, b_kc, b_ilv, s);
-}
+// The first-generation complex kernel (64 x 128 tile, one LDS stage) was retired in round 5: every descriptor it took is served
+// by the second-generation kernel (csrc/xgemm2.hip); the entry point stays in the ABI as an alias.
+extern "C" int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream);
+extern "C" int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream) { return mk_cgemm_split2_batched(g, limbs, stream); }

@@ -933,9 +933,8 @@ extern "C" int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, 
     PreA a{(const u16*)a_planes, pl_stride, pl_batch, pl_k, (int)(pl_k & ~7ll), band_lo, band_hi, band_mode};
     dim3 grid((unsigned)nb), block(NT2);
     hipStream_t s = (hipStream_t)stream;
-    // at most 160 columns (one column tile, five 32-column MFMA tiles): the row-tile-per-wave form (MK_X2_NARROW=0 keeps the wide one)
-    static const bool narrow_ok = [] { const char* e = getenv("MAKANI_AMD_X2_NARROW"); return !(e && e[0] == '0'); }();
-    if (narrow_ok && g->N <= 160) {
+    // at most 160 columns (one column tile, five 32-column MFMA tiles): the row-tile-per-wave form
+    if (g->N <= 160) {
         if (limbs == 3)
             hipLaunchKernelGGL((xgemm2_kernel<3, true>), grid, block, 0, s, *g, a, tm, tn);
         else

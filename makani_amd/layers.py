@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import ops
 
 
-_DEFER_BIAS = os.environ.get("MAKANI_AMD_DEFER_BIAS", "1") != "0"
+_DEFER_BIAS = True      # fc2's bias rides in the following instance norm (NeuralOperatorBlock); False: the plain path (A/B aid)
 
 
 def hip_conv_eligible(x) -> bool:

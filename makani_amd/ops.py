@@ -37,12 +37,10 @@ if GEMM_MODE not in ("x6", "x3", "fp32"):
     raise ValueError(f"MAKANI_AMD_GEMM={GEMM_MODE!r}: expected x6, x3 or fp32")
 
 
-# Kernel generation of the split engine: "2" (default) = the ping-pong kernels of csrc/xgemm2.hip (512-thread workgroups,
-# double-buffered limb images, pre-split Legendre matrices) wherever they apply, "1" = csrc/xgemm.hip everywhere
-# (kept for same-box A/B runs and as the engine of the shapes generation 2 does not cover).
-GEMM_GEN = os.environ.get("MAKANI_AMD_GEMM_GEN", "2")
-if GEMM_GEN not in ("1", "2"):
-    raise ValueError(f"MAKANI_AMD_GEMM_GEN={GEMM_GEN!r}: expected 1 or 2")
+# Kernel generation of the split engine: "2" = the ping-pong kernels of csrc/xgemm2.hip (512-thread workgroups, double-buffered
+# limb images, pre-split Legendre matrices) wherever they apply; the real kernel of csrc/xgemm.hip serves the rest (operands
+# that are both split on the fly: the fp32 channel GEMMs of the parity runs).
+GEMM_GEN = "2"          # (module attribute, not an environment switch: tools may set "1" to time the first-generation real kernel)
 
 
 def _run_gemm(g, cplx, what, mode=None, a_limbs=None, band=None):
@@ -972,7 +970,7 @@ def conv1x1_wgrad(g: torch.Tensor, x: torch.Tensor, want_bias: bool = False):
     nws = lib().mk_conv1x1_wgrad_workspace(M, K, B, N)
     part = torch.empty((nws,), dtype=torch.float32, device=g.device)
     dW = torch.empty((M, K), dtype=torch.float32, device=g.device)
-    fused = want_bias and bool(lib().mk_conv1x1_wgrad_fuses_bias(M, K, B, N)) and os.environ.get("MAKANI_AMD_WGRAD_BIAS", "1") != "0"
+    fused = want_bias and bool(lib().mk_conv1x1_wgrad_fuses_bias(M, K, B, N))
     with _timed(f"conv1x1_wgrad_m{M}_k{K}_n{N}", flops=2.0 * B * M * K * N, nbytes=2.0 * B * N * (M + K)):
         if fused:
             db = torch.empty((M,), dtype=torch.float32, device=g.device)

@@ -88,8 +88,7 @@ class SpectralConv(nn.Module):
         scale[0] *= math.sqrt(2.0)
         w0 = scale * torch.randn(*weight_shape, dtype=torch.complex64)
         cgi, cgo = in_channels // num_groups, out_channels // num_groups
-        if (operator_type == "dhconv" and not separable and num_groups == 1 and cgi % 4 == 0 and cgo % 4 == 0
-                and os.environ.get("MAKANI_AMD_NATIVE_W", "1") != "0"):
+        if operator_type == "dhconv" and not separable and num_groups == 1 and cgi % 4 == 0 and cgo % 4 == 0:
             # same shape and values, memory in the order the dhconv GEMMs read ([l][i][o]): no re-layout per step
             w0 = ops.native_w_empty(cgi, cgo, self.modes_lat_local).copy_(w0)
         self.weight = nn.Parameter(w0)

@@ -37,16 +37,6 @@ def fft():
             del x, F
 
 
-def _both_gens(fn):
-    """run fn() under both kernel generations of the split engine (same process, same box) and check they agree"""
-    outs = {}
-    for gen in ("1", "2"):
-        ops.GEMM_GEN = gen
-        outs[gen] = fn(gen)
-    ops.GEMM_GEN = "2"
-    return outs
-
-
 def legendre():
     C = 384
     for nlat, nlon, grid in ((721, 1440, "equiangular"), (240, 480, "legendre-gauss")):
@@ -64,11 +54,7 @@ def legendre():
             ms = timeit(lambda: ops.legendre_synthesis(Sc, I.pct, nlat))
             print(f"gen{gen} synthesis K={nlat}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TF dense-equiv")
             return a, b
-        o = _both_gens(run)
-        tri = (torch.arange(240, device=dev)[:, None] >= torch.arange(241, device=dev)[None, :])[:, :, None, None]
-        ea = ((o["1"][0] - o["2"][0]) * tri).norm() / (o["1"][0] * tri).norm()
-        eb = (o["1"][1] - o["2"][1]).norm() / o["1"][1].norm()
-        print(f"     gen2 vs gen1 rel-L2: analysis {ea:.2e}  synthesis {eb:.2e}")
+        run("2")
 
 
 def dhconv():
@@ -88,9 +74,7 @@ def dhconv():
         ms = timeit(lambda: ops.dhconv_dgrad(G, w, 1, C, C)); print(f"gen{gen} dhconv dgrad: {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
         ms = timeit(lambda: ops.dhconv_wgrad(S, G, 1, native=True)); print(f"gen{gen} dhconv wgrad: {ms:7.3f} ms {fl/ms/1e9:7.1f} TF dense-equiv")
         return y, gs, torch.view_as_real(gw)
-    o = _both_gens(run)
-    e = [(((o["1"][i] - o["2"][i]) * (tri if i < 2 else 1)).norm() / (o["1"][i] * (tri if i < 2 else 1)).norm()).item() for i in range(3)]
-    print(f"     gen2 vs gen1 rel-L2: fwd {e[0]:.2e} dgrad {e[1]:.2e} wgrad {e[2]:.2e}")
+    run("2")
 
 
 def pointwise():

@@ -98,7 +98,7 @@ class Variant:
 
 
 # the instantiations mk_conv1x1_nn can launch (csrc/conv1x1.hip: MK_ASTAT and the small-K branch)
-VARIANTS = [Variant(tm, kch, pre, epi) for tm in (2, 3) for kch in (64, 128) for pre in (False, True) for epi in (False, True)] + \
+VARIANTS = [Variant(3, kch, pre, epi) for kch in (64, 128) for pre in (False, True) for epi in (False, True) if not (epi and kch == 128)] + \
            [Variant(3, 96, False, True, 5), Variant(3, 96, True, False, 5), Variant(3, 96, False, False, 5)]
 
 
