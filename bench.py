@@ -72,8 +72,8 @@ for _k, _v in FCN3_CONFIGS.items():
     CONFIGS[_k] = dict(kind="fcn3", inp_shape=_v["model"]["inp_shape"], out_shape=_v["model"]["out_shape"],
                        inp_chans=len(_v["model"]["channel_names"]) + len(_v["model"]["aux_channel_names"]),
                        out_chans=len(_v["model"]["channel_names"]), **_v)
-PMC_TRAFFIC = "r04_pmc_hbm_traffic.json"              # written by tools/profile_round.sh on this round's code
-PMC_TRAFFIC_FCN3 = "r03_pmc_hbm_traffic_fcn3.json"   # the FourCastNet3 kernels have not changed since
+PMC_TRAFFIC = "r05_pmc_hbm_traffic.json"              # written by tools/profile_round.sh on this round's code (fallback of the live passes)
+PMC_TRAFFIC_FCN3 = "r05_pmc_hbm_traffic_fcn3.json"
 PEAK_F32_VALU_TF = 157.3      # packed fp32 FMA on the vector ALUs (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0    # dense
@@ -189,6 +189,66 @@ def load_pmc_traffic(fcn3=False):
             return {k: v["hbm_bytes"] for k, v in json.load(fh).items() if isinstance(v, dict) and "hbm_bytes" in v}
     except (OSError, ValueError):
         return {}
+
+
+def live_pmc_traffic(cfg_name, timeout_s=None):
+    """HBM bytes per launch of every kernel family, measured IN THIS RUN: two child runs of this same script (the same workload,
+    2 eager steps) under ``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` — separate passes, counters only, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes —, summarised per kernel symbol (tools/pmc_summary.py) and mapped to the
+    launch families with the guide's gfx950 corrections (tools/pmc_traffic.py).  Returns ({family: bytes}, note); an empty dict
+    when rocprofv3 is missing, a pass fails or runs out of time (the caller then falls back to the committed file and says so)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if timeout_s is None:
+        timeout_s = 420 if CONFIGS.get(cfg_name, {}).get("kind") == "fcn3" else 240
+    if shutil.which("rocprofv3") is None:
+        return {}, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary
+        import pmc_traffic
+    except Exception as e:
+        return {}, f"tools/pmc_*.py not importable ({type(e).__name__})"
+    work = tempfile.mkdtemp(prefix="mk_pmc_")
+    mds = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--config", cfg_name, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sht-metric", "--graph", "off", "--no-pmc"]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, cwd="/tmp",
+                                   env=dict(os.environ, TMPDIR="/tmp"))
+            except subprocess.TimeoutExpired:
+                return {}, f"the {counter} pass did not finish within {timeout_s} s"
+            files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not files:
+                return {}, f"the {counter} pass failed (rocprofv3 exit code {r.returncode}, {len(files)} counter files)"
+            md = os.path.join(work, counter + ".md")
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                pmc_summary.main(md, files)
+            mds[counter] = md
+        js = os.path.join(work, "traffic.json")
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            pmc_traffic.main(mds["FETCH_SIZE"], mds["WRITE_SIZE"], js, "fcn3" if CONFIGS.get(cfg_name, {}).get("kind") == "fcn3" else "sfno")
+        with open(js) as fh:
+            data = json.load(fh)
+        keep = os.environ.get("MAKANI_AMD_PMC_KEEP")          # tools/profile_round.sh: keep the per-kernel counter tables of this run
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            for src in (mds["FETCH_SIZE"], mds["WRITE_SIZE"], js):
+                shutil.copy(src, os.path.join(keep, os.path.basename(src)))
+        return ({k: v["hbm_bytes"] for k, v in data.items() if isinstance(v, dict) and "hbm_bytes" in v},
+                "measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over 2 eager steps of the same workload")
+    except Exception as e:                       # never lose the benchmark line to the counters
+        return {}, f"{type(e).__name__}: {str(e)[:160]}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def parse_parallelism(par):
@@ -681,6 +741,8 @@ def run_worker(args):
     graph, graph_note = None, None
     graph_mode = os.environ.get("MAKANI_AMD_BENCH_GRAPH", args.graph)
     want_graph = graph_mode == "on" or (graph_mode == "auto" and (world == 1 or backend == "nccl"))
+    if world > 1 and CONFIGS[args.config].get("kind") == "fcn3" and graph_mode != "on":
+        want_graph = False          # the DISCO halo exchange is a batched isend / irecv, which does not survive capture here
     if want_graph:
         try:
             side = torch.cuda.Stream()
@@ -821,11 +883,42 @@ def run_worker(args):
             print("[bench] train loop done; measuring fwd SHT", file=sys.stderr, flush=True)
             out["fwd_sht"] = sht_bandwidth(device)
             print("[bench] fwd SHT done; CPU baseline", file=sys.stderr, flush=True)
+        # roofline.traffic measured in THIS run: the two counter passes are child runs of this script under rocprofv3 and use
+        # the GPU; they run beside the CPU baseline child (host cores only), so the line is not later for them
+        pmc_thread, pmc_live = None, {}
+        want_pmc = (world == 1 and not args.no_pmc and roofline is not None and args.multistep_count == 1
+                    and args.config in ("sfno_sc3_layers8_edim384", "fcn3_sc2_edim45_layers10"))
+        if want_pmc:
+            # the counter passes build their own copy of the model: give the memory of this process back first (FourCastNet3
+            # holds 128 GB per copy)
+            model = net = opt = graph = graph_loss = loss = loss_fn = inp = tar = None      # noqa: F841 (drops the references)
+            import gc as _gc
+            _gc.collect()
+            torch.cuda.empty_cache()
+            import threading
+            pmc_thread = threading.Thread(target=lambda: pmc_live.update(zip(("data", "note"), live_pmc_traffic(args.config))), daemon=True)
+            pmc_thread.start()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, parity=probe)
             out["parity_rel_l2"] = probe.finish() if probe is not None else None
         else:
             out["cpu_baseline"] = None
+        if pmc_thread is not None:
+            pmc_thread.join(timeout=900)
+            live = pmc_live.get("data") or {}
+            for r in [out.get("roofline")] + list(out.get("roofline_runners_up") or []):
+                if not r:
+                    continue
+                if r["kernel"] in live:
+                    r["traffic"] = live[r["kernel"]]
+                    r["traffic_source"] = pmc_live.get("note")
+                elif r.get("traffic") is not None:
+                    r["traffic_source"] = (f"profiles/{PMC_TRAFFIC_FCN3 if fcn3 else PMC_TRAFFIC} (committed counter passes of the same "
+                                           f"command; the live passes of this run gave nothing for this family: {pmc_live.get('note')})")
+                else:
+                    r["traffic_source"] = f"none: {pmc_live.get('note')}"
+        elif out.get("roofline") and out["roofline"].get("traffic") is not None:
+            out["roofline"]["traffic_source"] = f"profiles/{PMC_TRAFFIC_FCN3 if fcn3 else PMC_TRAFFIC} (committed counter passes of the same command)"
     if world > 1:
         dist.barrier()
         if graph is not None:
@@ -987,6 +1080,8 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (not the BASELINE metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sht-metric", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 counter passes in this run "
+                                                          "(the committed profiles/ file is used instead)")
     ap.add_argument("--parallelism", default=os.environ.get("MAKANI_AMD_PARALLELISM", "auto"),
                     help="'auto' (default: dp on one GPU; on N > 1 the north-star split h x w over all N GPUs — 2: h2w1, "
                          "4: h4w1, 8: h4w2 — strong scaling), 'dp' (one sample per GPU, weak scaling) or 'hHwW': spatial "

@@ -169,7 +169,14 @@ def _worker_sht(rank, world, port, h, w, nlat, nlon, lmax, mmax, grid, B, C, fus
         fwd = thd.DistributedRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
         inv = thd.DistributedInverseRealSHT(nlat, nlon, lmax=lmax, mmax=mmax, grid=grid)
         from makani_amd import dist_pipeline as dp
+        dp.FALLBACKS.clear()
         assert dp.eligible(fwd, x.dtype) == fused and dp.eligible(inv, x.dtype) == fused
+        # a transform that leaves the fused schedule says so (once per transform and dtype), with the reason
+        if fused:
+            assert dp.FALLBACKS == []
+        else:
+            assert [f[0] for f in dp.FALLBACKS] == ["DistributedRealSHT", "DistributedInverseRealSHT"], dp.FALLBACKS
+            assert all("segmented" in f[3] for f in dp.FALLBACKS), dp.FALLBACKS          # (the plain test backend has no SEG kernels)
         assert fwd.lat_shapes == thd.compute_split_shapes(nlat, h) and fwd.m_shapes == thd.compute_split_shapes(mmax, w)
         lat0, lon0 = sum(fwd.lat_shapes[:ih]), sum(fwd.lon_shapes[:iw])
         l0, m0 = sum(fwd.l_shapes[:ih]), sum(fwd.m_shapes[:iw])

@@ -545,3 +545,15 @@ def test_fused_schedule_plan_invariants():
                     # (ih, iw): lat(ih) x M_loc(j) x 2 x sub(iw, i) rows of its block G[iw]
                     q = ps[(i, j)]
                     assert p.slab[j][i] == p.hl * q.Ml * 2 * q.sub[iw][i] == q.lat[ih] * q.Ml * 2 * p.sub[iw][i]
+
+
+def test_share_gpu_sets_disjoint_compute_unit_ranges(monkeypatch):
+    """ranks that share ONE GPU in a functional run get disjoint HSA_CU_MASK ranges (makani_amd/comm.py: share_gpu says why)"""
+    import makani_amd.comm as mcomm
+    monkeypatch.delenv("HSA_CU_MASK", raising=False)
+    masks = [mcomm.share_gpu(r, 8) for r in range(8)]
+    assert masks[0] == "0:0-31" and masks[7] == "0:224-255" and os.environ["HSA_CU_MASK"] == masks[7]
+    spans = [tuple(int(v) for v in m.split(":")[1].split("-")) for m in masks]
+    assert all(b - a == 31 for a, b in spans) and all(spans[i][1] < spans[i + 1][0] for i in range(7))
+    assert mcomm.share_gpu(0, 1) == "0:0-255"
+    monkeypatch.delenv("HSA_CU_MASK", raising=False)
