@@ -621,7 +621,11 @@ def default_parallelism(world, cfg_name="sfno_sc3_layers8_edim384"):
     (configs[3]): "8 MI355X, h=2 w=2 + data-parallel" """
     if CONFIGS.get(cfg_name, {}).get("kind") == "fcn3":
         return {1: "dp", 2: "h2w1", 4: "h2w2", 8: "h2w2"}.get(world, "dp")
-    return {1: "dp", 2: "h2w1", 4: "h4w1", 8: "h4w2"}.get(world, "dp")
+    # 2 GPUs: data parallel.  BASELINE.json prescribes the spatial split for 4 (configs[2]: h = 4) and 8 GPUs (configs[4]: h4 w2)
+    # only; the reference's partitioning has no 2-GPU split worth running on xGMI — h2 w1 sends 3.7 GB per step and rank over the
+    # ONE link between the two GPUs (24 ms at 153 GB/s: slower than one GPU, profiles/r05_shard_shapes.md) — while two
+    # data-parallel replicas exchange 2.3 GB of gradients behind their backward passes.  `--parallelism h2w1` still runs it.
+    return {1: "dp", 2: "dp", 4: "h4w1", 8: "h4w2"}.get(world, "dp")
 
 
 def run_worker(args):
@@ -1031,7 +1035,9 @@ def launch(args):
             nport += 1
             port = (base_port + nport) if under_torchrun else _free_port()
             os.environ.update(env_over)
-            res, err = _run_phase(args, par, ranks, world, port, timeout_s)
+            # the first attempt (captured step) gets a shorter leash: a capture that hangs must not eat the time of the eager retry
+            first_graph = (not env_over) and eager
+            res, err = _run_phase(args, par, ranks, world, port, min(timeout_s, 200) if first_graph else timeout_s)
             for k in env_over:
                 os.environ.pop(k, None)
             if env_over and res is not None and not err:

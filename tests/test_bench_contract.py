@@ -44,14 +44,14 @@ def test_bench_multistep_rollout_runs():
 
 @pytest.mark.gpu
 def test_bench_launches_its_own_ranks_headline_split_and_secondary_dp():
-    """``python bench.py --gpus 2`` (no torchrun): the script spawns its two ranks, measures the north-star split
-    (h2w1, strong scaling) and then data parallelism as ``secondary``.  Functional run on ONE GPU: both ranks share
-    cuda:0 and exchange through gloo (host-staged)."""
+    """``python bench.py --gpus 2 --parallelism h2w1`` (no torchrun): the script spawns its two ranks, measures the spatial split
+    (h2w1, strong scaling) and then data parallelism as ``secondary`` (the DEFAULT at 2 GPUs is data parallelism alone:
+    bench.default_parallelism).  Functional run on ONE GPU: both ranks share cuda:0 and exchange through gloo (host-staged)."""
     env = dict(os.environ, MAKANI_AMD_BENCH_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "sfno_debug", "--steps", "2",
-                          "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                          "--warmup", "1", "--parallelism", "h2w1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
