@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r05r
-timeout 600 python tools/glue_trace.py > gpurun_out/r05r/glue_trace.txt 2>&1; echo rc $?
-grep -v "amdgpu.ids\|Warning\|warn" gpurun_out/r05r/glue_trace.txt | head -120 | cut -c1-260
+mkdir -p gpurun_out/r05s
+timeout 600 python -m pytest tests/test_gpu_distributed.py -x -q -s -k "spatial_parallel_sfno" > gpurun_out/r05s/toy.log 2>&1; echo rc $?
+grep "rank \|passed\|failed\|Error" gpurun_out/r05s/toy.log | cut -c1-200 | head -40

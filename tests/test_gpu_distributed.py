@@ -26,6 +26,12 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
+# distributed against serial HIP in fp32, 16-channel toy network.  Rounds 2-4 needed 1e-4 / 2e-4 / 5e-4 here because the ranks
+# shared compute units (docs/LAB_NOTEBOOK.md 5.1); with a compute-unit range per rank the two schedules agree to summation order:
+# measured y 4e-7 ... 7e-7, gx 8e-7 ... 1.4e-6, worst parameter gradient 2.4e-6 ... 4.2e-6 (gpurun_out/r05s)
+TOL_Y, TOL_G = 5e-6, 2e-5
+
+
 def _worker(rank, world, port, h, w, norm="instance_norm"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -80,8 +86,9 @@ def _worker(rank, world, port, h, w, norm="instance_norm"):
         assert yl.shape == (B, 4, hl, wl)
         e_y = _rel(yl, ys[..., lat0:lat0 + hl, lon0:lon0 + wl])
         e_gx = _rel(xl.grad, xs.grad[..., lat0:lat0 + hl, lon0:lon0 + wl])
-        assert e_y < 1e-4 and e_gx < 2e-4, (rank, e_y, e_gx)
+        assert e_y < TOL_Y and e_gx < TOL_G, (rank, e_y, e_gx)
         sref = dict(serial.named_parameters())
+        worst = ("", 0.0)
         for k, p in model.named_parameters():
             g = (torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad).detach().cpu().contiguous()
             if k.endswith("filter.filter.weight"):           # sharded over h, shared over w
@@ -91,10 +98,12 @@ def _worker(rank, world, port, h, w, norm="instance_norm"):
             else:                                            # replicated: partial gradients sum over spatial
                 dist.all_reduce(g)
                 ref = sref[k].grad.cpu()
-            if k.endswith("mlp.fwd.3.bias"):
+            if k.endswith("mlp.fwd.3.bias"):                 # (exactly zero by construction: a constant in front of an instance norm)
                 continue
             e = _rel(g, ref)
-            assert e < 5e-4, (rank, k, e)
+            worst = max(worst, (k, e), key=lambda t: t[1])
+            assert e < TOL_G, (rank, k, e)
+        print(f"h{h}w{w} {norm} rank {rank}: y {e_y:.1e} gx {e_gx:.1e} worst parameter gradient {worst[0]} {worst[1]:.1e}", flush=True)
         dist.barrier()
     finally:
         dist.destroy_process_group()
