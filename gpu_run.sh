@@ -1,3 +1,7 @@
-mkdir -p gpurun_out/r05s
-timeout 600 python -m pytest tests/test_gpu_distributed.py -x -q -s -k "spatial_parallel_sfno" > gpurun_out/r05s/toy.log 2>&1; echo rc $?
-grep "rank \|passed\|failed\|Error" gpurun_out/r05s/toy.log | cut -c1-200 | head -40
+# the last GPU call of round 5: the whole GPU suite on the final tree, then smoke (tools/r05_final.sh lists how every record was made)
+mkdir -p gpurun_out/r05u
+export MAKANI_AMD_DIST_LOG=$PWD/gpurun_out/r05u/dist_fullsize.txt
+SECONDS=0
+timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=15 > gpurun_out/r05u/gpu_suite.log 2>&1; echo "pytest rc $? in $SECONDS s"
+tail -22 gpurun_out/r05u/gpu_suite.log | cut -c1-200
+python __graft_entry__.py smoke 2>&1 | tail -2
