@@ -1,12 +1,10 @@
-# the last GPU call of round 5: the whole GPU suite on the final tree, then smoke (tools/r05_final.sh lists how every record was made)
-mkdir -p gpurun_out/r05u
-export MAKANI_AMD_DIST_LOG=$PWD/gpurun_out/r05u/dist_fullsize.txt
-SECONDS=0
-timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=15 > gpurun_out/r05u/gpu_suite.log 2>&1; echo "pytest rc $? in $SECONDS s"
-tail -22 gpurun_out/r05u/gpu_suite.log | cut -c1-200
-python __graft_entry__.py smoke 2>&1 | tail -2
-# configs[4] per rank: the 4-step rollout on one rank of h4 w2 (phantom collectives) and serially
-for cfg in "1 1" "4 2"; do set -- $cfg
-  timeout 400 python tools/shadow_rank.py --h $1 --w $2 --steps 3 --multistep-count 4 --json gpurun_out/r05u/shadow_ms4_h$1w$2.json > gpurun_out/r05u/shadow_ms4_h$1w$2.log 2>&1; echo "shadow ms4 h$1w$2 rc $?"
-  tail -1 gpurun_out/r05u/shadow_ms4_h$1w$2.log | cut -c1-700
-done
+mkdir -p gpurun_out/r05v
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_headline.py tests/test_gpu_model.py -x -q -k "wgrad or conv1x1 or bias or mlp or block_240" > gpurun_out/r05v/pytest.log 2>&1; echo "pytest rc $?"; tail -2 gpurun_out/r05v/pytest.log
+cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sht-metric --no-pmc > $GRAFT_REPO_ROOT/gpurun_out/r05v/bench.json 2>/dev/null
+python - <<'PY'
+import json,os
+d=json.load(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r05v/bench.json"))
+print(d['value'], d['ms_per_step'], d['hip_kernel_ms_per_step'])
+k=d['hip_kernels']
+print(sum(v['ms_per_step'] for n,v in k.items() if 'wgrad' in n))
+PY

@@ -1751,11 +1751,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const ConvWgR p
 #endif
 }
 
+// one output per thread (counts that are not multiples of 4, and the M bias sums of a weight gradient: three blocks whose
+// threads each walk S partials — with one load in flight that was S dependent memory latencies, 34 us per launch; eight
+// splits in flight as below, same summation order)
 __global__ void reduce_splits(const float* __restrict__ part, float* __restrict__ out, long long n, int S, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = accumulate ? out[i] : 0.f;
-    for (int k = 0; k < S; ++k) s += part[(long long)k * n + i];
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < S; ++k) s += part[(long long)k * n + i];
     out[i] = s;
 }
 
