@@ -747,6 +747,7 @@ def run_worker(args):
     want_graph = graph_mode == "on" or (graph_mode == "auto" and (world == 1 or backend == "nccl"))
     if world > 1 and CONFIGS[args.config].get("kind") == "fcn3" and graph_mode != "on":
         want_graph = False          # the DISCO halo exchange is a batched isend / irecv, which does not survive capture here
+    capture_tried = want_graph and world > 1              # (decides the teardown at the end of this function)
     if want_graph:
         try:
             side = torch.cuda.Stream()
@@ -925,9 +926,10 @@ def run_worker(args):
             out["roofline"]["traffic_source"] = f"profiles/{PMC_TRAFFIC_FCN3 if fcn3 else PMC_TRAFFIC} (committed counter passes of the same command)"
     if world > 1:
         dist.barrier()
-        if graph is not None:
-            # the captured step holds RCCL's send / recv kernels: tearing the communicator down under the live graph hangs
-            # (tools/probes/rccl_graph_probe.py) — the rank prints its result and leaves without the teardown
+        if capture_tried:
+            # a captured step (replayed, or discarded because another rank's capture failed) holds RCCL's send / recv kernels:
+            # tearing the communicator down after such a capture hangs (tools/probes/rccl_graph_probe.py) — the rank prints its
+            # result and leaves without the teardown
             torch.cuda.synchronize()
             if out is not None:
                 print(json.dumps(out), flush=True)
