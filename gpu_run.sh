@@ -1,10 +1,8 @@
-mkdir -p gpurun_out/r05v
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_headline.py tests/test_gpu_model.py -x -q -k "wgrad or conv1x1 or bias or mlp or block_240" > gpurun_out/r05v/pytest.log 2>&1; echo "pytest rc $?"; tail -2 gpurun_out/r05v/pytest.log
-cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sht-metric --no-pmc > $GRAFT_REPO_ROOT/gpurun_out/r05v/bench.json 2>/dev/null
+mkdir -p gpurun_out/r05x
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_headline.py tests/test_gpu_model.py tests/test_gpu_fcn3_distributed.py -x -q -k "wgrad or conv1x1 or bias or mlp or block_240 or fcn3" > gpurun_out/r05x/pytest.log 2>&1; echo "pytest rc $?"; tail -2 gpurun_out/r05x/pytest.log
+timeout 300 python tools/shadow_rank.py --h 4 --w 2 --steps 4 --json gpurun_out/r05x/shadow_h4w2.json > gpurun_out/r05x/shadow_h4w2.log 2>&1; echo "shadow rc $?"
 python - <<'PY'
-import json,os
-d=json.load(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r05v/bench.json"))
-print(d['value'], d['ms_per_step'], d['hip_kernel_ms_per_step'])
-k=d['hip_kernels']
-print(sum(v['ms_per_step'] for n,v in k.items() if 'wgrad' in n))
+import json
+d=json.load(open('gpurun_out/r05x/shadow_h4w2.json'))
+print(d['hip_kernel_ms_per_step'], d['graph_ms_per_step_phantom'], d['families']['conv1x1_wgrad'])
 PY

@@ -1954,7 +1954,10 @@ WgPlan wgrad_plan(int M, int K, int B, long long N) {
         pl.qslabs = (q + 383) / 384;
         long long per_b = 256 / ((long long)pl.slabs * pl.qslabs * B);
         if (per_b < 1) per_b = 1;
-        const long long maxs = (N + 1023) / 1024;    // at least 16 pixel tiles per split
+        // at least 512 pixels (8 tiles of 64) per split.  1024 left most of the chip idle on shard-sized grids (14 400 pixels per rank
+        // at h4 w2: 45 workgroups); 512: -20 ... -25 % per launch there, +-1 % at 115 200 pixels and above, 256 / 128 no better
+        // (profiles/r05_ab_wgrad_shard_minpx.txt)
+        const long long maxs = (N + 511) / 512;
         if (per_b > maxs) per_b = maxs;
         long long chunk = ((N + per_b - 1) / per_b + 63) / 64 * 64;
         per_b = (N + chunk - 1) / chunk;             // no empty splits
