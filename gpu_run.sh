@@ -1,8 +1,7 @@
-# last GPU call of round 5: the distributed / full-size / bench-contract GPU tests on the final tree (the whole suite ran two commits
-# earlier: profiles/r05_gpu_suite.txt; the kernel-side commits since then were covered by the 59 channel-GEMM / FCN3 tests of call 30)
-mkdir -p gpurun_out/r05zz
-export MAKANI_AMD_DIST_LOG=$PWD/gpurun_out/r05zz/dist_fullsize.txt
+# the filter bases beyond Morlet and the general-K DISCO kernels: new GPU tests, then the whole DISCO / FourCastNet3 test files
+mkdir -p gpurun_out/r05b
 SECONDS=0
-timeout 700 python -m pytest tests/test_gpu_dist_fullsize.py tests/test_gpu_distributed.py tests/test_gpu_optim.py tests/test_bench_contract.py -x -q -m gpu > gpurun_out/r05zz/pytest.log 2>&1; echo "pytest rc $? in $SECONDS s"
-tail -3 gpurun_out/r05zz/pytest.log
-python __graft_entry__.py smoke 2>&1 | tail -1
+timeout 150 python -m pytest tests/test_gpu_disco.py tests/test_fcn3.py -q -m gpu -k "other_bases or piecewise or zernike" > gpurun_out/r05b/new.log 2>&1; echo "new tests rc $? in $SECONDS s"
+tail -15 gpurun_out/r05b/new.log
+timeout 120 python -m pytest tests/test_gpu_disco.py tests/test_fcn3.py -x -q -m gpu > gpurun_out/r05b/files.log 2>&1; echo "files rc $? at $SECONDS s"
+tail -3 gpurun_out/r05b/files.log

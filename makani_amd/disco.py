@@ -24,8 +24,9 @@ the whole grid:
     ``W regrouped x (psi^T (*) g)`` (``DiscoConvFn``), each through the same kernels on the tensor or its transpose;
   * strided case (encoder, nlon_in = 2 nlon_out) and shapes the run form does not cover (``csrc/disco.hip``): lists in LDS,
     a lane owns output longitudes 256 apart; adjoint as a deterministic gather (no atomics).
-The convolution tensor is computed in fp64 numpy at construction (vectorised over the input grid).  Filter basis: "morlet"
-(the one FourCastNet3's recipe selects, ``config/fourcastnet3.yaml:34``).
+The convolution tensor is computed in fp64 numpy at construction (vectorised over the input grid).  Filter bases: "morlet"
+(the one FourCastNet3's recipe selects, ``config/fourcastnet3.yaml:34``), "piecewise linear" and "zernike" (``basis_layout``);
+the kernels take the tensor as data and do not know the basis.
 """
 import ctypes as C
 import math
@@ -58,23 +59,105 @@ def _morlet_vals(kernel_shape, r, phi):
     return out
 
 
+def _piecewise_linear_vals(kernel_shape, r, phi):
+    """hat functions on the unit disk: nr = kernel_shape[0] collocation points across the DIAMETER (spacing dr = 2 / (nr + 1)),
+    nphi = kernel_shape[1] around the circle.  Odd nr: k = 0 is the centre function, ring q = 1 .. nr // 2 at radius q dr holds
+    k = 1 + (q - 1) nphi + s; even nr: ring q = 0 .. nr / 2 - 1 at (q + 1/2) dr holds k = q nphi + s, and the innermost hats reach
+    across the centre, where the point (r, phi) is seen as (-r, phi + pi).  nphi = 1: rings without an angular factor.
+    -> (values (K, n), support mask (K, n): the "support" normalisation integrates over it, zeros on its rim included)"""
+    nr, nphi = kernel_shape
+    K = (nr // 2) * nphi + nr % 2
+    dr = 2.0 / (nr + 1)
+    vals, live = np.zeros((K, r.shape[0])), np.zeros((K, r.shape[0]), dtype=bool)
+    two_pi = 2.0 * math.pi
+
+    def radial(rr, centre):
+        d = np.abs(rr - centre)
+        return 1.0 - d / dr, d <= dr
+
+    def angular(ph, centre):
+        d = np.abs(ph - centre)
+        d = np.minimum(d, two_pi - d)
+        return 1.0 - d / (two_pi / nphi), d <= two_pi / nphi
+    for k in range(K):
+        if nphi == 1:
+            vals[k], live[k] = radial(r, k * dr if nr % 2 else (k + 0.5) * dr)
+        elif nr % 2:
+            if k == 0:
+                vals[k], live[k] = radial(r, 0.0)
+            else:
+                hr, lr = radial(r, ((k - 1) // nphi + 1) * dr)
+                hp, lp = angular(phi, ((k - 1) % nphi) * two_pi / nphi)
+                vals[k], live[k] = hr * hp, lr & lp
+        else:
+            centre_r, centre_p = (k // nphi + 0.5) * dr, (k % nphi) * two_pi / nphi
+            hr, lr = radial(r, centre_r)
+            hp, lp = angular(phi, centre_p)
+            hrn, lrn = radial(-r, centre_r)
+            hpn, lpn = angular(np.where(phi + math.pi >= two_pi, phi - math.pi, phi + math.pi), centre_p)
+            vals[k] = np.where(lr & lp, hr * hp, 0.0) + np.where(lrn & lpn, hrn * hpn, 0.0)
+            live[k] = (lr & lp) | (lrn & lpn)
+    return np.where(live, vals, 0.0), live
+
+
+def _zernike_vals(levels, r, phi):
+    """Zernike polynomials on the unit disk, radial degrees n = 0 .. levels - 1: k = n (n + 1) / 2 + l, l = 0 .. n, azimuthal
+    order m = 2 l - n; R_n^|m|(r) cos(m phi) for m >= 0 and R_n^|m|(r) sin(m phi) (m negative inside the sine) otherwise"""
+    out = np.empty((levels * (levels + 1) // 2, r.shape[0]))
+    for n in range(levels):
+        for l in range(n + 1):
+            m = 2 * l - n
+            a = abs(m)
+            rad = np.zeros_like(r)
+            for s in range((n - a) // 2 + 1):
+                c = (-1) ** s * math.factorial(n - s) / (math.factorial(s) * math.factorial((n + a) // 2 - s) * math.factorial((n - a) // 2 - s))
+                rad += c * r ** (n - 2 * s)
+            out[n * (n + 1) // 2 + l] = rad * (np.sin(m * phi) if m < 0 else np.cos(m * phi))
+    return out
+
+
+BASES = ("morlet", "piecewise linear", "zernike")
+
+
+def basis_layout(basis_type, kernel_shape):
+    """-> (kernel_shape as the basis keeps it, number of basis functions).  torch-harmonics' ``get_filter_basis`` names of the
+    0.7.4 - 0.8.0 releases; "harmonic", the default ARGUMENT of the reference's FourCastNet3 classes (fourcastnet3.py:175; its
+    recipe passes "morlet"), is in no release whose source is known here and is refused rather than invented."""
+    if basis_type == "morlet":
+        ks = [kernel_shape, kernel_shape] if isinstance(kernel_shape, int) else list(kernel_shape)
+        if len(ks) != 2:
+            raise ValueError("expected kernel_shape to be a list or tuple of length 2")
+        return ks, ks[0] * ks[1]
+    if basis_type == "piecewise linear":
+        ks = [kernel_shape] if isinstance(kernel_shape, int) else list(kernel_shape)
+        if len(ks) == 1:
+            ks = [ks[0], 1]
+        if len(ks) != 2:
+            raise ValueError("expected kernel_shape to be a list or tuple of length 1 or 2")
+        return ks, (ks[0] // 2) * ks[1] + ks[0] % 2
+    if basis_type == "zernike":
+        n = kernel_shape if isinstance(kernel_shape, int) else int(kernel_shape[0])
+        return [n], n * (n + 1) // 2
+    raise NotImplementedError(f"filter basis {basis_type!r}: built are {BASES} (FourCastNet3's recipe: 'morlet', config/fourcastnet3.yaml:34)")
+
+
 def convolution_tensor(in_shape, out_shape, kernel_shape, basis_type="morlet", grid_in="equiangular", grid_out="equiangular",
                        theta_cutoff=0.01 * math.pi, theta_eps=1e-3, basis_norm_mode="mean", eps=1e-9):
-    """-> dict(k, t, i, j: int arrays of the non-zeros, v: float64 values with normalisation and quadrature merged)"""
-    if basis_type != "morlet":
-        raise NotImplementedError(f"filter basis {basis_type!r}: only 'morlet' is built (config/fourcastnet3.yaml:34)")
+    """-> dict(k, t, i, j: int arrays of the non-zeros, v: float64 values with normalisation and quadrature merged).  Every
+    basis function is stored at every grid point of the filter's disk (zeros outside its own support, piecewise linear basis):
+    per (k, t, input row) the entries stay ONE circular run in longitude, which is what the run kernels consume."""
+    kernel_shape, K = basis_layout(basis_type, kernel_shape)
     if basis_norm_mode not in ("none", "individual", "mean", "support"):
         raise ValueError(f"Unknown basis normalization mode {basis_norm_mode}.")
     nlat_in, nlon_in = in_shape
     nlat_out, _ = out_shape
-    K = kernel_shape[0] * kernel_shape[1]
     th_in, w_in = _leg.colatitudes(nlat_in, grid_in)
     th_out, _ = _leg.colatitudes(nlat_out, grid_out)
     lon = 2.0 * math.pi * np.arange(nlon_in) / nlon_in
     q_lat = w_in / nlon_in / 2.0                            # quadrature weights that integrate to one over the sphere
     cutoff = (1.0 + theta_eps) * theta_cutoff
     cb, sb = np.cos(lon)[None, :], np.sin(lon)[None, :]
-    ks, ts, is_, js, vs = [], [], [], [], []
+    ks, ts, is_, js, vs, ms = [], [], [], [], [], []
     for t in range(nlat_out):
         # only latitudes within the cutoff of the centre can fall inside the disk
         rows = np.nonzero(np.abs(th_in - th_out[t]) <= cutoff)[0]
@@ -93,18 +176,25 @@ def convolution_tensor(in_shape, out_shape, kernel_shape, basis_type="morlet", g
         ri, jj = np.nonzero(theta <= cutoff)
         if ri.size == 0:
             continue
-        vals = _morlet_vals(kernel_shape, theta[ri, jj] / cutoff, phi[ri, jj])          # (K, n)
+        live = None
+        if basis_type == "morlet":
+            vals = _morlet_vals(kernel_shape, theta[ri, jj] / cutoff, phi[ri, jj])          # (K, n)
+        elif basis_type == "zernike":
+            vals = _zernike_vals(kernel_shape[0], theta[ri, jj] / cutoff, phi[ri, jj])
+        else:
+            vals, live = _piecewise_linear_vals(kernel_shape, theta[ri, jj] / cutoff, phi[ri, jj])
         n = ri.size
+        ms.append(np.ones(K * n, dtype=bool) if live is None else live.reshape(-1))
         ks.append(np.repeat(np.arange(K), n))
         ts.append(np.full(K * n, t))
         is_.append(np.tile(rows[ri], K))
         js.append(np.tile(jj, K))
         vs.append(vals.reshape(-1))
-    k, t, i, j, v = (np.concatenate(a) for a in (ks, ts, is_, js, vs))
+    k, t, i, j, v, live = (np.concatenate(a) for a in (ks, ts, is_, js, vs, ms))
     q = q_lat[i]
     flat = k * nlat_out + t
     vnorm = np.bincount(flat, weights=np.abs(v) * q, minlength=K * nlat_out).reshape(K, nlat_out)
-    support = np.bincount(flat, weights=q, minlength=K * nlat_out).reshape(K, nlat_out)
+    support = np.bincount(flat, weights=q * live, minlength=K * nlat_out).reshape(K, nlat_out)
     if basis_norm_mode == "individual":
         v = v / (vnorm[k, t] + eps)
     elif basis_norm_mode == "mean":
@@ -112,7 +202,7 @@ def convolution_tensor(in_shape, out_shape, kernel_shape, basis_type="morlet", g
     elif basis_norm_mode == "support":
         v = v / (support[k, t] + eps)
     v = v * q
-    return dict(k=k.astype(np.int64), t=t.astype(np.int64), i=i.astype(np.int64), j=j.astype(np.int64), v=v, K=K)
+    return dict(k=k.astype(np.int64), t=t.astype(np.int64), i=i.astype(np.int64), j=j.astype(np.int64), v=v, K=K, live=live)
 
 
 _PSI_CACHE = {}          # constructor arguments -> convolution tensor (FourCastNet3's eight local blocks share one)
@@ -624,10 +714,7 @@ class DiscreteContinuousConvS2(nn.Module):
         super().__init__()
         self.nlat_in, self.nlon_in = in_shape
         self.nlat_out, self.nlon_out = out_shape
-        if isinstance(kernel_shape, int):
-            kernel_shape = [kernel_shape, kernel_shape]
-        self.kernel_shape = list(kernel_shape)
-        self.kernel_size = self.kernel_shape[0] * self.kernel_shape[1]
+        self.kernel_shape, self.kernel_size = basis_layout(basis_type, kernel_shape)
         if self.nlon_in % self.nlon_out != 0:
             raise ValueError("nlon_in must be an integer multiple of nlon_out")
         if theta_cutoff is None:

@@ -31,6 +31,11 @@ pinned sources: the restatement follows the published algorithm as the author of
 
   ``MorletFilterBasis.compute_support_vals``   filter_basis.py as introduced in 0.7.4 (Hann window cos^2(pi r / 2 r_cutoff) times
       sin / cos products in x = r sin(phi), y = r cos(phi), basis index k = m * kernel_shape[1] + n); unchanged in 0.7.5 / 0.8.0.
+  ``PiecewiseLinearFilterBasis``, ``ZernikeFilterBasis``   filter_basis.py of 0.7.4 - 0.8.0 (their docstrings give the indexing).  What
+      cannot be pinned from here is convention, not mathematics: which collocation angle sector 0 sits at (0, with phi in
+      [0, 2 pi)), the sign inside sin(m phi) of the Zernike functions with m < 0, and the float32 rounding the package's collocation
+      points carry (see ``_isotropic``); the hats' nodal / partition-of-unity properties and the Zernike orthogonality relations are
+      pinned (tests/test_oracle_disco.py).
   ``rotated_coordinates``                      convolution.py::_precompute_convolution_tensor_s2, 0.7.x - 0.8.0: YZY Euler rotation
       (alpha = -theta_out, beta = lon_in, gamma = theta_in), normalisation of (x, y, z) before arccos / atan2 (added in 0.7.4),
       phi wrapped to [0, 2 pi).
@@ -49,7 +54,8 @@ pinned sources: the restatement follows the published algorithm as the author of
 
 Known or suspected changes between 0.8.0 and the pin that this file does NOT reflect because they could not be read here:
 additional filter bases ("harmonic" is the reference classes' DEFAULT argument, makani/models/networks/fourcastnet3.py:175,315,495,660; the
-FourCastNet3 recipe itself uses "morlet", config/fourcastnet3.yaml:34 — only "morlet" is restated and built), a "bilinear-
+FourCastNet3 recipe itself uses "morlet", config/fourcastnet3.yaml:34 — "morlet", "piecewise linear" and "zernike", the three
+bases of the 0.7.4 - 0.8.0 releases, are restated), a "bilinear-
 spherical" resampling mode, optimised CUDA contraction kernels (which do not change results), and possibly further
 ``basis_norm_mode`` values.  Whether the normalisation constants of the restated modes changed after 0.8.0 CANNOT be known
 from inside this container; if they did, every fixture built on this file (``tests/golden/fcn3_*.npz``) inherits the
@@ -120,11 +126,145 @@ class MorletFilterBasis:
         return iidx, vals
 
 
+class PiecewiseLinearFilterBasis:
+    """Tensor-product hat functions on the disk (torch_harmonics.filter_basis.PiecewiseLinearFilterBasis, 0.7.4 - 0.8.0).
+    ``kernel_shape = [nr, nphi]``: nr collocation points ACROSS the diameter (spacing dr = 2 r_cutoff / (nr + 1)), nphi
+    around the circle (spacing 2 pi / nphi); ``kernel_size = (nr // 2) * nphi + nr % 2`` — odd nr has the centre function
+    k = 0 (isotropic) and rings at dr, 2 dr, ...; even nr has rings at dr / 2, 3 dr / 2, ... whose innermost hats reach
+    across the centre (a point at (r, phi) is also the point (-r, phi + pi)).  nphi = 1: isotropic rings."""
+
+    def __init__(self, kernel_shape):
+        if isinstance(kernel_shape, int):
+            kernel_shape = [kernel_shape]
+        if len(kernel_shape) == 1:
+            kernel_shape = [kernel_shape[0], 1]
+        elif len(kernel_shape) != 2:
+            raise ValueError("expected kernel_shape to be a list or tuple of length 1 or 2")
+        self.kernel_shape = list(kernel_shape)
+
+    @property
+    def kernel_size(self):
+        return (self.kernel_shape[0] // 2) * self.kernel_shape[1] + self.kernel_shape[0] % 2
+
+    def _isotropic(self, r, phi, r_cutoff):
+        # (the published code keeps the enumerator as an int64 tensor, whose product with a Python float is a float32 tensor: its
+        # collocation radii / angles carry float32 rounding, 1e-8 relative.  Here they are float64 — the values differ at that level)
+        ikernel = torch.arange(self.kernel_size, dtype=r.dtype).reshape(-1, 1, 1)
+        nr = self.kernel_shape[0]
+        dr = 2 * r_cutoff / (nr + 1)
+        ir = ikernel * dr if nr % 2 == 1 else (ikernel + 0.5) * dr
+        iidx = torch.argwhere(((r - ir).abs() <= dr) & (r <= r_cutoff))
+        vals = 1 - (r[iidx[:, 1], iidx[:, 2]] - ir[iidx[:, 0], 0, 0]).abs() / dr
+        return iidx, vals
+
+    def _anisotropic(self, r, phi, r_cutoff):
+        ikernel = torch.arange(self.kernel_size, dtype=r.dtype).reshape(-1, 1, 1)
+        nr, nphi = self.kernel_shape
+        dr = 2 * r_cutoff / (nr + 1)
+        dphi = 2.0 * math.pi / nphi
+        two_pi = 2.0 * math.pi
+
+        def hat_phi(d):                                    # periodic distance in angle
+            return torch.minimum(d, two_pi - d)
+        if nr % 2 == 1:
+            ir = ((ikernel - 1) // nphi + 1) * dr
+            iphi = ((ikernel - 1) % nphi) * dphi
+            cond_r = ((r - ir).abs() <= dr) & (r <= r_cutoff)
+            cond_phi = (ikernel == 0) | ((phi - iphi).abs() <= dphi) | ((two_pi - (phi - iphi).abs()) <= dphi)
+            iidx = torch.argwhere(cond_r & cond_phi)
+            k, i, j = iidx[:, 0], iidx[:, 1], iidx[:, 2]
+            dist_r = (r[i, j] - ir[k, 0, 0]).abs()
+            dist_phi = (phi[i, j] - iphi[k, 0, 0]).abs()
+            vals = 1 - dist_r / dr
+            vals = vals * torch.where(k > 0, 1 - hat_phi(dist_phi) / dphi, torch.ones_like(vals))
+        else:
+            ir = (ikernel // nphi + 0.5) * dr
+            iphi = (ikernel % nphi) * dphi
+            rn = -r                                        # the same point seen from across the centre
+            phin = torch.where(phi + math.pi >= two_pi, phi - math.pi, phi + math.pi)
+            cond_r = ((r - ir).abs() <= dr) & (r <= r_cutoff)
+            cond_phi = ((phi - iphi).abs() <= dphi) | ((two_pi - (phi - iphi).abs()) <= dphi)
+            cond_rn = ((rn - ir).abs() <= dr) & (rn <= r_cutoff)
+            cond_phin = ((phin - iphi).abs() <= dphi) | ((two_pi - (phin - iphi).abs()) <= dphi)
+            iidx = torch.argwhere((cond_r & cond_phi) | (cond_rn & cond_phin))
+            k, i, j = iidx[:, 0], iidx[:, 1], iidx[:, 2]
+            dist_r = (r[i, j] - ir[k, 0, 0]).abs()
+            dist_phi = (phi[i, j] - iphi[k, 0, 0]).abs()
+            dist_rn = (rn[i, j] - ir[k, 0, 0]).abs()
+            dist_phin = (phin[i, j] - iphi[k, 0, 0]).abs()
+            vals = cond_r[k, i, j] * (1 - dist_r / dr) * cond_phi[k, i, j] * (1 - hat_phi(dist_phi) / dphi)
+            vals = vals + cond_rn[k, i, j] * (1 - dist_rn / dr) * cond_phin[k, i, j] * (1 - hat_phi(dist_phin) / dphi)
+        return iidx, vals
+
+    def compute_support_vals(self, r, phi, r_cutoff):
+        if self.kernel_shape[1] > 1:
+            return self._anisotropic(r, phi, r_cutoff)
+        return self._isotropic(r, phi, r_cutoff)
+
+
+class ZernikeFilterBasis:
+    """Zernike polynomials on the disk of radius ``r_cutoff`` (torch_harmonics.filter_basis.ZernikeFilterBasis, 0.7.4 -
+    0.8.0): ``kernel_shape`` = number of radial degrees n = 0 .. kernel_shape - 1 (a tuple contributes its first entry),
+    ``kernel_size = kernel_shape (kernel_shape + 1) / 2``; basis function k sits at level n, position l = 0 .. n of the
+    pyramid (k = n (n + 1) / 2 + l), azimuthal order m = 2 l - n:  R_n^|m|(r) cos(m phi) for m >= 0, R_n^|m|(r) sin(m phi)
+    for m < 0 (with the sign of m inside the sine, as published)."""
+
+    def __init__(self, kernel_shape):
+        if isinstance(kernel_shape, (tuple, list)):
+            kernel_shape = kernel_shape[0]
+        if not isinstance(kernel_shape, int):
+            raise ValueError("expected kernel_shape to be an integer")
+        self.kernel_shape = kernel_shape
+
+    @property
+    def kernel_size(self):
+        return (self.kernel_shape * (self.kernel_shape + 1)) // 2
+
+    @staticmethod
+    def zernikeradial(r, n, m):
+        """R_n^m(r) = sum_k (-1)^k (n - k)! / (k! ((n + m) / 2 - k)! ((n - m) / 2 - k)!) r^(n - 2 k), n / m integer tensors"""
+        out = torch.zeros_like(r)
+        bound = (n - m) // 2 + 1
+        fact = lambda t: torch.exp(torch.lgamma(t.to(r.dtype) + 1.0)).round()
+        for k in range(int(bound.max().item())):
+            kk = torch.full_like(n, k)
+            ok = kk < bound
+            a, b, c = n - kk, (n + m) // 2 - kk, (n - m) // 2 - kk
+            a, b, c = (torch.where(ok, t, torch.zeros_like(t)) for t in (a, b, c))      # keep the factorials defined where unused
+            inc = (-1) ** k * fact(a) / (math.factorial(k) * fact(b) * fact(c)) * r ** torch.where(ok, n - 2 * kk, torch.zeros_like(n)).to(r.dtype)
+            out = out + torch.where(ok, inc, torch.zeros_like(inc))
+        return out
+
+    def zernikepoly(self, r, phi, n, l):
+        m = 2 * l - n
+        mf = m.to(r.dtype)
+        return torch.where(m < 0, self.zernikeradial(r, n, -m) * torch.sin(mf * phi), self.zernikeradial(r, n, m) * torch.cos(mf * phi))
+
+    def compute_support_vals(self, r, phi, r_cutoff):
+        ikernel = torch.arange(self.kernel_size).reshape(-1, 1, 1)
+        iidx = torch.argwhere((r <= r_cutoff) & torch.full_like(ikernel, True, dtype=torch.bool))
+        nshifts = torch.arange(self.kernel_shape)
+        nshifts = (nshifts + 1) * nshifts // 2                   # first index of each level of the pyramid
+        nkernel = torch.searchsorted(nshifts, ikernel.reshape(-1), right=True) - 1
+        lkernel = ikernel.reshape(-1) - nshifts[nkernel]
+        rs = r[iidx[:, 1], iidx[:, 2]] / r_cutoff
+        ph = phi[iidx[:, 1], iidx[:, 2]]
+        vals = self.zernikepoly(rs, ph, nkernel[iidx[:, 0]], lkernel[iidx[:, 0]])
+        return iidx, vals
+
+
 def get_filter_basis(kernel_shape, basis_type):
+    """torch_harmonics.filter_basis.get_filter_basis of 0.7.4 - 0.8.0: "piecewise linear", "morlet", "zernike".  "harmonic" —
+    the default ARGUMENT of the reference's FourCastNet3 classes (fourcastnet3.py:175,315,495,660; its recipe passes
+    "morlet", config/fourcastnet3.yaml:34) — exists in no release known to the author of this file and is not invented here."""
     if basis_type == "morlet":
         return MorletFilterBasis(kernel_shape)
-    raise NotImplementedError(f"filter basis {basis_type!r} is not restated (FourCastNet3's recipe uses 'morlet', "
-                              "config/fourcastnet3.yaml:34)")
+    if basis_type == "piecewise linear":
+        return PiecewiseLinearFilterBasis(kernel_shape)
+    if basis_type == "zernike":
+        return ZernikeFilterBasis(kernel_shape)
+    raise NotImplementedError(f"filter basis {basis_type!r} is not restated: 'morlet' (FourCastNet3's recipe, config/fourcastnet3.yaml:34), "
+                              "'piecewise linear' and 'zernike' are")
 
 
 # --------------------------------------------------------------------------- #

@@ -204,7 +204,7 @@ def crps_spectral_fixtures():
     print(f"crps_spectral.npz: {os.path.getsize(path)/1e6:.2f} MB")
 
 
-def fcn3_fixtures():
+def fcn3_fixtures(which="recipe"):
     """FourCastNet3 (makani/models/networks/fourcastnet3.py, the reference's own module) on top of the restated
     torch-harmonics operators: SHT (oracle/sht.py) and DISCO convolution / ResampleS2 (oracle/disco.py).  The DISCO
     restatement is parity-unpinned against the package itself (see its header), so these fixtures pin the NETWORK code
@@ -226,6 +226,20 @@ def fcn3_fixtures():
               normalization_layer="layer_norm", layer_scale=False, bias=True, activation_function="silu",
               model_grid_type="equiangular", sht_grid_type="legendre-gauss", hard_thresholding_fraction=0.75)),
     ]
+    # the other filter bases of torch-harmonics 0.7.4 - 0.8.0 through the reference's own network (kernel sizes 5 and 6 instead
+    # of Morlet's 9; the Zernike cutoff heuristic, fourcastnet3.py:46-50, reaches sqrt(8) times farther)
+    bases = [
+        ("fcn3_piecewise_linear_24x48.npz", 1, 352,
+         dict(inp_shape=(24, 48), out_shape=(24, 48), scale_factor=2, filter_basis_type="piecewise linear", kernel_shape=(3, 4),
+              channel_names=chans[:8] + ["t2m", "tcwv"], aux_channel_names=["xzen"], atmo_embed_dim=4, surf_embed_dim=4, aux_embed_dim=2,
+              num_layers=2, normalization_layer="instance_norm", sfno_block_frequency=2)),
+        ("fcn3_zernike_24x48.npz", 1, 353,
+         dict(inp_shape=(24, 48), out_shape=(24, 48), scale_factor=2, filter_basis_type="zernike", kernel_shape=(3, 3),
+              channel_names=chans[:8] + ["t2m", "tcwv"], aux_channel_names=["xzen"], atmo_embed_dim=4, surf_embed_dim=4, aux_embed_dim=2,
+              num_layers=2, normalization_layer="instance_norm", sfno_block_frequency=2, bias=True)),
+    ]
+    if which == "bases":
+        cases = bases
     for name, batch, seed, kwargs in cases:
         torch.manual_seed(seed)
         model = FCN3(**kwargs)
@@ -591,6 +605,8 @@ def main():
         stepper_fixtures()
     if "fcn3" in which:
         fcn3_fixtures()
+    if "fcn3_bases" in which:
+        fcn3_fixtures("bases")
     if "fcn3" in which or "fcn3_block" in which:
         fcn3_block_fixture()
     if "fcn3_real" in which:                     # (minutes of CPU: not part of the default set)

@@ -9,7 +9,7 @@ import torch
 
 from conftest import load_golden, rel_l2
 
-FCN3_GOLDEN = ["fcn3_small_33x64.npz", "fcn3_options_24x48.npz"]
+FCN3_GOLDEN = ["fcn3_small_33x64.npz", "fcn3_options_24x48.npz", "fcn3_piecewise_linear_24x48.npz", "fcn3_zernike_24x48.npz"]
 
 
 def _load(name):

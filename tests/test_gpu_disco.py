@@ -21,12 +21,14 @@ def _cutoff(nlat, factor):
     return factor * (3 + 1) * 0.5 * math.pi / float(nlat - 1)
 
 
-def _pair(cin, cout, in_shape, out_shape, gi, go, fac, groups, bias=True):
+def _pair(cin, cout, in_shape, out_shape, gi, go, fac, groups, bias=True, kernel_shape=(3, 3), basis_type="morlet", norm_mode="mean"):
     import makani_amd.disco as pd
     from oracle import disco as od
     torch.manual_seed(11)
-    kw = dict(kernel_shape=(3, 3), basis_type="morlet", basis_norm_mode="mean", grid_in=gi, grid_out=go, groups=groups, bias=bias,
-              theta_cutoff=_cutoff(in_shape[0], fac))
+    n0 = kernel_shape if isinstance(kernel_shape, int) else kernel_shape[0]
+    basis_factor = {"piecewise linear": 0.5, "morlet": 0.5, "zernike": math.sqrt(2.0)}[basis_type]      # fourcastnet3.py:46-50
+    kw = dict(kernel_shape=kernel_shape, basis_type=basis_type, basis_norm_mode=norm_mode, grid_in=gi, grid_out=go, groups=groups, bias=bias,
+              theta_cutoff=fac * (n0 + 1) * basis_factor * math.pi / float(in_shape[0] - 1))
     ref = od.DiscreteContinuousConvS2(cin, cout, in_shape, out_shape, **kw)
     mod = pd.DiscreteContinuousConvS2(cin, cout, in_shape, out_shape, **kw)
     mod.load_state_dict(ref.state_dict())
@@ -53,6 +55,34 @@ def test_disco_conv_matches_oracle_fp32(in_shape, out_shape, gi, go, fac, groups
     assert rel_l2(xd.grad, xr.grad) < 1e-5
     assert rel_l2(mod.weight.grad, ref.weight.grad) < 1e-5
     assert rel_l2(mod.bias.grad, ref.bias.grad) < 1e-5
+
+
+@pytest.mark.parametrize("basis,kshape", [("morlet", (2, 2)), ("morlet", (2, 4)), ("morlet", (4, 4)), ("piecewise linear", (3, 4)),
+                                          ("piecewise linear", (4, 3)), ("piecewise linear", (3,)), ("zernike", (3, 3)), ("zernike", 4)])
+@pytest.mark.parametrize("in_shape,out_shape,gi,go,groups", [((33, 64), (17, 32), "equiangular", "equiangular", 1),
+                                                             ((24, 48), (24, 48), "legendre-gauss", "legendre-gauss", 2)])
+def test_disco_conv_other_bases_and_kernel_sizes_match_oracle_fp32(basis, kshape, in_shape, out_shape, gi, go, groups):
+    """the kernels take the convolution tensor as data: every filter basis of torch-harmonics 0.7.4 - 0.8.0 and kernel sizes other
+    than FourCastNet3's nine (4, 5, 6, 8, 10, 16 basis functions: the general-K run / list kernels instead of the fused K = 9
+    one), strided and equal grids, grouped.  ("support" normalisation, where the rim of a hat decides its constant, is a host-side
+    matter: tests/test_oracle_disco.py)"""
+    mode = "individual" if basis == "piecewise linear" else "mean"
+    ref, mod = _pair(6, 4, in_shape, out_shape, gi, go, 1.0, groups, kernel_shape=kshape, basis_type=basis, norm_mode=mode)
+    assert mod.kernel_size == ref.kernel_size and mod.weight.shape == ref.weight.shape
+    assert abs(mod.psi_vals.double().abs().sum().item() / ref.psi_vals.double().abs().sum().item() - 1.0) < 1e-6
+    x = torch.randn(2, 6, *in_shape)
+    g = torch.randn(2, 4, *out_shape)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * g).sum().backward()
+    xd = x.to("cuda:0").requires_grad_(True)
+    yd = mod(xd)
+    (yd * g.to("cuda:0")).sum().backward()
+    tol = 1e-5
+    assert yd.shape == yr.shape and rel_l2(yd, yr) < tol
+    assert rel_l2(xd.grad, xr.grad) < tol
+    assert rel_l2(mod.weight.grad, ref.weight.grad) < tol
+    assert rel_l2(mod.bias.grad, ref.bias.grad) < tol
 
 
 def test_disco_conv_bf16_autocast():

@@ -379,13 +379,17 @@ def test_disco_run_lists_reproduce_the_convolution_tensor():
     assert np.all(vl[-K * 4:] == 0)
 
 
-def test_disco_lists_of_a_real_tensor_and_its_transpose():
+@pytest.mark.parametrize("basis,kshape", [("morlet", [3, 3]), ("morlet", [2, 4]), ("piecewise linear", [3, 4]), ("piecewise linear", [4, 3]),
+                                          ("zernike", [3])])
+def test_disco_lists_of_a_real_tensor_and_its_transpose(basis, kshape):
     """on a real convolution tensor: forward run lists, the adjoint's lists for latitude groups of 2 and 4 (image rows relative to
-    the group's first touched output latitude) and the transposed tensor's lists all carry every entry exactly once"""
+    the group's first touched output latitude) and the transposed tensor's lists all carry every entry exactly once — for every
+    filter basis and for basis counts other than nine"""
     from makani_amd import disco
     shape = (12, 24)
-    psi = disco.convolution_tensor(shape, shape, [3, 3], basis_type="morlet", grid_in="equiangular", grid_out="equiangular",
+    psi = disco.convolution_tensor(shape, shape, kshape, basis_type=basis, grid_in="equiangular", grid_out="equiangular",
                                    theta_cutoff=3 * math.pi / 11, basis_norm_mode="mean")
+    assert psi["K"] == disco.basis_layout(basis, kshape)[1]
     L = disco._Lists(psi, shape, shape, "cpu")
     assert L.runs is not None and L.runs.R == 4 and disco.runs_radix(1440) == 4 and disco.runs_radix(1152) == 8 and disco.runs_radix(36 * 4 + 2) is None
     tot = float(np.abs(psi["v"]).sum())

@@ -96,21 +96,51 @@ def test_direct_contraction_equals_dense_forward_and_gradient(in_shape, out_shap
         assert torch.allclose(a, b, atol=1e-12, rtol=1e-10)
 
 
-@pytest.mark.parametrize("in_shape,out_shape,gi,go,fac", CASES)
-@pytest.mark.parametrize("mode", ["mean", "individual"])
-def test_product_convolution_tensor_matches_oracle(in_shape, out_shape, gi, go, fac, mode):
+BASES = [("morlet", [3, 3]), ("morlet", [2, 4]), ("piecewise linear", [3, 4]), ("piecewise linear", [4, 3]), ("piecewise linear", [3]),
+         ("piecewise linear", [2]), ("zernike", [3, 3]), ("zernike", 4)]
+
+
+def _check_product_tensor(in_shape, out_shape, gi, go, cut, mode, basis, kshape):
     from makani_amd import disco as pd
-    cut = _cutoff(in_shape[0], fac)
-    idx, vals = od.precompute_convolution_tensor(in_shape, out_shape, od.MorletFilterBasis([3, 3]), grid_in=gi, grid_out=go,
-                                                 theta_cutoff=cut, basis_norm_mode=mode)
-    psi = pd.convolution_tensor(in_shape, out_shape, [3, 3], grid_in=gi, grid_out=go, theta_cutoff=cut, basis_norm_mode=mode)
-    size = (9, out_shape[0], in_shape[0] * in_shape[1])
+    fb = od.get_filter_basis(kshape, basis)
+    K = fb.kernel_size
+    idx, vals = od.precompute_convolution_tensor(in_shape, out_shape, fb, grid_in=gi, grid_out=go, theta_cutoff=cut, basis_norm_mode=mode)
+    psi = pd.convolution_tensor(in_shape, out_shape, kshape, basis_type=basis, grid_in=gi, grid_out=go, theta_cutoff=cut, basis_norm_mode=mode)
+    assert psi["K"] == K == pd.basis_layout(basis, kshape)[1]
+    size = (K, out_shape[0], in_shape[0] * in_shape[1])
     A = torch.sparse_coo_tensor(idx, vals, size=size).to_dense()
     pidx = torch.from_numpy(np.stack([psi["k"], psi["t"], psi["i"] * in_shape[1] + psi["j"]]))
     B = torch.sparse_coo_tensor(pidx, torch.from_numpy(psi["v"]), size=size).to_dense()
     # theta = arccos(z) near z = 1 carries sqrt(eps) conditioning: two fp64 evaluations agree to ~1e-8, not 1e-16
-    assert idx.shape == pidx.shape                      # same support
-    assert (A - B).abs().max() < 1e-6 * A.abs().max()
+    if basis == "piecewise linear":          # the product stores every basis function on the whole disk (zeros off its support)
+        assert pidx.shape[1] >= idx.shape[1] and pidx.shape[1] == K * int((psi["k"] == 0).sum())
+    else:
+        assert idx.shape == pidx.shape                  # same support
+        assert psi["live"].all()
+    if basis == "piecewise linear" and mode == "support":
+        # the support of a hat includes its rim, where the value is 0 and rounding decides membership (the grid's central meridian
+        # sits exactly on the sector rims): the two support sets may differ there and ONLY there, and where they do, the
+        # normalisation constant (the quadrature sum over the support) differs with them — compare with it taken out again
+        i0, v0 = od.precompute_convolution_tensor(in_shape, out_shape, fb, grid_in=gi, grid_out=go, theta_cutoff=cut, basis_norm_mode="none",
+                                                  merge_quadrature=False)
+        A0 = torch.sparse_coo_tensor(i0, v0, size=size).to_dense()
+        Mo = torch.sparse_coo_tensor(i0, torch.ones_like(v0), size=size).to_dense() > 0
+        Mp = torch.sparse_coo_tensor(pidx, torch.from_numpy(psi["live"].astype(np.float64)), size=size).to_dense() > 0
+        rim = Mo ^ Mp
+        assert A0[rim].abs().max() < 1e-9 if rim.any() else True
+        _, w = precompute_latitudes(in_shape[0], gi)
+        q = (torch.from_numpy(w) / in_shape[1] / 2.0).repeat_interleave(in_shape[1])
+        So, Sp = (Mo * q).sum(-1, keepdim=True), (Mp * q).sum(-1, keepdim=True)
+        assert (So - Sp).abs().max() <= 1.05 * (rim * q).sum(-1).max()
+        A, B = A * (So + 1e-9), B * (Sp + 1e-9)
+    return psi
+
+
+@pytest.mark.parametrize("in_shape,out_shape,gi,go,fac", CASES)
+@pytest.mark.parametrize("mode", ["mean", "individual"])
+def test_product_convolution_tensor_matches_oracle(in_shape, out_shape, gi, go, fac, mode):
+    from makani_amd import disco as pd
+    psi = _check_product_tensor(in_shape, out_shape, gi, go, _cutoff(in_shape[0], fac), mode, "morlet", [3, 3])
     # list form: every forward list entry points inside the staged rows, the transposed lists hold the same entries
     L = pd._Lists(psi, in_shape, out_shape, "cpu")
     assert int(L.f_off[-1]) == psi["v"].size == int(L.b_off[-1])
@@ -118,9 +148,80 @@ def test_product_convolution_tensor_matches_oracle(in_shape, out_shape, gi, go, 
     assert torch.allclose(L.f_val.double().sum(), L.b_val.double().sum(), rtol=1e-6)
 
 
-def test_morlet_only_and_argument_errors():
+@pytest.mark.parametrize("basis,kshape", BASES[1:])
+@pytest.mark.parametrize("mode", ["none", "individual", "mean", "support"])
+def test_product_convolution_tensor_matches_oracle_every_basis_and_norm_mode(basis, kshape, mode):
+    """the host-side precompute of makani_amd/disco.py (numpy, written on its own) against the oracle's restatement of
+    torch-harmonics' filter bases: morlet with a non-square shape, piecewise linear (odd / even radial counts, isotropic and
+    not), zernike; all four ``basis_norm_mode``s ("support" is where the piecewise linear supports enter); FourCastNet3's
+    cutoff heuristic per basis (fourcastnet3.py:46-50)"""
+    in_shape, out_shape, gi, go = (25, 48), (13, 24), "equiangular", "legendre-gauss"
+    n0 = kshape if isinstance(kshape, int) else kshape[0]
+    factor = {"piecewise linear": 0.5, "morlet": 0.5, "zernike": math.sqrt(2.0)}[basis]
+    cut = (n0 + 1) * factor * math.pi / float(in_shape[0] - 1)
+    _check_product_tensor(in_shape, out_shape, gi, go, cut, mode, basis, kshape)
+
+
+def test_piecewise_linear_basis_is_a_nodal_partition_of_unity():
+    """pins of the piecewise linear basis that do not depend on anybody's memory of the package: every function is a hat (values
+    in [0, 1]) that is 1 at its own collocation point (ring q, sector s) and 0 at every other one, and inside the outermost ring
+    the functions sum to one — across the centre too, where the even radial counts fold (-r, phi + pi) onto (r, phi)"""
+    rng = np.random.default_rng(5)
+    for kshape in ([3], [5], [2], [4], [3, 4], [5, 3], [2, 4], [4, 3], [6, 5]):
+        fb = od.PiecewiseLinearFilterBasis(kshape)
+        nr, nphi = fb.kernel_shape
+        K, dr = fb.kernel_size, 2.0 / (nr + 1)
+        assert K == (nr // 2) * nphi + nr % 2
+        # collocation points
+        if nr % 2:
+            pts = [(0.0, 0.0)] + [(q * dr, s * 2 * math.pi / nphi) for q in range(1, nr // 2 + 1) for s in range(nphi)]
+        else:
+            pts = [((q + 0.5) * dr, s * 2 * math.pi / nphi) for q in range(nr // 2) for s in range(nphi)]
+        assert len(pts) == K
+        r = torch.tensor([[p[0] for p in pts]], dtype=torch.float64)
+        phi = torch.tensor([[p[1] for p in pts]], dtype=torch.float64)
+        iidx, vals = fb.compute_support_vals(r, phi, r_cutoff=1.0)
+        M = torch.zeros(K, K, dtype=torch.float64)
+        M[iidx[:, 0], iidx[:, 2]] = vals
+        assert torch.allclose(M, torch.eye(K, dtype=torch.float64), atol=1e-12), kshape
+        # partition of unity inside the outermost ring (the isotropic even case has no fold: from its first ring outwards)
+        r_hi = (nr // 2) * dr if nr % 2 else (nr // 2 - 0.5) * dr
+        r_lo = 0.5 * dr if (nphi == 1 and nr % 2 == 0) else 0.0
+        rr = torch.from_numpy(rng.uniform(r_lo, r_hi, (1, 400)))
+        pp = torch.from_numpy(rng.uniform(0.0, 2 * math.pi, (1, 400)))
+        iidx, vals = fb.compute_support_vals(rr, pp, r_cutoff=1.0)
+        assert vals.min() >= -1e-12 and vals.max() <= 1.0 + 1e-12
+        tot = torch.zeros(400, dtype=torch.float64).index_add_(0, iidx[:, 2], vals)
+        assert torch.allclose(tot, torch.ones(400, dtype=torch.float64), atol=1e-12), kshape
+
+
+def test_zernike_basis_is_orthogonal_with_the_textbook_norms():
+    """int_disk Z_k Z_k' r dr dphi = eps_m pi / (2 n + 2) delta_kk' (eps_0 = 2, else 1) by Gauss-Legendre x trapezoid quadrature of
+    the oracle's own values, the pyramid indexing k = n (n + 1) / 2 + l, m = 2 l - n, and three closed forms"""
+    fb = od.ZernikeFilterBasis([5, 5])
+    K = fb.kernel_size
+    assert K == 15
+    x, w = np.polynomial.legendre.leggauss(24)
+    r, wr = 0.5 * (x + 1.0), 0.5 * w
+    phi = 2.0 * math.pi * np.arange(64) / 64
+    R, PHI = np.meshgrid(r, phi, indexing="ij")
+    iidx, vals = fb.compute_support_vals(torch.from_numpy(R), torch.from_numpy(PHI), r_cutoff=1.0)
+    Z = np.zeros((K,) + R.shape)
+    Z[iidx[:, 0].numpy(), iidx[:, 1].numpy(), iidx[:, 2].numpy()] = vals.numpy()
+    G = np.einsum("kij,lij,i->kl", Z, Z, wr * r) * (2.0 * math.pi / 64)
+    want = np.zeros(K)
+    for n in range(5):
+        for l in range(n + 1):
+            want[n * (n + 1) // 2 + l] = (2.0 if 2 * l - n == 0 else 1.0) * math.pi / (2 * n + 2)
+    assert np.abs(G - np.diag(want)).max() < 1e-12
+    assert np.allclose(Z[4], 2 * R ** 2 - 1)                          # (n, m) = (2, 0)
+    assert np.allclose(Z[2], R * np.cos(PHI)) and np.allclose(Z[1], R * np.sin(-PHI))      # (1, 1) and (1, -1): sin(m phi), m = -1
+    assert np.allclose(Z[12], 6 * R ** 4 - 6 * R ** 2 + 1)            # (4, 0)
+
+
+def test_unknown_basis_and_argument_errors():
     with pytest.raises(NotImplementedError):
-        od.get_filter_basis([3, 3], "zernike")
+        od.get_filter_basis([3, 3], "harmonic")         # the reference classes' default argument: in no known release, not invented
     with pytest.raises(ValueError):
         od.DiscreteContinuousConvS2(3, 4, (9, 16), (9, 16), (3, 3), groups=2)
     from makani_amd import disco as pd
@@ -232,6 +333,21 @@ def test_disco_quadrature_converges_to_the_continuous_convolution_integral(grid)
             errs.append(np.abs(got - exact).max() / scale)
         assert errs[2] < 2e-6, (colat_t, errs)          # measured 1.4e-7 ... 7.1e-7 at 361 x 720 (1.2e-5 ... 5.7e-5 at 91 x 180)
         assert errs[2] < errs[0] / 20.0, (colat_t, errs)
+
+
+@pytest.mark.parametrize("basis,kshape", [("piecewise linear", [3, 4]), ("piecewise linear", [2, 3]), ("zernike", 3)])
+def test_disco_quadrature_converges_for_the_other_bases(basis, kshape):
+    """the same pin for the bases that are not smooth: hats have kinks (second-order convergence of the grid's quadrature), Zernike
+    polynomials jump to zero at the rim of the disk (first order, not monotone) — the error still falls with the grid and is
+    < 2e-3 at 361 x 720 (measured: piecewise linear 2e-5 ... 8e-4, zernike 5e-4 ... 1.2e-3)"""
+    fb = od.get_filter_basis(kshape, basis)
+    r_cut = 0.3
+    for colat_t in (0.12, 0.9, 0.5 * math.pi):
+        exact = np.array([_continuous_convolution(fb, k, colat_t, r_cut, n_r=320, n_phi=1024) for k in range(fb.kernel_size)])
+        scale = np.abs(exact).max()
+        errs = [np.abs(_discrete_convolution(fb, colat_t, nlat, nlon, r_cut, "equiangular") - exact).max() / scale
+                for nlat, nlon in ((91, 180), (361, 720))]
+        assert errs[1] < 2e-3 and errs[1] < errs[0] / 3.0, (colat_t, errs)
 
 
 def test_precomputed_convolution_tensor_is_that_quadrature_sum():
