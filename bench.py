@@ -470,6 +470,73 @@ def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
         torch.save(_grad_record(model, l16), out_path + ".grads_bf16")
 
 
+def _cpu_worker_fcn3(cfg_name):
+    """child process of the FourCastNet3 line: the oracle's processor blocks (oracle/fcn3.py — the reference's network code restated,
+    pinned by fixtures written by the reference's own module: tests/test_oracle_fcn3.py) at the REAL internal grid and width, fp32,
+    one ensemble member.  Bounded sample: one "global" block (spectral convolution + MLP) and one "local" block (DISCO convolution
+    with the doubled cutoff + MLP), each whole, forward and forward + backward; the thread count is the faster of 32 / 64 on the
+    global block.  Encoders / decoders (five DISCO convolutions on the 721 x 1440 grid), the CRPS losses and the optimizer are NOT
+    in the sample: the figure derived from it is an upper bound of the host's training rate."""
+    from oracle import disco as od
+    from oracle import fcn3 as ofc
+    from oracle import sht as osht
+    cores = _host_cores()
+    cfg = CONFIGS[cfg_name]
+    m = cfg["model"]
+    H, W = m["inp_shape"]
+    h, w = H // m["scale_factor"], W // m["scale_factor"]
+    _, _, _, _, levels = ofc.get_channel_groups(m["channel_names"], m["aux_channel_names"])
+    total = len(levels) * m["atmo_embed_dim"] + m["surf_embed_dim"]
+    cin = total + m["aux_embed_dim"]
+    n_global = len([i for i in range(m["num_layers"]) if i % m["sfno_block_frequency"] == 0])
+    n_local = m["num_layers"] - n_global
+    torch.manual_seed(333)
+    od.DiscreteContinuousConvS2.contraction = "direct"
+    grid = m.get("sht_grid_type", "legendre-gauss")
+    sht = osht.RealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid=grid).float()
+    isht = osht.InverseRealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid=grid).float()
+    kw = dict(mlp_ratio=m.get("mlp_ratio", 2.0), normalization_layer=m.get("normalization_layer", "none"), use_mlp=m.get("use_mlp", True),
+              kernel_shape=tuple(m["kernel_shape"]), basis_type=m["filter_basis_type"], bias=m.get("bias", False))
+    x = torch.rand(1, cin, h, w, requires_grad=True)
+
+    def timed(blk):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            blk(x)
+        t_f = time.perf_counter() - t0
+        x.grad = None
+        t0 = time.perf_counter()
+        blk(x).square().mean().backward()
+        return t_f, time.perf_counter() - t0
+    blk = ofc.NeuralOperatorBlock(sht, isht, cin, total, conv_type="global", **kw)
+    best = None
+    for threads in sorted({min(cores, t) for t in (32, 64)}):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            blk(x)                                             # warm-up (thread pool, allocator)
+        t_f, t_fb = timed(blk)
+        if best is None or t_fb < best[1]:
+            best = (t_f, t_fb, threads)
+    t_f, t_fb, threads = best
+    torch.set_num_threads(threads)
+    rec = dict(t_global=t_f, t_global_fb=t_fb, threads=threads, cores=cores, h=h, w=w, channels=cin, n_global=n_global, n_local=n_local,
+               members=cfg["ensemble_size"])
+    print(json.dumps(rec), flush=True)
+    del blk
+    blk = ofc.NeuralOperatorBlock(sht, isht, cin, total, conv_type="local", **kw)
+    rec["psi_entries"] = int(blk.local_conv.psi_vals.numel())
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        blk(x)
+    rec["t_local"] = time.perf_counter() - t0
+    print(json.dumps(rec), flush=True)                         # forward-only figures complete from here on
+    x.grad = None
+    t0 = time.perf_counter()
+    blk(x).square().mean().backward()
+    rec["t_local_fb"] = time.perf_counter() - t0
+    print(json.dumps(rec), flush=True)
+
+
 class ParityProbe:
     """In-run parity of the measured model against the oracle: before the first train step the
     GPU model — initial weights, ``parity_input`` / ``parity_target`` — runs forward (fp32 and bf16 autocast, the benchmark's
@@ -567,6 +634,8 @@ def cpu_baseline(cfg_name, timeout_s=420, parity=None):
     the measured forward pass times the (forward+backward)/forward ratio measured on one internal-grid block; then the block
     alone scaled by the step/block FLOP ratio.  ``sample`` says which one was reported."""
     import subprocess
+    if cfg_name == "fcn3_sc2_edim45_layers10":          # (the small stand-in configurations carry no baseline)
+        return cpu_baseline_fcn3(cfg_name, timeout_s)
     if cfg_name != "sfno_sc3_layers8_edim384":
         return None
     mode = os.environ.get("MAKANI_AMD_CPU_BASELINE", "step")
@@ -614,6 +683,42 @@ def cpu_baseline(cfg_name, timeout_s=420, parity=None):
                        f"({rec['h']}x{rec['w']}, 384 ch) = {rec['t_mid']:.2f} s, scaled by the step/block FLOP ratio {scale:.1f} -> "
                        f"{step:.1f} s per step (optimizer excluded)",
                 ms_per_step=step * 1e3, measured="one block, extrapolated")
+
+
+def cpu_baseline_fcn3(cfg_name, timeout_s=420):
+    """``cpu_baseline`` of the FourCastNet3 line: see ``_cpu_worker_fcn3`` for the sample (processor blocks only)."""
+    import subprocess
+    recs, err = [], None
+    try:
+        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        try:
+            so, _ = pr.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            so, _ = pr.communicate()
+            err = f"time limit {timeout_s} s"
+        recs = [json.loads(l) for l in (so or "").splitlines() if l.startswith("{")]
+        if pr.returncode not in (0, None) and err is None:
+            err = f"exit code {pr.returncode}"
+    except Exception as e:   # never stall the GPU benchmark
+        err = type(e).__name__
+    if not recs or "t_local" not in recs[-1]:
+        return dict(value=None, unit="samples/s", cores=None, kind="port", sample=f"CPU baseline unavailable: {err}")
+    r = recs[-1]
+    fb = "t_local_fb" in r
+    t_g, t_l = (r["t_global_fb"], r["t_local_fb"]) if fb else (r["t_global"], r["t_local"])
+    t_sample = r["members"] * (r["n_global"] * t_g + r["n_local"] * t_l)
+    what = "forward + backward" if fb else "FORWARD ONLY (the backward sample did not finish: " + str(err) + ")"
+    return dict(value=1.0 / t_sample, unit="samples/s", cores=r["threads"], kind="port", measured=f"processor blocks, {'fwd + bwd' if fb else 'fwd only'}",
+                ms_per_step=t_sample * 1e3,
+                sample=(f"oracle fp32 (oracle/fcn3.py) on {r['threads']} host threads ({r['cores']} cores visible), PROCESSOR BLOCKS ONLY, {what}, at the "
+                        f"real internal grid {r['h']}x{r['w']} and width {r['channels']}: one global block (spectral convolution + MLP) = "
+                        f"{t_g:.1f} s (its forward pass {r['t_global']:.1f} s), one local block (DISCO convolution, {r['psi_entries']} entries of psi "
+                        f"per output longitude, + MLP) = {t_l:.1f} s (forward {r['t_local']:.1f} s); x ({r['n_global']} global + {r['n_local']} local "
+                        f"blocks) x {r['members']} ensemble members = {t_sample:.0f} s per sample.  The encoders / decoders (DISCO convolutions "
+                        f"on the 721x1440 grid), the CRPS losses and the optimizer are NOT included: an UPPER bound of the host's training "
+                        f"rate, not a measured train step"))
 
 
 def default_parallelism(world, cfg_name="sfno_sc3_layers8_edim384"):
@@ -1112,6 +1217,9 @@ def main():
     ap.add_argument("--cpu-state", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker and CONFIGS.get(args.cpu_worker, {}).get("kind") == "fcn3":
+        _cpu_worker_fcn3(args.cpu_worker)
+        return
     if args.cpu_worker:
         _cpu_worker(args.cpu_worker, args.cpu_mode, args.cpu_state, args.cpu_out)
         return

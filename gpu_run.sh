@@ -1,7 +1,11 @@
-# the filter bases beyond Morlet and the general-K DISCO kernels: new GPU tests, then the whole DISCO / FourCastNet3 test files
-mkdir -p gpurun_out/r05b
+# the FourCastNet3 line's cpu_baseline on the GPU box's host cores (no GPU work: the child process of bench.py alone)
+mkdir -p gpurun_out/r05c
 SECONDS=0
-timeout 150 python -m pytest tests/test_gpu_disco.py tests/test_fcn3.py -q -m gpu -k "other_bases or piecewise or zernike" > gpurun_out/r05b/new.log 2>&1; echo "new tests rc $? in $SECONDS s"
-tail -15 gpurun_out/r05b/new.log
-timeout 120 python -m pytest tests/test_gpu_disco.py tests/test_fcn3.py -x -q -m gpu > gpurun_out/r05b/files.log 2>&1; echo "files rc $? at $SECONDS s"
-tail -3 gpurun_out/r05b/files.log
+nproc > gpurun_out/r05c/host.txt; free -g | head -2 >> gpurun_out/r05c/host.txt
+timeout 240 python -c "
+import json, sys
+sys.argv=['bench.py']
+import bench
+print(json.dumps(bench.cpu_baseline('fcn3_sc2_edim45_layers10', timeout_s=200)))
+" > gpurun_out/r05c/fcn3_cpu_baseline.json 2> gpurun_out/r05c/err.log
+echo "rc $? in $SECONDS s"; cat gpurun_out/r05c/host.txt; cut -c1-1500 gpurun_out/r05c/fcn3_cpu_baseline.json

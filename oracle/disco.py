@@ -358,36 +358,54 @@ def disco_contraction_dense(x, psi, nlon_out):
 
 def _direct_fwd(x, idx, vals, in_shape, out_shape, K):
     """y[b, c, k, t, p] = sum_e vals[e] x[b, c, i_e, (j_e + p * pscale) mod nlon_in] over the entries e = (k, t, i, j) of psi:
-    the defining quadrature sum, evaluated one output longitude at a time (gather + index_add, no dense psi, no roll)."""
+    the defining quadrature sum, evaluated one output longitude at a time as ONE sparse (CSR) x dense product — rows (k, t),
+    columns = the entries' input points shifted by p, against the input with the channels last (no dense psi, no roll of the
+    input: torch-harmonics' CPU path rolls a copy of the input per longitude and multiplies by the same sparse psi)."""
+    import warnings
     nlat_in, nlon_in = in_shape
     nlat_out, nlon_out = out_shape
     pscale = nlon_in // nlon_out
     B, C = x.shape[:2]
     k, t, ij = idx
-    i, j = ij // nlon_in, ij % nlon_in
     seg = k * nlat_out + t
-    xf = x.reshape(B * C, nlat_in, nlon_in)
-    y = torch.zeros(B * C, K * nlat_out, nlon_out, dtype=x.dtype)
-    for p in range(nlon_out):
-        contrib = vals * xf[:, i, (j + p * pscale) % nlon_in]
-        y[:, :, p] = torch.zeros(B * C, K * nlat_out, dtype=x.dtype).index_add_(1, seg, contrib)
-    return y.reshape(B, C, K, nlat_out, nlon_out)
+    order = torch.argsort(seg, stable=True)
+    crow = torch.zeros(K * nlat_out + 1, dtype=torch.long)
+    crow[1:] = torch.cumsum(torch.bincount(seg, minlength=K * nlat_out), 0)
+    i, j, v = (ij // nlon_in)[order], (ij % nlon_in)[order], vals[order].to(x.dtype)
+    xT = x.reshape(B * C, nlat_in * nlon_in).t().contiguous()
+    yT = torch.zeros(nlon_out, K * nlat_out, B * C, dtype=x.dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                 # (torch announces its CSR support as beta, once per process)
+        for p in range(nlon_out):
+            psi_p = torch.sparse_csr_tensor(crow, i * nlon_in + (j + p * pscale) % nlon_in, v, size=(K * nlat_out, nlat_in * nlon_in))
+            yT[p] = psi_p @ xT
+    return yT.permute(2, 1, 0).reshape(B, C, K, nlat_out, nlon_out)
 
 
 def _direct_adj(g, idx, vals, in_shape, out_shape, K):
-    """the adjoint of ``_direct_fwd``: gx[b, c, i_e, (j_e + p * pscale) mod nlon_in] += vals[e] g[b, c, k_e, t_e, p]"""
+    """the adjoint of ``_direct_fwd``: gx[b, c, i_e, (j_e + p * pscale) mod nlon_in] += vals[e] g[b, c, k_e, t_e, p].  Per output
+    longitude the transposed tensor restricted to the input points it touches at p = 0 (a fixed sparse matrix: the shift only moves
+    where its rows are added) times the gradient of that longitude, channels last."""
+    import warnings
     nlat_in, nlon_in = in_shape
     nlat_out, nlon_out = out_shape
     pscale = nlon_in // nlon_out
     B, C = g.shape[:2]
     k, t, ij = idx
-    i, j = ij // nlon_in, ij % nlon_in
     seg = k * nlat_out + t
-    gf = g.reshape(B * C, K * nlat_out, nlon_out)
-    gx = torch.zeros(B * C, nlat_in * nlon_in, dtype=g.dtype)
-    for p in range(nlon_out):
-        gx.index_add_(1, i * nlon_in + (j + p * pscale) % nlon_in, vals * gf[:, seg, p])
-    return gx.reshape(B, C, nlat_in, nlon_in)
+    uniq, inv = torch.unique(ij, return_inverse=True)
+    order = torch.argsort(inv, stable=True)
+    crow = torch.zeros(uniq.numel() + 1, dtype=torch.long)
+    crow[1:] = torch.cumsum(torch.bincount(inv, minlength=uniq.numel()), 0)
+    ui, uj = uniq // nlon_in, uniq % nlon_in
+    gT = g.reshape(B * C, K * nlat_out, nlon_out).permute(2, 1, 0).contiguous()
+    gxT = torch.zeros(nlat_in * nlon_in, B * C, dtype=g.dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        psi_t = torch.sparse_csr_tensor(crow, seg[order], vals[order].to(g.dtype), size=(uniq.numel(), K * nlat_out))
+        for p in range(nlon_out):
+            gxT.index_add_(0, ui * nlon_in + (uj + p * pscale) % nlon_in, psi_t @ gT[p])
+    return gxT.t().reshape(B, C, nlat_in, nlon_in)
 
 
 class _DirectContraction(torch.autograd.Function):

@@ -191,3 +191,16 @@ def test_roofline_prices_the_disco_contraction_against_the_vector_peak():
     r = bench.roofline_of("disco_fwd", ["disco_fwd_360x720_p1354"], prof, "x6", None)
     assert r["bound"] == "valu" and r["peak"] == 157.3 and abs(r["achieved"] - 2.0 * 1354 * 720 * 585036 / 7.0e-3 / 1e12) < 0.01
     assert bench.default_parallelism(8, "fcn3_sc2_edim45_layers10") == "h2w2" and bench.default_parallelism(8) == "h4w2"
+
+
+def test_fcn3_cpu_baseline_child_on_the_small_stand_in():
+    """the FourCastNet3 line's ``cpu_baseline``: the child process times the oracle's global and local processor blocks (forward,
+    forward + backward) and the parent turns the records into the baseline object — run here on the small stand-in configuration
+    (the benchmark calls it for configs[3] only: there the blocks are 360 x 720 x 677 channels)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.cpu_baseline_fcn3("fcn3_debug", timeout_s=300)
+    assert r["kind"] == "port" and r["unit"] == "samples/s" and r["value"] > 0 and r["cores"] >= 1
+    assert r["measured"] == "processor blocks, fwd + bwd" and "NOT included" in r["sample"] and "32x64" in r["sample"]
+    assert abs(r["ms_per_step"] * 1e-3 * r["value"] - 1.0) < 1e-9
+    assert bench.cpu_baseline("fcn3_debug") is None and bench.cpu_baseline("sfno_debug") is None
