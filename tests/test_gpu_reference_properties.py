@@ -1,0 +1,79 @@
+"""Properties the reference's own model tests check (``/root/reference/tests/test_models.py``), run on the HIP path: forward /
+backward shapes of the registered networks (``:65-103``) and the gradient-accumulation identity (``:105-235``) — one batch of 2 B
+samples against two micro-batches of B with the loss halved: output, input gradient and every parameter gradient agree.  The
+reference runs it at 36 x 72 with the five channels of its test utilities, B = 4, and tolerates 5e-6 (SFNO) / 1e-6 (FCN3)
+absolute + relative on ITS code, where both evaluations are the same kernels on different batch sizes; here the batch size
+selects different kernel shapes (plane counts, weight-gradient splits), so the evaluations differ in summation order: the gate is
+rel-L2 <= 1e-5 per tensor (BASELINE.md §3's fp32 operator tolerance)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CHANNELS = ["u10m", "t2m", "u500", "z500", "t500"]            # tests/testutils.py:36
+SHAPE = (36, 72)                                             # tests/test_models.py:48-49
+BATCH = 4                                                    # tests/test_models.py:60
+
+
+def _model(nettype):
+    import makani_amd as ma
+    torch.manual_seed(333)                                   # tests/test_models.py:61
+    if nettype == "SFNO":
+        return ma.SphericalFourierNeuralOperatorNet(inp_shape=SHAPE, out_shape=SHAPE, inp_chans=5, out_chans=5, scale_factor=2, embed_dim=16,
+                                                    num_layers=3, normalization_layer="instance_norm", big_skip=True).to(DEV)
+    # the reference constructs FCN3 with its default basis ("harmonic": in no torch-harmonics release known here, see
+    # makani_amd/disco.py: basis_layout); the recipe's basis is used instead
+    return ma.AtmoSphericNeuralOperatorNet(inp_shape=SHAPE, out_shape=SHAPE, scale_factor=2, filter_basis_type="morlet", channel_names=CHANNELS,
+                                           aux_channel_names=[], atmo_embed_dim=8, surf_embed_dim=8, num_layers=3, sfno_block_frequency=2,
+                                           normalization_layer="instance_norm", big_skip=True).to(DEV)
+
+
+@pytest.mark.parametrize("nettype", ["SFNO", "FCN3"])
+def test_model_forward_backward_shapes(nettype):
+    model = _model(nettype)
+    inp = torch.randn(BATCH, 5, *SHAPE, device=DEV, requires_grad=True)
+    out = model(inp)
+    assert out.shape == (BATCH, 5, *SHAPE)
+    out.sum().backward()
+    assert inp.grad is not None and inp.grad.shape == inp.shape
+    assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("nettype", ["SFNO", "FCN3"])
+def test_gradient_accumulation(nettype):
+    model = _model(nettype)
+    inp = torch.randn(2 * BATCH, 5, *SHAPE, device=DEV)
+    tar = torch.randn_like(inp)
+    loss_fn = lambda out, t: (out - t).square().mean()         # the per-sample mean squared error, averaged over the batch
+
+    model.zero_grad(set_to_none=True)
+    x = inp.clone().requires_grad_(True)
+    out_single = model(x)
+    loss_fn(out_single, tar).backward()
+    igrad_single = x.grad.clone()
+    grads_single = {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    model.zero_grad(set_to_none=True)
+    outs, igrads = [], []
+    for xs, ts in zip(torch.split(inp, BATCH, dim=0), torch.split(tar, BATCH, dim=0)):
+        xs = xs.detach().clone().requires_grad_(True)
+        o = model(xs)
+        (loss_fn(o, ts) / 2.0).backward()                      # gradients ACCUMULATE in .grad across the two passes
+        outs.append(o.detach())
+        igrads.append(xs.grad.clone())
+    errs = {"output": rel_l2(torch.cat(outs), out_single), "input gradient": rel_l2(torch.cat(igrads), igrad_single)}
+    gmax = max(float(g.abs().max()) for g in grads_single.values())
+    worst, amax = ("", 0.0), 0.0
+    for n, p in model.named_parameters():
+        e = rel_l2(p.grad, grads_single[n])
+        d = p.grad - grads_single[n]
+        a = float((torch.view_as_real(d) if d.is_complex() else d).abs().max())
+        amax = max(amax, a / gmax)
+        if a >= 1e-6 * gmax and e > worst[1]:                  # (gradients that are zero in exact arithmetic: absolute scale)
+            worst = (n, e)
+    errs["worst parameter gradient"] = worst[1]
+    print(f"gradient accumulation {nettype}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items())
+          + f" ({worst[0] or 'none above the absolute floor'}); largest |difference| of any parameter gradient / largest gradient entry = {amax:.2e}")
+    assert all(v < 1e-5 for v in errs.values()), (errs, worst)
