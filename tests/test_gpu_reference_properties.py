@@ -77,3 +77,53 @@ def test_gradient_accumulation(nettype):
     print(f"gradient accumulation {nettype}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items())
           + f" ({worst[0] or 'none above the absolute floor'}); largest |difference| of any parameter gradient / largest gradient entry = {amax:.2e}")
     assert all(v < 1e-5 for v in errs.values()), (errs, worst)
+
+
+# --------------------------------------------------------------------------- #
+# /root/reference/tests/test_contractions.py:190-249: relations between the contraction kernels, here between the HIP engines behind
+# SpectralConv (split-bf16 MFMA GEMM for "dhconv", the per-(l, m) kernel for "diagonal", the separable kernel)
+# --------------------------------------------------------------------------- #
+def _conv(fwd, inv, C, op, separable):
+    import makani_amd as ma
+    return ma.SpectralConv(fwd, inv, C, C, operator_type=op, separable=separable).to(DEV)
+
+
+def _fwd_bwd(conv, x, g):
+    xd = x.clone().requires_grad_(True)
+    y, _ = conv(xd)
+    (y * g).sum().backward()
+    return y.detach(), xd.grad
+
+
+@pytest.mark.parametrize("nlat,nlon,grid", [(33, 64, "equiangular"), (24, 48, "legendre-gauss")])
+def test_contraction_relations(nlat, nlon, grid):
+    import makani_amd as ma
+    torch.manual_seed(333)
+    C, L, M = 8, nlat // 2, nlat // 2                      # (the reference's "diagonal" initialisation needs lmax == mmax)
+    fwd = ma.RealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid).to(DEV)
+    inv = ma.InverseRealSHT(nlat, nlon, lmax=L, mmax=M, grid=grid).to(DEV)
+    x = torch.randn(2, C, nlat, nlon, device=DEV)
+    g = torch.randn(2, C, nlat, nlon, device=DEV)
+    eye = torch.eye(C, device=DEV, dtype=torch.complex64)
+    res = {}
+    # (1) "diagonal" with a weight that is diagonal in the channels == separable "diagonal"      (test_contractions.py:198-214)
+    sep = _conv(fwd, inv, C, "diagonal", True)
+    full = _conv(fwd, inv, C, "diagonal", False)
+    with torch.no_grad():
+        full.weight.copy_(torch.einsum("io,gilm->giolm", eye, sep.weight))
+    res["lmwise diag == sep_lmwise"] = (_fwd_bwd(full, x, g), _fwd_bwd(sep, x, g))
+    # (2) "dhconv" with a channel-diagonal weight == separable "dhconv"                           (:216-232)
+    sep = _conv(fwd, inv, C, "dhconv", True)
+    full = _conv(fwd, inv, C, "dhconv", False)
+    with torch.no_grad():
+        full.weight.copy_(torch.einsum("io,gil->giol", eye, sep.weight))
+    res["lwise diag == sep_lwise"] = (_fwd_bwd(full, x, g), _fwd_bwd(sep, x, g))
+    # (3) "dhconv" == "diagonal" with a weight that is constant in m                              (:234-249)
+    lw = _conv(fwd, inv, C, "dhconv", False)
+    lm = _conv(fwd, inv, C, "diagonal", False)
+    with torch.no_grad():
+        lm.weight.copy_(lw.weight.unsqueeze(-1).expand(-1, -1, -1, -1, M))
+    res["lwise == lmwise mconst"] = (_fwd_bwd(lw, x, g), _fwd_bwd(lm, x, g))
+    errs = {k: (rel_l2(a[0], b[0]), rel_l2(a[1], b[1])) for k, (a, b) in res.items()}
+    print("contraction relations (output, input gradient):", {k: f"{v[0]:.1e} / {v[1]:.1e}" for k, v in errs.items()})
+    assert all(max(v) < 1e-5 for v in errs.values()), errs
