@@ -470,7 +470,12 @@ def _cpu_worker(cfg_name, mode, state_path=None, out_path=None):
         torch.save(_grad_record(model, l16), out_path + ".grads_bf16")
 
 
-def _cpu_worker_fcn3(cfg_name):
+def fcn3_parity_input(cin, h, w):
+    """input of the FourCastNet3 line's in-run block parity: seeded U[0, 1), identical in the GPU process and in the CPU child"""
+    return torch.rand(1, cin, h, w, generator=torch.Generator().manual_seed(PARITY_SEED + 2))
+
+
+def _cpu_worker_fcn3(cfg_name, state_path=None, out_path=None):
     """child process of the FourCastNet3 line: the oracle's processor blocks (oracle/fcn3.py — the reference's network code restated,
     pinned by fixtures written by the reference's own module: tests/test_oracle_fcn3.py) at the REAL internal grid and width, fp32,
     one ensemble member.  Bounded sample: one "global" block (spectral convolution + MLP) and one "local" block (DISCO convolution
@@ -497,7 +502,9 @@ def _cpu_worker_fcn3(cfg_name):
     isht = osht.InverseRealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid=grid).float()
     kw = dict(mlp_ratio=m.get("mlp_ratio", 2.0), normalization_layer=m.get("normalization_layer", "none"), use_mlp=m.get("use_mlp", True),
               kernel_shape=tuple(m["kernel_shape"]), basis_type=m["filter_basis_type"], bias=m.get("bias", False))
-    x = torch.rand(1, cin, h, w, requires_grad=True)
+    x = (fcn3_parity_input(cin, h, w) if state_path else torch.rand(1, cin, h, w)).requires_grad_(True)
+    state = torch.load(state_path, map_location="cpu") if state_path else None
+    outputs = {}
 
     def timed(blk):
         t0 = time.perf_counter()
@@ -509,6 +516,10 @@ def _cpu_worker_fcn3(cfg_name):
         blk(x).square().mean().backward()
         return t_f, time.perf_counter() - t0
     blk = ofc.NeuralOperatorBlock(sht, isht, cin, total, conv_type="global", **kw)
+    if state is not None:                                      # the GPU model's own blocks: the timed passes are the parity passes
+        blk.load_state_dict(state["global"], strict=True)
+        with torch.no_grad():
+            outputs["global"] = blk(x).detach().clone()
     best = None
     for threads in sorted({min(cores, t) for t in (32, 64)}):
         torch.set_num_threads(threads)
@@ -525,10 +536,17 @@ def _cpu_worker_fcn3(cfg_name):
     del blk
     blk = ofc.NeuralOperatorBlock(sht, isht, cin, total, conv_type="local", **kw)
     rec["psi_entries"] = int(blk.local_conv.psi_vals.numel())
+    if state is not None:
+        blk.load_state_dict(state["local"], strict=True)
     t0 = time.perf_counter()
     with torch.no_grad():
-        blk(x)
+        y = blk(x)
     rec["t_local"] = time.perf_counter() - t0
+    if state is not None and out_path:
+        outputs["local"] = y.detach()
+        torch.save(outputs, out_path)
+        rec["parity_output"] = out_path
+    del y
     print(json.dumps(rec), flush=True)                         # forward-only figures complete from here on
     x.grad = None
     t0 = time.perf_counter()
@@ -624,6 +642,56 @@ class ParityProbe:
         return out
 
 
+class Fcn3ParityProbe:
+    """In-run parity of the FourCastNet3 line, block level: the first "global" and the first "local" processor block of the measured
+    model — its initial weights, a seeded input of the real internal shape — run forward on the GPU in fp32 and under bf16 autocast;
+    their weights go to a scratch file.  The CPU child that times the oracle's blocks loads those weights and runs the same input:
+    its timed forward passes ARE the oracle side of ``parity_rel_l2``.  (The whole network's forward pass is many minutes of host
+    time; the whole network is compared against fixtures of the reference's own module in tests/test_fcn3.py.)"""
+
+    def __init__(self, model, cfg, device):
+        import tempfile
+        self.dir = tempfile.mkdtemp(prefix="mk_parity_fcn3_")
+        self.state_path = os.path.join(self.dir, "blocks.pt")
+        self.out_path = os.path.join(self.dir, "oracle_blocks.pt")
+        self.oracle_bf16 = None
+        blocks = {"global": next(b for b in model.blocks if hasattr(b, "global_conv")),
+                  "local": next(b for b in model.blocks if hasattr(b, "local_conv"))}
+        torch.save({k: {n: v.detach().cpu() for n, v in b.state_dict().items()} for k, b in blocks.items()}, self.state_path)
+        h, w = blocks["global"].inp_shape
+        cin = model.total_embed_dim + (model.aux_embed_dim if model.n_aux_chans > 0 else 0)
+        x = fcn3_parity_input(cin, h, w).to(device)
+        self.y32, self.y16 = {}, {}
+        with torch.no_grad():
+            for k, b in blocks.items():
+                self.y32[k] = b(x).float().cpu()
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    self.y16[k] = b(x).float().cpu()
+        del x
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+
+    def finish(self):
+        import shutil
+        out = None
+        try:
+            if os.path.exists(self.out_path):
+                ref = torch.load(self.out_path, map_location="cpu")
+                out = {}
+                for k in ("global", "local"):
+                    if k in ref:
+                        yo = ref[k].double()
+                        out[f"{k}_block_fp32"] = float((self.y32[k].double() - yo).norm() / yo.norm())
+                        out[f"{k}_block_bf16_autocast"] = float((self.y16[k].double() - yo).norm() / yo.norm())
+                out["what"] = ("rel-L2 of the forward output of the measured model's first global (spectral convolution + MLP) and first local "
+                               "(DISCO convolution + MLP) processor block — initial weights of this run, seeded U[0,1) input of the real internal "
+                               "shape — against the fp32 CPU oracle's output of the passes timed as cpu_baseline.  Gates: fp32 <= 1e-4 "
+                               "(BASELINE.md §3, end to end), bf16 autocast <= 2e-2 per block")
+        finally:
+            shutil.rmtree(self.dir, ignore_errors=True)
+        return out
+
+
 def cpu_baseline(cfg_name, timeout_s=420, parity=None):
     """Reference-equivalent CPU path, timed in a child process on this host's cores, fp32 (kind "port": the oracle — the
     reference's own modules cannot be imported on the benchmark host, /root/reference exists in the build container only; the
@@ -634,8 +702,8 @@ def cpu_baseline(cfg_name, timeout_s=420, parity=None):
     the measured forward pass times the (forward+backward)/forward ratio measured on one internal-grid block; then the block
     alone scaled by the step/block FLOP ratio.  ``sample`` says which one was reported."""
     import subprocess
-    if cfg_name == "fcn3_sc2_edim45_layers10":          # (the small stand-in configurations carry no baseline)
-        return cpu_baseline_fcn3(cfg_name, timeout_s)
+    if CONFIGS.get(cfg_name, {}).get("kind") == "fcn3":
+        return cpu_baseline_fcn3(cfg_name, timeout_s, parity)
     if cfg_name != "sfno_sc3_layers8_edim384":
         return None
     mode = os.environ.get("MAKANI_AMD_CPU_BASELINE", "step")
@@ -685,13 +753,15 @@ def cpu_baseline(cfg_name, timeout_s=420, parity=None):
                 ms_per_step=step * 1e3, measured="one block, extrapolated")
 
 
-def cpu_baseline_fcn3(cfg_name, timeout_s=420):
+def cpu_baseline_fcn3(cfg_name, timeout_s=420, parity=None):
     """``cpu_baseline`` of the FourCastNet3 line: see ``_cpu_worker_fcn3`` for the sample (processor blocks only)."""
     import subprocess
     recs, err = [], None
     try:
-        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name], stdout=subprocess.PIPE,
-                              stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name]
+        if parity is not None:
+            cmd += ["--cpu-state", parity.state_path, "--cpu-out", parity.out_path]
+        pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         try:
             so, _ = pr.communicate(timeout=timeout_s)
         except subprocess.TimeoutExpired:
@@ -782,6 +852,11 @@ def run_worker(args):
     probe = None
     if world == 1 and not args.no_cpu_baseline and args.config == "sfno_sc3_layers8_edim384":
         probe = ParityProbe(model, cfg, device)                    # before the first update: the weights the oracle will load
+    elif world == 1 and not args.no_cpu_baseline and fcn3:
+        try:
+            probe = Fcn3ParityProbe(model, cfg, device)            # block level (the whole network is minutes of host time)
+        except Exception as e:                                     # the probe must never cost the measurement
+            print(f"[bench] FourCastNet3 parity probe unavailable: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
     # mappings.py:321-525 (the model itself when world == 1); --zero: ZeRO-1 over the data group (reduce-scattered
     # gradients, sharded AdamW state, in-place parameter all-gather: makani_amd/optim.py)
     net = thd.init_gradient_reduction_hooks(model, device, zero=args.zero and dsize > 1)
@@ -1218,7 +1293,7 @@ def main():
     ap.add_argument("--cpu-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker and CONFIGS.get(args.cpu_worker, {}).get("kind") == "fcn3":
-        _cpu_worker_fcn3(args.cpu_worker)
+        _cpu_worker_fcn3(args.cpu_worker, args.cpu_state, args.cpu_out)
         return
     if args.cpu_worker:
         _cpu_worker(args.cpu_worker, args.cpu_mode, args.cpu_state, args.cpu_out)

@@ -1,5 +1,5 @@
-# the reference's own model properties on the HIP path (tests/test_models.py: shapes, gradient accumulation)
-mkdir -p gpurun_out/r05d
+# the FourCastNet3 bench line with its cpu_baseline and block-level in-run parity, on the small stand-in configuration
+mkdir -p gpurun_out/r05e
 SECONDS=0
-timeout 100 python -m pytest tests/test_gpu_reference_properties.py -q -m gpu -s > gpurun_out/r05d/props.log 2>&1; echo "rc $? in $SECONDS s"
-grep -v "amdgpu.ids" gpurun_out/r05d/props.log | tail -25
+timeout 100 python -m pytest tests/test_bench_contract.py -q -m gpu -s -k fcn3_workload > gpurun_out/r05e/fcn3_line.log 2>&1; echo "rc $? in $SECONDS s"
+grep -v "amdgpu.ids" gpurun_out/r05e/fcn3_line.log | tail -25 | cut -c1-600

@@ -181,6 +181,13 @@ def test_bench_fcn3_workload_runs_the_ensemble_recipe():
     assert d["config"]["workload"] == "fcn3_debug" and d["config"]["ensemble_size"] == 2 and d["config"]["global_batch"] == 1
     assert d["final_loss"] == d["final_loss"] and d["roofline"]["bound"] in ("hbm", "mfma", "valu")
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    # the line's cpu_baseline (the oracle's processor blocks on the host) and its in-run parity: the measured model's first global
+    # and first local block against the oracle passes that were timed
+    c, par = d["cpu_baseline"], d["parity_rel_l2"]
+    print("fcn3_debug cpu_baseline:", c["value"], c["measured"], "| parity:", {k: v for k, v in par.items() if k != "what"})
+    assert c["kind"] == "port" and c["value"] > 0 and c["measured"].startswith("processor blocks")
+    assert par["global_block_fp32"] < 1e-4 and par["local_block_fp32"] < 1e-4
+    assert par["global_block_bf16_autocast"] < 2e-2 and par["local_block_bf16_autocast"] < 2e-2
 
 
 def test_roofline_prices_the_disco_contraction_against_the_vector_peak():
@@ -203,4 +210,37 @@ def test_fcn3_cpu_baseline_child_on_the_small_stand_in():
     assert r["kind"] == "port" and r["unit"] == "samples/s" and r["value"] > 0 and r["cores"] >= 1
     assert r["measured"] == "processor blocks, fwd + bwd" and "NOT included" in r["sample"] and "32x64" in r["sample"]
     assert abs(r["ms_per_step"] * 1e-3 * r["value"] - 1.0) < 1e-9
-    assert bench.cpu_baseline("fcn3_debug") is None and bench.cpu_baseline("sfno_debug") is None
+    assert bench.cpu_baseline("sfno_debug") is None
+
+
+def test_fcn3_cpu_child_is_the_oracle_side_of_the_block_parity(tmp_path):
+    """with the weights of the measured model's blocks handed over (bench.Fcn3ParityProbe writes them from the GPU model; here the
+    oracle's own blocks stand in), the child's timed forward passes run THOSE weights on the seeded parity input and their outputs
+    come back: bit-identical to running the same blocks here"""
+    import types
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import fcn3 as ofc, sht as osht
+    m = bench.CONFIGS["fcn3_debug"]["model"]
+    h, w = m["inp_shape"][0] // m["scale_factor"], m["inp_shape"][1] // m["scale_factor"]
+    _, _, _, _, levels = ofc.get_channel_groups(m["channel_names"], m["aux_channel_names"])
+    total = len(levels) * m["atmo_embed_dim"] + m["surf_embed_dim"]
+    cin = total + m["aux_embed_dim"]
+    sht = osht.RealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid="legendre-gauss").float()
+    isht = osht.InverseRealSHT(h, w, lmax=h, mmax=w // 2 + 1, grid="legendre-gauss").float()
+    torch.manual_seed(5)
+    blocks = {k: ofc.NeuralOperatorBlock(sht, isht, cin, total, conv_type=k, mlp_ratio=m["mlp_ratio"], normalization_layer="none", use_mlp=True,
+                                         kernel_shape=(3, 3), basis_type="morlet") for k in ("global", "local")}
+    with torch.no_grad():
+        for b in blocks.values():
+            b.layer_scale.weight.normal_()
+    parity = types.SimpleNamespace(state_path=str(tmp_path / "blocks.pt"), out_path=str(tmp_path / "out.pt"), oracle_bf16=None)
+    torch.save({k: b.state_dict() for k, b in blocks.items()}, parity.state_path)
+    r = bench.cpu_baseline("fcn3_debug", timeout_s=300, parity=parity)
+    assert r["value"] > 0 and r["measured"] == "processor blocks, fwd + bwd"
+    got = torch.load(parity.out_path)
+    x = bench.fcn3_parity_input(cin, h, w)
+    with torch.no_grad():
+        for k, b in blocks.items():
+            assert torch.equal(got[k], b(x)), k
