@@ -58,13 +58,14 @@ def test_disco_conv_matches_oracle_fp32(in_shape, out_shape, gi, go, fac, groups
 
 
 @pytest.mark.parametrize("basis,kshape", [("morlet", (2, 2)), ("morlet", (2, 4)), ("morlet", (4, 4)), ("piecewise linear", (3, 4)),
-                                          ("piecewise linear", (4, 3)), ("piecewise linear", (3,)), ("zernike", (3, 3)), ("zernike", 4)])
+                                          ("piecewise linear", (4, 3)), ("piecewise linear", (3,)), ("piecewise linear", (5, 4)),
+                                          ("zernike", (3, 3)), ("zernike", 4)])
 @pytest.mark.parametrize("in_shape,out_shape,gi,go,groups", [((33, 64), (17, 32), "equiangular", "equiangular", 1),
                                                              ((24, 48), (24, 48), "legendre-gauss", "legendre-gauss", 2)])
 def test_disco_conv_other_bases_and_kernel_sizes_match_oracle_fp32(basis, kshape, in_shape, out_shape, gi, go, groups):
     """the kernels take the convolution tensor as data: every filter basis of torch-harmonics 0.7.4 - 0.8.0 and kernel sizes other
     than FourCastNet3's nine (4, 5, 6, 8, 10, 16 basis functions: the general-K run / list kernels instead of the fused K = 9
-    one), strided and equal grids, grouped.  ("support" normalisation, where the rim of a hat decides its constant, is a host-side
+    one; and nine HATS, which do take the fused kernel), strided and equal grids, grouped.  ("support" normalisation, where the rim of a hat decides its constant, is a host-side
     matter: tests/test_oracle_disco.py)"""
     mode = "individual" if basis == "piecewise linear" else "mean"
     ref, mod = _pair(6, 4, in_shape, out_shape, gi, go, 1.0, groups, kernel_shape=kshape, basis_type=basis, norm_mode=mode)
