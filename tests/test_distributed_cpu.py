@@ -633,8 +633,10 @@ def _worker_disco(rank, world, port, h, w):
             if i == ih:
                 wg = g
         thd.init(hg if h > 1 else None, wg if w > 1 else None)
-        for in_shape, out_shape, C in (((19, 36), (10, 18), 5), ((13, 24), (13, 24), 4), ((13, 24), (7, 12), 1)):
-            d = disco.DistributedDiscreteContinuousConvS2(C, 3, in_shape, out_shape, (3, 3), basis_type="morlet", bias=False,
+        for in_shape, out_shape, C, kshape, basis in (((19, 36), (10, 18), 5, (3, 3), "morlet"), ((13, 24), (13, 24), 4, (3, 3), "morlet"),
+                                                      ((13, 24), (7, 12), 1, (3, 3), "morlet"), ((13, 24), (13, 24), 2, (3, 4), "piecewise linear"),
+                                                      ((19, 36), (10, 18), 2, 3, "zernike")):
+            d = disco.DistributedDiscreteContinuousConvS2(C, 3, in_shape, out_shape, kshape, basis_type=basis, bias=False,
                                                           theta_cutoff=4.0 * math.pi / (in_shape[0] - 1))
             torch.manual_seed(3)
             x = torch.randn(2, C, *in_shape, dtype=torch.float64, requires_grad=True)
