@@ -1,5 +1,6 @@
-# FourCastNet3 under bf16 autocast with the other filter bases (5 / 6 basis functions), forward + backward
-mkdir -p gpurun_out/r05h
+# round 6, call 2: which victim kernel goes wrong under a second stream, and what do the wrong values look like
+mkdir -p gpurun_out/r06b
+export TMPDIR=/tmp
 SECONDS=0
-timeout 60 python -m pytest tests/test_fcn3.py -q -m gpu -s -k "bf16" > gpurun_out/r05h/bf16.log 2>&1; echo "rc $? in $SECONDS s"
-grep -v "amdgpu.ids" gpurun_out/r05h/bf16.log | tail -30 | cut -c1-300
+timeout 600 python tools/two_stream_micro.py --reps 30 > gpurun_out/r06b/micro.log 2>&1; echo "micro rc $? at $SECONDS s"
+grep -v "amdgpu.ids" gpurun_out/r06b/micro.log | tail -80 | cut -c1-330

@@ -1296,20 +1296,15 @@ def _all_reduce_sum(t, group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-_SHARD_COUNTS = {}      # (group, local count) -> (counts of all ranks as a device vector, their sum as a Python float)
+_COUNT_ROWS = {}        # (local count, device) -> a (1, 2) device row {count, 0}: a per-rank constant, no collective involved
 
 
-def _shard_counts(group, count: float, device):
-    """pixel counts (or quadrature-weight sums) of a plane's shards on the ranks of ``group``: constants of the grid split, so
-    they are gathered ONCE per (group, local count) — the only host read of the distributed norm, at the first call; the step
-    itself then contains no device -> host synchronisation (what a hipGraph capture of the h x w step requires)"""
-    key = (id(group), float(count), str(device))
-    hit = _SHARD_COUNTS.get(key)
-    if hit is None:
-        mine = torch.tensor([float(count)], dtype=torch.float32, device=device)
-        allc = _all_gather_stack(mine, group).reshape(-1).contiguous()
-        hit = _SHARD_COUNTS[key] = (allc, float(allc.double().sum()))
-    return hit
+def _count_row(count: float, device):
+    key = (float(count), str(device))
+    row = _COUNT_ROWS.get(key)
+    if row is None:
+        row = _COUNT_ROWS[key] = torch.tensor([[float(count), 0.0]], dtype=torch.float32, device=device)
+    return row
 
 
 class DistInstanceNormFn(torch.autograd.Function):
@@ -1319,7 +1314,7 @@ class DistInstanceNormFn(torch.autograd.Function):
     with the merged statistics (HIP).  Backward all-reduces the two per-plane sums between the HIP reduce and apply phases.
     With ``quad`` (this shard's quadrature weights, ``quad_sum`` their sum) the moments are area-weighted and the counts are
     the weight sums: ``DistributedGeometricInstanceNormS2`` (makani/mpu/layer_norm.py:173-253).
-    No host synchronisation after the first call (the shard counts are cached), no torch arithmetic between the kernels."""
+    No host synchronisation at all: the ranks' shard counts ride in the all-gathered statistics tensor and stay on the device."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, fuse_gelu, group, quad=None, quad_sum=0.0):
@@ -1328,14 +1323,20 @@ class DistInstanceNormFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         planes, hw = B * Cc, H * W
         dt = dtype_code(x)
-        stats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
+        # the ranks' shard sizes (pixel counts, or quadrature-weight sums) travel WITH the statistics as one extra row of the
+        # all-gathered tensor: every call sees the counts of THIS call's split on every rank — no cache that could go stale or
+        # let one rank skip a collective the others enter, no extra collective, and no device -> host read
+        # (what a hipGraph capture of the h x w step requires)
+        stats = torch.empty((planes + 1, 2), dtype=torch.float32, device=x.device)
+        stats[planes:].copy_(_count_row(float(quad_sum) if quad is not None else float(hw), x.device))
         ws = _ws(planes, hw, x.dtype, x.device)
         nb = float(x.numel() * x.element_size())
         tag = f"{'_gelu' if fuse_gelu else ''}_n{hw}"
         with _timed(f"instnorm_dist_stats{tag}", nbytes=nb):
             check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, ptr(quad), float(quad_sum), stream()), "instnorm_stats")
-        counts, total = _shard_counts(group, float(quad_sum) if quad is not None else float(hw), x.device)
-        allst = _all_gather_stack(stats, group)                  # (P, planes, 2): every rank's local {mean, rstd}
+        allst = _all_gather_stack(stats, group)                  # (P, planes + 1, 2): every rank's local {mean, rstd} + its count
+        counts = allst[:, planes, 0].contiguous()
+        allst = allst[:, :planes].contiguous()
         mstats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
         check(lib().mk_instnorm_merge(ptr(allst), ptr(counts), ptr(mstats), planes, allst.shape[0], eps, stream()), "instnorm_merge")
         g = gamma.float().contiguous() if gamma is not None else None
@@ -1344,14 +1345,14 @@ class DistInstanceNormFn(torch.autograd.Function):
         with _timed(f"instnorm_dist_apply{tag}", nbytes=2.0 * nb):
             check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(mstats), ptr(g), ptr(b), planes, Cc, hw,
                                           1 if fuse_gelu else 0, stream()), "instnorm_apply")
-        ctx.save_for_backward(x, mstats, g, b, quad)
-        ctx.meta = (fuse_gelu, group, total)
+        ctx.save_for_backward(x, mstats, g, b, quad, counts)
+        ctx.meta = (fuse_gelu, group)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, mstats, g, b, quad = ctx.saved_tensors
-        fuse_gelu, group, total = ctx.meta
+        x, mstats, g, b, quad, counts = ctx.saved_tensors
+        fuse_gelu, group = ctx.meta
         B, Cc, H, W = x.shape
         planes, hw = B * Cc, H * W
         gy = gy.contiguous()
@@ -1361,23 +1362,22 @@ class DistInstanceNormFn(torch.autograd.Function):
         sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
         ws = _ws(planes, hw, x.dtype, x.device)
         fg = 1 if fuse_gelu else 0
-        # unweighted: every shard of a plane has hw pixels except along ragged splits; the true total is the sum of the ranks'
-        # counts (exact small integers in fp32, summed in fp64 on the host once: _shard_counts)
-        hw_tot = int(round(total)) if quad is None else hw
         nb = float(x.numel() * x.element_size())
         tag = f"{'_gelu' if fuse_gelu else ''}_n{hw}"
         with _timed(f"instnorm_dist_bwd_reduce{tag}", nbytes=2.0 * nb):
             check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, None, 0.0, ptr(sums),
-                                        ptr(ws), planes, Cc, hw, hw_tot, 1, fg, stream()), "instnorm_bwd(reduce)")
+                                        ptr(ws), planes, Cc, hw, hw, 1, fg, stream()), "instnorm_bwd(reduce)")
         local = _batch_sum(sums, B, Cc).clone()                   # this rank's share of dgamma / dbeta
         _all_reduce_sum(sums, group)
-        if quad is not None:
-            # normalised weights p_i = q_i / Q (Q = merged count): gx = k (ga - p_i (S1 + n_i S2)); the kernel multiplies the
-            # sums by q_i per element, so they are divided by Q here and the kernel's crop term is switched off (sum = 1)
-            sums = (sums / total).contiguous()
+        # the kernel divides the sums by its `hw_total` argument (unweighted) or multiplies them by q_i per element (weighted);
+        # the true total — the sum of the ranks' counts along possibly ragged splits, exact small integers in fp32 — lives on the
+        # device: the sums are pre-scaled there (hw / total, resp. 1 / Q for the normalised weights p_i = q_i / Q with the
+        # kernel's crop term switched off) and the kernel is told the LOCAL count
+        total = counts.double().sum()
+        sums = (sums.double() * ((1.0 if quad is not None else float(hw)) / total)).float().contiguous()
         with _timed(f"instnorm_dist_bwd_apply{tag}", nbytes=3.0 * nb):
             check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(quad),
-                                        1.0 if quad is not None else 0.0, ptr(sums), ptr(ws), planes, Cc, hw, hw_tot, 2, fg, stream()),
+                                        1.0 if quad is not None else 0.0, ptr(sums), ptr(ws), planes, Cc, hw, hw, 2, fg, stream()),
                   "instnorm_bwd(apply)")
         dgamma = local[1] if g is not None else None
         dbeta = local[0] if b is not None else None

@@ -140,6 +140,23 @@ def cases(dev):
         add(f"conv1x1_nn+R m{Mo} k{K} {H}x{W}", lambda A=A, K=K, x=x, res=res: ops.conv1x1_nn(A, K, x, residual=res)[0])
         add(f"conv1x1_wgrad m{Mo} k{K} {H}x{W}", lambda gsrc=gsrc, x=x: ops.conv1x1_wgrad(gsrc, x))
         add(f"conv1x1_wgrad+bias m{Mo} k{K} {H}x{W}", lambda gsrc=gsrc, x=x: ops.conv1x1_wgrad(gsrc, x, want_bias=True))
+    # ---- probe kernels (tools/probes/lds_poison.hip; round 6): as a hog (RACE_HUNT_HOG_FILTER=probe_lds / probe_spin) they leave NaN
+    # patterns in every compute unit's LDS and vector registers / stay co-resident WITHOUT touching memory or the matrix cores
+    ppath = os.path.join(ROOT, "tools", "probes", "liblds_poison.so")
+    if os.path.exists(ppath):
+        import ctypes
+        lib = ctypes.CDLL(ppath)
+        lib.mk_probe_lds_poison.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+        lib.mk_probe_vgpr_poison.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        sink = torch.zeros(1024, dtype=torch.int32, device=dev)
+
+        def poison(spin=0, lds=64 * 1024):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            lib.mk_probe_lds_poison(0xFFFFFFFF, lds, 2048, 256, spin, ctypes.c_void_p(sink.data_ptr()), st)
+            lib.mk_probe_vgpr_poison(0xFFFFFFFF, 4096, ctypes.c_void_p(sink.data_ptr()), st)
+            return sink
+        add("probe_lds poison 64K", lambda: poison())
+        add("probe_spin 8K lds 20us", lambda: poison(spin=2000, lds=8 * 1024))
     return out
 
 
