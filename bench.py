@@ -9,8 +9,9 @@ bf16 autocast (fp32 spectral path), synthetic DummyLoader-shaped data resident i
 N > 1: one process per GPU over RCCL.  Launched either by the driver through ``torch.distributed.run`` (RANK /
 WORLD_SIZE / MASTER_* in the environment) or directly as ``python bench.py --gpus N`` (the script then spawns its N
 ranks itself).  The headline measurement at N > 1 is the north-star split — spatial model parallelism h x w over ALL N
-GPUs (N = 2: h2w1, 4: h4w1, 8: h4w2; "scaling": "strong", one sample per step) — and the same run then measures plain
-data parallelism (one sample per GPU, gradient all-reduce overlapped with backward, "weak") as ``secondary``.
+GPUs (N = 4: h4w1, 8: h4w2; "scaling": "strong", one sample per step) — and the same run then measures plain
+data parallelism (one sample per GPU, gradient all-reduce overlapped with backward, "weak") as ``secondary``.  At N = 2 the
+headline IS data parallelism (the reference's partitioning has no 2-GPU split worth running on xGMI: default_parallelism).
 ``--parallelism dp|hHwW`` picks the headline explicitly.
 
 Rank 0 prints ONE JSON line (see DESIGN.md §7 for every field).
@@ -914,7 +915,7 @@ def run_worker(args):
 
     # ---- hipGraph: the whole step (forward, backward, clip, AdamW: ~380 dependent launches) captured once, replayed
     # per step.  Nothing in the step depends on host state (the optimizer's step counter lives in device memory,
-    # inputs are static tensors, the distributed norm reads its shard counts on the host only once), so a replay IS the step.
+    # inputs are static tensors, the distributed norm's shard counts stay on the device), so a replay IS the step.
     # N > 1 over RCCL: the collectives are captured WITH the step (RCCL's kernels are ordinary stream work; torch's process
     # group records them on the capturing streams).  It is what makes the h x w step scale at all: eager, one rank of h4 w2
     # launches for 34 ms per step while its kernels run for 11 (tools/shadow_rank.py, profiles/r05_shard_shapes.md).  Every
@@ -954,6 +955,14 @@ def run_worker(args):
         if graph is not None:
             graph.replay()                                    # first replay outside the timed region
             torch.cuda.synchronize()
+            # a replay whose loss is not a finite number (a collective that did not survive the capture) must not be timed: every
+            # rank checks its own replayed loss, the ranks agree, and on disagreement all fall back to eager launches
+            okf = torch.isfinite(graph_loss.detach().float()).all().to(torch.int32).reshape(1)
+            if world > 1:
+                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                graph, graph_note = None, "the first replay of the captured step produced a non-finite loss; eager launches"
+                print(f"[bench] {graph_note}", file=sys.stderr, flush=True)
 
     ops.PROFILER.reset()
     ops.PROFILER.enabled = graph is None
@@ -1068,8 +1077,9 @@ def run_worker(args):
             print("[bench] train loop done; measuring fwd SHT", file=sys.stderr, flush=True)
             out["fwd_sht"] = sht_bandwidth(device)
             print("[bench] fwd SHT done; CPU baseline", file=sys.stderr, flush=True)
-        # roofline.traffic measured in THIS run: the two counter passes are child runs of this script under rocprofv3 and use
-        # the GPU; they run beside the CPU baseline child (host cores only), so the line is not later for them
+        # roofline.traffic measured in THIS run: the two counter passes are child runs of this script under rocprofv3.  They
+        # finish BEFORE the CPU baseline starts (each builds the model on the host and precomputes the Legendre matrices in fp64:
+        # beside the baseline they competed for its cores — ADVICE r5), at the price of about a minute of wall time
         pmc_thread, pmc_live = None, {}
         want_pmc = (world == 1 and not args.no_pmc and roofline is not None and args.multistep_count == 1
                     and args.config in ("sfno_sc3_layers8_edim384", "fcn3_sc2_edim45_layers10"))
@@ -1083,6 +1093,7 @@ def run_worker(args):
             import threading
             pmc_thread = threading.Thread(target=lambda: pmc_live.update(zip(("data", "note"), live_pmc_traffic(args.config))), daemon=True)
             pmc_thread.start()
+            pmc_thread.join(timeout=900)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, parity=probe)
             out["parity_rel_l2"] = probe.finish() if probe is not None else None
@@ -1157,9 +1168,11 @@ def _run_phase(args, parallelism, ranks, world, port, timeout_s):
         env.setdefault("LOCAL_RANK", str(r))
         if len(ranks) > 1:
             env["LOCAL_RANK"] = str(r)
-        if os.environ.get("MAKANI_AMD_BENCH_BACKEND", "nccl") != "nccl" and world > 1 and torch.cuda.device_count() == 1:
-            # the functional mode "N ranks on ONE GPU over gloo": disjoint compute units per rank (makani_amd/comm.py: share_gpu
-            # says why); the variable must be in the worker's environment before its HIP runtime starts
+        if (os.environ.get("MAKANI_AMD_BENCH_BACKEND", "nccl") != "nccl" and world > 1 and torch.cuda.device_count() == 1
+                and os.environ.get("MAKANI_AMD_BENCH_CU_MASK", "0") == "1"):
+            # the functional mode "N ranks on ONE GPU over gloo", optionally with disjoint compute units per rank (isolates the
+            # ranks' kernel timings; no longer needed for correct results: makani_amd/comm.py share_gpu); the variable must be
+            # in the worker's environment before its HIP runtime starts
             per = max(1, 256 // world)
             env["HSA_CU_MASK"] = f"0:{r * per}-{(r + 1) * per - 1}"
         keep_out = (r == 0)
@@ -1271,7 +1284,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 counter passes in this run "
                                                           "(the committed profiles/ file is used instead)")
     ap.add_argument("--parallelism", default=os.environ.get("MAKANI_AMD_PARALLELISM", "auto"),
-                    help="'auto' (default: dp on one GPU; on N > 1 the north-star split h x w over all N GPUs — 2: h2w1, "
+                    help="'auto' (default: dp on one or two GPUs; on 4 / 8 GPUs the north-star split h x w over all N GPUs — "
                          "4: h4w1, 8: h4w2 — strong scaling), 'dp' (one sample per GPU, weak scaling) or 'hHwW': spatial "
                          "model parallelism over H x W GPUs per model instance, remaining ranks data parallel")
     ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the second (data-parallel) measurement")

@@ -16,6 +16,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def file_flags(src):
+    """extra hipcc flags a source file asks for in a `// MK_HIPCC_FLAGS: ...` comment line (e.g. -fno-slp-vectorize for the
+    files whose scalar arithmetic must not be auto-vectorised into packed-fp32 instructions: docs/LAB_NOTEBOOK.md, round 6)"""
+    out = []
+    with open(src) as f:
+        for line in f:
+            if line.startswith("// MK_HIPCC_FLAGS:"):
+                out += line.split(":", 1)[1].split()
+    return out
+
+
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
@@ -30,14 +41,14 @@ def build(force=False, verbose=True, defines=(), tag=None):
     ``-D`` options — what tools/ab.py uses for A/B measurements inside one GPU call; the default build is untouched."""
     objdir = os.path.join(HERE, "build" + (f"_{tag}" if tag else ""))
     LIB = os.path.join(HERE, f"libmakani_amd_{tag}.so") if tag else globals()["LIB"]
-    FLAGS = globals()["FLAGS"] + [d if d.startswith("-D") else "-D" + d for d in defines]
+    FLAGS = globals()["FLAGS"] + [d if d.startswith("-") else "-D" + d for d in defines]      # (-D..., or any other compiler flag)
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, src):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + file_flags(src) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -25,17 +25,16 @@ MODEL_COMM_NAMES = ("h", "w", "spatial", "matmul", "fin", "fout", "model")
 
 
 def share_gpu(rank_on_gpu: int, ranks_on_gpu: int, ncu: int = 256) -> str:
-    """Functional runs that put SEVERAL ranks on ONE GPU (the one-GPU tests of the h x w path, ``bench.py`` with
-    ``MAKANI_AMD_BENCH_BACKEND=gloo``): give every rank its own range of compute units (``HSA_CU_MASK``, read by the ROCm
-    runtime when the process creates its queues — call this BEFORE the first GPU call of the process).
+    """Give every rank that shares ONE GPU its own range of compute units (``HSA_CU_MASK``, read by the ROCm runtime when the
+    process creates its queues — call this BEFORE the first GPU call of the process).  Returns the mask it set.
 
-    Why: on the MI355X boxes of this pool, kernels of DIFFERENT processes that share a compute unit disturb each other's
-    results — a process running reduction / FFT kernels next to another process's matrix-core kernels reads a few wrong
-    values per launch (transient, input tensors untouched, 1e-4 .. 1e-2 relative on per-plane sums; measured with
-    ``tools/race_hunt.py``: 0 of ~10 000 launches differ with one process per GPU or with disjoint compute units, every
-    launch differs with shared ones; docs/LAB_NOTEBOOK.md, round 5).  One process per GPU — the deployment model of this
-    package — is not affected; ranks sharing a GPU must not share compute units if their results are to be compared at
-    fp32 tolerances.  Returns the mask it set."""
+    History: round 5 needed this for functional runs with several ranks on one GPU — bf16 instance-norm backward and the
+    inverse FFT returned transiently wrong values next to another process's matrix kernels.  Round 6 reproduced the effect in
+    ONE process on two streams and traced it to an instruction form, not to process sharing: ``v_pk_mul/add/fma_f32`` with a
+    VGPR src1 read through ``op_sel`` (low result lane <- src0.lo x src1.hi) returns wrong results on gfx950 while the split-bf16
+    GEMM runs on the same compute unit (docs/LAB_NOTEBOOK.md 6.1; minimal repro: tools/pk_hazard_probe.py).  No kernel of the
+    package contains that form any more (tools/pk_opsel_scan.py is part of the CPU test suite), the tests run without masks, and
+    this helper remains for experiments that want the ranks of a shared GPU isolated (e.g. timing one rank's kernels)."""
     import os
     per = max(1, ncu // max(1, ranks_on_gpu))
     mask = f"0:{rank_on_gpu * per}-{(rank_on_gpu + 1) * per - 1}"

@@ -1,3 +1,7 @@
+// MK_HIPCC_FLAGS: -fno-slp-vectorize
+// (gfx950: v_pk_mul_f32 / v_pk_add_f32 whose src1 is a VGPR pair read through op_sel return wrong results while certain
+//  matrix-core kernels run on the same compute unit — tools/pk_hazard_probe.py, docs/LAB_NOTEBOOK.md round 6.  The SLP vectoriser
+//  emits exactly those forms from plain scalar code, so this file is compiled without it; tools/pk_opsel_scan.py checks the ISA.)
 // Longitude real FFTs of the spherical harmonic transform (gfx950).
 //
 //   mk_rfft_rows : x[row][lat][lon] (f32|bf16) -> F[m][ri][row][lat]  (truncated to mmax modes, weighted)

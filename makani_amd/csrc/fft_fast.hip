@@ -659,10 +659,10 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                         const cf Xa = cf_make(wv.x * re[i], wv.y * im[i]);
                         const cf Xc = cf_make(Xa.x, -Xa.y);
                         const cf wt = cmulc(Xa, tw);                           // conj(U) X
-                        buf[(r0 + i) * LS + m] = Xc - wt.yx;                   // conj(X + i conj(U) X)
+                        buf[(r0 + i) * LS + m] = sub_yx(Xc, wt);                   // conj(X + i conj(U) X)
                         if (m != 0) {
                             const cf w2 = cmul(Xc, tw);                        // U conj(X)
-                            buf[(r0 + i) * LS + N2 - m] = Xa - w2.yx;          // conj(conj(X) + i U conj(X))
+                            buf[(r0 + i) * LS + N2 - m] = sub_yx(Xa, w2);          // conj(conj(X) + i U conj(X))
                         }
                     }
                 }
@@ -712,11 +712,11 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                 const cf ua = add_conj(Xa, Xb), ub = add_conj(Xb, Xa);             // ub = conj(ua)
                 {
                     const cf wt = cmulc(sub_conj(Xa, Xb), twu[j]);
-                    buf[row * LS + j] = ub - wt.yx;                                // conj(ua + i wt)
+                    buf[row * LS + j] = sub_yx(ub, wt);                                // conj(ua + i wt)
                 }
                 if (j != 0 && j2 != j) {
                     const cf wt = cmulc(sub_conj(Xb, Xa), twu[j2]);
-                    buf[row * LS + j2] = ua - wt.yx;
+                    buf[row * LS + j2] = sub_yx(ua, wt);
                 }
             }
             __syncthreads();

@@ -1,3 +1,7 @@
+// MK_HIPCC_FLAGS: -fno-slp-vectorize
+// (gfx950: v_pk_mul_f32 / v_pk_add_f32 whose src1 is a VGPR pair read through op_sel return wrong results while certain
+//  matrix-core kernels run on the same compute unit — tools/pk_hazard_probe.py, docs/LAB_NOTEBOOK.md round 6.  The SLP vectoriser
+//  emits exactly those forms from plain scalar code, so this file is compiled without it; tools/pk_opsel_scan.py checks the ISA.)
 // Layout changes between torch-facing tensors and the internal spectral layouts (gfx950).
 //   complex64 dhconv parameter (Cin, Cout, L)  <->  W-layout W[l][ri][i][o]   (o padded to Cop)
 //   complex64 coefficients (B, C, L, M)        <->  S-layout S[l][m][ri][b][c] (c padded to Cp)

@@ -1,3 +1,7 @@
+// MK_HIPCC_FLAGS: -fno-slp-vectorize
+// (gfx950: v_pk_mul_f32 / v_pk_add_f32 whose src1 is a VGPR pair read through op_sel return wrong results while certain
+//  matrix-core kernels run on the same compute unit — tools/pk_hazard_probe.py, docs/LAB_NOTEBOOK.md round 6.  The SLP vectoriser
+//  emits exactly those forms from plain scalar code, so this file is compiled without it; tools/pk_opsel_scan.py checks the ISA.)
 // HBM-streaming pointwise kernels on NCHW planes (gfx950):
 //   instance norm (stats / apply / backward) with optional fused exact-erf GELU,
 //   bias + GELU forward / backward.
@@ -12,6 +16,9 @@
 // (one input, already cached by the statistics pass) is unchanged
 #ifndef MK_PW_NT
 #define MK_PW_NT 1
+#endif
+#ifndef MK_PW_DIAG_VGPR
+#define MK_PW_DIAG_VGPR 0
 #endif
 
 namespace {
@@ -360,7 +367,14 @@ __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, co
     const int chunk = blockIdx.x % chunks;
     const int c = (int)(plane % channels);
     const float pb = pre_bias ? pre_bias[c] : 0.f;
+#if MK_PW_DIAG_VGPR
+    // diagnostic build (tools/two_stream_micro.py): the per-plane scalars live in VECTOR registers
+    float mean, rstd;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(mean) : "s"(stats[2 * plane]));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(rstd) : "s"(stats[2 * plane + 1]));
+#else
     const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
+#endif
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const T* xp = x + plane * hw;
     const T* gp = gy + plane * hw;

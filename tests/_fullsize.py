@@ -23,10 +23,15 @@ CONFIG2 = dict(inp_shape=(721, 1440), out_shape=(721, 1440), inp_chans=73, out_c
 
 
 def share_gpu(rank, world, ncu=256):
-    """disjoint compute units for the ranks that share ONE GPU in a test (``HSA_CU_MASK``; must be in the environment before the
-    process's first GPU call): kernels of different processes on one compute unit disturb each other's results on these boxes
-    (makani_amd/comm.py: share_gpu; tools/race_hunt.py; docs/LAB_NOTEBOOK.md round 5) — with one process per GPU, the
-    deployment model, nothing of the kind exists"""
+    """Round 5 gave the ranks that share ONE GPU in a test disjoint compute units (``HSA_CU_MASK``) because kernels of different
+    processes on one compute unit disturbed each other's results.  Round 6 found the cause — packed-fp32 instructions that read a
+    VGPR src1 through op_sel are unreliable on gfx950 while certain matrix-core kernels share the compute unit
+    (docs/LAB_NOTEBOOK.md 6.1, tools/pk_hazard_probe.py) — and removed those instruction forms from every kernel
+    (tools/pk_opsel_scan.py, tests/test_packed_forms.py).  The tests therefore run WITHOUT the mask: N ranks on one GPU share
+    all compute units, which is the stronger check.  ``MAKANI_AMD_TEST_CU_MASK=1`` brings the mask back (must be in the
+    environment before the process's first GPU call)."""
+    if os.environ.get("MAKANI_AMD_TEST_CU_MASK", "0") != "1":
+        return
     per = max(1, ncu // max(1, world))
     os.environ["HSA_CU_MASK"] = f"0:{rank * per}-{(rank + 1) * per - 1}"
 

@@ -197,7 +197,8 @@ def _worker_fwd_bwd(rank, world, port, h, w, amp, hip_path):
             else "fp32: vs oracle / vs serial HIP"
         log_line(f"config2 h{h}w{w} rank {rank} (ih {ih}, iw {iw}; {hl}x{wl} px, l {l0}..{l0 + ll}) {mode}:  "
                  f"y {errs['y'][0]:.2e} / {errs['y'][1]:.2e}  gx {errs['gx'][0]:.2e} / {errs['gx'][1]:.2e}  "
-                 f"worst parameter gradient {worst[0]} {worst[1]:.2e}  "
+                 + (f"worst parameter gradient, as a RATIO to the oracle's own bf16 distance (gate 1.25): {worst[0]} x{worst[1]:.2f}  " if amp
+                    else f"worst parameter gradient {worst[0]} {worst[1]:.2e}  ") +
                  f"[blocks.0 spectral {errs['blocks.0.filter.filter.weight'][0]:.2e}, blocks.7 spectral "
                  f"{errs['blocks.7.filter.filter.weight'][0]:.2e}, encoder {errs['encoder.fwd.0.weight'][0]:.2e}]  "
                  f"peak {peak:.1f} GiB, setup {t1 - t0:.0f} s, fwd+bwd over gloo {t2 - t1:.1f} s")

@@ -70,19 +70,28 @@ def _launch_gemm(g, cplx, engine, a_planes=None):
 ENGINE_TOL = {"fp32": 2e-6, "x6": 2e-6, "x3": 2e-5, "x6v2": 2e-6, "x3v2": 2e-5}
 
 
-@pytest.mark.parametrize("engine", ["fp32", "x6", "x3", "x6v2", "x3v2"])
-@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
-@pytest.mark.parametrize("tri", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K,batch", [(68, 132, 37, 11), (200, 72, 129, 5), (12, 300, 16, 9),
-                                         # wide problems: the 256 x 256-tile kernel of the split-bf16 engine (Legendre shapes)
-                                         (240, 768, 100, 250), (300, 520, 70, 4)])
+def _sgemm_cases():
+    """every combination an engine actually serves (the wide shapes exist for the big-tile kernels of the default three-limb
+    engines; the pre-split kernel takes row-contiguous operands only — the Legendre layouts)"""
+    out = []
+    for (M, N, K, batch) in [(68, 132, 37, 11), (200, 72, 129, 5), (12, 300, 16, 9),
+                             # wide problems: the 256 x 256-tile kernel of the split-bf16 engine (Legendre shapes)
+                             (240, 768, 100, 250), (300, 520, 70, 4)]:
+        for tri in (0, 1, 2, 3, 4):
+            for (a_kc, b_kc) in [(True, True), (True, False), (False, True), (False, False)]:
+                for engine in ("fp32", "x6", "x3", "x6v2", "x3v2"):
+                    if N >= 512 and engine not in ("x6", "x6v2"):
+                        continue
+                    if engine.endswith("v2") and (a_kc or b_kc):
+                        continue
+                    out.append((engine, a_kc, b_kc, tri, M, N, K, batch))
+    return out
+
+
+@pytest.mark.parametrize("engine,a_kc,b_kc,tri,M,N,K,batch", _sgemm_cases())
 def test_sgemm_batched(engine, a_kc, b_kc, tri, M, N, K, batch):
     from makani_amd import _lib
     from makani_amd._lib import MkGemm, lib, check
-    if N >= 512 and engine not in ("x6", "x6v2"):
-        pytest.skip("the wide shapes exist for the big-tile kernels of the default (three-limb) engine")
-    if engine.endswith("v2") and (a_kc or b_kc):
-        pytest.skip("the pre-split kernel takes row-contiguous operands only (the Legendre layouts)")
     torch.manual_seed(M * 1000 + N + tri)
     A = torch.randn(batch, M, K)
     B = torch.randn(batch, N, K)
@@ -122,15 +131,22 @@ def test_sgemm_batched(engine, a_kc, b_kc, tri, M, N, K, batch):
         assert (out[:, :, :N][~vm] == -123.0).all(), "rows beyond the triangular bound must not be written"
 
 
-@pytest.mark.parametrize("engine", ["fp32", "x6", "x3", "x6v2", "x3v2"])
-@pytest.mark.parametrize("a_kc,b_kc", [(True, False), (True, True), (False, False), (False, True)])
-@pytest.mark.parametrize("tri,conj_a,conj_b,beta", [(3, 0, 0, 0), (3, 0, 1, 0), (4, 1, 0, 0), (4, 1, 0, 1), (0, 1, 1, 1)])
-@pytest.mark.parametrize("M,N,K,outer,inner", [(36, 140, 24, 7, 2), (100, 64, 52, 9, 1), (200, 132, 40, 210, 1)])
+def _cgemm_cases():
+    out = []
+    for (M, N, K, outer, inner) in [(36, 140, 24, 7, 2), (100, 64, 52, 9, 1), (200, 132, 40, 210, 1)]:
+        for (tri, conj_a, conj_b, beta) in [(3, 0, 0, 0), (3, 0, 1, 0), (4, 1, 0, 0), (4, 1, 0, 1), (0, 1, 1, 1)]:
+            for (a_kc, b_kc) in [(True, False), (True, True), (False, False), (False, True)]:
+                for engine in ("fp32", "x6", "x3", "x6v2", "x3v2"):
+                    if outer > 100 and engine not in ("x6", "x6v2"):      # the many-row-tile shape exists for the default engines
+                        continue
+                    out.append((engine, a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, inner))
+    return out
+
+
+@pytest.mark.parametrize("engine,a_kc,b_kc,tri,conj_a,conj_b,beta,M,N,K,outer,inner", _cgemm_cases())
 def test_cgemm_batched(engine, a_kc, b_kc, tri, conj_a, conj_b, beta, M, N, K, outer, inner):
     from makani_amd import _lib
     from makani_amd._lib import MkGemm, lib, check
-    if outer > 100 and engine not in ("x6", "x6v2"):
-        pytest.skip("the many-row-tile shape exists for the default (three-limb) engines")
     torch.manual_seed(17 + M + tri)
     batch = outer * inner
     A = torch.randn(batch, M, K, dtype=torch.complex128)
