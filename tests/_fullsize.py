@@ -98,11 +98,25 @@ def _compute_config2_oracle():
     return out
 
 
+def _oracle_fingerprint():
+    """what the cached results depend on: the oracle's sources, the configuration, this file's recipe (seeds) and the torch
+    version — a change of any of them computes a new file instead of silently comparing against stale results"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "oracle", "*.py"))) + [os.path.abspath(__file__)]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(repr(sorted(CONFIG2.items())).encode())
+    h.update(torch.__version__.encode())
+    return h.hexdigest()[:12]
+
+
 def config2_oracle():
     """the oracle side of the whole-network tests at 721 x 1440 x 73: state dict, input x, cotangent g, forward (fp32 and the
     reference's own CPU bf16 autocast), ONE backward pass of sum(y * g) in fp32 and one under bf16 autocast — input gradient
     and the gradient of every parameter (about three minutes on the GPU box's host the first time, then a file)"""
-    return cached("config2_oracle_v1.pt", _compute_config2_oracle)
+    return cached(f"config2_oracle_{_oracle_fingerprint()}.pt", _compute_config2_oracle)
 
 
 def spawn(fn, args, nprocs, timeout_s):
