@@ -203,6 +203,21 @@ int mk_instnorm_fwd(const void* x, void* y, int dtype, float* stats, float* ws, 
 int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
                     const float* beta, const float* pre_bias, const float* quad, float quad_sum, float* sums, float* ws, long long planes, int channels, long long hw,
                     long long hw_total, int phase, int fuse_gelu, void* stream);
+/* The same norm in ONE pass over the plane (round 6): a block keeps its chunk of the plane in registers between the
+ * statistics and the apply phase — 2 plane-sized transfers forward instead of 3, 3 backward instead of 5 — and the blocks of a
+ * plane hand their partial sums over through 64-bit agent-scope atomics (csrc/pointwise.hip: in_fwd_fused).  Serves unweighted
+ * statistics on planes whose size is a multiple of the 16-byte vector; mk_instnorm_fused_chunks returns 0 otherwise (use the
+ * two-kernel entry points above).  `slots`: planes * mk_instnorm_fused_chunks(..., kind) 64-bit words, ALL ONES before the first
+ * launch; `depart`: planes 32-bit words, ZERO before the first launch; the kernels leave both as they found them, so one pair
+ * serves every later launch on the same stream (never two launches that may run concurrently).  Same arithmetic and outputs
+ * as mk_instnorm_fwd / mk_instnorm_bwd (phase 0) — nn.InstanceNorm2d, makani/models/networks/sfnonet.py:618-620. */
+int mk_instnorm_fused_chunks(long long hw, int dtype, long long planes, int kind);   /* kind: 0 forward, 1 backward, 2 backward + GELU */
+int mk_instnorm_fwd_fused(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
+                          const float* pre_bias, void* slots, void* depart, long long planes, int channels, long long hw,
+                          float eps, int fuse_gelu, void* stream);
+int mk_instnorm_bwd_fused(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
+                          const float* beta, const float* pre_bias, float* sums, void* slots, void* depart, long long planes,
+                          int channels, long long hw, int fuse_gelu, void* stream);
 /* y = gelu(x + bias[c])  — the bias+activation of the 1x1 convolutions in MLP / EncoderDecoder
  * (makani/models/common/layers.py:603-643,768-823).  bias may be NULL (plain GELU).
  * Backward: gx = gy * gelu'(x + bias[c]); optional sums (2, planes): sums[0][p] = sum gx (bias grad). */

@@ -75,6 +75,9 @@ _SIGS = {
     "mk_instnorm_stats": ([c_vp, c_int, c_vp, c_vp, c_ll, c_ll, c_f, c_vp, c_f, c_vp], c_int),
     "mk_instnorm_merge": ([c_vp, c_vp, c_vp, c_ll, c_int, c_f, c_vp], c_int),
     "mk_instnorm_apply": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
+    "mk_instnorm_fused_chunks": ([c_ll, c_int, c_ll, c_int], c_int),
+    "mk_instnorm_fwd_fused": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_f, c_int, c_vp], c_int),
+    "mk_instnorm_bwd_fused": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp], c_int),
     "mk_instnorm_bwd": ([c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_ll, c_int, c_ll, c_ll, c_int, c_int, c_vp], c_int),
     "mk_chan_layernorm_chunks": ([c_int, c_ll], c_int),
     "mk_chan_layernorm_fwd": ([c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_f, c_vp], c_int),

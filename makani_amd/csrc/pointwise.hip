@@ -456,6 +456,241 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
     });
 }
 
+// ---- instance norm in ONE pass over the plane (round 6) -------------------------------------------------------------
+// The two-kernel forms above read the plane twice (statistics, then apply: 3 plane-sized transfers forward, 5 backward).
+// Here a block keeps its chunk of the plane IN REGISTERS between the two phases: load (every 16-byte vector in flight at
+// once) -> partial sums -> publish -> wait for the partial sums of the plane's other blocks -> normalise from registers
+// -> store: 2 transfers forward, 3 backward.
+//   * The blocks of one plane have consecutive block indices and a bounded register footprint, so they are co-resident
+//     or next in the dispatcher's in-order queue: the wait cannot deadlock (the lowest unfinished plane's blocks were all
+//     dispatched before any block of a later plane on their XCD).
+//   * Hand-over without fences: a block publishes its pair (s1, s2) as ONE 64-bit atomic store at agent scope into the
+//     slot (plane, chunk); a slot holds the sentinel (all ones: a NaN pair no sum produces) until then.  Readers spin on
+//     the slots with agent-scope atomic loads.  The last block of a plane to finish reading re-arms the plane's slots and
+//     its departure counter, so the buffer is ready for the next launch on the same stream (also under hipGraph replay).
+//   * Every block sums the plane's partial pairs in the same fixed order in fp64: all of them normalise with bit-identical
+//     statistics, and the result does not depend on timing.
+// 16-byte vectors a lane keeps per tensor (4 registers each), per kind of kernel (0 forward, 1 backward, 2 backward through the
+// fused GELU).  Fewer slots = more, smaller blocks per plane = more blocks in different phases at once; measured on rotating
+// 88 MB planes (profiles/r06_norm_one_pass.md): 15 slots 44.8 / 92.0 / 145 us, 8 slots 39.9 / 92.4 / 108, 5 slots 40.0 / 92.4 /
+// 97.5 (forward / backward / backward + GELU at 240 x 480 x 384; two-kernel path 52.0 / 97.3 / 107), and at 721 x 1440 8 slots
+// win the forward (0.375 ms) and the plain backward (0.520 vs 0.766 two-kernel), 5 the GELU backward (0.816 vs 0.910)
+#ifndef MK_FUSED_SLOTS_FWD
+#define MK_FUSED_SLOTS_FWD 8
+#endif
+#ifndef MK_FUSED_SLOTS_BWD
+#define MK_FUSED_SLOTS_BWD 8
+#endif
+#ifndef MK_FUSED_SLOTS_BWD_GELU
+#define MK_FUSED_SLOTS_BWD_GELU 5
+#endif
+__host__ __device__ constexpr int fused_slots(int kind) { return kind == 0 ? MK_FUSED_SLOTS_FWD : (kind == 1 ? MK_FUSED_SLOTS_BWD : MK_FUSED_SLOTS_BWD_GELU); }
+constexpr unsigned long long FUSED_SENTINEL = ~0ull;
+
+template <typename T>
+__host__ __device__ constexpr long long fused_chunk_cap(int kind) {
+    return (long long)NT * VecIO<T>::N * fused_slots(kind);
+}
+
+__device__ __forceinline__ void fused_publish(unsigned long long* slot, float s1, float s2) {
+    unsigned long long v = ((unsigned long long)__float_as_uint(s2) << 32) | (unsigned long long)__float_as_uint(s1);
+    if (v == FUSED_SENTINEL) v ^= 1ull;                  // (a NaN pair with this exact payload: keep it a NaN, not the sentinel)
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// totals of the plane's `chunks` (<= NT) published pairs, identical in every block of the plane; then the departure
+// protocol (the last block to leave re-arms the plane's slots).  All threads must call it.
+__device__ __forceinline__ void fused_gather(unsigned long long* slots, unsigned* depart, long long plane, int chunks, double& t1,
+                                             double& t2, double* redd /*[2*NT/64]*/) {
+    double a = 0.0, b = 0.0;
+    if ((int)threadIdx.x < chunks) {
+        unsigned long long* sp = slots + plane * chunks + threadIdx.x;
+        unsigned long long v;
+        while ((v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == FUSED_SENTINEL) __builtin_amdgcn_s_sleep(4);
+        a = (double)__uint_as_float((unsigned)(v & 0xffffffffull));
+        b = (double)__uint_as_float((unsigned)(v >> 32));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        redd[2 * w] = a;
+        redd[2 * w + 1] = b;
+    }
+    __syncthreads();                                     // (every thread of this block has read its slot)
+    t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < NT / 64; ++i) {
+        t1 += redd[2 * i];
+        t2 += redd[2 * i + 1];
+    }
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(depart + plane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)chunks - 1u) {              // everybody else has read: re-arm for the next launch
+            for (int c = 0; c < chunks; ++c)
+                __hip_atomic_store(slots + plane * chunks + c, FUSED_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(depart + plane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <typename T, bool GELU>
+__global__ __launch_bounds__(NT) void in_fwd_fused(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ stats,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   unsigned long long* __restrict__ slots, unsigned* __restrict__ depart, float eps,
+                                                   int channels, long long hw, int chunks, const float* __restrict__ pre_bias) {
+    constexpr int VEC = VecIO<T>::N;
+    constexpr int FUSED_SLOTS = fused_slots(0);
+    typedef typename VecIO<T>::Raw Raw;
+    __shared__ float red[2 * NT / 64];
+    __shared__ double redd[2 * NT / 64];
+    const long long plane = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const int c = (int)(plane % channels);
+    const bool has_pb = pre_bias != nullptr;
+    const float pb = has_pb ? pre_bias[c] : 0.f;
+    const T* xp = x + plane * hw;
+    T* yp = y + plane * hw;
+    const long long len = chunk_len(hw, chunks, VEC);
+    const long long c0 = (long long)chunk * len;
+    const long long c1 = min(hw, c0 + len);
+    Raw raw[FUSED_SLOTS];
+#pragma unroll
+    for (int s = 0; s < FUSED_SLOTS; ++s) {
+        const long long e = c0 + ((long long)s * NT + threadIdx.x) * VEC;
+        raw[s] = VecIO<T>::load_raw_nt(xp + (e < c1 ? e : c0));             // (lanes past the end re-read the chunk's first vector)
+    }
+    const float pivot = pre<T>(VecIO<T>::load1(xp), pb, has_pb);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < FUSED_SLOTS; ++s) {
+        const long long e = c0 + ((long long)s * NT + threadIdx.x) * VEC;
+        if (e < c1) {
+            float v[VEC];
+            VecIO<T>::unpack(raw[s], v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float d = pre<T>(v[i], pb, has_pb) - pivot;
+                s1 += d;
+                s2 += d * d;
+            }
+        }
+    }
+    block_reduce2(s1, s2, red);
+    if (threadIdx.x == 0) fused_publish(slots + plane * chunks + chunk, s1, s2);
+    double t1, t2;
+    fused_gather(slots, depart, plane, chunks, t1, t2, redd);
+    const double m = t1 / (double)hw;
+    double var = t2 / (double)hw - m * m;        // biased variance, as nn.InstanceNorm2d (same arithmetic as in_apply)
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)((double)pivot + m);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (chunk == 0 && threadIdx.x == 0) {
+        stats[2 * plane] = mean;
+        stats[2 * plane + 1] = rstd;
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = rstd * g, sh = b - mean * rstd * g;
+#pragma unroll
+    for (int s = 0; s < FUSED_SLOTS; ++s) {
+        const long long e = c0 + ((long long)s * NT + threadIdx.x) * VEC;
+        if (e < c1) {
+            float v[VEC], o[VEC];
+            VecIO<T>::unpack(raw[s], v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float a = pre<T>(v[i], pb, has_pb) * sc + sh;
+                o[i] = GELU ? gelu_t<T>(a) : a;
+            }
+            VecIO<T>::store(yp + e, o);
+        }
+    }
+}
+
+// backward in one pass: gx = rstd gamma (ga - S1 / hw - n S2 / hw) with S1 = sum ga, S2 = sum ga n over the plane
+template <typename T, bool GELU>
+__global__ __launch_bounds__(NT) void in_bwd_fused(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx,
+                                                   const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ sums,
+                                                   unsigned long long* __restrict__ slots, unsigned* __restrict__ depart, int channels,
+                                                   long long hw, int chunks, float inv_total, const float* __restrict__ pre_bias) {
+    constexpr int VEC = VecIO<T>::N;
+    constexpr int FUSED_SLOTS = fused_slots(GELU ? 2 : 1);
+    typedef typename VecIO<T>::Raw Raw;
+    __shared__ float red[2 * NT / 64];
+    __shared__ double redd[2 * NT / 64];
+    const long long plane = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const long long planes = gridDim.x / chunks;
+    const int c = (int)(plane % channels);
+    const bool has_pb = pre_bias != nullptr;
+    const float pb = has_pb ? pre_bias[c] : 0.f;
+    const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const T* xp = x + plane * hw;
+    const T* gp = gy + plane * hw;
+    T* op = gx + plane * hw;
+    const long long len = chunk_len(hw, chunks, VEC);
+    const long long c0 = (long long)chunk * len;
+    const long long c1 = min(hw, c0 + len);
+    Raw rx[FUSED_SLOTS], rg[FUSED_SLOTS];
+#pragma unroll
+    for (int s = 0; s < FUSED_SLOTS; ++s) {
+        const long long e = c0 + ((long long)s * NT + threadIdx.x) * VEC;
+        const long long a = e < c1 ? e : c0;
+        rx[s] = VecIO<T>::load_raw_nt(xp + a);
+        rg[s] = VecIO<T>::load_raw_nt(gp + a);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < FUSED_SLOTS; ++s) {
+        const long long e = c0 + ((long long)s * NT + threadIdx.x) * VEC;
+        if (e < c1) {
+            float v[VEC], d[VEC];
+            VecIO<T>::unpack(rx[s], v);
+            VecIO<T>::unpack(rg[s], d);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float n = (pre<T>(v[i], pb, has_pb) - mean) * rstd;
+                float ga = d[i];
+                if (GELU) ga *= gelu_grad_t<T>(n * g + b);
+                s1 += ga;
+                s2 += ga * n;
+            }
+        }
+    }
+    block_reduce2(s1, s2, red);
+    if (threadIdx.x == 0) fused_publish(slots + plane * chunks + chunk, s1, s2);
+    double d1, d2;
+    fused_gather(slots, depart, plane, chunks, d1, d2, redd);
+    const float t1 = (float)d1, t2 = (float)d2;
+    if (chunk == 0 && threadIdx.x == 0) {
+        sums[plane] = t1;
+        sums[planes + plane] = t2;
+    }
+    const float m1 = t1 * inv_total, m2 = t2 * inv_total;
+    const float k = rstd * g;
+#pragma unroll
+    for (int s = 0; s < FUSED_SLOTS; ++s) {
+        const long long e = c0 + ((long long)s * NT + threadIdx.x) * VEC;
+        if (e < c1) {
+            float v[VEC], d[VEC], o[VEC];
+            VecIO<T>::unpack(rx[s], v);
+            VecIO<T>::unpack(rg[s], d);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float n = (pre<T>(v[i], pb, has_pb) - mean) * rstd;
+                float ga = d[i];
+                if (GELU) ga *= gelu_grad_t<T>(n * g + b);
+                o[i] = k * (ga - (m1 + n * m2));
+            }
+            VecIO<T>::store(op + e, o);
+        }
+    }
+}
+
 // ---- bias + GELU -------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void bias_gelu_fwd(const T* __restrict__ x, const float* __restrict__ bias,
@@ -643,6 +878,14 @@ int chunks_for(long long hw, long long planes) {
     return (int)std::min(maxc, want);
 }
 
+// chunks per plane of the fused kernels: the two-kernel choice (chunks_for) when its chunks fit the registers, else as few as fit
+template <typename T>
+int fused_chunks_for(long long hw, long long planes, int kind) {
+    const int c = chunks_for<T>(hw, planes);
+    if (chunk_len(hw, c, VecIO<T>::N) <= fused_chunk_cap<T>(kind)) return c;
+    return (int)((hw + fused_chunk_cap<T>(kind) - 1) / fused_chunk_cap<T>(kind));
+}
+
 int check_common(const void* a, long long planes, long long hw, int dtype, const char* what) {
     MK_REQUIRE(a != nullptr, "%s: null pointer", what);
     MK_REQUIRE(planes > 0 && hw > 0, "%s: bad shape planes=%lld hw=%lld", what, planes, hw);
@@ -802,6 +1045,66 @@ extern "C" int mk_instnorm_bwd(const void* x, const void* gy, void* gx, int dtyp
     }
 #undef IN_BWD
     return mk_check_launch("mk_instnorm_bwd");
+}
+
+// ---- one-pass instance norm (in_fwd_fused / in_bwd_fused) ----
+// mk_instnorm_fused_chunks: chunks per plane of the one-pass kernels of `kind` (0 forward, 1 backward, 2 backward through the
+// fused GELU), 0 if the plane shape is not served (hw not a multiple of
+// the 16-byte vector, or more chunks than a block has threads).  `slots`: planes * chunks 64-bit words, ALL ONES before the
+// first launch; `depart`: planes 32-bit words, ZERO before the first launch.  The kernels leave both as they found them, so one
+// buffer pair serves every later launch on the same stream (not two launches that may run concurrently).
+extern "C" int mk_instnorm_fused_chunks(long long hw, int dtype, long long planes, int kind) {
+    if (hw <= 0 || planes <= 0 || kind < 0 || kind > 2) return 0;
+    const int vec = dtype == MK_BF16 ? VecIO<u16>::N : VecIO<float>::N;
+    if (hw % vec) return 0;
+    const int c = dtype == MK_BF16 ? fused_chunks_for<u16>(hw, planes, kind) : fused_chunks_for<float>(hw, planes, kind);
+    if (c > NT || planes * (long long)c >= (1ll << 31)) return 0;
+    return c;
+}
+
+extern "C" int mk_instnorm_fwd_fused(const void* x, void* y, int dtype, float* stats, const float* gamma, const float* beta,
+                                     const float* pre_bias, void* slots, void* depart, long long planes, int channels, long long hw,
+                                     float eps, int fuse_gelu, void* stream) {
+    int rc = check_common(x, planes, hw, dtype, "instnorm_fwd_fused");
+    if (rc) return rc;
+    const int ch = mk_instnorm_fused_chunks(hw, dtype, planes, 0);
+    MK_REQUIRE(ch > 0, "instnorm_fwd_fused: plane shape not served (hw = %lld)", hw);
+    MK_REQUIRE(y && stats && slots && depart && channels > 0, "instnorm_fwd_fused: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g((unsigned)(planes * ch));
+    unsigned long long* sl = (unsigned long long*)slots;
+    unsigned* dp = (unsigned*)depart;
+#define IN_FF(T, G) hipLaunchKernelGGL((in_fwd_fused<T, G>), g, dim3(NT), 0, s, (const T*)x, (T*)y, stats, gamma, beta, sl, dp, eps, channels, hw, ch, pre_bias)
+    if (dtype == MK_F32) {
+        if (fuse_gelu) IN_FF(float, true); else IN_FF(float, false);
+    } else {
+        if (fuse_gelu) IN_FF(u16, true); else IN_FF(u16, false);
+    }
+#undef IN_FF
+    return mk_check_launch("mk_instnorm_fwd_fused");
+}
+
+extern "C" int mk_instnorm_bwd_fused(const void* x, const void* gy, void* gx, int dtype, const float* stats, const float* gamma,
+                                     const float* beta, const float* pre_bias, float* sums, void* slots, void* depart, long long planes,
+                                     int channels, long long hw, int fuse_gelu, void* stream) {
+    int rc = check_common(x, planes, hw, dtype, "instnorm_bwd_fused");
+    if (rc) return rc;
+    const int ch = mk_instnorm_fused_chunks(hw, dtype, planes, fuse_gelu ? 2 : 1);
+    MK_REQUIRE(ch > 0, "instnorm_bwd_fused: plane shape not served (hw = %lld)", hw);
+    MK_REQUIRE(gy && gx && stats && sums && slots && depart && channels > 0, "instnorm_bwd_fused: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g((unsigned)(planes * ch));
+    const float inv_total = 1.0f / (float)hw;
+    unsigned long long* sl = (unsigned long long*)slots;
+    unsigned* dp = (unsigned*)depart;
+#define IN_BF(T, G) hipLaunchKernelGGL((in_bwd_fused<T, G>), g, dim3(NT), 0, s, (const T*)x, (const T*)gy, (T*)gx, stats, gamma, beta, sums, sl, dp, channels, hw, ch, inv_total, pre_bias)
+    if (dtype == MK_F32) {
+        if (fuse_gelu) IN_BF(float, true); else IN_BF(float, false);
+    } else {
+        if (fuse_gelu) IN_BF(u16, true); else IN_BF(u16, false);
+    }
+#undef IN_BF
+    return mk_check_launch("mk_instnorm_bwd_fused");
 }
 
 extern "C" int mk_plane_sums(const void* x, int dtype, float* sums, float* ws, long long planes, long long hw, void* stream) {

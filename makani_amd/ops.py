@@ -795,6 +795,32 @@ def _batch_sum(sums, B, Cc):
     return sums if B == 1 else sums.view(2, B, Cc).sum(1)
 
 
+_FUSED_SYNC = {}        # (device, stream) -> (slots, depart, capacity): hand-over buffers of the one-pass instance norm
+
+
+def _fused_sync(nslots: int, planes: int, device):
+    """``slots`` (all ones) / ``depart`` (zero) of csrc/pointwise.hip's one-pass norm kernels for the current stream.  The kernels
+    restore both before they finish, so the pair is allocated (and grown) outside the step only: the first call of a shape —
+    a warm-up step, never a hipGraph capture — pays for it."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    hit = _FUSED_SYNC.get(key)
+    if hit is None or hit[0].numel() < nslots or hit[1].numel() < planes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("one-pass instance norm: its hand-over buffers must exist before the step is captured (run a warm-up step)")
+        slots = torch.full((max(nslots, 1 << 16),), -1, dtype=torch.int64, device=device)
+        depart = torch.zeros((max(planes, 1 << 12),), dtype=torch.int32, device=device)
+        hit = _FUSED_SYNC[key] = (slots, depart)
+    return hit
+
+
+def _fused_norm_chunks(x, planes, hw, quad, kind):
+    """chunks per plane when the one-pass kernels serve this call (kind: 0 forward, 1 backward, 2 backward through the fused
+    GELU), else 0 (MAKANI_AMD_NORM_FUSED=0: the two-kernel A/B path)"""
+    if quad is not None or os.environ.get("MAKANI_AMD_NORM_FUSED", "1") != "1":
+        return 0
+    return int(lib().mk_instnorm_fused_chunks(hw, dtype_code(x), planes, kind))
+
+
 class InstanceNormFn(torch.autograd.Function):
     """nn.InstanceNorm2d(affine) (+ fused exact GELU); fp32 statistics, io in the input dtype.
     ``pre_bias`` (C,) folds a per-channel constant added right in front of the norm (the bias of the MLP's output
@@ -809,14 +835,21 @@ class InstanceNormFn(torch.autograd.Function):
         planes, hw = B * Cc, H * W
         dt = dtype_code(x)
         stats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
-        ws = _ws(planes, hw, x.dtype, x.device)
         g = gamma.float().contiguous() if gamma is not None else None
         b = beta.float().contiguous() if beta is not None else None
         pb = pre_bias.float().contiguous() if pre_bias is not None else None
         y = torch.empty_like(x)
-        with _timed(f"instnorm_fwd{'_gelu' if fuse_gelu else ''}_n{hw}", nbytes=3.0 * x.numel() * x.element_size()):
-            check(lib().mk_instnorm_fwd(ptr(x), ptr(y), dt, ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(pb), ptr(quad), float(quad_sum),
-                                        planes, Cc, hw, eps, 1 if fuse_gelu else 0, stream()), "instnorm_fwd")
+        ch = _fused_norm_chunks(x, planes, hw, quad, 0)
+        if ch:
+            slots, depart = _fused_sync(planes * ch, planes, x.device)
+            with _timed(f"instnorm_fwd{'_gelu' if fuse_gelu else ''}_n{hw}", nbytes=2.0 * x.numel() * x.element_size()):
+                check(lib().mk_instnorm_fwd_fused(ptr(x), ptr(y), dt, ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(slots), ptr(depart), planes, Cc, hw,
+                                                  eps, 1 if fuse_gelu else 0, stream()), "instnorm_fwd_fused")
+        else:
+            ws = _ws(planes, hw, x.dtype, x.device)
+            with _timed(f"instnorm_fwd{'_gelu' if fuse_gelu else ''}_n{hw}", nbytes=3.0 * x.numel() * x.element_size()):
+                check(lib().mk_instnorm_fwd(ptr(x), ptr(y), dt, ptr(stats), ptr(ws), ptr(g), ptr(b), ptr(pb), ptr(quad), float(quad_sum),
+                                            planes, Cc, hw, eps, 1 if fuse_gelu else 0, stream()), "instnorm_fwd")
         ctx.save_for_backward(x, stats, g, b, pb, quad)
         ctx.quad_sum = float(quad_sum)
         ctx.fuse_gelu = fuse_gelu
@@ -832,11 +865,18 @@ class InstanceNormFn(torch.autograd.Function):
             gy = gy.to(x.dtype)
         gx = torch.empty_like(x)
         sums = torch.empty((2, planes), dtype=torch.float32, device=x.device)
-        ws = _ws(planes, hw, x.dtype, x.device)
-        with _timed(f"instnorm_bwd{'_gelu' if ctx.fuse_gelu else ''}_n{hw}", nbytes=5.0 * x.numel() * x.element_size()):
-            check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(quad),
-                                        ctx.quad_sum, ptr(sums), ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0,
-                                        stream()), "instnorm_bwd")
+        ch = _fused_norm_chunks(x, planes, hw, quad, 2 if ctx.fuse_gelu else 1)
+        if ch:
+            slots, depart = _fused_sync(planes * ch, planes, x.device)
+            with _timed(f"instnorm_bwd{'_gelu' if ctx.fuse_gelu else ''}_n{hw}", nbytes=3.0 * x.numel() * x.element_size()):
+                check(lib().mk_instnorm_bwd_fused(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(sums),
+                                                  ptr(slots), ptr(depart), planes, Cc, hw, 1 if ctx.fuse_gelu else 0, stream()), "instnorm_bwd_fused")
+        else:
+            ws = _ws(planes, hw, x.dtype, x.device)
+            with _timed(f"instnorm_bwd{'_gelu' if ctx.fuse_gelu else ''}_n{hw}", nbytes=5.0 * x.numel() * x.element_size()):
+                check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(stats), ptr(g), ptr(b), ptr(pb), ptr(quad),
+                                            ctx.quad_sum, ptr(sums), ptr(ws), planes, Cc, hw, hw, 0, 1 if ctx.fuse_gelu else 0,
+                                            stream()), "instnorm_bwd")
         s = _batch_sum(sums, B, Cc)
         gpb = torch.zeros_like(pb) if (pb is not None and ctx.needs_input_grad[5]) else None
         return gx, (s[1] if g is not None else None), (s[0] if b is not None else None), None, None, gpb, None, None

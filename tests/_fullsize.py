@@ -82,9 +82,19 @@ def _compute_config2_oracle():
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):       # the reference's own op-by-op bf16 autocast, on the CPU
         yo_bf16 = omod(x).float()
     xo = x.clone().requires_grad_(True)
+    # the bias gradients of the full-resolution convolutions are sums over 1 038 240 pixels: next to the fp32 sums autograd
+    # returns, keep the SAME output gradients summed in fp64 (hooks on the same backward pass) — the yardstick that tells how much
+    # of a bias-gradient difference is the oracle's own fp32 summation (VERDICT r5 weak #1a)
+    bias64, hooks = {}, []
+    for name, mod in omod.named_modules():
+        if isinstance(mod, torch.nn.Conv2d) and mod.bias is not None:
+            hooks.append(mod.register_full_backward_hook(
+                lambda m, gi, go, name=name: bias64.__setitem__(name + ".bias", go[0].double().sum(dim=(0, 2, 3)))))
     yo = omod(xo)
     (yo * g).sum().backward()
-    out = dict(state={k: v.detach().clone() for k, v in omod.state_dict().items()}, x=x, g=g, y=yo.detach(), y_bf16=yo_bf16,
+    for h in hooks:
+        h.remove()
+    out = dict(bias_grads_fp64=bias64, state={k: v.detach().clone() for k, v in omod.state_dict().items()}, x=x, g=g, y=yo.detach(), y_bf16=yo_bf16,
                gx=xo.grad.detach(), grads={n: p.grad.detach().clone() for n, p in omod.named_parameters()})
     # ... and the reference's own bf16 arithmetic through the BACKWARD pass (op-by-op CPU bf16 autocast): the yardstick of the
     # bf16 gradient gates, as y_bf16 is of the forward gate

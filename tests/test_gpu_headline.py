@@ -192,7 +192,7 @@ def config2_pair():
     import makani_amd as ma
     _threads()
     d = config2_oracle()
-    ref = dict(gx=d["gx"], grads=d["grads"], bf16=dict(gx=d["bf16_gx"], grads=d["bf16_grads"]))
+    ref = dict(gx=d["gx"], grads=d["grads"], bf16=dict(gx=d["bf16_gx"], grads=d["bf16_grads"]), bias_grads_fp64=d.get("bias_grads_fp64"))
     model = ma.SphericalFourierNeuralOperatorNet(**CONFIG2)
     model.load_state_dict(d["state"], strict=True)
     return model.to(DEV).eval(), d["x"], d["y"], d["y_bf16"], d["g"], ref
@@ -260,6 +260,19 @@ def test_sfno_config2_fwd_bwd_721x1440_matches_oracle(config2_pair):
     for n in ("encoder.fwd.0.weight", "blocks.0.filter.filter.weight", "blocks.7.filter.filter.weight", "decoder.fwd.2.weight",
               "residual_transform.weight"):
         print(f"    {n}: {errs[n]:.2e}")
+    # whose rounding is the bias-gradient distance?  (VERDICT r5 weak #1a: the worst gradient, encoder.fwd.0.bias, sat at
+    # 9.86e-5 on the 1e-4 gate.)  b64 = the ORACLE's output gradient summed in fp64 over the 1 038 240 pixels: the fp32 oracle's
+    # own distance from it is its summation error; the HIP gradient's distance from it is HIP's summation error + everything
+    # upstream.  Gate: the HIP bias gradient is no further from the fp64 sums than the gate, with the measured margin printed.
+    b64 = ref.get("bias_grads_fp64") or {}
+    for n in sorted(b64):
+        hip, o32, o64 = dict(model.named_parameters())[n].grad, ref["grads"][n], b64[n]
+        scale = float(o64.abs().max())
+        if scale < 1e-5 * gmax:
+            continue                        # exactly-zero gradients (a per-channel constant in front of an instance norm)
+        e_hip, e_o32 = rel_l2(hip.double(), o64), rel_l2(o32.double(), o64)
+        print(f"    {n}: HIP vs fp32 oracle {errs[n]:.2e} | HIP vs the fp64-summed oracle gradient {e_hip:.2e} | fp32 oracle vs the same {e_o32:.2e}")
+        assert e_hip < TOL_E2E, (n, e_hip, e_o32)
     assert errs["y"] < TOL_E2E and errs["gx"] < TOL_E2E, errs
 
 

@@ -388,6 +388,100 @@ def test_instance_norm(dtype, tol, fuse_gelu, B, C, H, W):
     assert rel_l2(bd.grad, br.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+def _norm_fwd_bwd(x, gy, gamma, beta, fuse_gelu, pre_bias=None):
+    from makani_amd import ops
+    xd = x.clone().requires_grad_(True)
+    gd, bd = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = ops.InstanceNormFn.apply(xd, gd, bd, 1e-6, fuse_gelu, pre_bias)
+    y.backward(gy)
+    return y.detach(), xd.grad, gd.grad, bd.grad
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fuse_gelu", [False, True])
+@pytest.mark.parametrize("B,C,H,W,with_pb", [(2, 5, 12, 24, False), (1, 40, 240, 480, True), (1, 3, 721, 1440, False), (2, 7, 181, 1440, True)])
+def test_instance_norm_one_pass_matches_two_kernel_path(monkeypatch, dtype, fuse_gelu, B, C, H, W, with_pb):
+    """round 6: the one-pass kernels (a block keeps its chunk of the plane in registers, partial sums handed over through
+    64-bit agent-scope atomics) against the two-kernel path on the same inputs: same statistics arithmetic, so bit-identical
+    where the chunking is the same (small planes) and to fp32 round-off of the partial sums otherwise; and against fp64"""
+    from makani_amd import ops
+    from makani_amd._lib import lib, dtype_code
+    torch.manual_seed(B * C + H)
+    x = (torch.randn(B, C, H, W, device=_dev()) * 2 + 3).to(dtype)
+    gy = torch.randn(B, C, H, W, device=_dev()).to(dtype)
+    gamma, beta = torch.randn(C, device=_dev()) + 1, torch.randn(C, device=_dev())
+    pb = torch.randn(C, device=_dev()) * 0.3 if with_pb else None
+    assert lib().mk_instnorm_fused_chunks(H * W, dtype_code(x), B * C, 0) > 0
+    monkeypatch.setenv("MAKANI_AMD_NORM_FUSED", "1")
+    one = _norm_fwd_bwd(x, gy, gamma, beta, fuse_gelu, pb)
+    monkeypatch.setenv("MAKANI_AMD_NORM_FUSED", "0")
+    two = _norm_fwd_bwd(x, gy, gamma, beta, fuse_gelu, pb)
+    torch.cuda.synchronize()
+    tol = 1e-6 if dtype == torch.float32 else 4e-3          # bf16: one rounding step of a few elements when a statistic moves by an ulp
+    for a, b, name in zip(one, two, ("y", "gx", "dgamma", "dbeta")):
+        assert rel_l2(a, b) < (tol if name in ("y", "gx") else 1e-5), (name, rel_l2(a, b))
+    xr = (x.double() + (pb.double().view(1, -1, 1, 1) if with_pb else 0)).to(dtype).double().cpu().requires_grad_(True)
+    gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.instance_norm(xr, weight=gr, bias=br, eps=1e-6)
+    if fuse_gelu:
+        yr = torch.nn.functional.gelu(yr)
+    yr.backward(gy.double().cpu())
+    t = 2e-6 if dtype == torch.float32 else 6e-3
+    assert rel_l2(one[0], yr) < t
+    assert rel_l2(one[1], xr.grad) < (t * 5 if dtype == torch.float32 else 2e-2)
+    assert rel_l2(one[2], gr.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert rel_l2(one[3], br.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_instance_norm_one_pass_falls_back_on_unserved_planes():
+    from makani_amd._lib import lib, MK_BF16, MK_F32
+    assert lib().mk_instnorm_fused_chunks(7 * 9, MK_BF16, 4, 0) == 0          # not a multiple of the 8-element vector
+    assert lib().mk_instnorm_fused_chunks(7 * 9 * 4, MK_F32, 4, 0) > 0
+    assert lib().mk_instnorm_fused_chunks(721 * 1440, MK_BF16, 384, 0) == 64   # 8 slots: 16 384 elements per block
+    assert lib().mk_instnorm_fused_chunks(721 * 1440, MK_BF16, 384, 2) == 102  # 5 slots (backward through the GELU)
+    assert lib().mk_instnorm_fused_chunks(240 * 480, MK_BF16, 384, 1) == 8
+    assert lib().mk_instnorm_fused_chunks(12 * 24, MK_BF16, 10, 0) == 1        # small planes: the two-kernel chunking fits
+
+
+def test_instance_norm_one_pass_handover_survives_repetition_and_graph_replay():
+    """the hand-over buffers are re-armed by the kernels themselves: 200 back-to-back launches (forward + backward, two plane
+    shapes interleaved on one buffer pair) stay bit-identical, and so do replays of a captured forward + backward"""
+    torch.manual_seed(5)
+    shapes = [(1, 96, 60, 480), (1, 6, 721, 1440)]
+    data = []
+    for (B, C, H, W) in shapes:
+        x = torch.randn(B, C, H, W, device=_dev()).bfloat16()
+        gy = torch.randn(B, C, H, W, device=_dev()).bfloat16()
+        data.append((x, gy, torch.rand(C, device=_dev()) + 0.5, torch.randn(C, device=_dev())))
+    refs = [[t.clone() for t in _norm_fwd_bwd(*d, True)] for d in data]
+    for it in range(100):
+        for d, ref in zip(data, refs):
+            out = _norm_fwd_bwd(*d, True)
+            assert all(torch.equal(a.float(), b.float()) for a, b in zip(out, ref)), it
+    # graph: static tensors, capture one forward + backward of the first shape, replay on changing data
+    from makani_amd import ops
+    x, gy, gam, bet = data[0]
+    xs, gs = x.clone().requires_grad_(True), gy.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.InstanceNormFn.apply(xs, gam, bet, 1e-6, True).backward(gs)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    xs.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ys = ops.InstanceNormFn.apply(xs, gam, bet, 1e-6, True)
+        ys.backward(gs)
+    for k in range(4):
+        with torch.no_grad():
+            xs.copy_(x * (1.0 + 0.25 * k))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = _norm_fwd_bwd((x * (1.0 + 0.25 * k)).bfloat16(), gy, gam, bet, True)
+        assert torch.equal(ys.detach().float(), want[0].float()) and torch.equal(xs.grad.float(), want[1].float()), k
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C,H,W", [(2, 5, 12, 24), (1, 3, 37, 71), (1, 768, 240, 480), (3, 700, 9, 16),
                                      # block 7's MLP hidden gradient at the benchmark's size (VERDICT r3 weak #3): 768 planes of
