@@ -192,7 +192,7 @@ def load_pmc_traffic(fcn3=False):
         return {}
 
 
-def live_pmc_traffic(cfg_name, timeout_s=None):
+def live_pmc_traffic(cfg_name, timeout_s=None, spectral="train"):
     """HBM bytes per launch of every kernel family, measured IN THIS RUN: two child runs of this same script (the same workload,
     2 eager steps) under ``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` — separate passes, counters only, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes —, summarised per kernel symbol (tools/pmc_summary.py) and mapped to the
@@ -217,7 +217,8 @@ def live_pmc_traffic(cfg_name, timeout_s=None):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--config", cfg_name, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sht-metric", "--graph", "off", "--no-pmc"]
+                   "--config", cfg_name, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sht-metric", "--graph", "off", "--no-pmc", "--no-exact",
+                   "--spectral", spectral]
             try:
                 r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, cwd="/tmp",
                                    env=dict(os.environ, TMPDIR="/tmp"))
@@ -315,6 +316,7 @@ def train_step(model, opt, inp, tar, loss_fn, amp, sharded_clip):
 def sht_bandwidth(device, reps=5):
     """Secondary metric 'fwd SHT GB/s' (BASELINE.md §2): S1 ERA5-shaped, S2 model-shaped."""
     import makani_amd as ma
+    from makani_amd import ops
     out = {}
     for name, C, lmax, mmax in (("S1_c73_L721_M721", 73, 721, 721), ("S2_c384_L240_M241", 384, 240, 241)):
         S = ma.RealSHT(721, 1440, lmax=lmax, mmax=mmax, grid="equiangular").to(device)
@@ -327,7 +329,7 @@ def sht_bandwidth(device, reps=5):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         nbytes = C * 721 * 1440 * 4 + C * lmax * mmax * 8
-        out[name] = dict(ms=dt * 1e3, GBps=nbytes / dt / 1e9)
+        out[name] = dict(ms=dt * 1e3, GBps=nbytes / dt / 1e9, spectral_arithmetic=ops.gemm_mode())
         del S, x
         torch.cuda.empty_cache()
     return out
@@ -574,18 +576,25 @@ class ParityProbe:
         x, tar = parity_input(cfg).to(device), parity_target(cfg).to(device)
         was_training = model.training
         model.eval()
+        # the fp32 passes compare with the fp32 oracle at the reference's TEST settings (tests/testutils.py: disable_tf32): exact
+        # fp32-class spectral arithmetic; the bf16 autocast passes run as the benchmark does (the process-wide setting)
+        tf32_was = torch.backends.cuda.matmul.allow_tf32
         with torch.no_grad():
+            torch.backends.cuda.matmul.allow_tf32 = False
             self.y32 = model(x).float().cpu()
+            torch.backends.cuda.matmul.allow_tf32 = tf32_was
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 self.y16 = model(x).float().cpu()
         model.train(was_training)
         self.bwd = {}
         for name, amp in (("fp32", False), ("bf16_autocast", True)):
             model.zero_grad(set_to_none=True)
+            torch.backends.cuda.matmul.allow_tf32 = tf32_was if amp else False
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
                 y = model(x)
             loss = (y.float() - tar).square().mean()
             loss.backward()
+            torch.backends.cuda.matmul.allow_tf32 = tf32_was
             self.bwd[name] = _grad_record(model, loss)
             del y, loss
         model.zero_grad(set_to_none=True)
@@ -887,6 +896,14 @@ def run_worker(args):
         tar = tar[..., lat0:lat0 + hl, lon0:lon0 + wl].contiguous()
     amp = not args.fp32
     sharded_clip = ph > 1
+    # fp32 matrix products as the reference's TRAINING entry points run them: makani/train.py:87-88 (train_stochastic.py:102-103)
+    # set torch.backends.cuda.matmul.allow_tf32 = True, so on the reference's GPUs the fp32 einsums of the SHT and of the spectral
+    # contraction run in TF32 (10 mantissa bits).  gfx950 has no TF32 mode; makani_amd reads the same torch switch and then runs
+    # its spectral GEMMs on TWO bf16 limbs per fp32 factor (3 limb products, rel-L2 ~4e-6 vs fp64: 64x closer than TF32) instead
+    # of three (6 products, 1.8e-7).  --spectral exact leaves torch's default (and the reference's TEST setting) in place; the
+    # default run measures that variant too and reports it as `exact_fp32_spectral`.
+    spectral_train = amp and args.spectral == "train"
+    torch.backends.cuda.matmul.allow_tf32 = bool(spectral_train)
 
     # Per-kernel HIP events cost ~1.2 ms/step (2 events x ~300 C-ABI launches).  The LAST warm-up step is
     # profiled in full: it yields the per-kernel table and names the dominant HIP kernel; inside the timed region
@@ -1007,6 +1024,34 @@ def run_worker(args):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
+    # the same step with the spectral GEMMs in fp32-class arithmetic (three limbs): captured and timed the same way, reported
+    # beside the headline so that both settings of the switch are on record from ONE run
+    exact = None
+    if spectral_train and world == 1 and graph is not None and not args.no_exact:
+        try:
+            torch.backends.cuda.matmul.allow_tf32 = False
+            for _ in range(2):
+                train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+            torch.cuda.synchronize()
+            opt.zero_grad(set_to_none=True)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+            g2.replay()
+            torch.cuda.synchronize()
+            t0x = time.perf_counter()
+            for _ in range(args.steps):
+                g2.replay()
+            torch.cuda.synchronize()
+            ex = time.perf_counter() - t0x
+            exact = {"value": dsize * B * args.steps / ex, "unit": "samples/s", "ms_per_step": ex / args.steps * 1e3,
+                     "spectral_arithmetic": "three bf16 limbs per fp32 factor, 6 limb products: rel-L2 1.8e-7 vs fp64 (torch's default "
+                                            "allow_tf32 = False; what the reference's tests set)"}
+            del g2
+        except Exception as e:
+            exact = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        finally:
+            torch.backends.cuda.matmul.allow_tf32 = True
     final_loss = float(loss.detach())
 
     out = None
@@ -1018,7 +1063,7 @@ def run_worker(args):
             dom_family, dom_members = dominant_family(prof)
         kernels = kernel_table(warm_prof, prof, event_steps)
         pmc = load_pmc_traffic(fcn3) if (args.config in ("sfno_sc3_layers8_edim384", "fcn3_sc2_edim45_layers10") and msize == 1) else {}
-        roofline = roofline_of(dom_family, dom_members, prof, ops.GEMM_MODE, pmc.get(dom_family)) if dom_family else None
+        roofline = roofline_of(dom_family, dom_members, prof, ops.gemm_mode(), pmc.get(dom_family)) if dom_family else None
         # the runners-up, from the fully profiled warm-up step (one launch set, not an average over the timed steps)
         others = []
         if warm_prof:
@@ -1027,7 +1072,7 @@ def run_worker(args):
                 fams.setdefault(kernel_family(k), []).append(k)
             rank_f = sorted(fams, key=lambda f: -sum(warm_prof[k]["ms_total"] for k in fams[f]))
             for f in [f for f in rank_f if f != dom_family][:4]:
-                others.append(roofline_of(f, sorted(fams[f]), warm_prof, ops.GEMM_MODE, pmc.get(f)))
+                others.append(roofline_of(f, sorted(fams[f]), warm_prof, ops.gemm_mode(), pmc.get(f)))
         hip_ms = sum(v["ms_per_step"] for v in kernels.values())
         out = {
             "metric": (f"FourCastNet3 train samples/sec at {H}x{W}x{cfg['out_chans']}ch" if fcn3 else
@@ -1047,12 +1092,16 @@ def run_worker(args):
                        **({"ensemble_size": E, "loss": "ensemble_crps (skillspread) + 0.1 x ensemble_spectral_crps",
                            "state_channels": cfg["out_chans"], "aux_channels": cfg["inp_chans"] - cfg["out_chans"]} if fcn3 else {}),
                        "global_batch": dsize * B, "parallelism": f"dp{dsize}" + (f"_h{ph}w{pw}" if msize > 1 else ""),
-                       "amp": "bf16 autocast, fp32 SHT/contraction" if amp else "fp32",
+                       "amp": ("bf16 autocast, fp32 SHT/contraction" + (" under torch.backends.cuda.matmul.allow_tf32 = True as makani/train.py:87 "
+                               "sets it (two-limb bf16 split, 3 products, ~4e-6; the reference's GPUs run TF32 there)" if spectral_train else
+                               " in fp32-class arithmetic (three-limb bf16 split, 1.8e-7)")) if amp else "fp32",
+                       "spectral_arithmetic": ops.gemm_mode(),
                        "multistep_count": args.multistep_count,
                        "multistep_checkpoint": bool(args.multistep_checkpoint),
                        "collectives": (dist.get_backend() if world > 1 else None),
                        "launch": ("hipGraph replay of the captured step" if graph is not None else "eager"),
                        "channel_gemm": "hip (csrc/conv1x1.hip)"},
+            "exact_fp32_spectral": exact,
             "roofline": roofline,
             "roofline_runners_up": others,
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
@@ -1091,7 +1140,7 @@ def run_worker(args):
             _gc.collect()
             torch.cuda.empty_cache()
             import threading
-            pmc_thread = threading.Thread(target=lambda: pmc_live.update(zip(("data", "note"), live_pmc_traffic(args.config))), daemon=True)
+            pmc_thread = threading.Thread(target=lambda: pmc_live.update(zip(("data", "note"), live_pmc_traffic(args.config, spectral=args.spectral))), daemon=True)
             pmc_thread.start()
             pmc_thread.join(timeout=900)
         if world == 1 and not args.no_cpu_baseline:
@@ -1144,7 +1193,7 @@ def _free_port():
 def _worker_cmd(args, parallelism):
     cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--config", args.config, "--parallelism", parallelism, "--no-sht-metric",
-           "--no-cpu-baseline", "--multistep-count", str(args.multistep_count), "--graph", args.graph]
+           "--no-cpu-baseline", "--multistep-count", str(args.multistep_count), "--graph", args.graph, "--spectral", args.spectral]
     if args.fp32:
         cmd.append("--fp32")
     if args.zero:
@@ -1279,6 +1328,11 @@ def main():
                     help="sfno_sc3_layers8_edim384 = BASELINE configs[1] (the headline; with --multistep-count 4: configs[4]); "
                          "fcn3_sc2_edim45_layers10 = configs[3] (FourCastNet3, ensemble CRPS recipe); *_debug = small stand-ins")
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (not the BASELINE metric)")
+    ap.add_argument("--spectral", default="train", choices=["train", "exact"],
+                    help="fp32 matrix products of the spectral path: 'train' (default) = torch.backends.cuda.matmul.allow_tf32 = True, "
+                         "as the reference's training entry point sets it (makani/train.py:87-88): two-limb bf16 split; 'exact' = torch's "
+                         "default: three-limb split, fp32 round-off class")
+    ap.add_argument("--no-exact", action="store_true", help="skip the secondary measurement of the step with --spectral exact arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sht-metric", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 counter passes in this run "

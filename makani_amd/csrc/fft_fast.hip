@@ -412,6 +412,25 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
     const long long rstride = xnl * wl;                          // distance between the rows of an item (inside a piece)
     constexpr int NV = (RBH * VROW + NTH - 1) / NTH;
     uint4 rawv[NV];
+    // Everything below that depends on the LANE only — which vector of which row it fetches, where it lands in LDS, which order m
+    // and which four rows it untangles, the twiddle and weights of that order, where its two stores go — is computed ONCE here and
+    // kept in registers (the kernel runs one workgroup per CU: 256 registers per lane are there).  Round 4's stamps put 35 % of a
+    // wave's cycles into vector instructions; the ISA showed that two thirds of the non-butterfly ones re-derived these constants
+    // (divisions by constants, 64-bit address arithmetic, selects) for every item.  Per item only the uniform base moves.
+    // (SEG: the F-side offsets depend on the item through the slab tables; that path keeps the per-item arithmetic.)
+    // (HOIST off: instantiations held to 168 / 128 registers for three / four waves per SIMD — the 720- and 360-point kernels, the
+    //  forward 480-point bf16 kernel — would spill the constants; they keep the per-item arithmetic)
+    constexpr bool HOIST = !SEG && WGS <= 2 && !(MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) == 2);      // (WGS: waves per SIMD asked of the compiler)
+    unsigned pf_off[NV];                                        // element offset of this lane's vector q inside an item's rows
+    int pf_row[NV], cm_off[NV];                                 // its row (rows >= nr hold zeros) and its LDS offset (complex values)
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int idx = tid + q * NTH;
+        const int row = idx / VROW, c = idx % VROW;
+        pf_row[q] = row;
+        pf_off[q] = HOIST ? (unsigned)((long long)row * rstride + (long long)c * (2 * VP)) : 0u;
+        cm_off[q] = row * LS0 + c * VP;
+    }
     auto prefetch = [&](long long itm) {
         const long long kl_ = (unsigned)itm / (unsigned)ngr;             // (nitems < 2^31: 32-bit division)
         const long long p0_ = (itm - kl_ * ngr) * RB + rofs;
@@ -419,19 +438,22 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
         const T* xr_ = x + (p0_ * xnl + kl_) * wl;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int idx = tid + q * NTH;
-            const int row = idx / VROW, c = idx % VROW;
-            const long long coff = SEG ? (long long)(c / vpp) * sg.x_stride + (long long)(c % vpp) * (2 * VP) : (long long)c * (2 * VP);
-            rawv[q] = (row < nr_) ? *reinterpret_cast<const uint4*>(xr_ + (long long)row * rstride + coff)
-                                  : make_uint4(0, 0, 0, 0);
+            if constexpr (!HOIST) {
+                const int idx = tid + q * NTH;
+                const int row = idx / VROW, c = idx % VROW;
+                const long long coff = SEG ? (long long)(c / vpp) * sg.x_stride + (long long)(c % vpp) * (2 * VP) : (long long)c * (2 * VP);
+                rawv[q] = (row < nr_) ? *reinterpret_cast<const uint4*>(xr_ + (long long)row * rstride + coff) : make_uint4(0, 0, 0, 0);
+            } else {
+                rawv[q] = (pf_row[q] < nr_) ? *reinterpret_cast<const uint4*>(xr_ + pf_off[q]) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
     auto commit = [&]() {                                       // registers -> work buffer as fp32 pairs
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int idx = tid + q * NTH;
-            const int row = idx / VROW, c = idx % VROW;
-            float4* d = reinterpret_cast<float4*>(buf + row * LS0 + c * VP);
+            const int c = idx % VROW;
+            float4* d = reinterpret_cast<float4*>(buf + (HOIST ? cm_off[q] : (idx / VROW) * LS0 + c * VP));
             const uint4 u = rawv[q];
             if (idx < RBH * VROW) {
                 if constexpr (sizeof(T) == 4) {
@@ -462,6 +484,26 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
         commit();
     }
     __syncthreads();
+    // untangle constants of this lane (the tables in LDS are complete after the barrier above): trip q handles order un_m, rows
+    // r0 .. r0 + 3 — LDS offsets of (Z[m], Z[N2 - m]) in row r0, twiddle, output weights, float offset of its first store
+    constexpr int NQU = (MCAP * (RBH / 4) + NTH - 1) / NTH;
+    int un_za[NQU], un_zb[NQU], un_r0[NQU];
+    cf un_tw[NQU], un_hw[NQU];
+    unsigned un_fo[NQU];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int q = 0; q < NQU; ++q) {
+            const int idx = tid + q * NTH;
+            const int r0 = (idx % (RBH / 4)) * 4, m = idx / (RBH / 4);
+            const Untangle<N2> un(twu, min(m, mmax - 1), w_dc, w_pos, w_nyq);
+            un_za[q] = r0 * LS + un.ma;
+            un_zb[q] = r0 * LS + un.mb;
+            un_tw[q] = un.tw;
+            un_hw[q] = un.hw;
+            un_r0[q] = (m < mmax) ? r0 : (1 << 20);                              // (orders past mmax: never "r0 < nr")
+            un_fo[q] = (unsigned)(((long long)min(m, mmax - 1) * nlat) * 2 * rows + r0);
+        }
+    }
     skew_barriers<HV>(half == 1);                         // half 1 runs MK_FFT_SKEW barrier intervals behind half 0
 #if MK_FFT_DIAG
     unsigned long long dg[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -501,7 +543,29 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
 #endif
 
         // Hermitian untangle + truncation + weights
-        if (vec) {
+        if (vec && HOIST) {
+            // (vec: C % 4 == 0 (then Cp == C) or one batch entry — either way plane pr IS row pr of the F layout)
+            float* Fi = F + (klat * 2 * rows + p0);                                  // uniform: the item's part of the address
+#pragma unroll
+            for (int q = 0; q < NQU; ++q) {
+                if (un_r0[q] < nr) {
+                    const cf* za = buf + un_za[q];
+                    const cf* zb = buf + un_zb[q];
+                    cf R[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                                    // (rows >= nr hold zeros)
+                        const cf A = za[k * LS], B = zb[k * LS];
+                        R[k] = add_mi(add_conj(A, B), cmul(sub_conj(A, B), un_tw[q]));
+                    }
+                    // the scaling is scalar on purpose: its results are the components of the two 16-byte stores
+                    const float4 Xre = make_float4(R[0].x * un_hw[q].x, R[1].x * un_hw[q].x, R[2].x * un_hw[q].x, R[3].x * un_hw[q].x);
+                    const float4 Xim = make_float4(R[0].y * un_hw[q].y, R[1].y * un_hw[q].y, R[2].y * un_hw[q].y, R[3].y * un_hw[q].y);
+                    float* o = Fi + un_fo[q];
+                    *reinterpret_cast<float4*>(o) = Xre;
+                    *reinterpret_cast<float4*>(o + rows) = Xim;
+                }
+            }
+        } else if (vec) {
             for (int idx = tid; idx < mmax * (RBH / 4); idx += NTH) {
                 const int r0 = (idx % (RBH / 4)) * 4, m = idx / (RBH / 4);
                 if (r0 >= nr) continue;
@@ -605,10 +669,41 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     constexpr int NQ4 = (MCAP * (RBH / 4) + NTH - 1) / NTH;
     constexpr int NQ1 = (MCAP * RBH + NTH - 1) / NTH;
     float4 sre[NQ4], sim[NQ4];
+    // lane constants hoisted out of the item loop (see rfft_fast_kernel): float offset of this lane's spectrum quad q inside an
+    // item, its first row, and — for the pruned transform — where its pre-twiddled pair lands in LDS, the order's twiddle and weights
+    constexpr bool HOIST = !SEG && WGS <= 2;
+    unsigned pi_fo[NQ4];
+    int pi_r0[NQ4], pt_off[NQ4], pt_m[NQ4];
+    cf pt_tw[NQ4], pt_wv[NQ4];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) {
+            const int idx = tid + q * NTH;
+            const int r0 = (idx % (RBH / 4)) * 4, m = idx / (RBH / 4);
+            const int mc = min(m, mmax - 1);
+            pi_r0[q] = r0;
+            pi_fo[q] = (unsigned)(((long long)mc * nlat) * 2 * rows + r0);
+            pt_m[q] = (m < mmax) ? m : -1;
+            pt_off[q] = r0 * LS + mc;
+            pt_tw[q] = twu[mc];                                   // (tables complete: the barrier above)
+            pt_wv[q] = inverse_weights<N2>(mc, w_dc, w_pos, w_nyq);
+        }
+    }
     auto prefetch = [&](long long itm) {
         const long long kl_ = (unsigned)itm / (unsigned)ngr;             // (nitems < 2^31: 32-bit division)
         const long long p0_ = (itm - kl_ * ngr) * RB + rofs;
         const int nr_ = (int)max(0ll, min((long long)RBH, planes - p0_));
+        if constexpr (HOIST) {
+            // (same clamped, unconditional loads as below; rows >= nr_ read row 0 of the group, a half past the last plane reads plane 0)
+            const float* Fi = F + (kl_ * 2 * rows + (nr_ > 0 ? p0_ : 0));
+#pragma unroll
+            for (int q = 0; q < NQ4; ++q) {
+                const float* sp = Fi + ((pi_r0[q] < nr_) ? pi_fo[q] : pi_fo[q] - (unsigned)pi_r0[q]);
+                sre[q] = *reinterpret_cast<const float4*>(sp);
+                sim[q] = *reinterpret_cast<const float4*>(sp + rows);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NQ4; ++q) {
             const int idx = tid + q * NTH;
@@ -647,11 +742,13 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) {
                 const int idx = tid + q * NTH;
-                const int r0 = (idx % (RBH / 4)) * 4, m = idx / (RBH / 4);
-                if (m < mmax) {
+                const int r0 = HOIST ? pi_r0[q] : (idx % (RBH / 4)) * 4, m = HOIST ? pt_m[q] : idx / (RBH / 4);
+                if (HOIST ? (m >= 0) : (m < mmax)) {
                     // rows >= nr were loaded from a clamped (valid) position: zero weights instead of a select per value
-                    const cf wv = (r0 < nr) ? inverse_weights<N2>(m, w_dc, w_pos, w_nyq) : cf_make(0.f, 0.f);
-                    const cf tw = twu[m];
+                    const cf wv = (r0 < nr) ? (HOIST ? pt_wv[q] : inverse_weights<N2>(m, w_dc, w_pos, w_nyq)) : cf_make(0.f, 0.f);
+                    const cf tw = HOIST ? pt_tw[q] : twu[m];
+                    cf* za = buf + (HOIST ? pt_off[q] : r0 * LS + m);              // Z[m] of row r0
+                    cf* zb = za + (N2 - 2 * m);                                      // Z[N2 - m]
                     const float re[4] = {sre[q].x, sre[q].y, sre[q].z, sre[q].w};
                     const float im[4] = {sim[q].x, sim[q].y, sim[q].z, sim[q].w};
 #pragma unroll
@@ -659,10 +756,10 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                         const cf Xa = cf_make(wv.x * re[i], wv.y * im[i]);
                         const cf Xc = cf_make(Xa.x, -Xa.y);
                         const cf wt = cmulc(Xa, tw);                           // conj(U) X
-                        buf[(r0 + i) * LS + m] = sub_yx(Xc, wt);                   // conj(X + i conj(U) X)
+                        za[i * LS] = sub_yx(Xc, wt);                               // conj(X + i conj(U) X)
                         if (m != 0) {
                             const cf w2 = cmul(Xc, tw);                        // U conj(X)
-                            buf[(r0 + i) * LS + N2 - m] = sub_yx(Xa, w2);          // conj(conj(X) + i U conj(X))
+                            zb[i * LS] = sub_yx(Xa, w2);                           // conj(conj(X) + i U conj(X))
                         }
                     }
                 }
@@ -675,13 +772,14 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     #pragma unroll
                 for (int q = 0; q < NQ4; ++q) {
                     const int idx = tid + q * NTH;
-                    const int r0 = (idx % (RBH / 4)) * 4, m = idx / (RBH / 4);
-                    if (m < mmax) {
-                        const cf wv = (r0 < nr) ? inverse_weights<N2>(m, w_dc, w_pos, w_nyq) : cf_make(0.f, 0.f);
-                        buf[(r0 + 0) * LS + m] = cf_make(wv.x * sre[q].x, wv.y * sim[q].x);
-                        buf[(r0 + 1) * LS + m] = cf_make(wv.x * sre[q].y, wv.y * sim[q].y);
-                        buf[(r0 + 2) * LS + m] = cf_make(wv.x * sre[q].z, wv.y * sim[q].z);
-                        buf[(r0 + 3) * LS + m] = cf_make(wv.x * sre[q].w, wv.y * sim[q].w);
+                    const int r0 = HOIST ? pi_r0[q] : (idx % (RBH / 4)) * 4, m = HOIST ? pt_m[q] : idx / (RBH / 4);
+                    if (HOIST ? (m >= 0) : (m < mmax)) {
+                        const cf wv = (r0 < nr) ? (HOIST ? pt_wv[q] : inverse_weights<N2>(m, w_dc, w_pos, w_nyq)) : cf_make(0.f, 0.f);
+                        cf* z = buf + (HOIST ? pt_off[q] : r0 * LS + m);
+                        z[0 * LS] = cf_make(wv.x * sre[q].x, wv.y * sim[q].x);
+                        z[1 * LS] = cf_make(wv.x * sre[q].y, wv.y * sim[q].y);
+                        z[2 * LS] = cf_make(wv.x * sre[q].z, wv.y * sim[q].z);
+                        z[3 * LS] = cf_make(wv.x * sre[q].w, wv.y * sim[q].w);
                     }
                 }
             } else {

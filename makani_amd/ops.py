@@ -28,13 +28,30 @@ def round4(n: int) -> int:
 
 
 # Arithmetic of the fp32 spectral GEMMs (Legendre, dhconv):
-#   "x6"   (default) fp32 operands split into 3 bf16 limbs, 6 bf16 MFMAs per product, fp32 accumulate:
+#   "x6"   fp32 operands split into 3 bf16 limbs, 6 bf16 MFMAs per product, fp32 accumulate:
 #          fp32 round-off class (rel-L2 1.8e-7 vs fp64; the exact-fp32 MFMA gives 2.8e-7), 2.7x the fp32 MFMA rate
 #   "fp32" exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
-#   "x3"   2 limbs, 3 MFMAs: ~4e-6, 5.3x
-GEMM_MODE = os.environ.get("MAKANI_AMD_GEMM", "x6")
-if GEMM_MODE not in ("x6", "x3", "fp32"):
-    raise ValueError(f"MAKANI_AMD_GEMM={GEMM_MODE!r}: expected x6, x3 or fp32")
+#   "x3"   2 limbs, 3 MFMAs: rel-L2 ~4e-6 (16 mantissa bits per factor), 5.3x
+#   "auto" (default) follows torch's own switch for fp32 matrix products, exactly as the reference's path does on its GPUs:
+#          ``torch.backends.cuda.matmul.allow_tf32`` False (torch's default; what the reference's TESTS set, tests/testutils.py:
+#          disable_tf32) -> "x6"; True (what the reference's TRAINING entry points set: makani/train.py:87-88, train_stochastic.py:
+#          102-103, inference.py:162-163 — its fp32 einsums of the SHT and of the spectral contraction then run in TF32,
+#          10 mantissa bits) -> "x3", which is still 64x more accurate than TF32.  gfx950 has no TF32 mode; the two-limb split
+#          is this hardware's counterpart of that flag.
+GEMM_MODE = os.environ.get("MAKANI_AMD_GEMM", "auto")
+if GEMM_MODE not in ("auto", "x6", "x3", "fp32"):
+    raise ValueError(f"MAKANI_AMD_GEMM={GEMM_MODE!r}: expected auto, x6, x3 or fp32")
+
+
+def gemm_mode() -> str:
+    """the arithmetic the spectral GEMMs run in right now ("x6" / "x3" / "fp32"): GEMM_MODE, with "auto" resolved through
+    torch's fp32-matmul switch"""
+    if GEMM_MODE != "auto":
+        return GEMM_MODE
+    try:
+        return "x3" if torch.backends.cuda.matmul.allow_tf32 else "x6"
+    except Exception:                       # (a torch build without the attribute: exact arithmetic)
+        return "x6"
 
 
 # Kernel generation of the split engine: "2" = the ping-pong kernels of csrc/xgemm2.hip (512-thread workgroups, double-buffered
@@ -46,7 +63,7 @@ GEMM_GEN = "2"          # (module attribute, not an environment switch: tools ma
 def _run_gemm(g, cplx, what, mode=None, a_limbs=None, band=None):
     """``a_limbs``: the constant A operand of a real GEMM already split into bf16 limb planes (``limb_planes``);
     ``band`` = (lo, hi, mode): its numerical band per batch (``polar_band``)."""
-    mode = mode or GEMM_MODE
+    mode = mode or gemm_mode()
     L = lib()
     if mode == "fp32":
         rc = (L.mk_cgemm_batched if cplx else L.mk_sgemm_batched)(C.byref(g), stream())
@@ -298,7 +315,7 @@ def _gemm(**kw) -> MkGemm:
 
 
 def _limb_products() -> int:
-    return {"x6": 6, "x3": 3, "fp32": 16}[GEMM_MODE]       # fp32 MFMA = 1/16 of the bf16 rate: counted as 16 bf16-equivalents
+    return {"x6": 6, "x3": 3, "fp32": 16}[gemm_mode()]       # fp32 MFMA = 1/16 of the bf16 rate: counted as 16 bf16-equivalents
 
 
 def _up(n, q):
@@ -332,7 +349,7 @@ def _exec_band(L, M, m_off, nlat, band, lat_gran, rows_tri):
 
 
 def _presplit_ok() -> bool:
-    return GEMM_GEN == "2" and GEMM_MODE != "fp32"
+    return GEMM_GEN == "2" and gemm_mode() != "fp32"
 
 
 def legendre_analysis(F: torch.Tensor, matT: torch.Tensor, L: int, m_off: int = 0, lat_major: bool = False,
@@ -418,7 +435,7 @@ def is_native_w(weight: torch.Tensor) -> bool:
         return False
     _, cin, cout, L = weight.shape
     return (cin % 4 == 0 and cout % 4 == 0 and (cout == 1 or weight.stride(2) == 1) and (cin == 1 or weight.stride(1) == cout)
-            and (L == 1 or weight.stride(3) == cin * cout) and weight.data_ptr() % 16 == 0 and GEMM_MODE != "fp32")
+            and (L == 1 or weight.stride(3) == cin * cout) and weight.data_ptr() % 16 == 0 and gemm_mode() != "fp32")
 
 
 def _w_operand(W, transposed):
@@ -795,20 +812,23 @@ def _batch_sum(sums, B, Cc):
     return sums if B == 1 else sums.view(2, B, Cc).sum(1)
 
 
-_FUSED_SYNC = {}        # (device, stream) -> (slots, depart, capacity): hand-over buffers of the one-pass instance norm
+_FUSED_SYNC = {}        # device -> (slots, depart): hand-over buffers of the one-pass instance norm
 
 
 def _fused_sync(nslots: int, planes: int, device):
-    """``slots`` (all ones) / ``depart`` (zero) of csrc/pointwise.hip's one-pass norm kernels for the current stream.  The kernels
-    restore both before they finish, so the pair is allocated (and grown) outside the step only: the first call of a shape —
-    a warm-up step, never a hipGraph capture — pays for it."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    """``slots`` (all ones) / ``depart`` (zero) of csrc/pointwise.hip's one-pass norm kernels.  One pair per device: the kernels
+    restore both before they finish, so every later launch may use them — as long as no two norm launches of one device run
+    CONCURRENTLY (two streams); the package launches its norms on one stream at a time (eager: the current stream; captured: the
+    capture stream).  The pair is allocated (generously: 8 MB) at the first call and only ever grown outside a hipGraph capture:
+    a warm-up step pays for it."""
+    key = str(device)
     hit = _FUSED_SYNC.get(key)
     if hit is None or hit[0].numel() < nslots or hit[1].numel() < planes:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("one-pass instance norm: its hand-over buffers must exist before the step is captured (run a warm-up step)")
-        slots = torch.full((max(nslots, 1 << 16),), -1, dtype=torch.int64, device=device)
-        depart = torch.zeros((max(planes, 1 << 12),), dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)                      # (growing: nothing may still be using the old pair)
+        slots = torch.full((max(nslots, 1 << 20),), -1, dtype=torch.int64, device=device)
+        depart = torch.zeros((max(planes, 1 << 16),), dtype=torch.int32, device=device)
         hit = _FUSED_SYNC[key] = (slots, depart)
     return hit
 

@@ -100,17 +100,21 @@ def _setup_rank(rank, world, port, h, w):
     return mcomm.init(h, w)
 
 
-CONTRACT_KEYS = ("outer_skip.weight", "norm1.weight", "residual_transform.weight", "decoder.fwd.2.weight")
-
-
 def _contract(state, scale):
-    """the oracle's weights with every path that carries a perturbation from one rollout step into the next damped by ``scale``
-    (block skips, the affine weight of the second norm, the big skip, the decoder's output layer): with scale < 1 the rollout
-    map is CONTRACTIVE, so bf16 rounding stays bounded through the four steps and a distributed-vs-serial bf16 comparison can
-    fail for a wrong shard instead of drowning in chaos (VERDICT r5 weak #1b)"""
-    if scale is None or scale == 1.0:
+    """the oracle's weights made NON-CHAOTIC for rollouts: the big skip becomes the identity (73 -> 73 channels) and the decoder's
+    output layer is scaled by ``scale``, so one step is x -> x + scale * f(x) and a perturbation of x (bf16 rounding) is carried
+    into the next step by I + scale * J_f instead of by the full Jacobian of a random network: bf16 rounding stays bounded
+    through the four steps and a distributed-vs-serial bf16 comparison can fail for a wrong shard instead of drowning in chaos
+    (VERDICT r5 weak #1b).  Scaling skip / norm weights does not do it — the instance norms undo every amplitude change
+    (measured: y 0.68 / 0.52 / 0.28 from fp32 at 1/2, 1/4, 1/8; gradients 1.4)."""
+    if scale is None:
         return state
-    return {k: (v * scale if k.endswith(CONTRACT_KEYS) else v) for k, v in state.items()}
+    out = dict(state)
+    w = state["residual_transform.weight"]
+    assert w.shape[0] == w.shape[1], w.shape
+    out["residual_transform.weight"] = torch.eye(w.shape[0], dtype=w.dtype).reshape(w.shape)
+    out["decoder.fwd.2.weight"] = state["decoder.fwd.2.weight"] * scale
+    return out
 
 
 def _sharded_model(oracle, ih, scale=None):
@@ -255,7 +259,7 @@ def _serial_rollout_pass(model, net, oracle, G, amp):
 @pytest.fixture(scope="module")
 def serial_rollout(oracle):
     """the 4-step rollout of the SERIAL HIP network with rollout checkpointing: (1) fp32 on the oracle's weights = the reference
-    of the fp32 comparison; (2) on CONTRACTIVE weights (``_contract``; the largest scale of 1, 1/2, 1/4, 1/8 whose serial bf16
+    of the fp32 comparison; (2) on CONTRACTIVE weights (``_contract``; the largest scale of 0.2, 0.1, 0.05, 0.02, 0.01 whose serial bf16
     rollout stays within 1e-1 (output) / 1.5e-1 (input gradient) of its fp32 rollout) fp32 = the reference of the bf16
     comparison and bf16 autocast = its yardstick"""
     import makani_amd as ma
@@ -272,7 +276,7 @@ def serial_rollout(oracle):
              f"gx {_rel(chaos['gx'], plain['gx']):.2e} (chaotic: not a gate) ---")
     del chaos
     scale, f32, yard = None, None, None
-    for sc in (0.5, 0.25, 0.125):
+    for sc in (0.2, 0.1, 0.05, 0.02, 0.01):
         model.load_state_dict(_contract(oracle["state"], sc), strict=True)
         f32 = _serial_rollout_pass(model, net, oracle, G, False)
         b16 = _serial_rollout_pass(model, net, oracle, G, True)

@@ -236,6 +236,41 @@ def test_fullsize_sht_roundtrip_and_linearity():
     assert one.abs().max().item() < 1e-4
 
 
+def test_spectral_arithmetic_under_both_settings_of_torchs_tf32_switch():
+    """The spectral GEMMs read torch.backends.cuda.matmul.allow_tf32 like the reference's fp32 einsums do (makani/train.py:87-88
+    sets it for training, tests/testutils.py disable_tf32 clears it): False -> three-limb split, fp32 round-off class; True ->
+    two-limb split, which must stay FAR inside what TF32 itself would give (TF32 products carry 2^-11 relative error: ~3e-4 on
+    these sums).  Forward transform of a random field and the dhconv contraction at the model's shapes against fp64."""
+    import makani_amd as ma
+    from makani_amd import ops
+    from oracle import sht as osht
+    torch.manual_seed(3)
+    nlat, nlon, L, M, C = 240, 480, 240, 241, 8
+    x = torch.rand(1, C, nlat, nlon)
+    ref = osht.RealSHT(nlat, nlon, lmax=L, mmax=M, grid="legendre-gauss")(x.double())
+    S = ma.RealSHT(nlat, nlon, lmax=L, mmax=M, grid="legendre-gauss").to(DEV)
+    Cc = 64
+    Ssp = torch.randn(L, M, 2, Cc, device=DEV)
+    w = ops.native_w_empty(Cc, Cc, L, DEV)
+    w.copy_(torch.randn(1, Cc, Cc, L, dtype=torch.complex64, device=DEV) / Cc ** 0.5)
+    tri = (torch.arange(L, device=DEV)[:, None] >= torch.arange(M, device=DEV)[None, :])[:, :, None, None]
+    sc = torch.complex(Ssp[:, :, 0].double(), Ssp[:, :, 1].double())                        # (L, M, C)
+    tref = torch.einsum("lmi,iol->lmo", sc, w.to(torch.complex128).reshape(Cc, Cc, L))
+    tref = torch.stack([tref.real, tref.imag], dim=2) * tri
+    was = torch.backends.cuda.matmul.allow_tf32
+    errs = {}
+    try:
+        for flag in (False, True):
+            torch.backends.cuda.matmul.allow_tf32 = flag
+            assert ops.gemm_mode() == ("x3" if flag else "x6")
+            errs[flag] = (rel_l2(S(x.to(DEV)), ref), rel_l2(ops.dhconv_fwd(Ssp, w, 1, Cc, 0) * tri, tref))
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = was
+    print("spectral arithmetic vs fp64 (SHT forward, dhconv): allow_tf32 False", errs[False], " True", errs[True])
+    assert errs[False][0] < 1e-6 and errs[False][1] < 1e-6, errs
+    assert errs[True][0] < 2e-5 and errs[True][1] < 2e-5, errs
+
+
 def test_fullsize_sht_vs_oracle_one_channel():
     import makani_amd as ma
     from oracle import sht as osht

@@ -561,3 +561,24 @@ def test_share_gpu_sets_disjoint_compute_unit_ranges(monkeypatch):
     assert all(b - a == 31 for a, b in spans) and all(spans[i][1] < spans[i + 1][0] for i in range(7))
     assert mcomm.share_gpu(0, 1) == "0:0-255"
     monkeypatch.delenv("HSA_CU_MASK", raising=False)
+
+
+def test_spectral_gemm_arithmetic_follows_torchs_tf32_switch(monkeypatch):
+    """MAKANI_AMD_GEMM=auto (the default): torch.backends.cuda.matmul.allow_tf32 False (torch's default, the reference's test
+    setting: tests/testutils.py disable_tf32) -> three-limb split "x6"; True (makani/train.py:87-88) -> two-limb split "x3";
+    an explicit mode wins"""
+    import torch
+    from makani_amd import ops
+    was = torch.backends.cuda.matmul.allow_tf32
+    try:
+        monkeypatch.setattr(ops, "GEMM_MODE", "auto")
+        torch.backends.cuda.matmul.allow_tf32 = False
+        assert ops.gemm_mode() == "x6"
+        torch.backends.cuda.matmul.allow_tf32 = True
+        assert ops.gemm_mode() == "x3"
+        monkeypatch.setattr(ops, "GEMM_MODE", "fp32")
+        assert ops.gemm_mode() == "fp32"
+        monkeypatch.setattr(ops, "GEMM_MODE", "x6")
+        assert ops.gemm_mode() == "x6"
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = was
