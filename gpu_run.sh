@@ -1,10 +1,6 @@
-mkdir -p gpurun_out/r06p
+mkdir -p gpurun_out/r06q
 export TMPDIR=/tmp
 SECONDS=0
-MAKANI_AMD_LIB=$PWD/makani_amd/libmakani_amd_oldfft.so python tools/fft_plan_check.py /tmp/fft_old.pt 2>&1 | grep -v amdgpu.ids | tail -1
-python tools/fft_plan_check.py /tmp/fft_new.pt 2>&1 | grep -v amdgpu.ids | tail -1
-python tools/fft_plan_check.py /tmp/fft_old.pt /tmp/fft_new.pt
-timeout 600 python tools/ab.py run g5 g8 -- python tools/microbench.py cold pointwise > gpurun_out/r06p/gelu_slots.log 2>&1; echo "slots rc $? at $SECONDS s"; grep "bwd" gpurun_out/r06p/gelu_slots.log | cut -c1-130
-timeout 300 python tools/ab.py run oldfft g5 -- python tools/microbench.py fft > gpurun_out/r06p/fft_ab.log 2>&1; grep "irfft" gpurun_out/r06p/fft_ab.log | cut -c1-130
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "instance_norm or fft" > gpurun_out/r06p/tests.log 2>&1; echo "tests rc $? at $SECONDS s"; tail -2 gpurun_out/r06p/tests.log
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-sht-metric > gpurun_out/r06p/bench.json 2> gpurun_out/r06p/bench.err; echo "bench rc $? at $SECONDS s: $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/r06p/bench.json | head -2 | tr '\n' ' ')"
+timeout 900 python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "side_stream or rollout or tf32" > gpurun_out/r06q/tests.log 2>&1; echo "tests rc $? at $SECONDS s"; tail -5 gpurun_out/r06q/tests.log | cut -c1-300
+for ov in "" "--no-wgrad-overlap"; do timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-sht-metric --no-exact $ov > gpurun_out/r06q/bench$ov.json 2> gpurun_out/r06q/bench$ov.err; echo "bench [$ov] rc $? at $SECONDS s: $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/r06q/bench$ov.json | head -1) $(grep -o '"launch": "[a-zA-Z ]*' gpurun_out/r06q/bench$ov.json)"; done
+grep "graph capture failed" gpurun_out/r06q/*.err | cut -c1-300

@@ -1833,7 +1833,11 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     // -7 %, gelu' -14 ... -22 %, skip operand -10 ... -21 %; bias + GELU + pre-activation — two output streams, bound by the
     // stores — +0 ... 2 %: that variant stays on the one-group kernel)
     static const int astat2 = [] { const char* e = getenv("MAKANI_AMD_ASTAT2"); return e ? atoi(e) : 2; }();
-    if (astat2 && (astat2 == 1 || !(act && Ypre && !(R || G))) && !force_tile && !no_astat && K == 384 && M >= 256 &&
+    // shard-sized grids (one rank of h4 w2 holds 14 400 ... 32 400 pixels of the internal grid): for 384 <- 384 the ring kernel beats the
+    // weight-stationary ones by 10 - 25 % there (plain 14.5 / 16.3 us against 18.8 / 21.8, + skip operand 16.3 / 18.4 against 18.2 / 24.3:
+    // profiles/r05_ab_conv_shard_kernel_choice.txt); from 115 200 pixels on the stationary kernels win everywhere
+    const bool small_ring = K == 384 && M == 384 && (long long)B * N <= 32768 && !(act && Ypre) && astat2 != 1;
+    if (astat2 && (astat2 == 1 || !(act && Ypre && !(R || G))) && !small_ring && !force_tile && !no_astat && K == 384 && M >= 256 &&
         (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
         // two wave groups, one multiplying while the other runs its epilogue (conv_nn_astat2_kernel): 384-channel slabs
         const bool epi_loads = R || G;
@@ -1849,7 +1853,7 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
         else hipLaunchKernelGGL((conv_nn_astat2_kernel<false, false>), grid, blk, 0, s, p, slabs, tn);
         return mk_check_launch("mk_conv1x1_nn");
     }
-    if (!force_tile && !no_astat && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
+    if (!force_tile && !no_astat && !small_ring && K == 384 && M >= 256 && (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
         // weights stationary in registers: 384-channel slabs (4 waves x 3 row tiles; 256-row slabs measured slower), 64-pixel tiles,
         // persistent grid of 256-thread workgroups
         const bool epi_loads = R || G;

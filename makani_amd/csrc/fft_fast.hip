@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                     const float im[4] = {sim[q].x, sim[q].y, sim[q].z, sim[q].w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const cf Xa = cf_make(wv.x * re[i], wv.y * im[i]);
+                        const cf Xa = mul_parts(wv, re[i], im[i]);
                         const cf Xc = cf_make(Xa.x, -Xa.y);
                         const cf wt = cmulc(Xa, tw);                           // conj(U) X
                         za[i * LS] = sub_yx(Xc, wt);                               // conj(X + i conj(U) X)
@@ -776,10 +776,10 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
                     if (HOIST ? (m >= 0) : (m < mmax)) {
                         const cf wv = (r0 < nr) ? (HOIST ? pt_wv[q] : inverse_weights<N2>(m, w_dc, w_pos, w_nyq)) : cf_make(0.f, 0.f);
                         cf* z = buf + (HOIST ? pt_off[q] : r0 * LS + m);
-                        z[0 * LS] = cf_make(wv.x * sre[q].x, wv.y * sim[q].x);
-                        z[1 * LS] = cf_make(wv.x * sre[q].y, wv.y * sim[q].y);
-                        z[2 * LS] = cf_make(wv.x * sre[q].z, wv.y * sim[q].z);
-                        z[3 * LS] = cf_make(wv.x * sre[q].w, wv.y * sim[q].w);
+                        z[0 * LS] = mul_parts(wv, sre[q].x, sim[q].x);
+                        z[1 * LS] = mul_parts(wv, sre[q].y, sim[q].y);
+                        z[2 * LS] = mul_parts(wv, sre[q].z, sim[q].z);
+                        z[3 * LS] = mul_parts(wv, sre[q].w, sim[q].w);
                     }
                 }
             } else {

@@ -60,6 +60,14 @@ __device__ __forceinline__ cf sub_yx(cf a, cf b) {
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(b), "v"(a));
     return r;
 }
+// (w.re a, w.im b) from two scalars that live in unrelated registers: two plain multiplies, pinned — left to itself hipcc pairs the
+// operands of such products into v_pk_mul_f32 with op_sel on a VGPR src1, one of the unreliable forms (see sub_yx)
+__device__ __forceinline__ cf mul_parts(cf w, float a, float b) {
+    float x, y;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(x) : "v"(w.x), "v"(a));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(y) : "v"(w.y), "v"(b));
+    return cf_make(x, y);
+}
 // a + conj(b),  a - conj(b)
 __device__ __forceinline__ cf add_conj(cf a, cf b) { return pk_fma(b, cf_make(1.f, -1.f), a); }
 __device__ __forceinline__ cf sub_conj(cf a, cf b) { return pk_fma(b, cf_make(-1.f, 1.f), a); }

@@ -27,6 +27,17 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
+def _spawn(fn, nprocs, *args):
+    """mp.spawn with a fresh rendezvous port; one retry when another process grabbed the port between probing and binding"""
+    for attempt in (0, 1):
+        try:
+            mp.spawn(fn, args=(nprocs, _free_port()) + args, nprocs=nprocs, join=True)
+            return
+        except Exception as e:
+            if attempt == 1 or "EADDRINUSE" not in str(e):
+                raise
+
+
 def _setup(rank, world, port, h, w):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -118,7 +129,7 @@ def _worker_ops(rank, world, port, h, w):
 
 @pytest.mark.parametrize("h,w", [(2, 1), (1, 2), (2, 2), (3, 1)])
 def test_distributed_disco_and_resample_match_serial(h, w):
-    mp.spawn(_worker_ops, args=(h * w, _free_port(), h, w), nprocs=h * w, join=True)
+    _spawn(_worker_ops, h * w, h, w)
 
 
 def _worker_fcn3(rank, world, port, h, w, name):
@@ -181,4 +192,4 @@ def _worker_fcn3(rank, world, port, h, w, name):
 @pytest.mark.parametrize("h,w,name", [(2, 1, "fcn3_small_33x64.npz"), (1, 2, "fcn3_small_33x64.npz"),
                                       (2, 2, "fcn3_small_33x64.npz"), (2, 2, "fcn3_options_24x48.npz")])
 def test_spatial_parallel_fcn3_matches_serial(h, w, name):
-    mp.spawn(_worker_fcn3, args=(h * w, _free_port(), h, w, name), nprocs=h * w, join=True)
+    _spawn(_worker_fcn3, h * w, h, w, name)

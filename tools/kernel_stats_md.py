@@ -6,7 +6,7 @@ import sys
 
 FAMILIES = {
     "sfno": [("channel GEMM fwd/dgrad", r"conv_nn_"), ("channel GEMM wgrad", r"conv_wgrad_|reduce_splits"), ("dhconv", r"xcgemm2?_kernel"),
-             ("Legendre", r"xgemm2?_kernel|sgemm"), ("FFT", r"fft_(fast_)?kernel"), ("instance norm", r"in_(stats|apply|bwd)"),
+             ("Legendre", r"xgemm2?_kernel|sgemm"), ("FFT", r"fft_(fast_)?kernel"), ("instance norm", r"in_(stats|apply|bwd|fwd)"),
              ("AdamW + clip", r"adamw|sumsq|clip_coef"), ("plane sums", r"plane_sum|sum_chunks"), ("loss", r"quad_lp|spec_lp"),
              ("layout", r"weight_to_w|w_to_weight|slayout|complex_to"), ("torch glue", r"at::native|rocclr|Cijk")],
     "fcn3": [("DISCO contraction", r"disco_"), ("channel GEMM fwd/dgrad", r"conv_nn_"), ("channel GEMM wgrad", r"conv_wgrad_|reduce_splits"),

@@ -157,6 +157,7 @@ def main():
     tar = torch.rand(1, cfg["out_chans"] * a.multistep_count, hl, wl, device=dev)
     loss_fn = bench.make_loss(H, W, cfg["out_chans"] * a.multistep_count, dev, h * w > 1)
     amp, sharded_clip = not a.fp32, h > 1
+    torch.backends.cuda.matmul.allow_tf32 = bool(amp)        # as bench.py: the reference's training flag (makani/train.py:87-88)
     import gc
     gc.collect()
     gc.disable()
