@@ -73,8 +73,8 @@ for _k, _v in FCN3_CONFIGS.items():
     CONFIGS[_k] = dict(kind="fcn3", inp_shape=_v["model"]["inp_shape"], out_shape=_v["model"]["out_shape"],
                        inp_chans=len(_v["model"]["channel_names"]) + len(_v["model"]["aux_channel_names"]),
                        out_chans=len(_v["model"]["channel_names"]), **_v)
-PMC_TRAFFIC = "r05_pmc_hbm_traffic.json"              # written by tools/profile_round.sh on this round's code (fallback of the live passes)
-PMC_TRAFFIC_FCN3 = "r05_pmc_hbm_traffic_fcn3.json"
+PMC_TRAFFIC = "r06_pmc_hbm_traffic.json"              # written by tools/profile_round.sh on this round's code (fallback of the live passes)
+PMC_TRAFFIC_FCN3 = "r06_pmc_hbm_traffic_fcn3.json"
 PEAK_F32_VALU_TF = 157.3      # packed fp32 FMA on the vector ALUs (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TF = 2500.0    # dense
