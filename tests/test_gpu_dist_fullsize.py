@@ -259,7 +259,7 @@ def _serial_rollout_pass(model, net, oracle, G, amp):
 @pytest.fixture(scope="module")
 def serial_rollout(oracle):
     """the 4-step rollout of the SERIAL HIP network with rollout checkpointing: (1) fp32 on the oracle's weights = the reference
-    of the fp32 comparison; (2) on CONTRACTIVE weights (``_contract``; the largest scale of 0.2, 0.1, 0.05, 0.02, 0.01 whose serial bf16
+    of the fp32 comparison; (2) on CONTRACTIVE weights (``_contract``; the larger of the scales 0.02, 0.01 whose serial bf16
     rollout stays within 1e-1 (output) / 1.5e-1 (input gradient) of its fp32 rollout) fp32 = the reference of the bf16
     comparison and bf16 autocast = its yardstick"""
     import makani_amd as ma
@@ -276,7 +276,7 @@ def serial_rollout(oracle):
              f"gx {_rel(chaos['gx'], plain['gx']):.2e} (chaotic: not a gate) ---")
     del chaos
     scale, f32, yard = None, None, None
-    for sc in (0.2, 0.1, 0.05, 0.02, 0.01):
+    for sc in (0.02, 0.01):          # (0.2 / 0.1 / 0.05 were measured: y 9.0e-2 / 3.7e-2 / 1.2e-2, gx 0.64 / 0.42 / 0.18: docs/LAB_NOTEBOOK.md 6.6)
         model.load_state_dict(_contract(oracle["state"], sc), strict=True)
         f32 = _serial_rollout_pass(model, net, oracle, G, False)
         b16 = _serial_rollout_pass(model, net, oracle, G, True)
