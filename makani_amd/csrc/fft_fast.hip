@@ -30,6 +30,9 @@
 #ifndef MK_FFT_480_FWD_OCC
 #define MK_FFT_480_FWD_OCC 1
 #endif
+#ifndef MK_FFT_480_INV_OCC      // the inverse 480-point kernels held to 128 registers = two workgroups per CU (A/B: round 6)
+#define MK_FFT_480_INV_OCC 0
+#endif
 #ifndef MK_FFT_HV
 #define MK_FFT_HV 1
 #endif
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
 // MCAP: compile-time bound on mmax (N2/3+1 for the 3x-truncated spectra of the scale-3 model, else N2+1);
 // it sizes the registers that carry the next item's spectrum.
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG, int HV>
-__global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __restrict__ F, T* __restrict__ x,
+__global__ __launch_bounds__(NT, (MK_FFT_480_INV_OCC && N2 == 240 && !SEG) ? 4 : WGS) void irfft_fast_kernel(const float* __restrict__ F, T* __restrict__ x,
                                                              const cf* __restrict__ tw_g, int C, int Cp,
                                                              long long rows, long long planes, int nlat, int mmax,
                                                              int ngr, long long nitems, float w_dc, float w_pos,
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(NT, WGS) void irfft_fast_kernel(const float* __rest
     float4 sre[NQ4], sim[NQ4];
     // lane constants hoisted out of the item loop (see rfft_fast_kernel): float offset of this lane's spectrum quad q inside an
     // item, its first row, and — for the pruned transform — where its pre-twiddled pair lands in LDS, the order's twiddle and weights
-    constexpr bool HOIST = !SEG && WGS <= 2;
+    constexpr bool HOIST = !SEG && WGS <= 2 && !(MK_FFT_480_INV_OCC && N2 == 240);
     unsigned pi_fo[NQ4];
     int pi_r0[NQ4], pt_off[NQ4], pt_m[NQ4];
     cf pt_tw[NQ4], pt_wv[NQ4];
