@@ -951,7 +951,7 @@ def run_worker(args):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                     # one eager step on a side stream (torch's capture recipe)
-                train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
+                eager_loss = train_step(net, opt, inp, tar, loss_fn, amp, sharded_clip)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             opt.zero_grad(set_to_none=True)
@@ -974,11 +974,14 @@ def run_worker(args):
             torch.cuda.synchronize()
             # a replay whose loss is not a finite number (a collective that did not survive the capture) must not be timed: every
             # rank checks its own replayed loss, the ranks agree, and on disagreement all fall back to eager launches
-            okf = torch.isfinite(graph_loss.detach().float()).all().to(torch.int32).reshape(1)
+            # ... and it must be the loss of THIS training run: one optimizer update away from the eager step just before the capture
+            # (same data: within a factor of two of it), not the residue of a collective that replays differently than it captured
+            gl, el = graph_loss.detach().float().reshape(-1)[0], eager_loss.detach().float().reshape(-1)[0]
+            okf = (torch.isfinite(gl) & ((gl - el).abs() <= 0.5 * el.abs() + 1e-12)).to(torch.int32).reshape(1)
             if world > 1:
                 dist.all_reduce(okf, op=dist.ReduceOp.MIN)
             if int(okf.item()) == 0:
-                graph, graph_note = None, "the first replay of the captured step produced a non-finite loss; eager launches"
+                graph, graph_note = None, "the first replay of the captured step produced a loss that is not finite or far from the eager step's; eager launches"
                 print(f"[bench] {graph_note}", file=sys.stderr, flush=True)
 
     ops.PROFILER.reset()

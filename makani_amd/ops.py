@@ -1396,6 +1396,8 @@ class DistInstanceNormFn(torch.autograd.Function):
             check(lib().mk_instnorm_stats(ptr(x), dt, ptr(stats), ptr(ws), planes, hw, eps, ptr(quad), float(quad_sum), stream()), "instnorm_stats")
         allst = _all_gather_stack(stats, group)                  # (P, planes + 1, 2): every rank's local {mean, rstd} + its count
         counts = allst[:, planes, 0].contiguous()
+        # what the backward pass scales its all-reduced sums by (see there): hw / total, resp. 1 / Q — one device scalar, computed here
+        bscale = ((1.0 if quad is not None else float(hw)) / counts.double().sum()).float()
         allst = allst[:, :planes].contiguous()
         mstats = torch.empty((planes, 2), dtype=torch.float32, device=x.device)
         check(lib().mk_instnorm_merge(ptr(allst), ptr(counts), ptr(mstats), planes, allst.shape[0], eps, stream()), "instnorm_merge")
@@ -1405,13 +1407,13 @@ class DistInstanceNormFn(torch.autograd.Function):
         with _timed(f"instnorm_dist_apply{tag}", nbytes=2.0 * nb):
             check(lib().mk_instnorm_apply(ptr(x), ptr(y), dt, ptr(mstats), ptr(g), ptr(b), planes, Cc, hw,
                                           1 if fuse_gelu else 0, stream()), "instnorm_apply")
-        ctx.save_for_backward(x, mstats, g, b, quad, counts)
+        ctx.save_for_backward(x, mstats, g, b, quad, bscale)
         ctx.meta = (fuse_gelu, group)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, mstats, g, b, quad, counts = ctx.saved_tensors
+        x, mstats, g, b, quad, bscale = ctx.saved_tensors
         fuse_gelu, group = ctx.meta
         B, Cc, H, W = x.shape
         planes, hw = B * Cc, H * W
@@ -1432,9 +1434,8 @@ class DistInstanceNormFn(torch.autograd.Function):
         # the kernel divides the sums by its `hw_total` argument (unweighted) or multiplies them by q_i per element (weighted);
         # the true total — the sum of the ranks' counts along possibly ragged splits, exact small integers in fp32 — lives on the
         # device: the sums are pre-scaled there (hw / total, resp. 1 / Q for the normalised weights p_i = q_i / Q with the
-        # kernel's crop term switched off) and the kernel is told the LOCAL count
-        total = counts.double().sum()
-        sums = (sums.double() * ((1.0 if quad is not None else float(hw)) / total)).float().contiguous()
+        # kernel's crop term switched off; the factor was formed in fp64 in the forward pass) and the kernel is told the LOCAL count
+        sums = sums * bscale
         with _timed(f"instnorm_dist_bwd_apply{tag}", nbytes=3.0 * nb):
             check(lib().mk_instnorm_bwd(ptr(x), ptr(gy), ptr(gx), dtype_code(x), ptr(mstats), ptr(g), ptr(b), None, ptr(quad),
                                         1.0 if quad is not None else 0.0, ptr(sums), ptr(ws), planes, Cc, hw, hw, 2, fg, stream()),
