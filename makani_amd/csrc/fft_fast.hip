@@ -48,6 +48,8 @@
 
 namespace {
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
 #if MK_FFT_DIAG
 // 0 prefetch issue, 1 pass loads (LDS reads landed), 2 barriers, 3 twiddle + butterflies + LDS stores, 4 untangle (LDS reads, arithmetic,
 // global store issue), 5 commit (wait for the prefetched row vectors, convert, LDS stores), 6 whole kernel, 7 waves
@@ -625,6 +627,172 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Forward 1440-point transform with WAVE-PRIVATE passes (round 6, MK_FFT_WAVE).  rfft_fast_kernel above runs its passes over the 16
+// rows of an item with all eight waves in step: a barrier between the loads and the stores of every pass, one after it — five to
+// six workgroup barriers per item, every wave in the same phase at the same time, LDS round trips that two waves per SIMD cannot
+// cover (the kernel is bound by exactly that, not by its instruction count: docs/LAB_NOTEBOOK.md 6.4).  Here a wave owns TWO rows
+// of the item and runs both passes on them alone: within one wave the LDS instructions of a pass execute in program order (all
+// reads of a pass before its writes), so no barrier is needed and the eight waves drift apart — one waits for LDS while the other
+// wave of its SIMD multiplies.  Each row starts on a 32-lane half of the wave (24 / 30 of the 32 lanes carry a butterfly).  What
+// still needs the workgroup is the F side: 16 rows = 64-byte runs per (m, re / im), so the untangled spectrum goes through a
+// 33 KB staging image and is stored by all 512 lanes — two barriers per item (image written / image free again).
+// Same butterflies, twiddles and untangle arithmetic in the same order as rfft_fast_kernel: bit-identical outputs (tools/
+// fft_plan_check.py).  RESULT: not faster (0.51 - 0.53 ms against 0.49), so not dispatched; kept for its diagnostic builds
+// (MK_FFT_WAVE_DIAG): with neither loads nor stores the kernel still takes 0.344 of its 0.511 ms — the transform is bound by its
+// ON-CHIP work (LDS instruction time of the CU + vector time of the SIMDs add up instead of overlapping), loads add 0.08 ms and
+// stores 0.09 on top.
+#ifndef MK_FFT_WAVE          // 0 (default): not dispatched — measured 0.51 - 0.53 ms against 0.49 for rfft_fast_kernel (docs/LAB_NOTEBOOK.md 6.4)
+#define MK_FFT_WAVE 0
+#endif
+#ifndef MK_FFT_WAVE_TWR       // second-pass twiddles in registers (1: 38 spilled registers, 0.80 ms) or read from the LDS table per item (0)
+#define MK_FFT_WAVE_TWR 0
+#endif
+#ifndef MK_FFT_WAVE_DIAG      // diagnostic builds: 1 = no global stores, 2 = no global loads, 4 = no untangle / staging at all
+#define MK_FFT_WAVE_DIAG 0
+#endif
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void rfft_wave_kernel(const T* __restrict__ x, float* __restrict__ F, const cf* __restrict__ tw_g,
+                                                           long long rows, long long planes, int nlat, int mmax, int ngr,
+                                                           long long nitems, float w_dc, float w_pos, float w_nyq) {
+    constexpr int N2 = 720, N = 1440, R1 = 30, R2 = 24, RB = 16, NT = 512, NW = NT / 64, RW = RB / NW, MCAP = N2 / 3 + 1;
+    static_assert(RW == 2, "two rows per wave: one per 32-lane half");
+    // row strides (complex values) of the three generations of a wave's two-row region; each half-wave touches ONE row, so only the
+    // pattern inside a row matters for the passes (see the bank notes at Gen): g1 is padded by one value per 30 (stride 31 between
+    // the lanes' stores), g2's two rows are 128 bytes apart modulo 256 for the untangle reads, which alternate between the rows
+    using G0 = Gen<728, 0, 0>;
+    using G1 = Gen<744, R1, 1>;
+    using G2 = Gen<736, 0, 0>;
+    constexpr int LSM = 744, LS0 = G0::LS, LS2 = G2::LS;
+    constexpr int VP = RowVec<T>::PAIRS, VROW = N2 / VP;
+    using Tb = Tables<N2, R1, R2, 1, MCAP>;
+    constexpr int SST = 17;                                     // floats per (m, re / im) line of the staging image (16 rows + 1: bank spread)
+    __shared__ __attribute__((aligned(16))) cf smem[RB * LSM + Tb::SIZE];
+    __shared__ float stage[MCAP * 2 * SST];
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    cf* buf = smem + wave * (RW * LSM);
+    cf* tw2 = smem + RB * LSM;
+    cf* twu = tw2 + Tb::T2;
+    Tb::template fill<NT>(tw2, tw_g, (int)threadIdx.x);
+
+    const ItemRange it = my_items(nitems);
+    const long long rstride = (long long)nlat * N;              // distance between the rows (planes) of an item
+    // ---- lane constants ------------------------------------------------------------------------------------------------
+    constexpr int NV = (RW * VROW + 63) / 64;                   // 16-byte vectors of the wave's two rows per lane
+    uint4 rawv[NV];
+    // Global traffic goes through raw buffer instructions: a lane that has nothing to fetch / store gets an offset beyond the
+    // buffer (reads return zeros — what rows past the last plane must hold —, writes are dropped), so every load and store of an
+    // item is issued UNCONDITIONALLY.  With loads or stores under lane conditions the compiler cannot count what is in flight and
+    // answers with s_waitcnt vmcnt(0) wherever a prefetched value is needed: the wave then also waits for the stores it issued a
+    // moment ago (loads and stores retire through one in-order counter on gfx9) — a full memory round trip exposed per item.
+    constexpr unsigned OOB = 0x80000000u;
+    auto prefetch = [&](long long itm) {
+        const long long kl_ = (unsigned)itm / (unsigned)ngr;
+        const long long p0_ = (itm - kl_ * ngr) * RB;
+        const int nr_ = (int)max(0ll, min((long long)RB, planes - p0_));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (p0_ * nlat + kl_) * N), 0, OOB, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int idx = lane + q * 64;
+            const int row = idx / VROW, c = idx % VROW;         // (constants per lane, re-derived per item: registers are the scarce resource here)
+            const bool ok = idx < RW * VROW && wave * RW + row < nr_ && !(MK_FFT_WAVE_DIAG & 2);
+            const unsigned vo = ok ? (unsigned)(((long long)(wave * RW + row) * rstride + (long long)c * (2 * VP)) * (long long)sizeof(T)) : OOB;
+            const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            rawv[q] = make_uint4(r.x, r.y, r.z, r.w);
+        }
+    };
+    auto commit = [&]() {                                       // registers -> this wave's rows as fp32 pairs
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int idx = lane + q * 64;
+            if (idx < RW * VROW) {
+                float4* d = reinterpret_cast<float4*>(buf + (idx / VROW) * LS0 + (idx % VROW) * VP);
+                const uint4 u = rawv[q];
+                if constexpr (sizeof(T) == 4) {
+                    d[0] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+                } else {
+                    d[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                       __uint_as_float(u.y & 0xffff0000u));
+                    d[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                                       __uint_as_float(u.w & 0xffff0000u));
+                }
+            }
+        }
+    };
+    if (it.begin < it.end) {
+        prefetch(it.begin);
+        commit();
+    }
+    __syncthreads();                                            // the tables are complete
+    const int lrow = lane >> 5, lj = lane & 31;                 // second pass: this lane's row and butterfly (k = lj < 30)
+    cf twr[MK_FFT_WAVE_TWR ? R2 - 1 : 1];
+    if constexpr (MK_FFT_WAVE_TWR) {
+#pragma unroll
+        for (int r = 1; r < R2; ++r) twr[r - 1] = tw2[(r - 1) * R1 + (lj < R1 ? lj : 0)];
+    }
+    // untangle: trip q of a lane handles order m = idx / 2 of row idx % 2 of its wave (offsets, twiddle and weights are re-derived per
+    // item: eight trips' worth of constants would not fit the registers next to the 23 twiddles, and the vector unit has slack)
+    constexpr int NQU = (MCAP * RW + 63) / 64;
+    // store: trip q of a thread handles line mi = (m, re / im) and rows 4 quad .. 4 quad + 3 of the item
+    constexpr int NST = (MCAP * 2 * (RB / 4) + NT - 1) / NT;
+    auto ld_lds = [&](int, int, int addr) -> cf { return buf[addr]; };
+    auto st_lds = [&](int, int, int addr, cf val) { buf[addr] = val; };
+    for (long long item = it.begin; item < it.end; ++item) {
+        const long long klat = (unsigned)item / (unsigned)ngr;
+        const long long p0 = (item - klat * ngr) * RB;
+        const int nr = (int)max(0ll, min((long long)RB, planes - p0));
+        if (item + 1 < it.end) prefetch(item + 1);              // in flight during the passes
+        // the two passes on this wave's rows: no workgroup barrier (one wave: LDS instructions in program order)
+        fft_pass<N2, R1, 1, RW, 64, false, 32, G0, G1>(tw2, ld_lds, st_lds, lane);
+        if constexpr (!MK_FFT_WAVE_TWR) {
+            fft_pass<N2, R2, R1, RW, 64, false, 32, G1, G2>(tw2, ld_lds, st_lds, lane);
+        } else {   // second pass: as fft_pass<N2, R2, R1, RW, 64, false, 32, G1, G2>, the lane's 23 twiddles from registers (twr) instead
+            // of 12 dependent LDS round trips per item
+            cf v[1][R2];
+            pass_load<N2, R2, RW, 64, 32, G1>(v, ld_lds, lane);
+            if (lj < N2 / R2) {
+#pragma unroll
+                for (int r = 1; r < R2; ++r) v[0][r] = cmul(v[0][r], twr[r - 1]);
+                PDft<R2>::run(v[0]);
+                cf* o = buf + lrow * G2::LS + lj;
+#pragma unroll
+                for (int q = 0; q < R2; ++q) o[q * R1] = v[0][PDft<R2>::loc(q)];
+            }
+        }
+        __syncthreads();                                        // the staging image of the previous item has been stored
+#pragma unroll
+        for (int q = 0; q < NQU; ++q) {
+            const int idx = lane + q * 64;
+            const int m = idx >> 1, row = idx & 1;
+            if (m < mmax) {
+                const cf* z = buf + row * LS2;
+                const cf A = z[m], B = z[m == 0 ? 0 : N2 - m], tw = twu[m];
+                const float w = 0.5f * (m == 0 ? w_dc : w_pos);                 // (m < mmax <= N2 / 3 + 1: never the Nyquist order)
+                const cf R = add_mi(add_conj(A, B), cmul(sub_conj(A, B), tw));
+                float* sp = stage + (2 * m) * SST + wave * RW + row;
+                sp[0] = R.x * w;
+                sp[SST] = R.y * (m == 0 ? 0.f : w);
+            }
+        }
+        if (item + 1 < it.end) commit();                        // this wave's rows of the next item (its own region: program order)
+        __syncthreads();                                        // the staging image is complete
+        const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void*)(F + (klat * 2 * rows + p0)), 0, OOB, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int idx = (int)threadIdx.x + q * NT;
+            const int mi = idx / (RB / 4), quad = idx % (RB / 4);
+            const int m = mi >> 1, ri = mi & 1;
+            const float* sp = stage + min(mi, MCAP * 2 - 1) * SST + quad * 4;
+            const u32x4_t v4 = {__float_as_uint(sp[0]), __float_as_uint(sp[1]), __float_as_uint(sp[2]), __float_as_uint(sp[3])};
+            const bool ok = m < mmax && quad * 4 < nr && !(MK_FFT_WAVE_DIAG & 1);
+            const unsigned vo = ok ? (unsigned)((((long long)m * nlat) * 2 * rows + (long long)ri * rows + quad * 4) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v4, rsF, vo, 0, 0);
+        }
+    }
+}
+
 // MCAP: compile-time bound on mmax (N2/3+1 for the 3x-truncated spectra of the scale-3 model, else N2+1);
 // it sizes the registers that carry the next item's spectrum.
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG, int HV>
@@ -886,6 +1054,17 @@ int launch_inverse(const float* in, T* out, const float2* tw, int C, int Cp, lon
 template <int N2, int R1, int R2, int R3, int RB, int NT, int WGS, int MCAP, typename T, bool SEG>
 int launch_forward(const T* in, float* out, const float2* tw, int C, int Cp, long long rows, long long planes, int nlat,
                    int mmax, int ngr, long long nitems, float w_dc, float w_pos, float w_nyq, const MkFftSeg& sg, hipStream_t s) {
+    if constexpr (MK_FFT_WAVE && N2 == 720 && R1 == 30 && R2 == 24 && RB == 16 && NT == 512 && MCAP == N2 / 3 + 1 && !SEG && sizeof(T) == 2) {      // (fp32 rows: 24 more registers in flight per lane: spills)
+        // wave-private passes (rfft_wave_kernel): the float4 F access needs plane = row (C % 4 == 0 or one batch entry)
+        static const bool off = [] { const char* e = getenv("MAKANI_AMD_FFT_WAVE"); return e && e[0] == '0'; }();
+        if (!off && ((C % 4 == 0) || planes == C) && (long long)mmax * nlat * 2 * rows < (1ll << 32)) {
+            long long grid = 256;
+            if (grid > nitems) grid = nitems;
+            hipLaunchKernelGGL(rfft_wave_kernel<T>, dim3((unsigned)grid), dim3(512), 0, s, in, out, reinterpret_cast<const cf*>(tw), rows, planes,
+                               nlat, mmax, ngr, nitems, w_dc, w_pos, w_nyq);
+            return mk_check_launch("mk_rfft_rows(wave)");
+        }
+    }
     auto kern = rfft_fast_kernel<N2, R1, R2, R3, RB, NT, WGS, MCAP, T, SEG, fft_halves<N2, RB, NT, T, SEG, false>()>;
     static int per_cu = 0;
     if (per_cu == 0) {
