@@ -619,8 +619,7 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
                             v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
                         }
                         if (p.act) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+                            gelu_fast_n<8>(v);
                         }
                         if (p.G) {
                             const uint32_t gw[4] = {gq[u4].x, gq[u4].y, gq[u4].z, gq[u4].w};
@@ -968,8 +967,7 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                         v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
                     }
                     if (p.act) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+                        gelu_fast_n<8>(v);
                     }
                     if (EPI_LOADS && p.G) {
                         const uint32_t gw[4] = {ev.x, ev.y, ev.z, ev.w};
@@ -1257,8 +1255,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
                     v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
                 }
                 if (p.act) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+                    gelu_fast_n<8>(v);
                 }
                 if (EPI_LOADS && p.G) {
                     const uint32_t gw[4] = {ev.x, ev.y, ev.z, ev.w};
