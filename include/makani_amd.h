@@ -97,6 +97,13 @@ int mk_cgemm_split_batched(const MkGemm* g, int limbs, void* stream);
  *   of k (analysis: the latitude sum is clipped); 2: a range of rows (synthesis: output latitudes outside the band are
  *   written as exact zeros); 0: no band.  Neither A nor B is read outside the band. */
 int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream);
+/* mk_cgemm_split2_batched that also hands back the sum of re^2 + im^2 over everything it writes, as one fp32 partial per workgroup
+ * (ssq_part[0 .. mk_cgemm_split2_ssq_count(g)), fixed summation order; workgroups without work write 0): the weight gradient of
+ * _contract_lwise (makani/models/common/contractions.py:23-24) is 283 MB per layer, and the global-norm clipping of
+ * makani/utils/training/training_helpers.py:123-165 would otherwise read it once more just to square it (mk_grad_clip_coef_pre
+ * takes the partials instead).  With beta = 1 the sums are those of the accumulated values. */
+long long mk_cgemm_split2_ssq_count(const MkGemm* g);
+int mk_cgemm_split2_batched_ssq(const MkGemm* g, int limbs, float* ssq_part, void* stream);
 int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, long long pl_stride, long long pl_batch,
                               long long pl_k, int limbs, const int* band_lo, const int* band_hi, int band_mode,
                               void* stream);
@@ -338,6 +345,12 @@ int mk_adamw_multi(const MkAdamTensor* tensors, int count, const float* grad_sca
  * `partial` needs mk_grad_norm_workspace() floats.  ceil(count / 48) + 1 launches, fixed summation order. */
 long long mk_grad_norm_workspace(const MkAdamTensor* tensors, int count);
 int mk_grad_clip_coef(const MkAdamTensor* tensors, int count, float max_norm, float* partial, float* out, void* stream);
+/* The same with `npre` buffers of ALREADY SQUARED partial sums (pre[i].g = the buffer, pre[i].n = its length; e.g. the ssq_part of
+ * mk_cgemm_split2_batched_ssq) standing in for the tensors they were formed from: norm^2 = sum of squares of tensors[] + sum of pre[].
+ * `partial` needs mk_grad_norm_workspace_pre() floats; count or npre may be 0. */
+long long mk_grad_norm_workspace_pre(const MkAdamTensor* tensors, int count, const MkAdamTensor* pre, int npre);
+int mk_grad_clip_coef_pre(const MkAdamTensor* tensors, int count, const MkAdamTensor* pre, int npre, float max_norm, float* partial,
+                          float* out, void* stream);
 
 /* ---- layer norm over the channels of an NCHW tensor ------------------------------------------------------------------
  * Replaces DistributedLayerNorm (makani/mpu/layer_norm.py:256-290: nn.LayerNorm(C) between two transposes of the NCHW

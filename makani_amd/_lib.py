@@ -54,6 +54,8 @@ _SIGS = {
     "mk_sgemm_split_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
     "mk_cgemm_split_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
     "mk_cgemm_split2_batched": ([C.POINTER(MkGemm), c_int, c_vp], c_int),
+    "mk_cgemm_split2_ssq_count": ([C.POINTER(MkGemm)], c_ll),
+    "mk_cgemm_split2_batched_ssq": ([C.POINTER(MkGemm), c_int, c_vp, c_vp], c_int),
     "mk_sgemm_presplit_batched": ([C.POINTER(MkGemm), c_vp, c_ll, c_ll, c_ll, c_int, c_vp, c_vp, c_int, c_vp], c_int),
     "mk_rfft_rows": ([c_vp, c_int, c_vp, c_vp, C.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_f, c_f, c_f, c_vp], c_int),
@@ -96,6 +98,8 @@ _SIGS = {
     "mk_instnorm_fwd": ([c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_ll, c_int, c_ll, c_f, c_int, c_vp], c_int),
     "mk_grad_norm_workspace": ([c_vp, c_int], c_ll),
     "mk_grad_clip_coef": ([c_vp, c_int, c_f, c_vp, c_vp, c_vp], c_int),
+    "mk_grad_norm_workspace_pre": ([c_vp, c_int, c_vp, c_int], c_ll),
+    "mk_grad_clip_coef_pre": ([c_vp, c_int, c_vp, c_int, c_f, c_vp, c_vp, c_vp], c_int),
     "mk_spec_lp_blocks": ([c_int, c_int], c_ll),
     "mk_spec_lp_fwd": ([c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_int, c_f, c_f, c_f, c_vp], c_int),
     "mk_spec_lp_bwd": ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_int, c_f, c_f, c_f, c_vp], c_int),

@@ -257,9 +257,53 @@ extern "C" long long mk_grad_norm_workspace(const MkAdamTensor* tensors, int cou
     return blocks;
 }
 
+// partial sums of squares that producers already formed (mk_cgemm_split2_batched_ssq): summed NT at a time into the array behind the
+// partials of the tensors that are read here, so that clip_coef_kernel sums ONE array in ONE fixed order
+static __global__ __launch_bounds__(NT) void gather_partials_kernel(const SumsqMulti a, float* __restrict__ partial) {
+    __shared__ float red[NT / 64];
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.first[t + 1]) ++t;
+    const long long i = (long long)((int)blockIdx.x - a.first[t]) * NT + threadIdx.x;
+    float s = i < a.n[t] ? a.g[t][i] : 0.f;                 // NT of the producer's partials -> one (fixed order)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tsum = 0.f;
+        for (int w = 0; w < NT / 64; ++w) tsum += red[w];
+        partial[blockIdx.x] = tsum;
+    }
+}
+
+static long long pre_slots(const MkAdamTensor* pre, int npre) {
+    long long blocks = 0;
+    for (int t = 0; t < npre; ++t) blocks += (pre[t].n + NT - 1) / NT;
+    return blocks;
+}
+
+extern "C" long long mk_grad_norm_workspace_pre(const MkAdamTensor* tensors, int count, const MkAdamTensor* pre, int npre) {
+    return mk_grad_norm_workspace(tensors, count) + pre_slots(pre, npre);
+}
+
+static int grad_clip_coef_impl(const MkAdamTensor* tensors, int count, const MkAdamTensor* pre, int npre, float max_norm,
+                               float* partial, float* out, void* stream);
+
 extern "C" int mk_grad_clip_coef(const MkAdamTensor* tensors, int count, float max_norm, float* partial, float* out,
                                  void* stream) {
-    MK_REQUIRE(tensors && count > 0 && partial && out, "grad_clip_coef: bad args");
+    MK_REQUIRE(tensors && count > 0, "grad_clip_coef: bad args");
+    return grad_clip_coef_impl(tensors, count, nullptr, 0, max_norm, partial, out, stream);
+}
+
+extern "C" int mk_grad_clip_coef_pre(const MkAdamTensor* tensors, int count, const MkAdamTensor* pre, int npre, float max_norm,
+                                     float* partial, float* out, void* stream) {
+    MK_REQUIRE((count > 0 || npre > 0) && (count == 0 || tensors) && (npre == 0 || pre), "grad_clip_coef_pre: bad args");
+    return grad_clip_coef_impl(tensors, count, pre, npre, max_norm, partial, out, stream);
+}
+
+static int grad_clip_coef_impl(const MkAdamTensor* tensors, int count, const MkAdamTensor* pre, int npre, float max_norm,
+                               float* partial, float* out, void* stream) {
+    MK_REQUIRE(partial && out, "grad_clip_coef: bad args");
     hipStream_t s = (hipStream_t)stream;
     long long done = 0;
     for (int base = 0; base < count; base += MULTI_MAX) {
@@ -278,6 +322,23 @@ extern "C" int mk_grad_clip_coef(const MkAdamTensor* tensors, int count, float m
         hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, a, partial + done);
         done += blocks;
     }
+    for (int base = 0; base < npre; base += MULTI_MAX) {
+        SumsqMulti a;
+        a.count = npre - base < MULTI_MAX ? npre - base : MULTI_MAX;
+        long long blocks = 0;
+        for (int t = 0; t < a.count; ++t) {
+            const MkAdamTensor& d = pre[base + t];
+            MK_REQUIRE(d.g && d.n > 0, "grad_clip_coef_pre: partial buffer %d is empty", base + t);
+            a.g[t] = d.g, a.n[t] = d.n;
+            a.first[t] = (int)blocks;
+            blocks += (d.n + NT - 1) / NT;
+            MK_REQUIRE(blocks < (1ll << 22), "grad_clip_coef_pre: too many partials");
+        }
+        a.first[a.count] = (int)blocks;
+        hipLaunchKernelGGL(gather_partials_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, a, partial + done);
+        done += blocks;
+    }
+    MK_REQUIRE(done < (1ll << 31), "grad_clip_coef: too many partials");
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(NT), 0, s, partial, (int)done, max_norm, out);
     return mk_check_launch("mk_grad_clip_coef");
 }

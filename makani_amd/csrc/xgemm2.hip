@@ -369,7 +369,7 @@ __device__ __forceinline__ void cmma_split2acc(const bf16x8* ar, bf16x8* ai, con
 // tile (re += ar br + ai (-bi) with the sign bits of the bi fragment flipped once per k-step: 128 accumulator registers
 // instead of 192), with one staging register set.
 template <bool A_KC, bool B_KC, int NP, bool B_ILV, int RT = 2>
-__global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM, int tilesN) {
+__global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM, int tilesN, float* __restrict__ ssq) {
     constexpr int BM = 64 * RT, BN = 128;
     constexpr bool TALL = RT == 4;
     static_assert(RT == 2 || (RT == 4 && A_KC), "row tiles per wave: 2, or 4 with a k-contiguous A");
@@ -379,7 +379,10 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
     __shared__ __attribute__((aligned(16))) u16 smem[2 * STG];
 
     const BlockCoord c = decode_block2<BM, BN>(p, tilesM, tilesN);
-    if (!c.active) return;
+    if (!c.active) {
+        if (ssq && threadIdx.x == 0) ssq[blockIdx.x] = 0.f;
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2, cs = wave & 3;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -569,6 +572,7 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
 
     float* Cb = p.C + bo * p.c_batch + bi * p.c_inner;
     const int col = c.j0 + cs * 32 + l31;
+    float sq = 0.f;                                         // sum of re^2 + im^2 over the entries this lane writes (ssq)
 #pragma unroll
     for (int j = 0; j < RT; ++j) {
         if (!live[j]) continue;
@@ -583,6 +587,7 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
                     vr += *dr;
                     vi += *di;
                 }
+                sq = fmaf(vr, vr, fmaf(vi, vi, sq));
                 if (p.c_col == 2) {          // interleaved complex C: one 8-byte store per entry
 #if MK_X2_WGRAD_NT
                     typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -595,6 +600,21 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
                     *di = vi;
                 }
             }
+        }
+    }
+    // Sum of squares of everything this workgroup wrote, in a fixed order (lanes by shuffle tree, waves 0..7 in sequence): the
+    // weight gradient's contribution to the global gradient norm, so that the clipping pass need not read 283 MB per layer again
+    if (ssq) {                                              // (kernel argument: uniform)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        float* red = reinterpret_cast<float*>(smem);        // the last k-step ended with a barrier: the stages are dead
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT2 / 64; ++w) t += red[w];
+            ssq[blockIdx.x] = t;
         }
     }
 #if MK_X2_DIAG & 32
@@ -849,7 +869,7 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
 }
 
 template <int NP>
-int launch_cplx2(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t s) {
+int launch_cplx2(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t s, float* ssq = nullptr) {
     // more than 128 rows and a k-contiguous A (the dhconv forward / data gradient: A = the coefficients of one degree, rows = orders):
     // the 256 x 128 form.  MAKANI_AMD_X2_TALL=0 keeps the 128 x 128 tile everywhere
     static const bool tall_ok = [] { const char* e = getenv("MAKANI_AMD_X2_TALL"); return !(e && e[0] == '0'); }();
@@ -859,8 +879,8 @@ int launch_cplx2(const MkGemm* g, bool a_kc, bool b_kc, bool b_ilv, hipStream_t 
     const long long nb = (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
     MK_REQUIRE(nb < (1ll << 31), "xcgemm2: grid too large");
     dim3 grid((unsigned)nb), block(NT2);
-#define MK_XC2(AK, BK_, IL) hipLaunchKernelGGL((xcgemm2_kernel<AK, BK_, NP, IL>), grid, block, 0, s, *g, tm, tn)
-#define MK_XC2T(BK_, IL) hipLaunchKernelGGL((xcgemm2_kernel<true, BK_, NP, IL, 4>), grid, block, 0, s, *g, tm, tn)
+#define MK_XC2(AK, BK_, IL) hipLaunchKernelGGL((xcgemm2_kernel<AK, BK_, NP, IL>), grid, block, 0, s, *g, tm, tn, ssq)
+#define MK_XC2T(BK_, IL) hipLaunchKernelGGL((xcgemm2_kernel<true, BK_, NP, IL, 4>), grid, block, 0, s, *g, tm, tn, ssq)
     if (b_ilv) {
         MK_REQUIRE(a_kc, "xcgemm2: an interleaved B operand needs a k-contiguous A");
         if (tall) {
@@ -910,6 +930,31 @@ extern "C" int mk_cgemm_split2_batched(const MkGemm* g, int limbs, void* stream)
     MK_REQUIRE(limbs == 2 || limbs == 3, "split gemm: limbs must be 2 or 3");
     hipStream_t s = (hipStream_t)stream;
     return limbs == 3 ? launch_cplx2<3>(g, a_kc, b_kc, b_ilv, s) : launch_cplx2<2>(g, a_kc, b_kc, b_ilv, s);
+}
+
+// grid of launch_cplx2 (one partial per workgroup)
+static long long cplx2_blocks(const MkGemm* g, bool a_kc) {
+    static const bool tall_ok = [] { const char* e = getenv("MAKANI_AMD_X2_TALL"); return !(e && e[0] == '0'); }();
+    const bool tall = tall_ok && a_kc && g->M > 128;
+    const int BM = tall ? 256 : 128, BN = 128;
+    const int tm = (g->M + BM - 1) / BM, tn = (g->N + BN - 1) / BN;
+    return (long long)((g->batch + MK_NUM_XCD - 1) / MK_NUM_XCD) * MK_NUM_XCD * tm * tn;
+}
+
+extern "C" long long mk_cgemm_split2_ssq_count(const MkGemm* g) {
+    bool a_kc, b_kc, b_ilv;
+    if (validate(g, true, &a_kc, &b_kc, true, &b_ilv)) return -1;
+    return cplx2_blocks(g, a_kc);
+}
+
+extern "C" int mk_cgemm_split2_batched_ssq(const MkGemm* g, int limbs, float* ssq_part, void* stream) {
+    bool a_kc, b_kc, b_ilv;
+    int rc = validate(g, true, &a_kc, &b_kc, true, &b_ilv);
+    if (rc) return rc;
+    MK_REQUIRE(limbs == 2 || limbs == 3, "split gemm: limbs must be 2 or 3");
+    MK_REQUIRE(ssq_part, "split gemm with sums of squares: null partial buffer");
+    hipStream_t s = (hipStream_t)stream;
+    return limbs == 3 ? launch_cplx2<3>(g, a_kc, b_kc, b_ilv, s, ssq_part) : launch_cplx2<2>(g, a_kc, b_kc, b_ilv, s, ssq_part);
 }
 
 extern "C" int mk_sgemm_presplit_batched(const MkGemm* g, const void* a_planes, long long pl_stride, long long pl_batch,

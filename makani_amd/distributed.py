@@ -630,6 +630,7 @@ class GradReducer:
             return
         self._arm()
         g = _real(p.grad)
+        ops.grad_ssq_drop(g)           # the reduced gradient is not the tensor whose squares its producer summed (in-place collectives do not bump versions)
         dense = g if g.is_contiguous() else _dense(g)
         if dense is not None and dense.numel() * dense.element_size() >= self.big_bytes:
             self.pending.append([self._issue_stage(p, dense, list(stages)), dense, list(stages), p])

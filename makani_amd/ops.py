@@ -60,25 +60,67 @@ def gemm_mode() -> str:
 GEMM_GEN = "2"          # (module attribute, not an environment switch: tools may set "1" to time the first-generation real kernel)
 
 
-def _run_gemm(g, cplx, what, mode=None, a_limbs=None, band=None):
+def _run_gemm(g, cplx, what, mode=None, a_limbs=None, band=None, ssq=None):
     """``a_limbs``: the constant A operand of a real GEMM already split into bf16 limb planes (``limb_planes``);
-    ``band`` = (lo, hi, mode): its numerical band per batch (``polar_band``)."""
+    ``band`` = (lo, hi, mode): its numerical band per batch (``polar_band``); ``ssq``: buffer for the per-workgroup sums of
+    squares of the result (``grad_ssq_buffer``: only the second-generation complex engine forms them)."""
     mode = mode or gemm_mode()
     L = lib()
     if mode == "fp32":
+        assert ssq is None
         rc = (L.mk_cgemm_batched if cplx else L.mk_sgemm_batched)(C.byref(g), stream())
     else:
         limbs = 3 if mode == "x6" else 2
         if GEMM_GEN == "2" and cplx:
-            rc = L.mk_cgemm_split2_batched(C.byref(g), limbs, stream())
+            if ssq is not None:
+                rc = L.mk_cgemm_split2_batched_ssq(C.byref(g), limbs, ptr(ssq), stream())
+            else:
+                rc = L.mk_cgemm_split2_batched(C.byref(g), limbs, stream())
         elif GEMM_GEN == "2" and a_limbs is not None:
             pl = a_limbs
             lo, hi, bm = band if band is not None else (None, None, 0)
             rc = L.mk_sgemm_presplit_batched(C.byref(g), ptr(pl), pl.stride(0), pl.stride(1), pl.stride(2), limbs,
                                              ptr(lo), ptr(hi), bm, stream())
         else:
+            assert ssq is None
             rc = (L.mk_cgemm_split_batched if cplx else L.mk_sgemm_split_batched)(C.byref(g), limbs, stream())
     check(rc, what)
+
+
+# --------------------------------------------------------------------------- #
+# Sums of squares formed by the kernel that WROTE a gradient (the dhconv weight gradient: 283 MB per layer of the SFNO), for
+# the global-norm clipping of FusedAdamW (makani/utils/training/training_helpers.py:123-165) — which would otherwise read every
+# gradient once more only to square it (0.37 ms of the 37 ms step).  An entry says: "the tensor that starts at this address, has
+# this many fp32 elements and this autograd version was written by one kernel launch whose per-workgroup sums of squares are in
+# `part`".  It is used only while all three still match (any torch-level write to the gradient — accumulation into an existing
+# .grad, hooks, unscaling, all-reduce through copy_ — bumps the version or changes the address), every weight-gradient call that
+# does not form sums drops the entry of its address, the optimizer's step() and the gradient reducers drop all of them.
+# MAKANI_AMD_GRAD_SSQ=0: never form them.
+# --------------------------------------------------------------------------- #
+GRAD_SSQ = os.environ.get("MAKANI_AMD_GRAD_SSQ", "1") != "0"
+_GRAD_SSQ = {}
+
+
+def grad_ssq_register(t: torch.Tensor, part: torch.Tensor):
+    if len(_GRAD_SSQ) > 256:            # never consumed (no FusedAdamW in the loop): do not grow with the allocator's addresses
+        _GRAD_SSQ.clear()
+    r = torch.view_as_real(t) if t.is_complex() else t
+    _GRAD_SSQ[r.data_ptr()] = (part, r.numel(), t._version, t.device)
+
+
+def grad_ssq_drop(t: torch.Tensor = None):
+    if t is None:
+        _GRAD_SSQ.clear()
+    else:
+        _GRAD_SSQ.pop(t.data_ptr(), None)
+
+
+def grad_ssq_lookup(flat: torch.Tensor, version: int):
+    """the partial sums of squares of the fp32 gradient whose memory-order view is ``flat``, or None"""
+    e = _GRAD_SSQ.get(flat.data_ptr())
+    if e is None or e[1] != flat.numel() or e[2] != version or e[3] != flat.device:
+        return None
+    return e[0]
 
 
 _LIMB_PLANES = {}      # id(matrix tensor) -> (weak reference to it, version, limb planes); entries die with the matrix
@@ -524,16 +566,25 @@ def dhconv_wgrad(S: torch.Tensor, gT: torch.Tensor, B: int, tri_off: int = 0, gr
     else:
         gW = torch.empty((L, 2, cip, cop), dtype=torch.float32, device=S.device)
         cdesc = dict(c_batch=2 * cip * cop, c_row=cop, c_im=cip * cop)
+    # the whole gradient from ONE launch (native order, one sample, one group): the launch also sums its squares
+    want_ssq = GRAD_SSQ and native and B == 1 and grp is None and GEMM_GEN == "2" and gemm_mode() != "fp32"
+    grad_ssq_drop(gW)
     for b in range(B):
         g = _gemm(A=S.data_ptr() + 4 * (b * xld + a_off), B=gT.data_ptr() + 4 * (b * yld + c_off), C=gW.data_ptr(),
                   a_batch=M * 2 * R, a_row=1, a_k=2 * R, a_im=R,
                   b_batch=M * 2 * Ro, b_col=1, b_k=2 * Ro, b_im=Ro, **cdesc,
                   M=cip, N=cop, K=M, batch=L, inner=1, tri_mode=_lib.TRI_K_LE, tri_off=tri_off, conj_a=1,
                   beta=1 if b > 0 else 0)
+        part = None
+        if want_ssq:
+            n = lib().mk_cgemm_split2_ssq_count(C.byref(g))
+            part = torch.empty((n,), dtype=torch.float32, device=S.device) if n > 0 else None
         with _timed("dhconv_wgrad", flops=8.0 * cip * cop * L * M,
                     nbytes=4.0 * (2 * cip * L * M + 2 * cop * L * M + 2 * cip * cop * L),
                     mfma_flops=lambda: 8.0 * _limb_products() * _up(cip, 32) * _up(cop, 32) * _exec_le(M, L, tri_off, 16)):
-            _run_gemm(g, True, "dhconv_wgrad")
+            _run_gemm(g, True, "dhconv_wgrad", ssq=part)
+        if part is not None:
+            grad_ssq_register(gW, part)
     return gW
 
 

@@ -11,6 +11,7 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
+from . import ops as _ops
 from ._lib import MkAdamTensor, check, dense_view, lib, ptr, stream
 
 SMALL = 1 << 20          # tensors below this many floats share multi-tensor launches
@@ -29,16 +30,24 @@ def _k_adamw(pr, gr, m, v, scale, lr, b1, b2, eps, wd, sdev):
                                   stream()), "mk_adamw_step")
 
 
-def _k_sumsq_clip(grads, max_grad_norm):
-    """(2,) device tensor [min(1, max_norm / (||g|| + 1e-6)), ||g||] over a list of flat fp32 tensors"""
-    arr = (MkAdamTensor * len(grads))(*[MkAdamTensor(None, g.data_ptr(), None, None, g.numel(), None, None, 0, 0, 0) for g in grads])
-    nws = lib().mk_grad_norm_workspace(C.cast(arr, C.c_void_p), len(grads))
-    ws = torch.empty((nws,), dtype=torch.float32, device=grads[0].device)
-    out = torch.empty((2,), dtype=torch.float32, device=grads[0].device)
+def _descs(ts):
+    arr = (MkAdamTensor * max(1, len(ts)))(*[MkAdamTensor(None, t.data_ptr(), None, None, t.numel(), None, None, 0, 0, 0) for t in ts])
+    return C.cast(arr, C.c_void_p), arr
+
+
+def _k_sumsq_clip(grads, max_grad_norm, pre=()):
+    """(2,) device tensor [min(1, max_norm / (||g|| + 1e-6)), ||g||] over a list of flat fp32 tensors; ``pre``: buffers of partial
+    sums of squares that stand in for gradients not in ``grads`` (``ops.grad_ssq_lookup``)"""
+    dev = (grads[0] if grads else pre[0]).device
+    ga, _keep_g = _descs(grads)
+    pa, _keep_p = _descs(pre)
+    nws = lib().mk_grad_norm_workspace_pre(ga, len(grads), pa, len(pre))
+    ws = torch.empty((nws,), dtype=torch.float32, device=dev)
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
     from .ops import _timed
-    with _timed("adamw_grad_norm", nbytes=4.0 * sum(g.numel() for g in grads)):
-        check(lib().mk_grad_clip_coef(C.cast(arr, C.c_void_p), len(grads), float(max_grad_norm or 0.0), ptr(ws), ptr(out), stream()),
-              "mk_grad_clip_coef")
+    with _timed("adamw_grad_norm", nbytes=4.0 * (sum(g.numel() for g in grads) + sum(t.numel() for t in pre))):
+        check(lib().mk_grad_clip_coef_pre(ga, len(grads), pa, len(pre), float(max_grad_norm or 0.0), ptr(ws), ptr(out), stream()),
+              "mk_grad_clip_coef_pre")
     return out
 
 
@@ -96,7 +105,7 @@ class FusedAdamW(torch.optim.Optimizer):
         """(2,) device tensor: [min(1, max_norm / (||g|| + 1e-6)), ||g||] over the gradients of this data-parallel replica:
         whole gradients where they were all-reduced, this rank's shards (summed over the data group) where they were
         reduce-scattered."""
-        full, shards, group = [], [], None
+        full, pre, shards, group = [], [], [], None
         for g in self.param_groups:
             for p in g["params"]:
                 z = self.zero_shard(p)
@@ -105,13 +114,15 @@ class FusedAdamW(torch.optim.Optimizer):
                     shards.append(z[0])
                     group = z[1]
                 elif p.grad is not None:
-                    full.append(_flat(p.grad))
+                    f = _flat(p.grad)
+                    part = _ops.grad_ssq_lookup(f, p.grad._version)      # squares already summed by the kernel that wrote this gradient
+                    (pre if part is not None else full).append(part if part is not None else f)
         if not shards:
-            return _k_sumsq_clip(full, max_grad_norm)
+            return _k_sumsq_clip(full, max_grad_norm, pre)
         sq = _k_sumsq_clip(shards, None)[1:].square()
         dist.all_reduce(sq, group=group)
-        if full:
-            sq = sq + _k_sumsq_clip(full, None)[1:].square()
+        if full or pre:
+            sq = sq + _k_sumsq_clip(full, None, pre)[1:].square()
         norm = sq.sqrt()
         coef = torch.clamp(float(max_grad_norm) / (norm + 1e-6), max=1.0) if max_grad_norm else torch.ones_like(norm)
         return torch.cat([coef, norm])
@@ -275,4 +286,5 @@ class FusedAdamW(torch.optim.Optimizer):
             for p in shadowed:               # valid for exactly this version (and storage) of the parameter
                 p._mk_shadow_version = p._version
                 p._mk_shadow_ptr = p.data_ptr()
+        _ops.grad_ssq_drop()                 # the producers' sums of squares belong to the gradients of THIS step
         return None

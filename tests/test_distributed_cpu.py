@@ -530,8 +530,8 @@ def _worker_zero(rank, world, port):
             v.mul_(b2).addcmul_(g, g, value=1 - b2)
             pr.mul_(1 - lr * wd).sub_(lr * float(sdev[1]) * m / (v.sqrt() * float(sdev[2]) + eps))
 
-        def sumsq_clip(grads, max_norm):
-            n = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float().reshape(1)
+        def sumsq_clip(grads, max_norm, pre=()):
+            n = torch.sqrt(sum((g.double() ** 2).sum() for g in grads) + sum(t.double().sum() for t in pre)).float().reshape(1)
             coef = torch.clamp(max_norm / (n + 1e-6), max=1.0) if max_norm else torch.ones(1)
             return torch.cat([coef, n])
         mo._k_advance, mo._k_adamw, mo._k_sumsq_clip = advance, adamw, sumsq_clip

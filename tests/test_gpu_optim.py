@@ -140,3 +140,87 @@ def test_fused_adamw_resumes_bias_correction_from_a_cpu_loaded_checkpoint(source
     assert float(resumed.param_groups[0]["_mk_step_state"][0]) == 8.0
     for a, b in zip(pa, pb):
         assert torch.allclose(_r(a.detach()), _r(b.detach()), rtol=2e-5, atol=2e-6), float((_r(a) - _r(b)).abs().max())
+
+
+def _dhconv_setup(C_in, C_out, L, M, seed=0):
+    """one dhconv layer's worth of autograd graph on random spectral coefficients: returns (weight parameter, loss closure)"""
+    from makani_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w = ops.native_w_empty(C_in, C_out, L, dev)
+    with torch.no_grad():
+        w.copy_(torch.randn(1, C_in, C_out, L, dtype=torch.complex64, generator=g).to(dev) / C_in ** 0.5)
+    w = torch.nn.Parameter(w)
+    x = torch.randn(1, C_in, L, M, dtype=torch.complex64, generator=g).to(dev)
+    S = ops.complex_to_s(x)                                     # (L, M, 2, round4(C_in))
+    G = torch.randn(L, M, 2, (C_out + 3) // 4 * 4, generator=g).to(dev)
+
+    def loss():
+        return (ops.DhconvFn.apply(S, w, 1, 0) * G).sum()
+    return w, loss
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 40, 41), (384, 384, 24, 25), (132, 260, 17, 18)])   # (C_in, C_out, L, M)
+def test_gradient_norm_from_the_sums_of_squares_of_the_weight_gradient_kernel(shape, monkeypatch):
+    """FusedAdamW.clip_coef with the dhconv weight gradient's squares summed by the kernel that wrote it
+    (mk_cgemm_split2_batched_ssq -> mk_grad_clip_coef_pre; makani/utils/training/training_helpers.py:123-165) against the same
+    norm from reading the gradient, and against torch in fp64; the stand-in must be dropped as soon as the gradient changes."""
+    import makani_amd.optim as mo
+    from makani_amd import ops
+    w, loss = _dhconv_setup(*shape)
+    other = torch.nn.Parameter(torch.randn(1000, 77, device="cuda:0"))
+    opt = mo.FusedAdamW([w, other], lr=1e-3)
+    (loss() + (other ** 2).sum() * 1e-3).backward()
+    flat = mo._flat(w.grad)
+    part = ops.grad_ssq_lookup(flat, w.grad._version)
+    assert part is not None and part.numel() > 0, "the weight-gradient launch did not register its sums of squares"
+    want = torch.sqrt((torch.view_as_real(w.grad).double() ** 2).sum() + (other.grad.double() ** 2).sum()).item()
+    # the partial sums themselves: their total is the gradient's squared norm
+    assert abs(part.double().sum().item() - (torch.view_as_real(w.grad).double() ** 2).sum().item()) <= 1e-6 * want ** 2
+    fused = opt.clip_coef(0.5 * want)
+    monkeypatch.setattr(ops, "_GRAD_SSQ", {})
+    plain = opt.clip_coef(0.5 * want)
+    assert abs(fused[1].item() - want) <= 2e-6 * want and abs(plain[1].item() - want) <= 2e-6 * want
+    assert abs(fused[0].item() - 0.5) < 1e-5 and abs(plain[0].item() - 0.5) < 1e-5
+    monkeypatch.undo()
+    # a torch-level write to the gradient invalidates the stand-in ...
+    w.grad.mul_(3.0)
+    assert ops.grad_ssq_lookup(mo._flat(w.grad), w.grad._version) is None
+    want3 = torch.sqrt(9.0 * (torch.view_as_real(w.grad).double() ** 2).sum() / 9.0 + (other.grad.double() ** 2).sum()).item()
+    assert abs(opt.clip_coef(None)[1].item() - want3) <= 2e-6 * want3
+    # ... so does accumulation into an existing .grad (second backward without zero_grad) ...
+    (loss() + (other ** 2).sum() * 1e-3).backward()
+    acc = torch.sqrt((torch.view_as_real(w.grad).double() ** 2).sum() + (other.grad.double() ** 2).sum()).item()
+    assert abs(opt.clip_coef(None)[1].item() - acc) <= 2e-6 * acc
+    # ... and step() drops whatever is left
+    opt.zero_grad(set_to_none=True)
+    (loss() + (other ** 2).sum() * 1e-3).backward()
+    assert ops.grad_ssq_lookup(mo._flat(w.grad), w.grad._version) is not None
+    opt.step(max_grad_norm=1.0)
+    assert not ops._GRAD_SSQ
+
+
+def test_sums_of_squares_of_the_complex_split_gemm_cover_every_workgroup():
+    """mk_cgemm_split2_batched_ssq directly: ragged tiles, batches that are not a multiple of the 8 XCDs (idle workgroups write 0),
+    both limb counts; sum of the partials against the squares of C"""
+    import ctypes as C
+    from makani_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    for (Mm, Nn, K, batch), limbs in (((72, 52, 33, 5), 2), ((200, 132, 64, 11), 3), ((384, 384, 40, 16), 2)):
+        A = torch.randn(batch, K, 2, Mm, device=dev)            # [b][k][re/im][row]
+        Bm = torch.randn(batch, K, 2, Nn, device=dev)
+        Cc = torch.empty(batch, Mm, Nn, 2, device=dev)          # interleaved complex result
+        g = ops._gemm(A=A.data_ptr(), B=Bm.data_ptr(), C=Cc.data_ptr(), a_batch=K * 2 * Mm, a_row=1, a_k=2 * Mm, a_im=Mm,
+                      b_batch=K * 2 * Nn, b_col=1, b_k=2 * Nn, b_im=Nn, c_batch=Mm * Nn * 2, c_row=Nn * 2, c_col=2, c_im=1,
+                      M=Mm, N=Nn, K=K, batch=batch, inner=1, conj_a=1)
+        n = _lib.lib().mk_cgemm_split2_ssq_count(C.byref(g))
+        assert n > 0
+        part = torch.full((n,), float("nan"), device=dev)
+        _lib.check(_lib.lib().mk_cgemm_split2_batched_ssq(C.byref(g), limbs, _lib.ptr(part), _lib.stream()), "ssq")
+        ref = torch.einsum("bkm,bkn->bmn", torch.complex(A[:, :, 0], -A[:, :, 1]).to(torch.complex128), torch.complex(Bm[:, :, 0], Bm[:, :, 1]).to(torch.complex128))
+        got = torch.view_as_complex(Cc)
+        assert ((got - ref).abs().max() / ref.abs().max()).item() < (1e-4 if limbs == 2 else 1e-5)
+        assert torch.isfinite(part).all()
+        tot, want = part.double().sum().item(), (Cc.double() ** 2).sum().item()
+        assert abs(tot - want) <= 1e-6 * want, (Mm, Nn, K, batch, tot, want)
