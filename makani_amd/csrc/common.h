@@ -106,9 +106,8 @@ __device__ __forceinline__ float mk_relu_f(float x) {
     return r;
 }
 __device__ __forceinline__ mk_f32x2 mk_splat2(float v) { return mk_f32x2{v, v}; }
-// two values at a time: the Horner chain as v_pk_fma_f32 (coefficient pairs in scalar registers)
-__device__ __forceinline__ mk_f32x2 gelu_exp2_x2(mk_f32x2 x) {
-    const mk_f32x2 a = {__builtin_amdgcn_fmed3f(fabsf(x.x), 0.0f, 9.0f), __builtin_amdgcn_fmed3f(fabsf(x.y), 0.0f, 9.0f)};     // min(|x|, 9): one v_med3_f32
+// S(a): -log2(erfc(a / sqrt 2)) / a on [0, 9]
+__device__ __forceinline__ mk_f32x2 mk_phi_poly(mk_f32x2 a) {
 #if MK_GELU_EXP2 == 9
     mk_f32x2 s = mk_splat2(1.188001586e-09f);
     s = __builtin_elementwise_fma(s, a, mk_splat2(-5.194742769e-08f));
@@ -130,7 +129,12 @@ __device__ __forceinline__ mk_f32x2 gelu_exp2_x2(mk_f32x2 x) {
     s = __builtin_elementwise_fma(s, a, mk_splat2(4.582903981e-01f));
     s = __builtin_elementwise_fma(s, a, mk_splat2(1.151269913e+00f));
 #endif
-    const mk_f32x2 e = __builtin_elementwise_fma(a, s, mk_splat2(1.0f));
+    return s;
+}
+// two values at a time: the Horner chain as v_pk_fma_f32 (coefficient pairs in scalar registers)
+__device__ __forceinline__ mk_f32x2 gelu_exp2_x2(mk_f32x2 x) {
+    const mk_f32x2 a = {__builtin_amdgcn_fmed3f(fabsf(x.x), 0.0f, 9.0f), __builtin_amdgcn_fmed3f(fabsf(x.y), 0.0f, 9.0f)};     // min(|x|, 9): one v_med3_f32
+    const mk_f32x2 e = __builtin_elementwise_fma(a, mk_phi_poly(a), mk_splat2(1.0f));
     const mk_f32x2 h = {__builtin_amdgcn_exp2f(-e.x), __builtin_amdgcn_exp2f(-e.y)};      // Phi(-|x|)
     const mk_f32x2 r = {mk_relu_f(x.x), mk_relu_f(x.y)};
     return __builtin_elementwise_fma(-a, h, r);               // x Phi(x) = relu(x) - |x| Phi(-|x|) on both sides of zero, no cancellation
@@ -143,6 +147,46 @@ __device__ __forceinline__ float gelu_fast_f(float x) {
     float er, ex;
     erf_as_f(x, er, ex);
     return 0.5f * x * (1.0f + er);
+#endif
+}
+#ifndef MK_GELU_GRAD_EXP2       // GELU' of the bf16 kernels: 0 = erf_as_f (default), 1 = the exp2 form below (two exponentials, no reciprocal).
+#define MK_GELU_GRAD_EXP2 0     // Measured equal (gpurun_out/r07j: norm backward, GEMM epilogues and the step within noise): GELU' is hidden behind
+#endif                          // the two operand streams of the kernels that evaluate it, so the form with the smaller error around zero stays
+// GELU'(x) = Phi(x) + x phi(x) with the same Phi (selected, not subtracted: relative error 1e-6 at x = -5 where the erf form has 3 %)
+// and phi(x) = 2^(-x^2 log2(e) / 2) / sqrt(2 pi): absolute error 1.5e-6 around zero (the 3e-6 of Phi), tools/gelu_fit.py
+__device__ __forceinline__ mk_f32x2 gelu_grad_exp2_x2(mk_f32x2 x) {
+    const mk_f32x2 a = {__builtin_amdgcn_fmed3f(fabsf(x.x), 0.0f, 9.0f), __builtin_amdgcn_fmed3f(fabsf(x.y), 0.0f, 9.0f)};
+    const mk_f32x2 e = __builtin_elementwise_fma(a, mk_phi_poly(a), mk_splat2(1.0f));
+    const mk_f32x2 h = {__builtin_amdgcn_exp2f(-e.x), __builtin_amdgcn_exp2f(-e.y)};      // Phi(-|x|)
+    const mk_f32x2 q = (x * x) * mk_splat2(0.72134752044448170f);
+    const mk_f32x2 t = {__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};      // exp(-x^2 / 2)
+    const mk_f32x2 u = mk_splat2(1.0f) - h;
+    const mk_f32x2 phi = {x.x < 0.f ? h.x : u.x, x.y < 0.f ? h.y : u.y};
+    return __builtin_elementwise_fma(x * mk_splat2(0.39894228040143268f), t, phi);
+}
+__device__ __forceinline__ float gelu_grad_fast_f(float x) {
+#if MK_GELU_GRAD_EXP2
+    return gelu_grad_exp2_x2(mk_f32x2{x, x}).x;
+#else
+    float er, ex;
+    erf_as_f(x, er, ex);
+    return fmaf(x * 0.39894228040143268f, ex, 0.5f * (1.0f + er));
+#endif
+}
+// out[i] = GELU'(arg[i]) for N_ values (pairs through the packed form)
+template <int N_>
+__device__ __forceinline__ void gelu_grad_fast_n(const float* arg, float* out) {
+#if MK_GELU_GRAD_EXP2
+#pragma unroll
+    for (int e = 0; e + 1 < N_; e += 2) {
+        const mk_f32x2 r = gelu_grad_exp2_x2(mk_f32x2{arg[e], arg[e + 1]});
+        out[e] = r.x;
+        out[e + 1] = r.y;
+    }
+    if (N_ & 1) out[N_ - 1] = gelu_grad_fast_f(arg[N_ - 1]);
+#else
+#pragma unroll
+    for (int e = 0; e < N_; ++e) out[e] = gelu_grad_fast_f(arg[e]);
 #endif
 }
 // N_ values in place (pairs through the packed form)
@@ -161,8 +205,4 @@ __device__ __forceinline__ void gelu_fast_n(float* v) {
     for (int e = 0; e < N_; ++e) v[e] = gelu_fast_f(v[e]);
 #endif
 }
-__device__ __forceinline__ float gelu_grad_fast_f(float x) {
-    float er, ex;
-    erf_as_f(x, er, ex);
-    return fmaf(x * 0.39894228040143268f, ex, 0.5f * (1.0f + er));
-}
+

@@ -625,8 +625,11 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
                             const uint32_t gw[4] = {gq[u4].x, gq[u4].y, gq[u4].z, gq[u4].w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                v[2 * e] *= gelu_grad_fast_f(__uint_as_float(gw[e] << 16));
-                                v[2 * e + 1] *= gelu_grad_fast_f(__uint_as_float(gw[e] & 0xffff0000u));
+                                const float ga2[2] = {__uint_as_float(gw[e] << 16), __uint_as_float(gw[e] & 0xffff0000u)};
+                                float gd2[2];
+                                gelu_grad_fast_n<2>(ga2, gd2);
+                                v[2 * e] *= gd2[0];
+                                v[2 * e + 1] *= gd2[1];
                             }
                         }
                         if (p.R) {
@@ -973,8 +976,11 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                         const uint32_t gw[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[2 * e] *= gelu_grad_fast_f(__uint_as_float(gw[e] << 16));
-                            v[2 * e + 1] *= gelu_grad_fast_f(__uint_as_float(gw[e] & 0xffff0000u));
+                            const float ga2[2] = {__uint_as_float(gw[e] << 16), __uint_as_float(gw[e] & 0xffff0000u)};
+                            float gd2[2];
+                            gelu_grad_fast_n<2>(ga2, gd2);
+                            v[2 * e] *= gd2[0];
+                            v[2 * e + 1] *= gd2[1];
                         }
                     }
                     if (EPI_LOADS && !p.G) {
@@ -1261,8 +1267,11 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
                     const uint32_t gw[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[2 * e] *= gelu_grad_fast_f(__uint_as_float(gw[e] << 16));
-                        v[2 * e + 1] *= gelu_grad_fast_f(__uint_as_float(gw[e] & 0xffff0000u));
+                        const float ga2[2] = {__uint_as_float(gw[e] << 16), __uint_as_float(gw[e] & 0xffff0000u)};
+                        float gd2[2];
+                        gelu_grad_fast_n<2>(ga2, gd2);
+                        v[2 * e] *= gd2[0];
+                        v[2 * e + 1] *= gd2[1];
                     }
                 }
                 if (EPI_LOADS && !p.G) {

@@ -168,6 +168,19 @@ __device__ __forceinline__ float gelu_grad_t(float a) {
     if constexpr (sizeof(T) == 2) return gelu_grad_fast_f(a);
     else return gelu_grad_f(a);
 }
+// out[i] = GELU'(n[i] g + b): the ONE form every backward kernel of the norm uses (the statistics pass, the apply pass and the one-pass
+// kernel must multiply by the same bits)
+template <typename T, int N_>
+__device__ __forceinline__ void gelu_grad_affine_n(const float* n, float g, float b, float* out) {
+    float arg[N_];
+#pragma unroll
+    for (int i = 0; i < N_; ++i) arg[i] = fmaf(n[i], g, b);
+    if constexpr (sizeof(T) == 2) gelu_grad_fast_n<N_>(arg, out);
+    else {
+#pragma unroll
+        for (int i = 0; i < N_; ++i) out[i] = gelu_grad_f(arg[i]);
+    }
+}
 
 __device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[2*NT/64]*/) {
 #pragma unroll
@@ -386,11 +399,15 @@ __global__ __launch_bounds__(NT) void in_bwd_partial(const T* __restrict__ x, co
     const T* gp = gy + plane * hw;
     float s1 = 0.f, s2 = 0.f;
     for_chunk<T, 2>(hw, chunks, chunk, xp, gp, [&](long long e, auto cnt, const float* v, const float* d) {
+        float nn[cnt()], dg[cnt()];
+#pragma unroll
+        for (int i = 0; i < cnt(); ++i) nn[i] = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
+        if (GELU) gelu_grad_affine_n<T, cnt()>(nn, g, b, dg);
 #pragma unroll
         for (int i = 0; i < cnt(); ++i) {
-            const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
+            const float n = nn[i];
             float ga = d[i];
-            if (GELU) ga *= gelu_grad_t<T>(n * g + b);
+            if (GELU) ga *= dg[i];
             s1 += ga;
             s2 += ga * n;
         }
@@ -449,12 +466,15 @@ __global__ __launch_bounds__(NT) void in_bwd_apply(const T* __restrict__ x, cons
     const T* gp = gy + plane * hw;
     T* op = gx + plane * hw;
     for_chunk<T, 2, true>(hw, chunks, chunk, xp, gp, [&](long long e, auto cnt, const float* v, const float* d) {
-        float o[cnt()];
+        float o[cnt()], nn[cnt()], dg[cnt()];
+#pragma unroll
+        for (int i = 0; i < cnt(); ++i) nn[i] = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
+        if (GELU) gelu_grad_affine_n<T, cnt()>(nn, g, b, dg);
 #pragma unroll
         for (int i = 0; i < cnt(); ++i) {
-            const float n = (pre<T>(v[i], pb, pre_bias != nullptr) - mean) * rstd;
+            const float n = nn[i];
             float ga = d[i];
-            if (GELU) ga *= gelu_grad_t<T>(n * g + b);
+            if (GELU) ga *= dg[i];
             const float w = q ? q[e + i] : 1.f;
             o[i] = k * (ga - w * (m1 + (n - cq) * m2));
         }
@@ -656,15 +676,18 @@ __global__ __launch_bounds__(NT) void in_bwd_fused(const T* __restrict__ x, cons
     for (int s = 0; s < FUSED_SLOTS; ++s) {
         const long long e = c0 + ((long long)s * NT + threadIdx.x) * VEC;
         if (e < c1) {
-            float v[VEC], d[VEC];
+            float v[VEC], d[VEC], nn[VEC], dg[VEC];
             VecIO<T>::unpack(rx[s], v);
             VecIO<T>::unpack(rg[s], d);
 #pragma unroll
+            for (int i = 0; i < VEC; ++i) nn[i] = (pre<T>(v[i], pb, has_pb) - mean) * rstd;
+            if (GELU) gelu_grad_affine_n<T, VEC>(nn, g, b, dg);
+#pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                const float n = (pre<T>(v[i], pb, has_pb) - mean) * rstd;
+                const float n = nn[i];
                 float ga = d[i];
                 if (GELU) {
-                    ga *= gelu_grad_t<T>(n * g + b);
+                    ga *= dg[i];
                     gak[s * VEC + i] = ga;
                 }
                 s1 += ga;
