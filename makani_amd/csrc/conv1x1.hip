@@ -62,9 +62,24 @@ struct ConvNN {
     int M, K, lda, B;
     long long N;
     int act;
+    int nt;              // output stores with the streaming (nt) cache policy: set by the launcher for outputs that fit the memory-side cache
 };
 
 __device__ __forceinline__ uint4 ld16(const u16* p) { return *reinterpret_cast<const uint4*>(p); }
+// Output stores.  Measured (gpurun_out/r07l, same box): with the streaming (nt) policy the K = 384 / 768 kernels are 7-15 % faster at
+// 115 200 pixels — the 88-177 MB outputs stop evicting the activations the previous kernel left in the 256 MB memory-side cache — and
+// 0-3 % slower at 1 038 240 pixels (0.8-1.6 GB outputs); the launcher sets p.nt by the output size.  One store is issued either way
+// (uniform branch): the counted waits of the ring kernels do not change.
+__device__ __forceinline__ void mk_st16(u16* p, uint4 v, int nt) {
+    typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+    if (nt) __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(p));
+    else *reinterpret_cast<uint4*>(p) = v;
+}
+#define MK_BUF_ST16(VAL, RS, VOFF, NT)                                            \
+    do {                                                                          \
+        if (NT) __builtin_amdgcn_raw_buffer_store_b128(VAL, RS, VOFF, 0, 2);      \
+        else __builtin_amdgcn_raw_buffer_store_b128(VAL, RS, VOFF, 0, 0);         \
+    } while (0)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -608,9 +623,9 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
                 if (live[u4]) {
                     const long long o = off[u4];
                     if (!p.act && !p.G && !p.R) {
-                        *reinterpret_cast<uint4*>(p.Y + o) = raw;
+                        mk_st16(p.Y + o, raw, p.nt);
                     } else {
-                        if (p.act && p.Ypre) *reinterpret_cast<uint4*>(p.Ypre + o) = raw;
+                        if (p.act && p.Ypre) mk_st16(p.Ypre + o, raw, p.nt);
                         const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
                         float v[8];
 #pragma unroll
@@ -645,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void conv_nn_ring_kernel(const ConvNN p, in
                         out.y = pack_bf16x2(v[2], v[3]);
                         out.z = pack_bf16x2(v[4], v[5]);
                         out.w = pack_bf16x2(v[6], v[7]);
-                        *reinterpret_cast<uint4*>(p.Y + o) = out;
+                        mk_st16(p.Y + o, out, p.nt);
                     }
                 }
             }
@@ -719,6 +734,7 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
     unsigned char* const stg = ebuf + EBYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool nt_st = p.nt != 0;                       // (kernel argument: scalar, the branch around each store is uniform)
     const int l31 = lane & 31, lh = lane >> 5;
     const int s15 = lane & 15, g1 = (lane >> 4) & 1;
 #if MK_ASTAT_DIAG
@@ -957,7 +973,7 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                 const int row = idx >> 3, ch = idx & 7;
                 const uint4 raw = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ ((row >> 1) & 7)) * 16));
                 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-                if (PRE) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{raw.x, raw.y, raw.z, raw.w}, rsP, voff[u4], 0, 0);
+                if (PRE) MK_BUF_ST16((u32x4_t{raw.x, raw.y, raw.z, raw.w}), rsP, voff[u4], nt_st);
                 uint4 ev = make_uint4(0, 0, 0, 0);          // EPI_LOADS: the DMA image of this round (rows of 128 B, linear)
                 if constexpr (EPI_LOADS) ev = *reinterpret_cast<const uint4*>(ebuf + i * 16384 + row * 128 + ch * 16);
                 uint4 out = raw;
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(256, (KS < 24 && !EPI_LOADS) ? 2 : 1) void conv_nn_
                     out.z = pack_bf16x2(v[4], v[5]);
                     out.w = pack_bf16x2(v[6], v[7]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff[u4], 0, 0);
+                MK_BUF_ST16((u32x4_t{out.x, out.y, out.z, out.w}), rsY, voff[u4], nt_st);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             MK_AS_STAMP(5);
@@ -1067,6 +1083,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
     unsigned char* const ebuf = stg + 2 * 192 * 128;    // [group][192 rows][128 B], linear (as the DMA writes it)
 
     const int tid = threadIdx.x, lane = tid & 63;
+    const bool nt_st = p.nt != 0;                       // (kernel argument: scalar, the branch around each store is uniform)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wg = wave & 3;
     const int c16 = lane & 15, q4 = lane >> 4;
@@ -1248,7 +1265,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
             const bool live = m < p.M && nb < nbytes;
             const unsigned voff = live ? (unsigned)m * nbytes + nb : 0xC0000000u;   // out of range: the store is dropped
             const uint4 raw = *reinterpret_cast<const uint4*>(stgG + srow * 128 + ((ch ^ ((srow >> 1) & 7)) * 16));
-            if (PRE) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{raw.x, raw.y, raw.z, raw.w}, rsP, voff, 0, 0);
+            if (PRE) MK_BUF_ST16((u32x4_t{raw.x, raw.y, raw.z, raw.w}), rsP, voff, nt_st);
             uint4 ev = make_uint4(0, 0, 0, 0);
             if constexpr (EPI_LOADS) ev = *reinterpret_cast<const uint4*>(ebufG + grow * 128 + ch * 16);
             uint4 out = raw;
@@ -1287,7 +1304,7 @@ __global__ __launch_bounds__(512) void conv_nn_astat2_kernel(const ConvNN p, int
                 out.z = pack_bf16x2(v[4], v[5]);
                 out.w = pack_bf16x2(v[6], v[7]);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{out.x, out.y, out.z, out.w}, rsY, voff, 0, 0);
+            MK_BUF_ST16((u32x4_t{out.x, out.y, out.z, out.w}), rsY, voff, nt_st);
         }
     };
 
@@ -1816,7 +1833,11 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     MK_REQUIRE((lda % 8) == 0 && lda >= K, "conv1x1_nn: lda=%d must be a multiple of 8 and >= K=%d", lda, K);
     MK_REQUIRE((N % 8) == 0, "conv1x1_nn: pixel count %lld must be a multiple of 8", N);
     MK_REQUIRE((((uintptr_t)A | (uintptr_t)X) & 15) == 0, "conv1x1_nn: operands must be 16-byte aligned");
-    ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act};
+    // streaming stores for outputs that fit the memory-side cache (256 MB) — see mk_st16.  MAKANI_AMD_CONV_NT=0 / 1: never / always
+    static const int nt_env = [] { const char* e = getenv("MAKANI_AMD_CONV_NT"); return e ? atoi(e) : -1; }();
+    const long long out_bytes = (long long)B * M * N * 2 * ((act && Ypre) ? 2 : 1);
+    const int nt = nt_env >= 0 ? (nt_env != 0) : (out_bytes <= (256ll << 20));
+    ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act, nt};
     static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
     static const bool no_astat = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 'r'; }();   // "ring": no weight-stationary kernel
     if (!force_tile && !no_astat && lda == 80 && K > 64 && K <= 80 && M >= 256 && (long long)M * N * 2 < (1ll << 31) &&
