@@ -68,11 +68,31 @@ __device__ __forceinline__ float2 load_pair<u16>(const u16* p) {
 }
 template <typename T>
 __device__ __forceinline__ void store_pair(T* p, float a, float b);
+#ifndef MK_FFT_ST_NT           // A/B knob: the transforms' outputs with the streaming (nt) store policy
+#define MK_FFT_ST_NT 0
+#endif
+typedef float mk_fft_f2 __attribute__((ext_vector_type(2)));
+typedef float mk_fft_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fft_st4(float* p, float4 v) {
+#if MK_FFT_ST_NT
+    __builtin_nontemporal_store(mk_fft_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<mk_fft_f4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 template <>
 __device__ __forceinline__ void store_pair<float>(float* p, float a, float b) {
+#if MK_FFT_ST_NT
+    __builtin_nontemporal_store(mk_fft_f2{a, b}, reinterpret_cast<mk_fft_f2*>(p));
+#else
     *reinterpret_cast<float2*>(p) = make_float2(a, b);
+#endif
 }
 template <>
 __device__ __forceinline__ void store_pair<u16>(u16* p, float a, float b) {
+#if MK_FFT_ST_NT
+    __builtin_nontemporal_store(pack_bf16x2(a, b), reinterpret_cast<uint32_t*>(p));
+#else
     *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b);
+#endif
 }

@@ -566,8 +566,8 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
                     const float4 Xre = make_float4(R[0].x * un_hw[q].x, R[1].x * un_hw[q].x, R[2].x * un_hw[q].x, R[3].x * un_hw[q].x);
                     const float4 Xim = make_float4(R[0].y * un_hw[q].y, R[1].y * un_hw[q].y, R[2].y * un_hw[q].y, R[3].y * un_hw[q].y);
                     float* o = Fi + un_fo[q];
-                    *reinterpret_cast<float4*>(o) = Xre;
-                    *reinterpret_cast<float4*>(o + rows) = Xim;
+                    fft_st4(o, Xre);
+                    fft_st4(o + rows, Xim);
                 }
             }
         } else if (vec) {
@@ -584,14 +584,14 @@ __global__ __launch_bounds__(NT, (MK_FFT_480_FWD_OCC && N2 == 240 && sizeof(T) =
                 if constexpr (SEG) {
                     int ims;
                     float* o = F + seg_f_offset(segtab, sg.nw, sg.nh, m, klat, pr, &ims);
-                    *reinterpret_cast<float4*>(o) = Xre;
-                    *reinterpret_cast<float4*>(o + ims) = Xim;
+                    fft_st4(o, Xre);
+                    fft_st4(o + ims, Xim);
                 } else {
                     // vec: C % 4 == 0 (then Cp == C) or one batch entry — either way plane pr IS row pr of the F layout
                     // (the general (pr / C) * Cp + pr % C costs two 64-bit divisions per lane and store)
                     float* o = F + ((long long)m * nlat + klat) * 2 * rows + pr;
-                    *reinterpret_cast<float4*>(o) = Xre;
-                    *reinterpret_cast<float4*>(o + rows) = Xim;
+                    fft_st4(o, Xre);
+                    fft_st4(o + rows, Xim);
                 }
             }
         } else {

@@ -17,6 +17,9 @@
 #ifndef MK_PW_NT
 #define MK_PW_NT 1
 #endif
+#ifndef MK_PW_ST_NT            // A/B knob: plane-sized outputs with the streaming (nt) store policy
+#define MK_PW_ST_NT 0
+#endif
 #ifndef MK_PW_DIAG_VGPR
 #define MK_PW_DIAG_VGPR 0
 #endif
@@ -44,7 +47,8 @@ struct VecIO<float> {
         f32x4 r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = v[i];
-        *reinterpret_cast<f32x4*>(p) = r;
+        if constexpr (MK_PW_ST_NT) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(p));
+        else *reinterpret_cast<f32x4*>(p) = r;
     }
     __device__ static __forceinline__ float load1(const float* p) { return *p; }
     __device__ static __forceinline__ void store1(float* p, float v) { *p = v; }
@@ -67,7 +71,8 @@ struct VecIO<u16> {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        if constexpr (MK_PW_ST_NT) __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4*>(p));
+        else *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     __device__ static __forceinline__ float load1(const u16* p) { return bf16_to_f32(*p); }
     __device__ static __forceinline__ void store1(u16* p, float v) { *p = f32_to_bf16(v); }

@@ -22,6 +22,9 @@
 
 #include "xsplit.h"
 
+#ifndef MK_X2_ST_NT            // A/B knob: results of the Legendre / dhconv forward and data-gradient GEMMs with the streaming (nt) store policy
+#define MK_X2_ST_NT 0
+#endif
 namespace {
 
 using gemm::BlockCoord;
@@ -595,6 +598,9 @@ __global__ __launch_bounds__(NT2) void xcgemm2_kernel(const MkGemm p, int tilesM
 #else
                     *reinterpret_cast<float2*>(dr) = make_float2(vr, vi);
 #endif
+                } else if constexpr (MK_X2_ST_NT) {
+                    __builtin_nontemporal_store(vr, dr);
+                    __builtin_nontemporal_store(vi, di);
                 } else {
                     *dr = vr;
                     *di = vi;
@@ -841,7 +847,8 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
                         float* dst = Cb + (long long)row * p.c_row + col;
                         float val = acc[n >> 1][n & 1][r];
                         if (p.beta) val += *dst;
-                        *dst = val;
+                        if constexpr (MK_X2_ST_NT) __builtin_nontemporal_store(val, dst);
+                        else *dst = val;
                     }
                 }
             }
@@ -861,7 +868,8 @@ __global__ __launch_bounds__(NT2) void xgemm2_kernel(const MkGemm p, const PreA 
                     float* dst = Cb + (long long)row * p.c_row + col;
                     float val = acc[j][n][r];
                     if (p.beta) val += *dst;
-                    *dst = val;
+                    if constexpr (MK_X2_ST_NT) __builtin_nontemporal_store(val, dst);
+                    else *dst = val;
                 }
             }
         }
