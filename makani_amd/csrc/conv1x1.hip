@@ -1833,10 +1833,10 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
     MK_REQUIRE((lda % 8) == 0 && lda >= K, "conv1x1_nn: lda=%d must be a multiple of 8 and >= K=%d", lda, K);
     MK_REQUIRE((N % 8) == 0, "conv1x1_nn: pixel count %lld must be a multiple of 8", N);
     MK_REQUIRE((((uintptr_t)A | (uintptr_t)X) & 15) == 0, "conv1x1_nn: operands must be 16-byte aligned");
-    // streaming stores for outputs that fit the memory-side cache (256 MB) — see mk_st16.  MAKANI_AMD_CONV_NT=0 / 1: never / always
+    // streaming stores for outputs that fit the memory-side cache (256 MB) — see mk_st16.  MAKANI_AMD_CONV_NT=0 / 1: never / always (2: by the sum of both outputs)
     static const int nt_env = [] { const char* e = getenv("MAKANI_AMD_CONV_NT"); return e ? atoi(e) : -1; }();
-    const long long out_bytes = (long long)B * M * N * 2 * ((act && Ypre) ? 2 : 1);
-    const int nt = nt_env >= 0 ? (nt_env != 0) : (out_bytes <= (256ll << 20));
+    const long long out_bytes = (long long)B * M * N * 2;          // per output tensor (with the pre-activation there are two)
+    const int nt = nt_env >= 0 ? (nt_env == 1 || (nt_env == 2 && out_bytes * ((act && Ypre) ? 2 : 1) <= (256ll << 20))) : (out_bytes <= (256ll << 20));
     ConvNN p{(const u16*)A, (const u16*)X, (u16*)Y, (u16*)Ypre, bias, (const u16*)R, (const u16*)G, M, K, lda, B, N, act, nt};
     static const bool force_tile = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 't'; }();
     static const bool no_astat = [] { const char* e = getenv("MAKANI_AMD_CONV_NN"); return e && e[0] == 'r'; }();   // "ring": no weight-stationary kernel
