@@ -688,6 +688,22 @@ def test_weight_stationary_kernel_forms(form):
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
+@pytest.mark.parametrize("policy", ["0", "1"])
+def test_channel_gemm_store_policies(policy):
+    """the output stores of the channel GEMMs take the streaming (nt) cache policy for outputs of at most 256 MiB and the default one
+    above (csrc/conv1x1.hip: mk_st16 / MK_BUF_ST16, MAKANI_AMD_CONV_NT unset): the test shapes are all small, so the default-policy
+    branch of every kernel would never run here.  The switch is read once per process: both policies of every variant in child
+    processes ("0" = never, "1" = always); a cache policy must not change a single value."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-k",
+                          "test_conv1x1_nn_and_wgrad or test_bf16_forward_gelu"], env=dict(os.environ, MAKANI_AMD_CONV_NT=policy),
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
 @pytest.mark.parametrize("engine", ["x6", "x3"])
 @pytest.mark.parametrize("native", [True, False])
 def test_dhconv_high_degrees_all_row_tiles(engine, native, monkeypatch):
