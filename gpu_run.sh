@@ -1,5 +1,8 @@
 #!/bin/bash
-O=gpurun_out/r07t; mkdir -p $O
-for v in 0 128 0 128 0 128; do
-  MAKANI_AMD_CONV_NT_MIN=$v timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-exact --no-sht-metric 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ntmin=$v', round(d['ms_per_step'],3), d['final_loss'])" >> $O/bench.txt 2>&1; done
-cat $O/bench.txt
+O=gpurun_out/r07y; mkdir -p $O
+for r in 1 2; do
+for v in d 1; do
+  if [ $v = d ]; then unset MAKANI_AMD_ASTAT2; else export MAKANI_AMD_ASTAT2=$v; fi
+  python tools/microbench.py conv 2>&1 | grep -E "conv M=(768|384) K=384" | sed "s/^/astat2=$v | /" | cut -c1-175 >> $O/micro.txt
+done; done
+sort -k4,4 -k6,6 -s $O/micro.txt

@@ -1856,15 +1856,17 @@ extern "C" int mk_conv1x1_nn(const void* A, const void* X, void* Y, void* Ypre, 
         else hipLaunchKernelGGL((conv_nn_astat_kernel<3, 96, false, false, 5>), grid, blk, 0, s, p, slabs, tn);
         return mk_check_launch("mk_conv1x1_nn");
     }
-    // MAKANI_AMD_ASTAT2: 0 = never, 1 = every K = 384 launch, unset = where it measured faster (profiles/r04_ab_astat2.txt: plain
-    // -7 %, gelu' -14 ... -22 %, skip operand -10 ... -21 %; bias + GELU + pre-activation — two output streams, bound by the
-    // stores — +0 ... 2 %: that variant stays on the one-group kernel)
+    // MAKANI_AMD_ASTAT2: 0 = never, unset / 1 = every K = 384 launch, 3 = round 4's rule (profiles/r04_ab_astat2.txt: plain -7 %, gelu'
+    // -14 ... -22 %, skip operand -10 ... -21 %; bias + GELU + pre-activation — two output streams, then bound by its stores —
+    // +0 ... 2 %, so that variant stayed on the one-group kernel).  Round 6, with the streaming stores and the one-exponential GELU
+    // (gpurun_out/r07y, same box): that variant now runs 10 - 11 % faster on the two-group kernel at 115 200 pixels (0.134 -> 0.119,
+    // 0.072 -> 0.065 ms), 4 % at 384 <- 384 / 1 038 240 pixels, equal at 768 <- 384 / 1 038 240: every K = 384 launch takes it
     static const int astat2 = [] { const char* e = getenv("MAKANI_AMD_ASTAT2"); return e ? atoi(e) : 2; }();
     // shard-sized grids (one rank of h4 w2 holds 14 400 ... 32 400 pixels of the internal grid): for 384 <- 384 the ring kernel beats the
     // weight-stationary ones by 10 - 25 % there (plain 14.5 / 16.3 us against 18.8 / 21.8, + skip operand 16.3 / 18.4 against 18.2 / 24.3:
     // profiles/r05_ab_conv_shard_kernel_choice.txt); from 115 200 pixels on the stationary kernels win everywhere
     const bool small_ring = K == 384 && M == 384 && (long long)B * N <= 32768 && !(act && Ypre) && astat2 != 1;
-    if (astat2 && (astat2 == 1 || !(act && Ypre && !(R || G))) && !small_ring && !force_tile && !no_astat && K == 384 && M >= 256 &&
+    if (astat2 && (astat2 != 3 || !(act && Ypre && !(R || G))) && !small_ring && !force_tile && !no_astat && K == 384 && M >= 256 &&
         (long long)M * N * 2 < (1ll << 31) && N >= 64 && !(R && G)) {
         // two wave groups, one multiplying while the other runs its epilogue (conv_nn_astat2_kernel): 384-channel slabs
         const bool epi_loads = R || G;
